@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X self-play hot path (contract: see DESIGN.md, "Measurement").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): per GPU, 4096 parallel Othello boards from
+the standard start position are played to the end by the fused HIP rollout
+kernel with the reference's shipped RolloutPolicy weights (82 floats, kept as
+golden data in tests/golden/simulate.json) -- rollout-policy-only self-play.
+One step = one launch = 4096 finished games per GPU.  With N > 1 every rank
+plays its own 4096-board shard (weak scaling, Philox streams keyed by the
+global game id) and the finished (final boards, z, turns) tuples of the whole
+round are all-gathered over RCCL inside the timed region.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the rollout kernel against the
+HBM roof with SURVEY.md section 8(d)'s algorithmic bytes (33 B per board-step);
+`cpu_baseline` times the CPU oracle (oracle/, a C port of the reference's
+Python loops) on the host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BOARDS_PER_GPU = 4096
+START_OWN = 0x0000000810000000  # colour 1 (moves first): (3,4), (4,3)
+START_OPP = 0x0000001008000000  # colour 2: (3,3), (4,4)
+BYTES_PER_BOARD_STEP = 33       # load+store 2 x u64, + 1 B action
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def shipped_rollout_weights():
+    with open(os.path.join(ROOT, "tests", "golden", "simulate.json")) as f:
+        g = json.load(f)
+    return np.asarray(g["shipped_w"], np.float32), np.asarray(g["shipped_b"], np.float32)
+
+
+def cpu_baseline(w, b, budget_s=12.0):
+    """Oracle rollouts (same start position, same weights, same Philox keying)
+    on all host cores; ctypes releases the GIL so plain threads scale."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    orc.build()
+    cores = os.cpu_count() or 1
+    s0 = orc.initial_state()
+    t0 = time.perf_counter()
+    orc.simulate_batch(s0, 1, w, b, 0, 0, 200)
+    per_game = (time.perf_counter() - t0) / 200
+    n_each = max(200, int(budget_s / per_game))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        futs = [ex.submit(orc.simulate_batch, s0, 1, w, b, 0, 10_000_000 + i * n_each, n_each)
+                for i in range(cores)]
+        steps = sum(f.result()[1] for f in futs)
+    dt = time.perf_counter() - t0
+    games = n_each * cores
+    return {"value": games / dt, "unit": "games/s", "cores": cores, "kind": "port",
+            "sample": "%d rollout-policy games from the start position (%d per thread, "
+                      "oracle/othello_oracle.c, %.1f s)" % (games, n_each, dt),
+            "board_steps_per_game": steps / games}
+
+
+def measured_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes, if any."""
+    path = os.path.join(ROOT, "profiles", "rollout_traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from iago_amd import ops
+    from iago_amd.dist import gather_tuples
+
+    B, K, W = args.boards, args.steps, args.warmup
+    w, b = shipped_rollout_weights()
+    weights = ops.RolloutWeights(w, b)
+    own = torch.full((B,), START_OWN, dtype=torch.int64, device="cuda")
+    opp = torch.full((B,), START_OPP, dtype=torch.int64, device="cuda")
+    # the round's finished tuples, resident in HBM: K steps x B games
+    z = torch.empty((K, B), dtype=torch.int8, device="cuda")
+    fo = torch.empty((K, B), dtype=torch.int64, device="cuda")
+    fp = torch.empty((K, B), dtype=torch.int64, device="cuda")
+    nt = torch.empty((K, B), dtype=torch.uint8, device="cuda")
+    outs = []
+    for k in range(K):
+        r = ops.RolloutResult()
+        r.z, r.final_own, r.final_opp, r.n_turns = z[k], fo[k], fp[k], nt[k]
+        outs.append(r)
+
+    def step(k, slot):
+        # global game id = ((step * world) + rank) * B + board: results do not depend on N
+        ops.rollout(own, opp, weights, seed=2024, id_base=((k * world + rank) * B) & 0xFFFFFFFF,
+                    out=outs[slot])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for k in range(W):
+        step(1_000_000 + k, k % K)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for k in range(K):
+        step(k, k)
+    ev1.record()
+    gathered = None
+    if dist is not None:
+        gathered = gather_tuples(dict(z=z.view(-1), final_own=fo.view(-1), final_opp=fp.view(-1),
+                                      n_turns=nt.view(-1)))
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / K
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    steps_total = nt.to(torch.int64).sum().reshape(1)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(steps_total)
+        assert gathered["z"].numel() == world * K * B
+    dt = float(tmax.item())
+    board_steps = int(steps_total.item())
+
+    if rank == 0:
+        games = world * K * B
+        alg_bytes_per_launch = BYTES_PER_BOARD_STEP * board_steps / (world * K)
+        achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "self-play games/sec", "value": games / dt, "unit": "games/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 bitboards + f32 policy", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d parallel Othello boards per GPU, "
+                                   "rollout-policy-only playouts from the start position, "
+                                   "shipped RolloutPolicy weights" % B,
+                       "boards_per_gpu": B, "games_per_step": world * B,
+                       "tuple_allgather": "rccl" if world > 1 else "none"},
+            "board_steps_per_sec": board_steps / dt,
+            "board_steps_per_game": board_steps / games,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                         "kernel": "rollout_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w, b)
+        print(json.dumps(line), flush=True)
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""ctypes binding of the C ABI declared in include/iago_hip.h.
+
+There is no CPU fallback.  If libiago_hip.so has not been built, importing
+anything that needs it raises; if it is loaded on a host without a HIP device,
+every launch returns IAGO_ERR_HIP and `check` raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libiago_hip.so")
+
+IAGO_OK = 0
+IAGO_MAX_TURNS = 128
+IAGO_ROLLOUT_TABLE_FLOATS = 3 * 2 * 256 * 8
+TRACE_PASS = 0xFF
+
+# every symbol include/iago_hip.h declares (tests/test_abi.py checks the list
+# against the header and the built library)
+SYMBOLS = [
+    "iago_abi_version", "iago_last_error", "iago_device_count",
+    "iago_legal_moves", "iago_apply_moves", "iago_encode_planes", "iago_judge",
+    "iago_rollout_build_table", "iago_rollout",
+]
+
+
+class IagoError(RuntimeError):
+    pass
+
+
+class RolloutArgs(C.Structure):
+    _fields_ = [
+        ("own", C.c_void_p), ("opp", C.c_void_p), ("n", C.c_int64),
+        ("table", C.c_void_p), ("bias", C.c_void_p), ("uniforms", C.c_void_p),
+        ("seed", C.c_uint64), ("id_base", C.c_uint32), ("stream_id", C.c_uint32),
+        ("z", C.c_void_p), ("final_own", C.c_void_p), ("final_opp", C.c_void_p),
+        ("n_turns", C.c_void_p), ("trace", C.c_void_p), ("uniform_policy", C.c_int),
+    ]
+
+
+class MctsTree(C.Structure):
+    """Mirror of iago_mcts_tree (include/iago_hip.h)."""
+    _fields_ = [
+        ("n_games", C.c_int64), ("capacity", C.c_int32), ("_pad", C.c_int32),
+        ("parent", C.c_void_p), ("first_child", C.c_void_p), ("n_children", C.c_void_p),
+        ("action", C.c_void_p), ("n_visits", C.c_void_p), ("q", C.c_void_p), ("p", C.c_void_p),
+        ("n_nodes", C.c_void_p), ("root", C.c_void_p), ("overflow", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises IagoError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise IagoError(
+            "iago_amd/libiago_hip.so is missing: run `python -m iago_amd.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    L = C.CDLL(SO_PATH)
+    vp, i64 = C.c_void_p, C.c_int64
+    L.iago_abi_version.restype = C.c_int
+    L.iago_last_error.restype = C.c_char_p
+    L.iago_device_count.restype = C.c_int
+    L.iago_legal_moves.argtypes = [vp, vp, vp, i64, vp]
+    L.iago_apply_moves.argtypes = [vp, vp, vp, i64, vp]
+    L.iago_encode_planes.argtypes = [vp, vp, vp, i64, vp]
+    L.iago_judge.argtypes = [vp, vp, vp, i64, vp]
+    L.iago_rollout_build_table.argtypes = [vp, vp]
+    L.iago_rollout.argtypes = [C.POINTER(RolloutArgs), vp]
+    for name in ("iago_legal_moves", "iago_apply_moves", "iago_encode_planes", "iago_judge",
+                 "iago_rollout_build_table", "iago_rollout"):
+        getattr(L, name).restype = C.c_int
+    if hasattr(L, "iago_mcts_select"):
+        tp = C.POINTER(MctsTree)
+        L.iago_mcts_select.argtypes = [tp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp, vp, vp,
+                                       vp]
+        L.iago_mcts_expand.argtypes = [tp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp]
+        L.iago_mcts_backup.argtypes = [tp, vp, vp, vp, vp]
+        L.iago_mcts_best_move.argtypes = [tp, vp, vp, vp]
+        L.iago_mcts_advance_root.argtypes = [tp, vp, vp, vp]
+        L.iago_leaf_values.argtypes = [vp, vp, C.c_float, vp, i64, vp]
+        for name in ("iago_mcts_select", "iago_mcts_expand", "iago_mcts_backup",
+                     "iago_mcts_best_move", "iago_mcts_advance_root", "iago_leaf_values"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != IAGO_OK:
+        msg = lib().iago_last_error().decode("utf-8", "replace")
+        raise IagoError("%s failed (%d): %s" % (what or "iago call", rc, msg))
+
+
+def device_count():
+    return lib().iago_device_count()

@@ -1,0 +1,139 @@
+// rules_kernels.hip -- batched Othello rule kernels (gfx950) + their C ABI.
+// Entry points and the reference interfaces they replace: include/iago_hip.h.
+#include "abi_common.hpp"
+#include "othello_dev.hpp"
+
+using namespace iago;
+
+namespace {
+
+constexpr int BLOCK = 256; // 4 waves, 32 boards per block
+
+// 8 lanes per board; lane 0 of each group stores the mask.
+__global__ __launch_bounds__(BLOCK) void legal_moves_kernel(const uint64_t *__restrict__ own,
+                                                            const uint64_t *__restrict__ opp,
+                                                            uint64_t *__restrict__ legal, int64_t n)
+{
+    const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t b = gtid >> 3;
+    const Lane8 L = make_lane8(threadIdx.x);
+    const bool live = b < n;
+    const uint64_t o = live ? own[b] : 0ull, p = live ? opp[b] : 0ull;
+    const uint64_t mv = group8_legal(to_lane(o, L), to_lane(p, L), L);
+    if (live && L.l8 == 0)
+        legal[b] = mv;
+}
+
+__global__ __launch_bounds__(BLOCK) void apply_moves_kernel(uint64_t *__restrict__ own,
+                                                            uint64_t *__restrict__ opp,
+                                                            const int8_t *__restrict__ action,
+                                                            int64_t n)
+{
+    __shared__ uint64_t ray[RAY_TABLE_WORDS];
+    fill_ray_table(ray);
+    __syncthreads();
+    const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t b = gtid >> 3;
+    const Lane8 L = make_lane8(threadIdx.x);
+    const bool live = b < n;
+    const uint64_t o = live ? own[b] : 0ull, p = live ? opp[b] : 0ull;
+    const int a = live ? (int)action[b] : -1;
+    const uint32_t pos = (uint32_t)a & 63u;
+    const uint64_t f = group8_flips(to_lane(o, L), to_lane(p, L), pos, L, ray);
+    if (live && L.l8 == 0 && a >= 0) {
+        const uint64_t bit = 1ull << pos;
+        own[b] = o | f | bit;
+        opp[b] = p & ~f & ~bit;
+    }
+}
+
+// One thread per float4 of the (n,2,8,8) tensor: 32 threads cover the 512 B
+// of one board, so a wave writes 1 KiB contiguous (fully coalesced stores).
+__global__ __launch_bounds__(BLOCK) void encode_planes_kernel(const uint64_t *__restrict__ own,
+                                                              const uint64_t *__restrict__ opp,
+                                                              float4 *__restrict__ planes,
+                                                              int64_t n)
+{
+    const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t b = gtid >> 5;
+    if (b >= n)
+        return;
+    const uint32_t k = (uint32_t)gtid & 31u;
+    // channel 0 = opponent of the side to move, channel 1 = side to move
+    // (game.py:168-174: the colour-1 swap puts the mover in `state==2`)
+    const uint64_t bits = (k < 16u) ? opp[b] : own[b];
+    const uint32_t nib = (uint32_t)(bits >> ((k & 15u) * 4u)) & 15u;
+    float4 v;
+    v.x = (nib & 1u) ? 1.0f : 0.0f;
+    v.y = (nib & 2u) ? 1.0f : 0.0f;
+    v.z = (nib & 4u) ? 1.0f : 0.0f;
+    v.w = (nib & 8u) ? 1.0f : 0.0f;
+    planes[gtid] = v;
+}
+
+__global__ __launch_bounds__(BLOCK) void judge_kernel(const uint64_t *__restrict__ own,
+                                                      const uint64_t *__restrict__ opp,
+                                                      int8_t *__restrict__ z, int64_t n)
+{
+    const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= n)
+        return;
+    const int d = __popcll(own[b]) - __popcll(opp[b]);
+    z[b] = (int8_t)((d > 0) - (d < 0));
+}
+
+inline unsigned grid_for(int64_t threads) { return (unsigned)((threads + BLOCK - 1) / BLOCK); }
+
+} // namespace
+
+extern "C" {
+
+int iago_legal_moves(const uint64_t *own, const uint64_t *opp, uint64_t *legal, int64_t n,
+                     void *stream)
+{
+    if (n < 0 || (n > 0 && (!own || !opp || !legal)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_legal_moves: null pointer or negative n");
+    if (n == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(legal_moves_kernel, dim3(grid_for(n * 8)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, own, opp, legal, n);
+    return iago_check_launch("iago_legal_moves");
+}
+
+int iago_apply_moves(uint64_t *own, uint64_t *opp, const int8_t *action, int64_t n, void *stream)
+{
+    if (n < 0 || (n > 0 && (!own || !opp || !action)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_apply_moves: null pointer or negative n");
+    if (n == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(apply_moves_kernel, dim3(grid_for(n * 8)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, own, opp, action, n);
+    return iago_check_launch("iago_apply_moves");
+}
+
+int iago_encode_planes(const uint64_t *own, const uint64_t *opp, float *planes, int64_t n,
+                       void *stream)
+{
+    if (n < 0 || (n > 0 && (!own || !opp || !planes)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_encode_planes: null pointer or negative n");
+    if (((uintptr_t)planes & 15u) != 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_encode_planes: planes must be 16-byte aligned");
+    if (n == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(encode_planes_kernel, dim3(grid_for(n * 32)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, own, opp, (float4 *)planes, n);
+    return iago_check_launch("iago_encode_planes");
+}
+
+int iago_judge(const uint64_t *own, const uint64_t *opp, int8_t *z, int64_t n, void *stream)
+{
+    if (n < 0 || (n > 0 && (!own || !opp || !z)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_judge: null pointer or negative n");
+    if (n == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(judge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, own,
+                       opp, z, n);
+    return iago_check_launch("iago_judge");
+}
+
+} // extern "C"

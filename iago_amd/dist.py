@@ -1,0 +1,73 @@
+"""Game-level sharding and the one collective of the path.
+
+Self-play games are independent, so they shard over ranks with no data-path
+collective; the only exchange is the all-gather of finished training tuples at
+the end of a self-play round (the reference's analogue is the list
+concatenation of src/train_rl.py:48-51).  One process per GPU,
+torch.distributed backend "nccl" (= RCCL over xGMI); "gloo" in the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_games, rank=None, world=None):
+    """Contiguous block of global game ids owned by `rank`: [lo, hi)."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    base, rem = divmod(n_games, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_tuples(fields, group=None):
+    """All-gather per-rank tuple arrays (dict name -> tensor, same length along
+    dim 0 on a rank, lengths may differ between ranks).  Returns a dict of
+    tensors holding rank 0's rows first, then rank 1's, ...
+
+    Two collectives regardless of the number of fields: one all-gather of the
+    row counts, one all-gather of a byte buffer padded to the longest shard
+    (payloads are MBs: latency-, not bandwidth-bound on 7 x 153 GB/s xGMI links).
+    """
+    names = sorted(fields)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return {k: fields[k] for k in names}
+    world = dist.get_world_size(group)
+    first = fields[names[0]]
+    n = first.shape[0]
+    dev = first.device
+    for k in names:
+        if fields[k].shape[0] != n:
+            raise ValueError("field %s has %d rows, expected %d" % (k, fields[k].shape[0], n))
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([n], dtype=torch.int64, device=dev),
+                                group=group)
+    counts = counts.cpu().tolist()
+    nmax = max(counts)
+    # pack every field's rows as bytes, 8-byte aligned segments
+    segs, offs, off = [], [], 0
+    for k in names:
+        t = fields[k].contiguous()
+        row_elems = 1
+        for d in t.shape[1:]:
+            row_elems *= int(d)
+        row_bytes = t.element_size() * row_elems
+        seg = (row_bytes * nmax + 7) // 8 * 8
+        segs.append((k, t, row_bytes, seg))
+        offs.append(off)
+        off += seg
+    send = torch.zeros(off, dtype=torch.uint8, device=dev)
+    for (k, t, row_bytes, seg), o in zip(segs, offs):
+        send[o:o + row_bytes * n] = t.view(-1).view(torch.uint8)
+    recv = torch.empty(world * off, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    out = {}
+    for (k, t, row_bytes, seg), o in zip(segs, offs):
+        parts = []
+        for r in range(world):
+            base = r * off + o
+            parts.append(recv[base:base + row_bytes * counts[r]])
+        flat = torch.cat(parts).view(t.dtype)
+        out[k] = flat.view((sum(counts),) + tuple(t.shape[1:]))
+    return out

@@ -1,0 +1,154 @@
+"""Tensor-level wrappers over the C ABI (include/iago_hip.h).
+
+Boards are int64 CUDA tensors holding the 64-bit bitboards (bit a = row*8+col;
+`own` = side to move).  Every function launches on torch's current stream and
+requires CUDA tensors: there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import IAGO_MAX_TURNS, IAGO_ROLLOUT_TABLE_FLOATS, RolloutArgs, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.IagoError("%s must be a CUDA tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return C.c_void_p(t.data_ptr())
+
+
+def bits_to_tensor(values, device="cuda"):
+    """Python ints / numpy uint64 -> int64 tensor with the same bit patterns."""
+    a = np.asarray(values, dtype=np.uint64).reshape(-1)
+    return torch.from_numpy(a.view(np.int64).copy()).to(device)
+
+
+def tensor_to_bits(t):
+    """int64 tensor -> numpy uint64 array."""
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+def legal_moves(own, opp):
+    """Bit mask of legal moves per board (game.py:210-235, rl_env.py:114-138)."""
+    n = own.numel()
+    out = torch.empty_like(own)
+    check(_lib.lib().iago_legal_moves(_dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp"),
+                                      _dev(out, torch.int64, "legal"), n, _stream()),
+          "iago_legal_moves")
+    return out
+
+
+def apply_moves(own, opp, action):
+    """In place place_stone (game.py:180-207); action int8, -1 = pass."""
+    n = own.numel()
+    if action.numel() != n or opp.numel() != n:
+        raise ValueError("own/opp/action sizes differ")
+    check(_lib.lib().iago_apply_moves(_dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp"),
+                                      _dev(action, torch.int8, "action"), n, _stream()),
+          "iago_apply_moves")
+    return own, opp
+
+
+def encode_planes(own, opp, out=None):
+    """(n,2,8,8) float32 planes, channel 0 = opp, channel 1 = own (game.py:168-174)."""
+    n = own.numel()
+    if out is None:
+        out = torch.empty((n, 2, 8, 8), dtype=torch.float32, device=own.device)
+    elif out.numel() != n * 128:
+        raise ValueError("planes buffer has the wrong size")
+    check(_lib.lib().iago_encode_planes(_dev(own, torch.int64, "own"),
+                                        _dev(opp, torch.int64, "opp"),
+                                        _dev(out, torch.float32, "planes"), n, _stream()),
+          "iago_encode_planes")
+    return out
+
+
+def judge(own, opp):
+    """sign(#own - #opp) as int8 (mcts_self_play.py:113-121)."""
+    n = own.numel()
+    out = torch.empty(n, dtype=torch.int8, device=own.device)
+    check(_lib.lib().iago_judge(_dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp"),
+                                _dev(out, torch.int8, "z"), n, _stream()), "iago_judge")
+    return out
+
+
+class RolloutWeights(object):
+    """Device-resident RolloutPolicy parameters (network.py:49-64) in the form
+    the rollout kernel consumes: the 48 KiB row table and the 64 biases."""
+
+    def __init__(self, w, b, device="cuda"):
+        w = np.ascontiguousarray(np.asarray(w, dtype=np.float32).reshape(18))
+        b = np.ascontiguousarray(np.asarray(b, dtype=np.float32).reshape(64))
+        table = np.empty(IAGO_ROLLOUT_TABLE_FLOATS, dtype=np.float32)
+        check(_lib.lib().iago_rollout_build_table(C.c_void_p(w.ctypes.data),
+                                                  C.c_void_p(table.ctypes.data)),
+              "iago_rollout_build_table")
+        self.w, self.b = w, b
+        self.table = torch.from_numpy(table).to(device)
+        self.bias = torch.from_numpy(b).to(device)
+
+
+class RolloutResult(object):
+    __slots__ = ("z", "final_own", "final_opp", "n_turns", "trace")
+
+    def __init__(self):
+        self.z = self.final_own = self.final_opp = self.n_turns = self.trace = None
+
+
+def rollout(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=None,
+            want_final=False, want_turns=False, want_trace=False, out=None):
+    """Simulate(state)(color) for every board (mcts_self_play.py:9-134).
+
+    weights=None plays uniformly random legal moves.  `uniforms`
+    (IAGO_MAX_TURNS, n) float32 replaces the Philox stream (parity tests).
+    `out` may be a RolloutResult with preallocated tensors to reuse.
+    """
+    n = own.numel()
+    res = out if out is not None else RolloutResult()
+    dev = own.device
+    if res.z is None:
+        res.z = torch.empty(n, dtype=torch.int8, device=dev)
+    if want_final and res.final_own is None:
+        res.final_own = torch.empty(n, dtype=torch.int64, device=dev)
+        res.final_opp = torch.empty(n, dtype=torch.int64, device=dev)
+    if want_turns and res.n_turns is None:
+        res.n_turns = torch.empty(n, dtype=torch.uint8, device=dev)
+    if want_trace and res.trace is None:
+        res.trace = torch.full((IAGO_MAX_TURNS, n), 0xFE, dtype=torch.uint8, device=dev)
+    a = RolloutArgs()
+    a.own = _dev(own, torch.int64, "own")
+    a.opp = _dev(opp, torch.int64, "opp")
+    a.n = n
+    if weights is not None:
+        a.table = _dev(weights.table, torch.float32, "table")
+        a.bias = _dev(weights.bias, torch.float32, "bias")
+        a.uniform_policy = 0
+    else:
+        a.uniform_policy = 1
+    if uniforms is not None:
+        if tuple(uniforms.shape) != (IAGO_MAX_TURNS, n):
+            raise ValueError("uniforms must have shape (%d, n)" % IAGO_MAX_TURNS)
+        a.uniforms = _dev(uniforms, torch.float32, "uniforms")
+    a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    a.id_base = int(id_base) & 0xFFFFFFFF
+    a.stream_id = int(stream_id) & 0xFFFFFFFF
+    a.z = _dev(res.z, torch.int8, "z")
+    if res.final_own is not None:
+        a.final_own = _dev(res.final_own, torch.int64, "final_own")
+        a.final_opp = _dev(res.final_opp, torch.int64, "final_opp")
+    if res.n_turns is not None:
+        a.n_turns = _dev(res.n_turns, torch.uint8, "n_turns")
+    if res.trace is not None:
+        a.trace = _dev(res.trace, torch.uint8, "trace")
+    check(_lib.lib().iago_rollout(C.byref(a), _stream()), "iago_rollout")
+    return res

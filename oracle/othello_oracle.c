@@ -242,7 +242,7 @@ ORC_API void orc_masked_probs(const float *prob, const int *actions, int n_actio
 /* Philox4x32-10 counter RNG (Salmon et al., SC'11) -- the build's      */
 /* replacement for numpy's MT19937 stream (RNG     */
 /* parity is by replay).  key = (seed_lo, seed_hi), counter = (game,    */
-/* step, stream, 0); uniform = (word0 >> 8) * 2^-24 in [0,1).           */
+/* turn>>2, stream, 0); uniform = (word[turn&3] >> 8) * 2^-24 in [0,1). */
 /* ------------------------------------------------------------------ */
 static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
 {
@@ -269,9 +269,10 @@ ORC_API void orc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, ui
 
 ORC_API float orc_uniform(uint64_t seed, uint32_t game, uint32_t step, uint32_t stream)
 {
-    uint32_t c[4] = {game, step, stream, 0};
+    /* one Philox block serves 4 consecutive turns: word step&3 of counter step>>2 */
+    uint32_t c[4] = {game, step >> 2, stream, 0};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+    return (float)(c[step & 3] >> 8) * (1.0f / 16777216.0f);
 }
 
 /* ------------------------------------------------------------------ */

@@ -1,0 +1,66 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol that
+include/iago_hip.h declares.  No compute calls (no GPU here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from iago_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def so():
+    return build.build()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "iago_hip.h")).read()
+    return sorted(set(re.findall(r"IAGO_API[^;(]*?\b(iago_\w+)\s*\(", text)))
+
+
+def test_header_matches_symbol_list(so):
+    assert header_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_symbol(so):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    exported = set(re.findall(r" T (iago_\w+)", out))
+    assert set(header_symbols()) <= exported
+    L = _lib.lib()
+    for name in header_symbols():
+        assert hasattr(L, name), name
+    assert L.iago_abi_version() == 1
+
+
+def test_gfx950_code_object(so):
+    data = open(so, "rb").read()
+    assert b"gfx950" in data
+
+
+def test_no_cpu_fallback_in_product():
+    """Nothing under iago_amd/ may import the oracle."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "iago_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "liboracle" not in text, f
+
+
+def test_ops_refuse_cpu_tensors(so):
+    import torch
+    from iago_amd import ops
+    t = torch.zeros(4, dtype=torch.int64)
+    with pytest.raises(_lib.IagoError):
+        ops.legal_moves(t, t)
+
+
+def test_invalid_arguments_are_reported(so):
+    L = _lib.lib()
+    assert L.iago_legal_moves(None, None, None, 4, None) == -1
+    assert b"iago_legal_moves" in L.iago_last_error()
+    assert L.iago_legal_moves(None, None, None, 0, None) == 0
+    assert L.iago_rollout(None, None) == -1

@@ -71,7 +71,8 @@ def test_philox_known_answer():
     assert orc.philox(0x299f31d0a4093822, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
     u = orc.uniform(1, 2, 3)
-    assert 0.0 <= u < 1.0 and u == (orc.philox(1, 2, 3, 0, 0)[0] >> 8) / 16777216.0
+    assert 0.0 <= u < 1.0 and u == (orc.philox(1, 2, 0, 0, 0)[3] >> 8) / 16777216.0
+    assert orc.uniform(1, 2, 9, 5) == (orc.philox(1, 2, 2, 5, 0)[1] >> 8) / 16777216.0
 
 
 def test_simulate(golden_json):

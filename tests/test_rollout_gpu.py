@@ -1,0 +1,172 @@
+"""Parity of the fused HIP rollout kernel (iago_rollout, through the C ABI)
+with the CPU oracle and the golden Simulate traces recorded from the reference.
+
+* uniform policy: bit-exact full-game parity (actions, final boards, z, turns)
+  with oracle.random_playout -- the arithmetic is exact in float32;
+* rollout policy: every recorded turn is replayed through the oracle's rules
+  (legal set, flips, passes, termination bit-exact); the sampled cell must be
+  the oracle's own draw unless u lies within TOL of a CDF boundary (float32
+  softmax rounding; tolerance 1e-5 as BASELINE.json's north_star states).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.conftest import load_json
+from tests.gpu_util import random_positions, state_of
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+MAXT = 128
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from iago_amd import ops as o
+    assert torch.cuda.is_available(), "the -m gpu tests need a HIP device"
+    return o
+
+
+def run(ops, own, opp, weights=None, **kw):
+    res = ops.rollout(ops.bits_to_tensor(own), ops.bits_to_tensor(opp), weights, want_final=True,
+                      want_turns=True, want_trace=True, **kw)
+    torch.cuda.synchronize()
+    return (res.z.cpu().numpy(), ops.tensor_to_bits(res.final_own), ops.tensor_to_bits(res.final_opp),
+            res.n_turns.cpu().numpy(), res.trace.cpu().numpy())
+
+
+def trace_list(trace, b, nt):
+    return [(-1 if a == 0xFF else int(a)) for a in trace[:nt, b]]
+
+
+@pytest.mark.parametrize("n,seed,id_base", [(1, 1, 0), (8, 2, 5), (300, 3, 1000), (2048, 4, 0)])
+def test_uniform_policy_bit_exact(ops, n, seed, id_base):
+    own, opp = random_positions(n, seed=seed)
+    own[: n // 3] = 0x0000000810000000  # standard start, colour 1 to move
+    opp[: n // 3] = 0x0000001008000000
+    z, fo, fp, nt, tr = run(ops, own, opp, None, seed=seed, id_base=id_base)
+    for b in range(n):
+        oz, final, otr = orc.random_playout(state_of(own[b], opp[b]), 1, seed=seed,
+                                            game_id=id_base + b)
+        assert trace_list(tr, b, nt[b]) == otr, b
+        assert nt[b] == len(otr)
+        assert (int(fo[b]), int(fp[b])) == orc.state_to_bits(final), b
+        assert z[b] == oz
+
+
+def replay_check(own, opp, z, fo, fp, nt, tr, w, bvec, uniform_of):
+    """Replay GPU traces through the oracle rules; returns (#sampled, #exact)."""
+    sampled = exact = 0
+    for b in range(len(own)):
+        s = state_of(own[b], opp[b])
+        color, stone_num, pass_flg, t = 1, 64 - int(np.sum(s == 0)), False, 0
+        while stone_num < 64:
+            for c in (color, 3 - color):
+                acts = orc.legal_actions(s, c)
+                a = -1 if tr[t, b] == 0xFF else int(tr[t, b])
+                if acts:
+                    assert a in acts, (b, t, a, acts)
+                    prob, _ = orc.rollout_policy(orc.make_state_var(s, c), w, bvec)
+                    p = orc.masked_probs(prob, acts)
+                    u = uniform_of(b, t)
+                    cdf = np.cumsum(p)
+                    lo = cdf[a - 1] if a > 0 else 0.0
+                    assert lo - TOL <= u < cdf[a] + TOL, (b, t, a, u, lo, cdf[a])
+                    sampled += 1
+                    exact += int(orc.choice_cdf(p, u) == a)
+                    orc.place_stone(s, a, c)
+                    pass_flg = False
+                    stone_num += 1
+                else:
+                    assert a == -1, (b, t, a)
+                    if pass_flg:
+                        stone_num = 64
+                    pass_flg = True
+                t += 1
+        assert t == nt[b], (b, t, nt[b])
+        assert np.all(tr[t:, b] == 0xFE)  # nothing written past the end
+        assert orc.state_to_bits(s) == (int(fo[b]), int(fp[b])), b
+        assert z[b] == orc.judge(s, 1)
+    return sampled, exact
+
+
+@pytest.mark.parametrize("which", ["random", "shipped"])
+def test_policy_rollout_replay(ops, which):
+    g = load_json("simulate.json")
+    w, bvec = (g["w"], g["b"]) if which == "random" else (g["shipped_w"], g["shipped_b"])
+    weights = ops.RolloutWeights(w, bvec)
+    n, seed, id_base, stream = 600, 11, 77, 3
+    own, opp = random_positions(n, seed=5)
+    own[:200] = 0x0000000810000000
+    opp[:200] = 0x0000001008000000
+    out = run(ops, own, opp, weights, seed=seed, id_base=id_base, stream_id=stream)
+    sampled, exact = replay_check(own, opp, *out, w, bvec,
+                                  lambda b, t: orc.uniform(seed, id_base + b, t, stream))
+    assert sampled > 10000
+    assert exact >= sampled - 3, (sampled, exact)
+
+
+def test_golden_simulate_with_recorded_uniforms(ops):
+    """The real reference Simulate runs (tests/golden/simulate.json), driven by
+    the uniforms numpy drew: same actions, same final board, same z."""
+    g = load_json("simulate.json")
+    for wi in (0, 1):
+        w, bvec = (g["w"], g["b"]) if wi == 0 else (g["shipped_w"], g["shipped_b"])
+        weights = ops.RolloutWeights(w, bvec)
+        cases = [c for c in g["cases"] if c["weights"] == wi]
+        n = len(cases)
+        own = np.array([c["p1"] if c["color"] == 1 else c["p2"] for c in cases], np.uint64)
+        opp = np.array([c["p2"] if c["color"] == 1 else c["p1"] for c in cases], np.uint64)
+        us = np.zeros((MAXT, n), np.float32)
+        for i, c in enumerate(cases):
+            us[:len(c["uniforms"]), i] = c["uniforms"]
+        z, fo, fp, nt, tr = run(ops, own, opp, weights, uniforms=torch.from_numpy(us).cuda())
+        for i, c in enumerate(cases):
+            assert trace_list(tr, i, nt[i]) == c["trace"], i
+            assert z[i] == c["z"]
+            q_own, q_opp = (c["q1"], c["q2"]) if c["color"] == 1 else (c["q2"], c["q1"])
+            assert (int(fo[i]), int(fp[i])) == (q_own, q_opp)
+
+
+def test_edge_positions(ops, golden_rules):
+    """Full board, dead position, forced passes, empty board: termination logic."""
+    boards = golden_rules["edge_boards"]
+    own = np.concatenate([boards[:, 0], boards[:, 1]])
+    opp = np.concatenate([boards[:, 1], boards[:, 0]])
+    z, fo, fp, nt, tr = run(ops, own, opp, None, seed=9)
+    for b in range(len(own)):
+        oz, final, otr = orc.random_playout(state_of(own[b], opp[b]), 1, seed=9, game_id=b)
+        assert trace_list(tr, b, nt[b]) == otr
+        assert (int(fo[b]), int(fp[b])) == orc.state_to_bits(final)
+        assert z[b] == oz
+
+
+def test_full_size_properties(ops):
+    """BASELINE config 2 size (4096 boards from the start position):
+    determinism, layout independence of the Philox keying, z == judge(final),
+    stone conservation, and a 64k-board run of the same."""
+    g = load_json("simulate.json")
+    weights = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    for n in (4096, 65536):
+        own = torch.full((n,), 0x0000000810000000, dtype=torch.int64, device="cuda")
+        opp = torch.full((n,), 0x0000001008000000, dtype=torch.int64, device="cuda")
+        r1 = ops.rollout(own, opp, weights, seed=42, id_base=0, want_final=True, want_turns=True)
+        r2 = ops.rollout(own, opp, weights, seed=42, id_base=0, want_final=True, want_turns=True)
+        r3 = ops.rollout(own[: n - 1000], opp[: n - 1000], weights, seed=42, id_base=1000,
+                         want_final=True, want_turns=True)
+        torch.cuda.synchronize()
+        assert torch.equal(r1.z, r2.z) and torch.equal(r1.final_own, r2.final_own)
+        assert torch.equal(r1.z[1000:], r3.z) and torch.equal(r1.final_own[1000:], r3.final_own)
+        assert torch.equal(ops.judge(r1.final_own, r1.final_opp), r1.z)
+        assert not torch.any(r1.final_own & r1.final_opp)
+        legal_a = ops.legal_moves(r1.final_own, r1.final_opp)
+        legal_b = ops.legal_moves(r1.final_opp, r1.final_own)
+        assert not torch.any(legal_a | legal_b)  # terminal: nobody can move
+        nt = r1.n_turns.cpu().numpy()
+        assert nt.min() >= 2 and nt.max() <= 124 and np.all(nt % 2 == 0)
+        zs = r1.z.cpu().numpy()
+        assert len(np.unique(zs)) >= 2  # not degenerate
+        r4 = ops.rollout(own, opp, weights, seed=43, want_final=True)
+        torch.cuda.synchronize()
+        assert not torch.equal(r1.final_own, r4.final_own)
