@@ -43,24 +43,39 @@ def shipped_rollout_weights():
     return np.asarray(g["shipped_w"], np.float32), np.asarray(g["shipped_b"], np.float32)
 
 
-def cpu_baseline(w, b, budget_s=12.0):
+def host_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(w, b, budget_s=10.0):
     """Oracle rollouts (same start position, same weights, same Philox keying)
-    on all host cores; ctypes releases the GIL so plain threads scale."""
+    on the host cores; ctypes releases the GIL so plain threads scale.  The
+    sample is sized from a short parallel probe so the leg takes ~budget_s."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
     orc.build()
-    cores = os.cpu_count() or 1
+    cores = min(host_cores(), 64)
     s0 = orc.initial_state()
-    t0 = time.perf_counter()
-    orc.simulate_batch(s0, 1, w, b, 0, 0, 200)
-    per_game = (time.perf_counter() - t0) / 200
-    n_each = max(200, int(budget_s / per_game))
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        futs = [ex.submit(orc.simulate_batch, s0, 1, w, b, 0, 10_000_000 + i * n_each, n_each)
-                for i in range(cores)]
-        steps = sum(f.result()[1] for f in futs)
-    dt = time.perf_counter() - t0
+
+    def run(n_each, base):
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            futs = [ex.submit(orc.simulate_batch, s0, 1, w, b, 0, base + i * n_each, n_each)
+                    for i in range(cores)]
+            steps = sum(f.result()[1] for f in futs)
+        return time.perf_counter() - t0, steps
+
+    probe_t, _ = run(100, 5_000_000)
+    n_each = max(100, min(200_000, int(100 * budget_s / probe_t)))
+    dt, steps = run(n_each, 10_000_000)
     games = n_each * cores
     return {"value": games / dt, "unit": "games/s", "cores": cores, "kind": "port",
             "sample": "%d rollout-policy games from the start position (%d per thread, "

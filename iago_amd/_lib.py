@@ -60,6 +60,17 @@ def lib():
         raise IagoError(
             "iago_amd/libiago_hip.so is missing: run `python -m iago_amd.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (same
+    # SONAME as /opt/rocm's).  Load torch's copy first so that this library's
+    # NEEDED libamdhip64.so.7 binds to it instead of pulling in a second runtime
+    # (two runtimes in one process: "no ROCm-capable device is detected").
+    try:
+        import torch
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+    except ImportError:  # C-only hosts use the system runtime through RUNPATH
+        pass
     L = C.CDLL(SO_PATH)
     vp, i64 = C.c_void_p, C.c_int64
     L.iago_abi_version.restype = C.c_int

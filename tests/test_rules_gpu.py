@@ -134,10 +134,9 @@ def test_full_size_symmetry_property(ops):
         assert np.array_equal(lt, _transform(lb[:4096], kind)), kind
     # play the lowest legal move everywhere: stone counts grow by 1 + flips,
     # opp loses exactly the flips, no cell is owned twice
-    lowest = torch.where(legal != 0, (legal & -legal), torch.zeros_like(legal))
-    act = torch.where(legal != 0, torch.log2(lowest.abs().double()).round().to(torch.int8),
-                      torch.full_like(legal, -1, dtype=torch.int8))
-    # bit 63 as lowest legal move gives a negative int64: log2(|x|) still is 63
+    low = lb & (~lb + np.uint64(1))
+    act_np = np.where(lb != 0, np.log2(np.maximum(low, 1).astype(np.float64)).round(), -1)
+    act = torch.from_numpy(act_np.astype(np.int8)).cuda()
     o2, p2 = o.clone(), p.clone()
     ops.apply_moves(o2, p2, act.to(torch.int8))
     a, b, a2, b2 = (ops.tensor_to_bits(x) for x in (o, p, o2, p2))

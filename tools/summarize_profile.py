@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_rollout.sh output directory into the files kept
+under profiles/: the rocprofv3 kernel-stats CSV, a PMC summary (mean per launch
+of the named kernel) and the HBM traffic figure bench.py reports.
+
+    python tools/summarize_profile.py gpurun_out/prof_r01a r01a [kernel-substring]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+kern = sys.argv[3] if len(sys.argv) > 3 else "rollout_kernel"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+if stats:
+    rows = list(csv.reader(open(stats[0])))
+    with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w") as f:
+        w = csv.writer(f)
+        for r in rows:
+            r[0] = r[0][:120]
+            w.writerow(r)
+
+pmc = collections.OrderedDict()
+for path in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+    agg = collections.defaultdict(list)
+    meta = {}
+    for r in csv.DictReader(open(path)):
+        if kern in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                                      "SGPR_Count")}
+    for k, v in agg.items():
+        pmc[k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+    if meta:
+        pmc["_dispatch"] = meta
+summary = {"kernel": kern, "source": "rocprofv3 --pmc (separate passes), bench.py --steps 100 "
+           "--warmup 10 --no-cpu-baseline", "counters": pmc}
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    fetch_kb, write_kb = pmc["FETCH_SIZE"]["mean"], pmc["WRITE_SIZE"]["mean"]
+    # MI355X_MICROARCH.md, HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+    # reports half the bytes of a 16 B/lane coalesced read stream -> doubled;
+    # WRITE_SIZE is exact.
+    hbm = (2.0 * fetch_kb + write_kb) * 1024.0
+    summary["hbm_bytes_per_launch"] = hbm
+    summary["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KiB per launch; FETCH_SIZE doubled per "
+                               "the gfx950 correction for 16 B/lane reads (the 48 KiB table staging "
+                               "is float4 loads; board loads are 8 B/lane and uncalibrated)")
+    with open(os.path.join(out, "rollout_traffic.json"), "w") as f:
+        json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kib": fetch_kb,
+                   "write_size_kib": write_kb, "profile": tag,
+                   "note": summary["traffic_note"]}, f, indent=1)
+with open(os.path.join(out, "%s_pmc_summary.json" % tag), "w") as f:
+    json.dump(summary, f, indent=1)
+print(json.dumps(summary, indent=1)[:3000])
