@@ -20,7 +20,10 @@ TRACE_PASS = 0xFF
 SYMBOLS = [
     "iago_abi_version", "iago_last_error", "iago_device_count",
     "iago_legal_moves", "iago_apply_moves", "iago_encode_planes", "iago_judge",
+    "iago_sample_moves",
     "iago_rollout_build_table", "iago_rollout",
+    "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_leaf_values",
+    "iago_mcts_backup", "iago_mcts_best_move", "iago_mcts_advance_root",
 ]
 
 
@@ -41,7 +44,7 @@ class RolloutArgs(C.Structure):
 class MctsTree(C.Structure):
     """Mirror of iago_mcts_tree (include/iago_hip.h)."""
     _fields_ = [
-        ("n_games", C.c_int64), ("capacity", C.c_int32), ("_pad", C.c_int32),
+        ("n_games", C.c_int64), ("capacity", C.c_int32), ("reserved", C.c_int32),
         ("parent", C.c_void_p), ("first_child", C.c_void_p), ("n_children", C.c_void_p),
         ("action", C.c_void_p), ("n_visits", C.c_void_p), ("q", C.c_void_p), ("p", C.c_void_p),
         ("n_nodes", C.c_void_p), ("root", C.c_void_p), ("overflow", C.c_void_p),
@@ -80,23 +83,21 @@ def lib():
     L.iago_apply_moves.argtypes = [vp, vp, vp, i64, vp]
     L.iago_encode_planes.argtypes = [vp, vp, vp, i64, vp]
     L.iago_judge.argtypes = [vp, vp, vp, i64, vp]
+    L.iago_sample_moves.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
+                                    i64, vp]
     L.iago_rollout_build_table.argtypes = [vp, vp]
     L.iago_rollout.argtypes = [C.POINTER(RolloutArgs), vp]
-    for name in ("iago_legal_moves", "iago_apply_moves", "iago_encode_planes", "iago_judge",
-                 "iago_rollout_build_table", "iago_rollout"):
+    tp = C.POINTER(MctsTree)
+    L.iago_mcts_reset.argtypes = [tp, vp, vp]
+    L.iago_mcts_select.argtypes = [tp, vp, vp, vp, C.c_float, C.c_int32, C.c_int, vp, vp, vp, vp,
+                                   vp, vp]
+    L.iago_mcts_expand.argtypes = [tp, vp, i64, vp, vp, vp, vp]
+    L.iago_leaf_values.argtypes = [vp, vp, C.c_float, vp, i64, vp]
+    L.iago_mcts_backup.argtypes = [tp, vp, vp, vp, vp]
+    L.iago_mcts_best_move.argtypes = [tp, vp, vp, vp, vp]
+    L.iago_mcts_advance_root.argtypes = [tp, vp, vp, vp]
+    for name in SYMBOLS[3:]:
         getattr(L, name).restype = C.c_int
-    if hasattr(L, "iago_mcts_select"):
-        tp = C.POINTER(MctsTree)
-        L.iago_mcts_select.argtypes = [tp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp, vp, vp,
-                                       vp]
-        L.iago_mcts_expand.argtypes = [tp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp]
-        L.iago_mcts_backup.argtypes = [tp, vp, vp, vp, vp]
-        L.iago_mcts_best_move.argtypes = [tp, vp, vp, vp]
-        L.iago_mcts_advance_root.argtypes = [tp, vp, vp, vp]
-        L.iago_leaf_values.argtypes = [vp, vp, C.c_float, vp, i64, vp]
-        for name in ("iago_mcts_select", "iago_mcts_expand", "iago_mcts_backup",
-                     "iago_mcts_best_move", "iago_mcts_advance_root", "iago_leaf_values"):
-            getattr(L, name).restype = C.c_int
     _lib = L
     return L
 

@@ -1,0 +1,397 @@
+// mcts_kernels.hip -- PV-MCTS tree arithmetic for thousands of lockstep games.
+//
+// Replaces the reference's recursive dict tree (MCTS.py:10-154); contracts
+// and citations per entry point are in include/iago_hip.h.  The tree lives in
+// HBM as struct-of-arrays pools (one segment per game); the host loop launches
+//   select -> [policy net] -> expand -> select(continue) -> [value net, rollout]
+//   -> leaf_values -> backup
+// once per simulation for all games at once.
+//
+// Mapping: 8 lanes per game (othello_dev.hpp).  In select, the children of a
+// node are scored 8 at a time (lane j takes children j, j+8, ...; their
+// (n, Q, P) are contiguous, so a group reads 3 coalesced 32-byte runs), the
+// argmax is a 3-step DPP butterfly on (float64 score, child index), and the
+// chosen move is applied with the direction-per-lane flip primitive.
+// Scores are float64 exactly as the reference computes them under numpy >= 2
+// (float32 P and Q, float64 sqrt / divide / add); no FMA contraction can occur
+// in these expressions (no multiply feeds an add).
+#include "abi_common.hpp"
+#include "othello_dev.hpp"
+
+#include <math.h>
+
+using namespace iago;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_DEPTH = 512; // bound on the descent (a path adds a node per expansion)
+
+typedef iago_mcts_tree Tree;
+
+__device__ __forceinline__ void init_node(const Tree &T, int64_t i, int parent, int action, float p)
+{
+    T.parent[i] = parent;
+    T.first_child[i] = -1;
+    T.n_children[i] = 0;
+    T.action[i] = (int8_t)action;
+    T.n_visits[i] = 0;
+    T.q[i] = 0.0f;
+    T.p[i] = p;
+}
+
+__global__ __launch_bounds__(BLOCK) void reset_kernel(Tree T, const uint8_t *__restrict__ mask)
+{
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= T.n_games || (mask && !mask[g]))
+        return;
+    init_node(T, g * T.capacity, -1, -2, 1.0f + 0.1f); // Node(None, 1.0), MCTS.py:81
+    T.n_nodes[g] = 1;
+    T.root[g] = 0;
+    T.overflow[g] = 0;
+}
+
+template <int CTRL>
+__device__ __forceinline__ void argmax_step(double &v, int &idx)
+{
+    const uint64_t bits = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = dpp_u32<CTRL>((uint32_t)bits), hi = dpp_u32<CTRL>((uint32_t)(bits >> 32));
+    const double ov = __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    const int oi = (int)dpp_u32<CTRL>((uint32_t)idx);
+    const bool take = (ov > v) || (ov == v && oi < idx);
+    v = take ? ov : v;
+    idx = take ? oi : idx;
+}
+
+__global__ __launch_bounds__(BLOCK) void select_kernel(
+    Tree T, const uint64_t *__restrict__ root_own, const uint64_t *__restrict__ root_opp,
+    const uint8_t *__restrict__ active, float c_puct, int n_thr, int from_root,
+    int32_t *__restrict__ cur_node, uint64_t *__restrict__ cur_own, uint64_t *__restrict__ cur_opp,
+    uint8_t *__restrict__ needs_expand, uint64_t *__restrict__ legal_out)
+{
+    __shared__ uint64_t ray[RAY_TABLE_WORDS];
+    fill_ray_table(ray);
+    __syncthreads();
+
+    const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t g = gtid >> 3;
+    const Lane8 L = make_lane8(threadIdx.x);
+    const bool live = g < T.n_games && active[g] != 0;
+    const int64_t base = live ? g * (int64_t)T.capacity : 0;
+
+    int node = 0;
+    uint64_t own = 0, opp = 0;
+    if (live) {
+        node = from_root ? T.root[g] : cur_node[g];
+        own = from_root ? root_own[g] : cur_own[g];
+        opp = from_root ? root_opp[g] : cur_opp[g];
+    }
+    bool descending = live;
+    for (int depth = 0; depth < MAX_DEPTH; depth++) {
+        const int fc = descending ? T.first_child[base + node] : -1;
+        descending = descending && fc >= 0; // leaf reached (MCTS.py:107)
+        if (__builtin_amdgcn_ballot_w64(descending) == 0ull)
+            break;
+        const int k = descending ? (int)T.n_children[base + node] : 0;
+        const int pn = descending ? T.n_visits[base + node] : 0;
+        const double sq = sqrt((double)pn); // np.sqrt(parent.n_visits), MCTS.py:49
+        double best_v = -INFINITY;
+        int best_i = 0x7fffffff;
+        for (int j = (int)L.l8; j < k; j += 8) {
+            const int64_t c = base + fc + j;
+            const float cp = c_puct * T.p[c];                        // float32, MCTS.py:49
+            const double u = (double)cp * sq / (0.01 + (double)T.n_visits[c]);
+            const double v = (double)T.q[c] + u;                     // get_value, MCTS.py:75-76
+            if (v > best_v) { // strict: the first maximum wins (python max, MCTS.py:46)
+                best_v = v;
+                best_i = j;
+            }
+        }
+        argmax_step<DPP_XOR1>(best_v, best_i);
+        argmax_step<DPP_XOR2>(best_v, best_i);
+        argmax_step<DPP_HALF_MIRROR>(best_v, best_i);
+        const int child = fc + best_i;
+        const int a = descending ? (int)T.action[base + child] : -1;
+        // GameFunctions.place_stone(state, action, c); c = 3 - c  (MCTS.py:131-132)
+        const uint64_t f =
+            group8_flips(to_lane(own, L), to_lane(opp, L), (uint32_t)a & 63u, L, ray);
+        if (descending) {
+            uint64_t no = own, np_ = opp;
+            if (a >= 0) {
+                const uint64_t bit = 1ull << (a & 63);
+                no = own | f | bit;
+                np_ = opp & ~f & ~bit;
+            }
+            own = np_;
+            opp = no;
+            node = child;
+        }
+    }
+    // leaf: expansion test (MCTS.py:109) and its legal moves (MCTS.py:111)
+    const uint64_t legal = group8_legal(to_lane(own, L), to_lane(opp, L), L);
+    if (live && L.l8 == 0) {
+        cur_node[g] = node;
+        cur_own[g] = own;
+        cur_opp[g] = opp;
+        const bool ne = T.first_child[base + node] < 0 && T.n_visits[base + node] >= n_thr;
+        needs_expand[g] = ne ? 1 : 0;
+        legal_out[g] = legal;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void expand_kernel(Tree T, const int32_t *__restrict__ games,
+                                                       int64_t n_expand,
+                                                       const int32_t *__restrict__ cur_node,
+                                                       const uint64_t *__restrict__ legal,
+                                                       const float *__restrict__ probs)
+{
+    const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t i = gtid >> 3;
+    const uint32_t r = threadIdx.x & 7u;
+    const bool live = i < n_expand;
+    const int64_t g = live ? games[i] : 0;
+    const int64_t base = g * (int64_t)T.capacity;
+    const int node = live ? cur_node[g] : 0;
+    const uint64_t lg = live ? legal[g] : 0ull;
+    const int k = lg ? __popcll(lg) : 1;
+    // lane 0 allocates k nodes; every lane of the group learns the start
+    uint32_t fc1 = 0; // first child + 1, 0 = no room / already expanded
+    if (live && r == 0u && T.first_child[base + node] < 0) {
+        const int at = T.n_nodes[g];
+        if (at + k <= T.capacity) {
+            T.n_nodes[g] = at + k;
+            fc1 = (uint32_t)at + 1u;
+        } else {
+            T.overflow[g] = 1;
+        }
+    }
+    fc1 = group8_add(fc1);
+    if (!live || fc1 == 0u)
+        return;
+    const int fc = (int)fc1 - 1;
+    if (lg == 0ull || k == 1) {
+        // pass child / single legal move: Node(node, 1), no net (MCTS.py:112-117)
+        if (r == 0u) {
+            const int a = lg ? (int)__builtin_ctzll(lg) : -1;
+            init_node(T, base + fc, node, a, 1.0f + 0.1f);
+        }
+    } else {
+        // Node.expand (MCTS.py:27-37): lane r creates the children of board row r
+        uint32_t row = (uint32_t)(lg >> (8u * r)) & 0xFFu;
+        int at = fc + __popcll(lg & ((1ull << (8u * r)) - 1ull));
+        while (row) {
+            const int a = (int)(8u * r) + __builtin_ctz(row);
+            row &= row - 1u;
+            init_node(T, base + at, node, a, probs[i * 64 + a] + 0.1f); // MCTS.py:19
+            at++;
+        }
+    }
+    if (r == 0u) {
+        T.first_child[base + node] = fc;
+        T.n_children[base + node] = (uint8_t)k;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void leaf_values_kernel(const float *__restrict__ v,
+                                                            const int8_t *__restrict__ z,
+                                                            float lmbda, float *__restrict__ out,
+                                                            int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    // (1-lmbda)*v + lmbda*z with numpy>=2 scalar promotion (MCTS.py:123-125):
+    // the python-float factors are rounded to float32, products and sum in float32
+    const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * v[i] : 0.0f;
+    const float b = (lmbda > 0.0f) ? (float)((double)lmbda * (double)z[i]) : 0.0f;
+    out[i] = a + b;
+}
+
+__global__ __launch_bounds__(BLOCK) void backup_kernel(Tree T, const uint8_t *__restrict__ active,
+                                                       const int32_t *__restrict__ cur_node,
+                                                       const float *__restrict__ leaf_value)
+{
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= T.n_games || !active[g])
+        return;
+    const int64_t base = g * (int64_t)T.capacity;
+    const float lv = leaf_value[g];
+    int node = cur_node[g];
+    for (int depth = 0; node >= 0 && depth <= MAX_DEPTH; depth++) {
+        const int n = T.n_visits[base + node] + 1; // MCTS.py:61
+        const float q = T.q[base + node];
+        T.n_visits[base + node] = n;
+        T.q[base + node] = q + (lv - q) / (float)n; // MCTS.py:63
+        node = T.parent[base + node];               // MCTS.py:71-72, same value, no sign flip
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void best_move_kernel(Tree T, const uint8_t *__restrict__ active,
+                                                          int8_t *__restrict__ move,
+                                                          int32_t *__restrict__ visits)
+{
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= T.n_games || (active && !active[g]))
+        return;
+    const int64_t base = g * (int64_t)T.capacity;
+    const int root = T.root[g];
+    const int fc = T.first_child[base + root];
+    const int k = fc >= 0 ? (int)T.n_children[base + root] : 0;
+    int best = -2, best_n = -1;
+    if (visits)
+        for (int a = 0; a < 64; a++)
+            visits[g * 64 + a] = 0;
+    for (int j = 0; j < k; j++) {
+        const int n = T.n_visits[base + fc + j];
+        const int a = (int)T.action[base + fc + j];
+        if (n > best_n) { // first maximum wins (MCTS.py:147)
+            best_n = n;
+            best = a;
+        }
+        if (visits && a >= 0)
+            visits[g * 64 + a] = n;
+    }
+    move[g] = (int8_t)best;
+}
+
+__global__ __launch_bounds__(BLOCK) void advance_root_kernel(Tree T, const uint8_t *__restrict__ mask,
+                                                             const int8_t *__restrict__ move)
+{
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= T.n_games || (mask && !mask[g]))
+        return;
+    const int64_t base = g * (int64_t)T.capacity;
+    const int root = T.root[g];
+    const int fc = T.first_child[base + root];
+    const int k = fc >= 0 ? (int)T.n_children[base + root] : 0;
+    const int a = (int)move[g];
+    for (int j = 0; j < k; j++) {
+        if ((int)T.action[base + fc + j] == a) { // last_move in self.root.children (MCTS.py:150)
+            T.root[g] = fc + j;
+            T.parent[base + fc + j] = -1; // self.root.parent = None (MCTS.py:152)
+            return;
+        }
+    }
+    init_node(T, base, -1, -2, 1.0f + 0.1f); // self.root = Node(None, 1.0) (MCTS.py:154)
+    T.n_nodes[g] = 1;
+    T.root[g] = 0;
+}
+
+inline unsigned grid_for(int64_t threads) { return (unsigned)((threads + BLOCK - 1) / BLOCK); }
+
+int check_tree(const Tree *t, const char *who)
+{
+    if (!t)
+        return iago_fail(IAGO_ERR_INVALID, who);
+    if (t->n_games < 0 || t->capacity < 1 || !t->parent || !t->first_child || !t->n_children ||
+        !t->action || !t->n_visits || !t->q || !t->p || !t->n_nodes || !t->root || !t->overflow)
+        return iago_fail(IAGO_ERR_INVALID, who);
+    return IAGO_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int iago_mcts_reset(const iago_mcts_tree *tree, const uint8_t *mask, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_reset: bad tree"))
+        return IAGO_ERR_INVALID;
+    if (tree->n_games == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(reset_kernel, dim3(grid_for(tree->n_games)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, *tree, mask);
+    return iago_check_launch("iago_mcts_reset");
+}
+
+int iago_mcts_select(const iago_mcts_tree *tree, const uint64_t *root_own, const uint64_t *root_opp,
+                     const uint8_t *active, float c_puct, int32_t n_thr, int from_root,
+                     int32_t *cur_node, uint64_t *cur_own, uint64_t *cur_opp, uint8_t *needs_expand,
+                     uint64_t *legal, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_select: bad tree"))
+        return IAGO_ERR_INVALID;
+    if (!active || !cur_node || !cur_own || !cur_opp || !needs_expand || !legal ||
+        (from_root && (!root_own || !root_opp)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_select: null pointer");
+    if (n_thr < 1)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_select: n_thr must be >= 1 (n_thr = 0 never "
+                                           "terminates in the reference either)");
+    if (tree->n_games == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(select_kernel, dim3(grid_for(tree->n_games * 8)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, *tree, root_own, root_opp, active, c_puct, n_thr,
+                       from_root, cur_node, cur_own, cur_opp, needs_expand, legal);
+    return iago_check_launch("iago_mcts_select");
+}
+
+int iago_mcts_expand(const iago_mcts_tree *tree, const int32_t *games, int64_t n_expand,
+                     const int32_t *cur_node, const uint64_t *legal, const float *probs,
+                     void *stream)
+{
+    if (check_tree(tree, "iago_mcts_expand: bad tree"))
+        return IAGO_ERR_INVALID;
+    if (n_expand < 0 || (n_expand > 0 && (!games || !cur_node || !legal || !probs)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_expand: null pointer or negative count");
+    if (n_expand == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(expand_kernel, dim3(grid_for(n_expand * 8)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, *tree, games, n_expand, cur_node, legal, probs);
+    return iago_check_launch("iago_mcts_expand");
+}
+
+int iago_leaf_values(const float *v, const int8_t *z, float lmbda, float *leaf_value, int64_t n,
+                     void *stream)
+{
+    if (n < 0 || (n > 0 && (!leaf_value || (lmbda < 1.0f && !v) || (lmbda > 0.0f && !z))))
+        return iago_fail(IAGO_ERR_INVALID, "iago_leaf_values: null pointer or negative n");
+    if (n == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(leaf_values_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       v, z, lmbda, leaf_value, n);
+    return iago_check_launch("iago_leaf_values");
+}
+
+int iago_mcts_backup(const iago_mcts_tree *tree, const uint8_t *active, const int32_t *cur_node,
+                     const float *leaf_value, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_backup: bad tree"))
+        return IAGO_ERR_INVALID;
+    if (!active || !cur_node || !leaf_value)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_backup: null pointer");
+    if (tree->n_games == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(backup_kernel, dim3(grid_for(tree->n_games)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, *tree, active, cur_node, leaf_value);
+    return iago_check_launch("iago_mcts_backup");
+}
+
+int iago_mcts_best_move(const iago_mcts_tree *tree, const uint8_t *active, int8_t *move,
+                        int32_t *visits, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_best_move: bad tree"))
+        return IAGO_ERR_INVALID;
+    if (!move)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_best_move: null pointer");
+    if (tree->n_games == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(best_move_kernel, dim3(grid_for(tree->n_games)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, *tree, active, move, visits);
+    return iago_check_launch("iago_mcts_best_move");
+}
+
+int iago_mcts_advance_root(const iago_mcts_tree *tree, const uint8_t *mask, const int8_t *move,
+                           void *stream)
+{
+    if (check_tree(tree, "iago_mcts_advance_root: bad tree"))
+        return IAGO_ERR_INVALID;
+    if (!move)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_advance_root: null pointer");
+    if (tree->n_games == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(advance_root_kernel, dim3(grid_for(tree->n_games)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, *tree, mask, move);
+    return iago_check_launch("iago_mcts_advance_root");
+}
+
+} // extern "C"

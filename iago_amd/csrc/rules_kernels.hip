@@ -82,6 +82,45 @@ __global__ __launch_bounds__(BLOCK) void judge_kernel(const uint64_t *__restrict
     z[b] = (int8_t)((d > 0) - (d < 0));
 }
 
+
+// One thread per board; float64 in cell order like the reference's numpy code.
+__global__ __launch_bounds__(BLOCK) void sample_moves_kernel(
+    const float *__restrict__ probs, const uint64_t *__restrict__ legal,
+    const double *__restrict__ uniforms, uint32_t key0, uint32_t key1, uint32_t id_base,
+    uint32_t step, uint32_t stream_id, int8_t *__restrict__ action, int64_t n)
+{
+    const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= n)
+        return;
+    const uint64_t lg = legal[b];
+    if (lg == 0ull) {
+        action[b] = -1;
+        return;
+    }
+    double u;
+    if (uniforms) {
+        u = uniforms[b];
+    } else {
+        uint32_t c[4] = {id_base + (uint32_t)b, step >> 2, stream_id, 0u};
+        philox4x32_10(c, key0, key1);
+        u = (double)((float)(c[step & 3u] >> 8) * (1.0f / 16777216.0f));
+    }
+    const float *pr = probs + b * 64;
+    double s = 0.0; // np.sum(prob * valid)
+    for (int k = 0; k < 64; k++)
+        s += ((lg >> k) & 1ull) ? (double)pr[k] : 0.0;
+    double last = 0.0; // cdf[-1] of cumsum(p / s)
+    for (int k = 0; k < 64; k++)
+        last += (((lg >> k) & 1ull) ? (double)pr[k] : 0.0) / s;
+    double acc = 0.0;
+    int idx = 0;
+    for (int k = 0; k < 64; k++) {
+        acc += (((lg >> k) & 1ull) ? (double)pr[k] : 0.0) / s;
+        idx += (acc / last <= u) ? 1 : 0; // searchsorted(cdf, u, side='right')
+    }
+    action[b] = (int8_t)idx; // 64 would mean NaN probabilities: the reference raises there
+}
+
 inline unsigned grid_for(int64_t threads) { return (unsigned)((threads + BLOCK - 1) / BLOCK); }
 
 } // namespace
@@ -134,6 +173,20 @@ int iago_judge(const uint64_t *own, const uint64_t *opp, int8_t *z, int64_t n, v
     hipLaunchKernelGGL(judge_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, own,
                        opp, z, n);
     return iago_check_launch("iago_judge");
+}
+
+int iago_sample_moves(const float *probs, const uint64_t *legal, const double *uniforms,
+                      uint64_t seed, uint32_t id_base, uint32_t step, uint32_t stream_id,
+                      int8_t *action, int64_t n, void *stream)
+{
+    if (n < 0 || (n > 0 && (!probs || !legal || !action)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_sample_moves: null pointer or negative n");
+    if (n == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(sample_moves_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       probs, legal, uniforms, (uint32_t)seed, (uint32_t)(seed >> 32), id_base,
+                       step, stream_id, action, n);
+    return iago_check_launch("iago_sample_moves");
 }
 
 } // extern "C"

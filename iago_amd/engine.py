@@ -1,0 +1,280 @@
+"""Batched PV-MCTS and lockstep self-play on one GPU.
+
+Host-side select/expand/backup loop over thousands of games (the reference runs
+one game, one playout at a time: MCTS.py:105-147, game.py:117-142).  Every
+tree operation, board update and the leaf rollout is a HIP kernel behind the C
+ABI (include/iago_hip.h); the policy and value nets are PyTorch-ROCm modules
+(or any callables on a CUDA planes tensor).  The reference's constants and
+quirks are the defaults: lmbda=0.5, c_puct=1, n_thr=15,
+P = prior + 0.1, U = c*P*sqrt(N)/(0.01+n), root evaluated itself for its first
+n_thr simulations, no sign flip in backup, pass = action -1, subtree reuse.
+The wall-clock budget (10 s per move, MCTS.py:142) becomes a simulation count.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import MctsTree, check
+
+START_OWN = 0x0000000810000000  # colour 1 "X", moves first: (3,4), (4,3)  (game.py:26-30)
+START_OPP = 0x0000001008000000  # colour 2 "O": (3,3), (4,4)
+HANDICAP_CELLS = (2 * 8 + 4, 3 * 8 + 5, 4 * 8 + 2, 5 * 8 + 3)  # src/train_rl.py:45
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class TreePool(object):
+    """Device memory of the per-game search trees (iago_mcts_tree)."""
+
+    def __init__(self, n_games, capacity, device="cuda"):
+        if not torch.cuda.is_available():
+            raise _lib.IagoError("TreePool needs a HIP device (no CPU fallback)")
+        n = n_games * capacity
+        kw = dict(device=device)
+        self.n_games, self.capacity = n_games, capacity
+        self.parent = torch.empty(n, dtype=torch.int32, **kw)
+        self.first_child = torch.empty(n, dtype=torch.int32, **kw)
+        self.n_children = torch.empty(n, dtype=torch.uint8, **kw)
+        self.action = torch.empty(n, dtype=torch.int8, **kw)
+        self.n_visits = torch.empty(n, dtype=torch.int32, **kw)
+        self.q = torch.empty(n, dtype=torch.float32, **kw)
+        self.p = torch.empty(n, dtype=torch.float32, **kw)
+        self.n_nodes = torch.zeros(n_games, dtype=torch.int32, **kw)
+        self.root = torch.zeros(n_games, dtype=torch.int32, **kw)
+        self.overflow = torch.zeros(n_games, dtype=torch.int32, **kw)
+        t = MctsTree()
+        t.n_games, t.capacity = n_games, capacity
+        for f in ("parent", "first_child", "n_children", "action", "n_visits", "q", "p", "n_nodes",
+                  "root", "overflow"):
+            setattr(t, f, getattr(self, f).data_ptr())
+        self.c = t
+        self.reset()
+
+    def ref(self):
+        return C.byref(self.c)
+
+    def reset(self, mask=None):
+        check(_lib.lib().iago_mcts_reset(self.ref(), _p(mask) if mask is not None else None,
+                                         _stream()), "iago_mcts_reset")
+
+    def bytes(self):
+        return sum(getattr(self, f).numel() * getattr(self, f).element_size()
+                   for f in ("parent", "first_child", "n_children", "action", "n_visits", "q", "p"))
+
+    def dump(self, g, max_depth=6):
+        """Host copy of game g's tree in the format of oracle.mcts_py.dump_tree."""
+        lo, hi = g * self.capacity, g * self.capacity + int(self.n_nodes[g].item())
+        arr = {f: getattr(self, f)[lo:hi].cpu().numpy()
+               for f in ("first_child", "n_children", "action", "n_visits", "q", "p")}
+
+        def rec(i, depth):
+            d = dict(n=int(arr["n_visits"][i]), Q=float(arr["q"][i]), P=float(arr["p"][i]),
+                     children={}, order=[])
+            fc, k = int(arr["first_child"][i]), int(arr["n_children"][i])
+            if fc >= 0:
+                d["order"] = [int(arr["action"][fc + j]) for j in range(k)]
+                if depth < max_depth:
+                    for j in range(k):
+                        d["children"][str(int(arr["action"][fc + j]))] = rec(fc + j, depth + 1)
+            return d
+
+        return rec(int(self.root[g].item()), 0)
+
+
+class BatchedMCTS(object):
+    """MCTS(lmbda, c_puct, n_thr) of MCTS.py:78-154 for n_games trees at once.
+
+    policy_fn(planes) -> (L,64) probabilities, value_fn(planes) -> (L,) values,
+    planes = (L,2,8,8) float32 CUDA tensor (GameFunctions.make_state_var
+    layout).  rollout_weights: ops.RolloutWeights (None = uniform random
+    rollouts).  rollout_hook(z) lets tests record / replace rollout results.
+    """
+
+    def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
+                 n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda"):
+        if n_thr < 1:
+            raise ValueError("n_thr must be >= 1")
+        self.n_games = n_games
+        self.policy_fn, self.value_fn, self.rollout_weights = policy_fn, value_fn, rollout_weights
+        self.lmbda, self.c_puct, self.n_thr = float(lmbda), float(c_puct), int(n_thr)
+        self.seed, self.game_id_base = seed, game_id_base
+        self.tree = TreePool(n_games, capacity, device)
+        kw = dict(device=device)
+        self.cur_node = torch.zeros(n_games, dtype=torch.int32, **kw)
+        self.cur_own = torch.zeros(n_games, dtype=torch.int64, **kw)
+        self.cur_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
+        self.needs_expand = torch.zeros(n_games, dtype=torch.uint8, **kw)
+        self.legal = torch.zeros(n_games, dtype=torch.int64, **kw)
+        self.leaf_value = torch.zeros(n_games, dtype=torch.float32, **kw)
+        self.planes = torch.zeros((n_games, 2, 8, 8), dtype=torch.float32, **kw)
+        self.z = torch.zeros(n_games, dtype=torch.int8, **kw)
+        self.v = torch.zeros(n_games, dtype=torch.float32, **kw)
+        self.move = torch.zeros(n_games, dtype=torch.int8, **kw)
+        self.visits = torch.zeros((n_games, 64), dtype=torch.int32, **kw)
+        self.sim_counter = 0          # Philox stream id: one per simulation
+        self.n_leaf_evals = 0
+        self.n_policy_evals = 0
+        self.rollout_hook = None
+        self._rollout_out = ops.RolloutResult()
+        self._rollout_out.z = self.z
+
+    # -- one simulation = MCTS.playout for every active game (MCTS.py:105-133)
+    def _select(self, own, opp, active, from_root):
+        L = _lib.lib()
+        check(L.iago_mcts_select(self.tree.ref(), _p(own), _p(opp), _p(active), self.c_puct,
+                                 self.n_thr, 1 if from_root else 0, _p(self.cur_node),
+                                 _p(self.cur_own), _p(self.cur_opp), _p(self.needs_expand),
+                                 _p(self.legal), _stream()), "iago_mcts_select")
+
+    def simulate(self, own, opp, active, n_active=None):
+        L = _lib.lib()
+        self._select(own, opp, active, True)
+        idx = torch.nonzero(self.needs_expand & active).reshape(-1)  # host sync: usually small
+        if idx.numel() > 0:
+            games = idx.to(torch.int32)
+            sub_planes = ops.encode_planes(self.cur_own[idx], self.cur_opp[idx])
+            with torch.no_grad():
+                probs = self.policy_fn(sub_planes).to(torch.float32).contiguous()
+            self.n_policy_evals += int(idx.numel())
+            check(L.iago_mcts_expand(self.tree.ref(), _p(games), games.numel(), _p(self.cur_node),
+                                     _p(self.legal), _p(probs), _stream()), "iago_mcts_expand")
+            sub_active = torch.zeros_like(active)
+            sub_active[idx] = 1
+            self._select(own, opp, sub_active, False)  # MCTS.py:121: recurse into the same node
+        # leaf evaluation (MCTS.py:123-127)
+        if self.lmbda < 1.0:
+            ops.encode_planes(self.cur_own, self.cur_opp, out=self.planes)
+            with torch.no_grad():
+                self.v = self.value_fn(self.planes).to(torch.float32).contiguous()
+        if self.lmbda > 0.0:
+            ops.rollout(self.cur_own, self.cur_opp, self.rollout_weights, seed=self.seed,
+                        id_base=self.game_id_base, stream_id=self.sim_counter,
+                        out=self._rollout_out)
+            if self.rollout_hook is not None:
+                self.rollout_hook(self)
+        check(L.iago_leaf_values(_p(self.v) if self.lmbda < 1.0 else None,
+                                 _p(self.z) if self.lmbda > 0.0 else None, self.lmbda,
+                                 _p(self.leaf_value), self.n_games, _stream()), "iago_leaf_values")
+        check(L.iago_mcts_backup(self.tree.ref(), _p(active), _p(self.cur_node),
+                                 _p(self.leaf_value), _stream()), "iago_mcts_backup")
+        self.sim_counter = (self.sim_counter + 1) & 0xFFFFFFFF
+        if n_active is not None:
+            self.n_leaf_evals += n_active
+
+    def search(self, own, opp, active, n_sims):
+        """n_sims playouts from the current roots; (own, opp) = root positions
+        with own = side to move; active: uint8 mask of participating games."""
+        n_active = int(active.sum().item())
+        if n_active == 0:
+            return
+        for _ in range(n_sims):
+            self.simulate(own, opp, active, n_active)
+        if int(self.tree.overflow.sum().item()) != 0:
+            raise _lib.IagoError("MCTS node pool exhausted: raise `capacity` (%d nodes per game)"
+                                 % self.tree.capacity)
+
+    def best_move(self, active=None, want_visits=True):
+        """argmax visit count of the root's children, first wins (MCTS.py:147)."""
+        check(_lib.lib().iago_mcts_best_move(self.tree.ref(),
+                                             _p(active) if active is not None else None,
+                                             _p(self.move), _p(self.visits) if want_visits else None,
+                                             _stream()), "iago_mcts_best_move")
+        return self.move, self.visits
+
+    def update_with_move(self, move, mask=None):
+        """MCTS.update_with_move (MCTS.py:149-154); move int8 tensor, -1 = pass."""
+        check(_lib.lib().iago_mcts_advance_root(self.tree.ref(),
+                                                _p(mask) if mask is not None else None, _p(move),
+                                                _stream()), "iago_mcts_advance_root")
+
+
+class SelfPlayResult(object):
+    """Training tuples of one self-play round, device resident.
+
+    own/opp: (T, B) int64 positions before each searched move (own = mover),
+    pi: (T, B, 64) int32 root visit counts, valid: (T, B) uint8 (the game moved
+    at that turn), move: (T, B) int8, z: (B,) int8 result from colour 1's view,
+    mover: (T,) colour to move at that turn (1 or 2)."""
+
+    def tuples(self):
+        """Flat (s, pi, z) rows of all searched moves; z from the mover's view."""
+        m = self.valid.reshape(-1).bool()
+        T, B = self.valid.shape
+        sign = torch.tensor([1 if c == 1 else -1 for c in self.mover], dtype=torch.int8,
+                            device=self.z.device).reshape(T, 1)
+        zz = (self.z.reshape(1, B) * sign).reshape(-1)
+        return dict(own=self.own.reshape(-1)[m], opp=self.opp.reshape(-1)[m],
+                    pi=self.pi.reshape(-1, 64)[m], z=zz[m], move=self.move.reshape(-1)[m])
+
+
+class SelfPlayEngine(object):
+    """Lockstep PV-MCTS self-play: both colours search the shared tree, moves
+    are the most visited children, passes advance the tree with -1
+    (game.py:117-142 turn structure, both sides driven by MCTS.get_move)."""
+
+    def __init__(self, mcts, max_turns=_lib.IAGO_MAX_TURNS):
+        self.mcts = mcts
+        self.B = mcts.n_games
+        self.max_turns = max_turns
+
+    def play(self, n_sims, handicap=None, record=True):
+        m, B = self.mcts, self.B
+        dev = m.cur_own.device
+        own = torch.full((B,), START_OWN, dtype=torch.int64, device=dev)
+        opp = torch.full((B,), START_OPP, dtype=torch.int64, device=dev)
+        if handicap is not None:  # (B,) int64 bit masks of extra colour-2 stones
+            opp = opp | handicap
+        m.tree.reset()
+        stone_num = torch.full((B,), 4, dtype=torch.int32, device=dev)  # game.py:32
+        pass_flg = torch.zeros(B, dtype=torch.bool, device=dev)
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        res = SelfPlayResult()
+        T = self.max_turns
+        if record:
+            res.own = torch.zeros((T, B), dtype=torch.int64, device=dev)
+            res.opp = torch.zeros((T, B), dtype=torch.int64, device=dev)
+            res.pi = torch.zeros((T, B, 64), dtype=torch.int32, device=dev)
+            res.valid = torch.zeros((T, B), dtype=torch.uint8, device=dev)
+            res.move = torch.full((T, B), -1, dtype=torch.int8, device=dev)
+        res.mover = []
+        t = 0
+        while t < T:
+            legal = ops.legal_moves(own, opp)
+            has = legal != 0
+            active = (has & ~done).to(torch.uint8)
+            m.search(own, opp, active, n_sims)
+            move, visits = m.best_move(active)
+            mv = torch.where(active.bool(), move, torch.full_like(move, -1))
+            if record:
+                res.own[t], res.opp[t], res.valid[t], res.move[t] = own, opp, active, mv
+                res.pi[t] = visits * active.reshape(B, 1).to(torch.int32)
+            res.mover.append(1 if t % 2 == 0 else 2)
+            ops.apply_moves(own, opp, mv)
+            placed = active.bool()
+            stone_num = stone_num + placed.to(torch.int32)
+            passing = ~placed & ~done
+            stone_num = torch.where(passing & pass_flg, torch.full_like(stone_num, 64), stone_num)
+            pass_flg = torch.where(done, pass_flg, passing)
+            m.update_with_move(mv, (~done).to(torch.uint8))  # game.py:84,108,140
+            own, opp = opp, own
+            t += 1
+            if t % 2 == 0:  # `while game.stone_num < 64` once per pair of turns (game.py:253-255)
+                done = done | (stone_num >= 64)
+                if bool(done.all().item()):
+                    break
+        # colour 1's stones are `own` after an even number of turns
+        p1, p2 = (own, opp) if t % 2 == 0 else (opp, own)
+        res.z = ops.judge(p1, p2)
+        res.final_p1, res.final_p2 = p1, p2
+        res.n_turns = t
+        if record:
+            for name in ("own", "opp", "pi", "valid", "move"):
+                setattr(res, name, getattr(res, name)[:t])
+        return res

@@ -1,0 +1,161 @@
+"""SLPolicy / RolloutPolicy / Value as PyTorch(-ROCm) modules.
+
+Same architecture, call signature and parameter names as the reference's
+network.py:5-96 (Chainer): `model(x)` with x (B,2,8,8) float32 planes
+(channel 0 = opponent of the side to move, channel 1 = side to move) returns
+(B,64) softmax probabilities for the policies and (B,) values for Value.
+`load_npz` / `save_npz` read and write the reference's Chainer npz layout
+(models/*.npz: `block1/conv/W`, `conv9/W`, `bias10/b`, `fc10/W`, ...), so the
+shipped checkpoints drive these modules unchanged.
+
+On the GPU the 3x3 convolutions run through MIOpen / hipBLASLt (MFMA); the
+rollout policy additionally lives fused inside the HIP rollout kernel
+(csrc/rollout_kernel.hip).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Block(nn.Module):
+    """network.py:5-13: Convolution2D(None, out, 3, pad=1) + ReLU."""
+
+    def __init__(self, in_channels, out_channels, ksize=3, pad=1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, ksize, padding=pad)
+
+    def forward(self, x):
+        return F.relu(self.conv(x))
+
+
+def _lecun_normal_(w):
+    # Chainer's default initialiser: LeCunNormal, std = sqrt(1 / fan_in); biases zero
+    # (Chainer source is not in the reference tree: from its documentation, unpinned)
+    fan_in = w[0].numel()
+    with torch.no_grad():
+        w.normal_(0.0, 1.0 / math.sqrt(fan_in))
+
+
+class _NpzMixin(object):
+    """Chainer `serializers.save_npz/load_npz` interop (MCTS.py:83-85,
+    mcts_self_play.py:19, src/train_rl.py:23,76)."""
+
+    def _npz_map(self):
+        out = {}
+        for name, p in self.named_parameters():
+            parts = name.split(".")
+            leaf = {"weight": "W", "bias": "b", "b": "b"}[parts[-1]]
+            out["/".join(parts[:-1] + [leaf])] = p
+        return out
+
+    def load_npz(self, path_or_dict, prefix=""):
+        src = np.load(path_or_dict) if isinstance(path_or_dict, str) else path_or_dict
+        keys = set(src.files) if hasattr(src, "files") else set(src.keys())
+        m = self._npz_map()
+        missing = [k for k in m if prefix + k not in keys]
+        if missing:
+            raise KeyError("npz is missing %s (has %s)" % (missing, sorted(keys)[:6]))
+        with torch.no_grad():
+            for k, p in m.items():
+                a = np.asarray(src[prefix + k], dtype=np.float32)
+                if tuple(a.shape) != tuple(p.shape):
+                    raise ValueError("%s: shape %s, expected %s" % (k, a.shape, tuple(p.shape)))
+                p.copy_(torch.from_numpy(a))
+        return self
+
+    def npz_dict(self):
+        return {k: p.detach().cpu().numpy() for k, p in self._npz_map().items()}
+
+    def save_npz(self, path):
+        np.savez(path, **self.npz_dict())
+
+    def reset_parameters_chainer(self, seed=None):
+        if seed is not None:
+            torch.manual_seed(seed)
+        for name, p in self.named_parameters():
+            if name.endswith("weight"):
+                _lecun_normal_(p)
+            else:
+                nn.init.zeros_(p)
+        return self
+
+
+class Bias(nn.Module):
+    """L.Bias(shape=(64,)): adds a learned vector along axis 1 (network.py:32,57)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.b = nn.Parameter(torch.zeros(n))
+
+    def forward(self, x):
+        return x + self.b
+
+
+class SLPolicy(nn.Module, _NpzMixin):
+    """network.py:15-47."""
+
+    def __init__(self):
+        super().__init__()
+        self.block1 = Block(2, 64)
+        for k in range(2, 9):
+            setattr(self, "block%d" % k, Block(64 if k == 2 else 128, 128))
+        self.conv9 = nn.Conv2d(128, 1, 1, bias=False)
+        self.bias10 = Bias(64)
+        self.reset_parameters_chainer()
+
+    def logits(self, x):
+        h = x
+        for k in range(1, 9):
+            h = getattr(self, "block%d" % k)(h)
+        h = self.conv9(h).reshape(-1, 64)
+        return self.bias10(h)
+
+    def forward(self, x):
+        return F.softmax(self.logits(x), dim=1)
+
+
+class RolloutPolicy(nn.Module, _NpzMixin):
+    """network.py:49-64."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(2, 1, 3, padding=1, bias=False)
+        self.bias2 = Bias(64)
+        self.reset_parameters_chainer()
+
+    def logits(self, x):
+        return self.bias2(self.conv1(x).reshape(-1, 64))
+
+    def forward(self, x):
+        return F.softmax(self.logits(x), dim=1)
+
+    def kernel_weights(self):
+        """(w18, b64) numpy arrays for ops.RolloutWeights."""
+        return (self.conv1.weight.detach().cpu().numpy().reshape(18),
+                self.bias2.b.detach().cpu().numpy().reshape(64))
+
+
+class Value(nn.Module, _NpzMixin):
+    """network.py:66-96: no tanh, no activation after fc10, dropout 0.4 in
+    training mode only (MCTS.py:86 runs it with train=False)."""
+
+    def __init__(self):
+        super().__init__()
+        self.block1 = Block(2, 64)
+        for k in range(2, 9):
+            setattr(self, "block%d" % k, Block(64 if k == 2 else 128, 128))
+        self.block9 = Block(128, 1)
+        self.fc10 = nn.Linear(64, 128, bias=False)
+        self.fc11 = nn.Linear(128, 1, bias=False)
+        self.reset_parameters_chainer()
+
+    def forward(self, x):
+        h = x
+        for k in range(1, 10):
+            h = getattr(self, "block%d" % k)(h)
+        h = self.fc10(h.reshape(-1, 64))
+        h = F.dropout(h, 0.4, training=self.training)
+        return self.fc11(h).reshape(-1)

@@ -82,6 +82,23 @@ def judge(own, opp):
     return out
 
 
+def sample_moves(probs, legal, uniforms=None, seed=0, id_base=0, step=0, stream_id=0):
+    """Masked inverse-CDF sampling (src/rl_self_play.py:111-122); int8 actions,
+    -1 where there is no legal move.  uniforms: optional float64 (n,)."""
+    n = legal.numel()
+    if probs.numel() != n * 64:
+        raise ValueError("probs must be (n, 64)")
+    out = torch.empty(n, dtype=torch.int8, device=legal.device)
+    up = _dev(uniforms, torch.float64, "uniforms") if uniforms is not None else None
+    check(_lib.lib().iago_sample_moves(_dev(probs, torch.float32, "probs"),
+                                       _dev(legal, torch.int64, "legal"), up,
+                                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(id_base) & 0xFFFFFFFF,
+                                       int(step) & 0xFFFFFFFF, int(stream_id) & 0xFFFFFFFF,
+                                       _dev(out, torch.int8, "action"), n, _stream()),
+          "iago_sample_moves")
+    return out
+
+
 class RolloutWeights(object):
     """Device-resident RolloutPolicy parameters (network.py:49-64) in the form
     the rollout kernel consumes: the 48 KiB row table and the 64 biases."""

@@ -1,0 +1,95 @@
+"""Policy-vs-policy self-play games of the REINFORCE trainer
+(src/rl_self_play.py:8-149): `Game(model1, model2)()` with the reference's
+return value, plus `play_batch`, the lockstep batched form the GPU engine is
+built for.  model1 is the learner (colour 1, moves first); only colour-1 plies
+are recorded, as perspective-swapped boards with their actions
+(src/rl_self_play.py:134-138)."""
+import numpy as np
+import torch
+
+from . import boards, engine, ops
+
+
+def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, uniforms=None,
+               device="cuda"):
+    """n_games lockstep games.  handicap: optional (n_games,) int64 bit masks of
+    extra colour-2 stones (src/train_rl.py:43-46).  uniforms: optional iterator
+    of float64 (n_games,) tensors, one per turn that has a mover (parity tests).
+
+    Returns dict: own/opp (T1,B) int64 recorded learner positions (own = colour
+    1 = the mover), action (T1,B) int8 (-1 where that game did not move),
+    z (B,) int8 from colour 1's view, final_p1/final_p2, n_turns."""
+    B = n_games
+    own = torch.full((B,), engine.START_OWN, dtype=torch.int64, device=device)
+    opp = torch.full((B,), engine.START_OPP, dtype=torch.int64, device=device)
+    if handicap is not None:
+        opp = opp | handicap
+    stone_num = torch.full((B,), 4, dtype=torch.int32, device=device)  # src/rl_self_play.py:20
+    pass_flg = torch.zeros(B, dtype=torch.bool, device=device)
+    done = torch.zeros(B, dtype=torch.bool, device=device)
+    rec_own, rec_opp, rec_act = [], [], []
+    t = 0
+    while t < ops.IAGO_MAX_TURNS:
+        color = 1 if t % 2 == 0 else 2
+        legal = ops.legal_moves(own, opp)
+        active = (legal != 0) & ~done
+        with torch.no_grad():
+            probs = (model1 if color == 1 else model2)(ops.encode_planes(own, opp))
+        u = next(uniforms) if (uniforms is not None and bool(active.any().item())) else None
+        a = ops.sample_moves(probs.to(torch.float32).contiguous(),
+                             torch.where(active, legal, torch.zeros_like(legal)), uniforms=u,
+                             seed=seed, id_base=game_id_base, step=t)
+        if color == 1:
+            rec_own.append(own.clone())
+            rec_opp.append(opp.clone())
+            rec_act.append(a.clone())
+        ops.apply_moves(own, opp, a)
+        stone_num = stone_num + active.to(torch.int32)
+        passing = ~active & ~done
+        stone_num = torch.where(passing & pass_flg, torch.full_like(stone_num, 64), stone_num)
+        pass_flg = torch.where(done, pass_flg, passing)
+        own, opp = opp, own
+        t += 1
+        if t % 2 == 0:  # `while stone_num < 64` per pair of turns (src/rl_self_play.py:28-30)
+            done = done | (stone_num >= 64)
+            if bool(done.all().item()):
+                break
+    p1, p2 = (own, opp) if t % 2 == 0 else (opp, own)
+    return dict(own=torch.stack(rec_own), opp=torch.stack(rec_opp), action=torch.stack(rec_act),
+                z=ops.judge(p1, p2), final_p1=p1, final_p2=p2, n_turns=t)
+
+
+class Game(object):
+    """src/rl_self_play.py:8-31: one game; `game.state` may be edited before the
+    call (the handicap stone of src/train_rl.py:43-46)."""
+
+    def __init__(self, model1, model2, seed=0, uniforms=None):
+        self.state = boards.initial_state()
+        self.states, self.actions = [], []
+        self.stone_num, self.pass_flg = 4, False
+        self.model1, self.model2 = model1, model2
+        self.seed, self.uniforms = seed, uniforms
+
+    def __call__(self):
+        p1, p2 = boards.state_to_bits(self.state)
+        extra = p2 & ~engine.START_OPP
+        if p1 != engine.START_OWN or (p2 & engine.START_OPP) != engine.START_OPP:
+            raise ValueError("Game starts from the standard position (+ optional colour-2 stones)")
+        hc = torch.from_numpy(np.array([extra], dtype=np.uint64).view(np.int64)).cuda()
+        us = None
+        if self.uniforms is not None:
+            it = iter(self.uniforms)
+            us = (torch.tensor([next(it)], dtype=torch.float64, device="cuda")
+                  for _ in iter(int, 1))
+        r = play_batch(self.model1, self.model2, 1, handicap=hc, seed=self.seed, uniforms=us)
+        own, opp, act = (ops.tensor_to_bits(r["own"])[:, 0], ops.tensor_to_bits(r["opp"])[:, 0],
+                         r["action"].cpu().numpy()[:, 0])
+        for o, p, a in zip(own, opp, act):
+            if a >= 0:
+                # the recorded board is colour-swapped: the learner's stones are 2s
+                self.states.append(boards.bits_to_state(p, o))
+                self.actions.append(int(a))
+        boards.bits_to_state(ops.tensor_to_bits(r["final_p1"])[0],
+                             ops.tensor_to_bits(r["final_p2"])[0], out=self.state)
+        self.stone_num = 64
+        return self.states, self.actions, int(r["z"].item())

@@ -69,7 +69,7 @@ IAGO_API int iago_legal_moves(const uint64_t *own, const uint64_t *opp, uint64_t
                      void *stream);
 
 /*
- * In place: own[b] |= bit(action[b]) | flips, opp[b] &= ~flips, where flips are
+ * In place: own[b] |= bit(action[b]) | flips, opp[b] &= ~(flips | bit), where flips are
  * the opponent runs bracketed from action[b] in the 8 directions.  action -1
  * (IAGO_PASS) leaves the board unchanged.  Like the reference, NO legality
  * check: an illegal or occupied target is overwritten and whatever it brackets
@@ -97,6 +97,22 @@ IAGO_API int iago_encode_planes(const uint64_t *own, const uint64_t *opp, float 
  * (rl_env.py:141-149), rl_self_play.Game.judge (src/rl_self_play.py:91-100).
  */
 IAGO_API int iago_judge(const uint64_t *own, const uint64_t *opp, int8_t *z, int64_t n, void *stream);
+
+/*
+ * Masked sampling of one move per board from a policy's probabilities:
+ * Simulate.get_action / rl_self_play.Game.get_action (mcts_self_play.py:100-106,
+ * src/rl_self_play.py:111-122): p = prob(float32) * valid(float64 0/1),
+ * normalised by its float64 sum, then numpy.random.choice = inverse CDF
+ * (cumsum / last, first index with cdf > u).  Arithmetic is float64 in cell
+ * order, bit-identical to oracle/othello_oracle.c (orc_masked_probs +
+ * orc_choice_cdf).  probs: float32 [n][64]; legal: masks from
+ * iago_legal_moves; action: int8 [n], -1 where legal == 0.
+ * u per board: uniforms[b] (float64, optional) or the Philox draw
+ * (id_base + b, step>>2, stream_id, 0)[step&3] >> 8 scaled to [0,1).
+ */
+IAGO_API int iago_sample_moves(const float *probs, const uint64_t *legal, const double *uniforms,
+                               uint64_t seed, uint32_t id_base, uint32_t step, uint32_t stream_id,
+                               int8_t *action, int64_t n, void *stream);
 
 /* ---------------------------------------------------------------- rollout */
 
@@ -136,6 +152,109 @@ typedef struct iago_rollout_args {
  * termination in the reference's paired-turn loop, judge.
  */
 IAGO_API int iago_rollout(const iago_rollout_args *args, void *stream);
+
+
+/* ------------------------------------------------------------------- MCTS */
+
+/*
+ * Device-resident search trees of `n_games` lockstep games, struct-of-arrays.
+ * Game g owns nodes [g*capacity, (g+1)*capacity); node ids stored in the
+ * arrays are LOCAL to the game (0 .. capacity-1).  Replaces the reference's
+ * dict-of-Node tree (MCTS.py:10-76): parent / children{action: Node} /
+ * n_visits / Q / P.  The children of a node are stored contiguously in
+ * ascending action order (the reference's dict insertion order, MCTS.py:34-36),
+ * so "first maximum wins" (MCTS.py:46,147) is "lowest child index wins".
+ * dtypes follow the reference under numpy >= 2: Q, P float32; scores float64.
+ */
+typedef struct iago_mcts_tree {
+    int64_t n_games;
+    int32_t capacity;      /* nodes per game */
+    int32_t reserved;
+    int32_t *parent;       /* [n_games*capacity] local id, -1 = root (MCTS.py:12,21) */
+    int32_t *first_child;  /* local id of child 0, -1 = leaf (MCTS.py:24-25) */
+    uint8_t *n_children;
+    int8_t *action;        /* move leading to the node; -1 = pass child (MCTS.py:114) */
+    int32_t *n_visits;     /* MCTS.py:14 */
+    float *q;              /* MCTS.py:15,63 */
+    float *p;              /* prior + 0.1 (MCTS.py:19) */
+    int32_t *n_nodes;      /* [n_games] nodes allocated so far */
+    int32_t *root;         /* [n_games] local id of the current root */
+    int32_t *overflow;     /* [n_games] set to 1 when an expansion did not fit */
+} iago_mcts_tree;
+
+/*
+ * (Re)initialise every game flagged in `mask` (NULL = all) to a single fresh
+ * root Node(None, 1.0) (MCTS.py:81,154): n=0, Q=0, P=1.1.
+ */
+IAGO_API int iago_mcts_reset(const iago_mcts_tree *tree, const uint8_t *mask, void *stream);
+
+/*
+ * Descend from the cursor to a leaf with Node.select (MCTS.py:39-49,75-76):
+ * child score = Q + c_puct*P*sqrt(parent.n)/(0.01+n), argmax, first wins;
+ * apply the chosen move to the cursor board (GameFunctions.place_stone,
+ * game.py:180-207; -1 = pass) and switch sides (MCTS.py:130-133).
+ * This is the non-leaf branch of MCTS.playout (MCTS.py:129-133).
+ *   from_root != 0: the cursor starts at the game's root with board
+ *     (root_own, root_opp) (own = side to move at the root);
+ *   from_root == 0: it continues from (cur_node, cur_own, cur_opp) -- used after
+ *     an expansion, mirroring the recursion of MCTS.py:121.
+ * Games with active[g] == 0 are skipped.  On return, per active game:
+ *   cur_node/cur_own/cur_opp: the leaf and its position (own = side to move),
+ *   needs_expand: 1 iff leaf.n_visits >= n_thr (MCTS.py:109),
+ *   legal: the leaf's legal-move mask (game.py:210-235) when needs_expand.
+ */
+IAGO_API int iago_mcts_select(const iago_mcts_tree *tree, const uint64_t *root_own,
+                              const uint64_t *root_opp, const uint8_t *active, float c_puct,
+                              int32_t n_thr, int from_root, int32_t *cur_node, uint64_t *cur_own,
+                              uint64_t *cur_opp, uint8_t *needs_expand, uint64_t *legal,
+                              void *stream);
+
+/*
+ * Expand the leaves listed in `games` (int32 game ids, n_expand of them):
+ * MCTS.playout's expansion branch (MCTS.py:110-120) + Node.expand
+ * (MCTS.py:27-37).  0 legal moves: one pass child (-1) with prior 1; exactly
+ * one: that child with prior 1 (no net); otherwise one child per legal move,
+ * ascending, with prior probs[i][a] (raw softmax entry, not renormalised,
+ * MCTS.py:96-98).  probs: float32 [n_expand][64], row i belongs to games[i]
+ * (rows of single-move / pass leaves are ignored and may be garbage).
+ * A game whose pool is full gets overflow[g] = 1 and is left unexpanded.
+ */
+IAGO_API int iago_mcts_expand(const iago_mcts_tree *tree, const int32_t *games, int64_t n_expand,
+                              const int32_t *cur_node, const uint64_t *legal, const float *probs,
+                              void *stream);
+
+/*
+ * leaf_value = (1-lmbda)*v + lmbda*z in the reference's float32 arithmetic
+ * (MCTS.py:123-125); v may be NULL when lmbda >= 1, z when lmbda <= 0.
+ */
+IAGO_API int iago_leaf_values(const float *v, const int8_t *z, float lmbda, float *leaf_value,
+                              int64_t n, void *stream);
+
+/*
+ * Node.update_recursive (MCTS.py:51-72) from cur_node up to the root of every
+ * active game: n += 1; Q += (leaf_value - Q)/n; the SAME value at every
+ * level (the reference does not flip the sign).
+ */
+IAGO_API int iago_mcts_backup(const iago_mcts_tree *tree, const uint8_t *active,
+                              const int32_t *cur_node, const float *leaf_value, void *stream);
+
+/*
+ * MCTS.get_move's final choice (MCTS.py:147): the most visited child of the
+ * root, first wins.  move[g] = action (int8, -1 = pass) or -2 if the root has
+ * no children; visits (optional, int32 [n_games][64]) receives the root
+ * children's visit counts by action (pass is not recorded), zero elsewhere --
+ * the build's pi target, which the reference does not have.
+ */
+IAGO_API int iago_mcts_best_move(const iago_mcts_tree *tree, const uint8_t *active, int8_t *move,
+                                 int32_t *visits, void *stream);
+
+/*
+ * MCTS.update_with_move (MCTS.py:149-154) for every game with mask[g] != 0:
+ * the child reached by move[g] becomes the root (its parent link is cut), or,
+ * if the root has no such child, the game's pool is reset to a fresh root.
+ */
+IAGO_API int iago_mcts_advance_root(const iago_mcts_tree *tree, const uint8_t *mask,
+                                    const int8_t *move, void *stream);
 
 #ifdef __cplusplus
 }

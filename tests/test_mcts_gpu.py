@@ -1,0 +1,153 @@
+"""Bit-exact parity of the batched HIP PV-MCTS (select / expand / leaf_values /
+backup / best_move / advance_root through the C ABI) with the oracle's
+restatement of MCTS.py, game by game: same visit counts, same float32 Q and P,
+same child order, same chosen move, also after subtree reuse.
+
+Both sides see identical network outputs (deterministic stand-in nets computed
+from the planes, exactly representable in float32) and identical rollout
+results (the GPU rollout's z is recorded per simulation and replayed into the
+oracle; the rollout kernel itself is checked in test_rollout_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mcts_py
+from oracle import oracle as orc
+from tests.gpu_util import random_positions, state_of
+from tests.test_oracle_golden import _cmp_tree, _hash_probs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from iago_amd import engine, ops
+    assert torch.cuda.is_available()
+    return engine, ops
+
+
+def fake_nets(salt):
+    def policy_np(x):
+        return _hash_probs(x, salt)[0] / np.float32(65536.0)
+
+    def value_np(x):
+        h = _hash_probs(x, salt)[1]
+        return np.float32((((h >> 20) & 0x7FF) - 1024) / 1024.0)
+
+    def policy_t(planes):
+        p = planes.cpu().numpy()
+        return torch.from_numpy(np.stack([policy_np(p[i]) for i in range(len(p))])).cuda()
+
+    def value_t(planes):
+        p = planes.cpu().numpy()
+        return torch.from_numpy(np.array([value_np(p[i]) for i in range(len(p))], np.float32)).cuda()
+
+    return policy_np, value_np, policy_t, value_t
+
+
+def positions(n, seed, golden_rules):
+    own, opp = random_positions(n, seed=seed)
+    own[0], opp[0] = 0x0000000810000000, 0x0000001008000000
+    eb = golden_rules["edge_boards"]
+    # 'pass1' (index 6): colour 1 must pass; 'dead' (5): nobody can move; 'full' (8)
+    own[1], opp[1] = eb[6][0], eb[6][1]
+    own[2], opp[2] = eb[5][0], eb[5][1]
+    own[3], opp[3] = eb[8][0], eb[8][1]
+    return own, opp
+
+
+@pytest.mark.parametrize("lmbda,c_puct,n_thr,n_sims", [(0.5, 1.0, 15, 100), (0.5, 1.0, 1, 40),
+                                                        (0.0, 2.5, 4, 60), (0.25, 1.0, 2, 50)])
+def test_search_trees_bit_exact(eng, golden_rules, lmbda, c_puct, n_thr, n_sims):
+    engine, ops = eng
+    G = 12
+    own, opp = positions(G, 21, golden_rules)
+    policy_np, value_np, policy_t, value_t = fake_nets(int(n_thr))
+    m = engine.BatchedMCTS(G, policy_t, value_t, None, lmbda=lmbda, c_puct=c_puct, n_thr=n_thr,
+                           capacity=2048, seed=5)
+    zs = []
+    m.rollout_hook = lambda mm: zs.append(mm.z.cpu().numpy().copy())
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    active = torch.ones(G, dtype=torch.uint8, device="cuda")
+    active[5] = 0  # an idle game must stay untouched
+    m.search(o, p, active, n_sims)
+    move = m.best_move(active)[0].cpu().numpy()
+    visits = m.visits.cpu().numpy()
+    assert m.n_leaf_evals == n_sims * (G - 1)
+    assert int(m.tree.n_nodes[5].item()) == 1 and int(m.tree.n_visits[5 * 2048].item()) == 0
+
+    oracles = {}
+    for g in range(G):
+        if g == 5:
+            continue
+        it = iter([z[g] for z in zs])
+        om = mcts_py.MCTS(policy_np, value_np, lambda s, c: int(next(it)), lmbda=lmbda,
+                          c_puct=c_puct, n_thr=n_thr)
+        want_move = om.get_move(state_of(own[g], opp[g]), 1, n_sims)
+        _cmp_tree(m.tree.dump(g), mcts_py.dump_tree(om.root), "g%d" % g)
+        if want_move is None:
+            assert move[g] == -2
+        else:
+            assert move[g] == want_move, g
+            for a, ch in om.root.children.items():
+                if a >= 0:
+                    assert visits[g, a] == ch.n_visits
+        oracles[g] = om
+
+    # subtree reuse: advance by the chosen move, search again from the new root
+    mv = torch.from_numpy(np.where(move == -2, -1, move).astype(np.int8)).cuda()
+    mask = active.clone()
+    m.update_with_move(mv, mask)
+    o2, p2 = o.clone(), p.clone()
+    ops.apply_moves(o2, p2, mv)
+    zs.clear()
+    m.search(p2, o2, active, 30)  # the other side is to move now
+    for g, om in oracles.items():
+        a = int(mv[g].item())
+        om.update_with_move(a)
+        s = state_of(own[g], opp[g])
+        orc.place_stone(s, a, 1)
+        it = iter([z[g] for z in zs])
+        om.rollout_fn = lambda st, c, it=it: int(next(it))
+        om.get_move(s, 2, 30)
+        _cmp_tree(m.tree.dump(g), mcts_py.dump_tree(om.root), "g%d'" % g)
+
+
+def test_leaf_values_and_unknown_move_resets_root(eng):
+    engine, ops = eng
+    from iago_amd import _lib
+    import ctypes as C
+    v = torch.tensor([0.3, -0.7, 1.25, 0.0], device="cuda")
+    z = torch.tensor([1, -1, 0, 1], dtype=torch.int8, device="cuda")
+    out = torch.empty(4, device="cuda")
+    for lm in (0.5, 0.0, 1.0, 0.25):
+        _lib.check(_lib.lib().iago_leaf_values(C.c_void_p(v.data_ptr()), C.c_void_p(z.data_ptr()),
+                                               lm, C.c_void_p(out.data_ptr()), 4, None))
+        torch.cuda.synchronize()
+        want = [orc.leaf_value(lm, float(v[i]), int(z[i])) for i in range(4)]
+        if lm == 1.0:
+            want = [np.float32(int(z[i])) for i in range(4)]
+        assert out.cpu().numpy().tolist() == [float(w) for w in want], lm
+    m = engine.BatchedMCTS(2, None, None, None, lmbda=1.0, n_thr=1, capacity=64)
+    o = torch.full((2,), 0x0000000810000000, dtype=torch.int64, device="cuda")
+    p = torch.full((2,), 0x0000001008000000, dtype=torch.int64, device="cuda")
+    act = torch.ones(2, dtype=torch.uint8, device="cuda")
+    m.policy_fn = lambda x: torch.full((x.shape[0], 64), 1.0 / 64, device="cuda")
+    m.search(o, p, act, 5)
+    assert int(m.tree.n_nodes[0].item()) > 1
+    mv = torch.tensor([0, 19], dtype=torch.int8, device="cuda")  # 0 is not a child; 19 is
+    m.update_with_move(mv)
+    torch.cuda.synchronize()
+    assert int(m.tree.n_nodes[0].item()) == 1 and int(m.tree.root[0].item()) == 0
+    assert int(m.tree.root[1].item()) != 0
+
+
+def test_pool_overflow_is_reported(eng):
+    engine, ops = eng
+    from iago_amd import _lib
+    m = engine.BatchedMCTS(1, lambda x: torch.full((x.shape[0], 64), 1.0 / 64, device="cuda"),
+                           None, None, lmbda=1.0, n_thr=1, capacity=8)
+    o = torch.full((1,), 0x0000000810000000, dtype=torch.int64, device="cuda")
+    p = torch.full((1,), 0x0000001008000000, dtype=torch.int64, device="cuda")
+    with pytest.raises(_lib.IagoError):
+        m.search(o, p, torch.ones(1, dtype=torch.uint8, device="cuda"), 20)

@@ -1,0 +1,197 @@
+"""The host-side mirrors of the reference's Python interfaces (GameFunctions,
+Simulate, MCTS, rl_self_play.Game, GameEnv) against the golden vectors recorded
+from the reference and against the oracle.  These read like the calls the
+reference itself makes (MCTS.py:94-137, src/train_rl.py:41-47, game.py:117-142).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mcts_py
+from oracle import oracle as orc
+from tests.conftest import load_json
+
+pytestmark = pytest.mark.gpu
+
+
+def st(p1, p2):
+    return orc.bits_to_state(int(p1), int(p2))
+
+
+def test_game_functions(golden_rules):
+    from iago_amd.game import GameFunctions as gf
+    tr = golden_rules["trace"]
+    for rec in tr[:: 97]:
+        p1, p2, color, legal, action, q1, q2 = (int(x) for x in rec)
+        s = st(p1, p2)
+        acts = gf.legal_actions(s, color)
+        assert acts == orc.legal_actions(s, color) and orc.actions_to_mask(acts) == legal
+        a = -1 if action == 0xFF else action
+        s2 = gf.place_stone(s, a, color)
+        assert s2 is s and orc.state_to_bits(s) == (q1, q2)
+        x = gf.make_state_var(s, color)
+        assert tuple(x.shape) == (1, 2, 8, 8)
+        assert np.array_equal(x.cpu().numpy(), orc.make_state_var(s, color))
+    assert gf.ac2pos([0, 19, 63]) == [[1, 1], [3, 4], [8, 8]]
+    assert gf.is_outside([8, 0]) and not gf.is_outside([7, 7])
+
+
+def test_simulate_mirror():
+    from iago_amd import mcts_self_play, ops
+    g = load_json("simulate.json")
+    w = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    for c in g["cases"][:10]:
+        sim = mcts_self_play.Simulate(st(c["p1"], c["p2"]), weights=w, seed=3)
+        z = sim(c["color"])
+        assert z in (-1, 0, 1)
+        assert z == orc.judge(sim.state, c["color"])
+        assert not orc.legal_actions(sim.state, 1) and not orc.legal_actions(sim.state, 2)
+        # replay with the oracle: same Philox stream -> same game (within sampling tolerance
+        # the test in test_rollout_gpu.py covers; here only terminal consistency)
+    with pytest.raises(RuntimeError):
+        mcts_self_play._DEFAULT_WEIGHTS = None
+        mcts_self_play.Simulate(orc.initial_state())
+
+
+class _Rollout(torch.nn.Module):
+    """RolloutPolicy-shaped stand-in model on the GPU (float32 conv + softmax)."""
+
+    def __init__(self, w, b):
+        super().__init__()
+        from iago_amd import network
+        self.m = network.RolloutPolicy()
+        with torch.no_grad():
+            self.m.conv1.weight.copy_(torch.tensor(w, dtype=torch.float32).reshape(1, 2, 3, 3))
+            self.m.bias2.b.copy_(torch.tensor(b, dtype=torch.float32))
+        self.m.cuda().eval()
+
+    def forward(self, x):
+        return self.m(x)
+
+
+def test_rl_game_mirror_replays_reference_games():
+    """src/rl_self_play.Game with the uniforms numpy drew in the reference run:
+    same recorded (swapped) states, same actions, same z."""
+    from iago_amd import rl_self_play
+    hcs = [None, (2, 4), (3, 5), (4, 2), (5, 3)]
+    for c in load_json("rl_game.json"):
+        game = rl_self_play.Game(_Rollout(c["w1"], c["b1"]), _Rollout(c["w2"], c["b2"]),
+                                 uniforms=c["uniforms"])
+        if c["handicap"]:
+            pos = hcs[c["handicap"]]
+            game.state[pos[0], pos[1]] = 2  # src/train_rl.py:43-46
+        states, actions, z = game()
+        assert actions == c["actions"]
+        assert z == c["z"]
+        assert [list(orc.state_to_bits(s)) for s in states] == c["states"]
+        assert orc.state_to_bits(game.state) == (c["q1"], c["q2"])
+
+
+def test_rl_play_batch_matches_oracle_games():
+    """Batched lockstep games with Philox sampling == the oracle's rl_game driven
+    by the same uniforms, game by game."""
+    from iago_amd import ops, rl_self_play
+    rs = np.random.RandomState(4)
+    w1, b1 = rs.randn(18).astype(np.float32), (0.5 * rs.randn(64)).astype(np.float32)
+    w2, b2 = rs.randn(18).astype(np.float32), (0.5 * rs.randn(64)).astype(np.float32)
+    B, seed, base = 48, 77, 1000
+    hc_cells = [None, (2, 4), (3, 5), (4, 2), (5, 3)]
+    hc = np.array([0 if g % 5 == 0 else 1 << (hc_cells[g % 5][0] * 8 + hc_cells[g % 5][1])
+                   for g in range(B)], np.uint64)
+    r = rl_self_play.play_batch(_Rollout(w1, b1), _Rollout(w2, b2), B,
+                                handicap=ops.bits_to_tensor(hc), seed=seed, game_id_base=base)
+    act = r["action"].cpu().numpy()
+    z = r["z"].cpu().numpy()
+    f1, f2 = ops.tensor_to_bits(r["final_p1"]), ops.tensor_to_bits(r["final_p2"])
+    p1 = lambda x: orc.rollout_policy(x, w1, b1)[0]
+    p2 = lambda x: orc.rollout_policy(x, w2, b2)[0]
+    mismatches = 0
+    for g in range(B):
+        # the oracle consumes one uniform per move; turn t of game g draws uniform(seed, base+g, t)
+        class Us(object):
+            def __init__(self):
+                self.t = 0
+        # replay turn by turn to know t at each draw
+        state = orc.initial_state(hc_cells[g % 5])
+        stone_num, pass_flg, t, acts_l = 4, False, 0, []
+        ok = True
+        while stone_num < 64 and ok:
+            for color in (1, 2):
+                la = orc.legal_actions(state, color)
+                if la:
+                    prob = (p1 if color == 1 else p2)(orc.make_state_var(state, color))
+                    a = orc.choice_cdf(orc.masked_probs(prob, la), orc.uniform(seed, base + g, t))
+                    if color == 1:
+                        got = int(act[t // 2, g])
+                        if got != a:  # float32 policy on the GPU vs the oracle's: rounding flip
+                            ok = False
+                            mismatches += 1
+                            break
+                        acts_l.append(a)
+                    orc.place_stone(state, a, color)
+                    pass_flg, stone_num = False, stone_num + 1
+                else:
+                    if pass_flg:
+                        stone_num = 64
+                    pass_flg = True
+                t += 1
+        if ok:
+            assert orc.state_to_bits(state) == (int(f1[g]), int(f2[g])), g
+            assert z[g] == orc.judge(state, 1)
+    assert mismatches <= 1
+
+
+def test_mcts_mirror_get_move_and_update():
+    from iago_amd import MCTS as mcts_mod
+    from tests.test_mcts_gpu import fake_nets
+    policy_np, value_np, policy_t, value_t = fake_nets(7)
+    m = mcts_mod.MCTS(lmbda=0.0, c_puct=1, n_thr=3, policy_net=policy_t, value_net=value_t,
+                      n_sims=60, capacity=4096)
+    om = mcts_py.MCTS(policy_np, value_np, None, lmbda=0.0, c_puct=1, n_thr=3)
+    state, color = orc.initial_state(), 1
+    for ply in range(6):
+        a = m.get_move(state, color)
+        assert a == om.get_move(state, color, 60)
+        m.update_with_move(a)
+        om.update_with_move(a)
+        orc.place_stone(state, a, color)
+        color = 3 - color
+    with pytest.raises(ValueError):
+        mcts_mod.MCTS(lmbda=0.5)
+    m2 = mcts_mod.MCTS(lmbda=0.0, n_thr=15, policy_net=policy_t, value_net=value_t, n_sims=5)
+    with pytest.raises(ValueError):
+        m2.get_move(orc.initial_state(), 1)  # root never expanded: max() of empty dict
+
+
+def test_game_env_mirror():
+    from iago_amd import rl_env
+    c = load_json("env.json")[0]
+    base = _Rollout(c["w2"], c["b2"])
+
+    class Opp(torch.nn.Module):
+        def forward(self, x):
+            out = base(x).reshape(64).clone()
+            s = (x[0, 0] + 2 * x[0, 1]).cpu().numpy().astype(np.float32)
+            for a in orc.legal_actions(s, 2):
+                out[a] += 0.25
+            return out.reshape(1, 64)
+
+    np.random.seed(0)
+    env = rl_env.GameEnv(None, Opp())
+    obs = env.reset()
+    assert np.array_equal(obs.cpu().numpy(), orc.env_obs(orc.initial_state()))
+    assert env.valid_pos(1) == [[3, 4], [4, 3], [5, 6], [6, 5]]
+    done, steps = False, 0
+    while not done:
+        pos = env.valid_pos(1)
+        a = (pos[0][0] - 1) * 8 + pos[0][1] - 1 if pos else 0
+        before = env.state.copy()
+        obs, r, done, info = env.step(a)
+        assert r == 0 and info is None
+        assert np.array_equal(obs.cpu().numpy(), orc.env_obs(env.state))
+        if pos:
+            assert env.state[pos[0][0] - 1, pos[0][1] - 1] != 0 and before[pos[0][0] - 1, pos[0][1] - 1] == 0
+        steps += 1
+        assert steps < 70
+    assert env() == orc.judge(env.state, 1)
+    assert done and (env.stone_num >= 64 or env.pass_flg)
