@@ -83,6 +83,60 @@ def cpu_baseline(w, b, budget_s=10.0):
             "board_steps_per_game": steps / games}
 
 
+def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
+    """BASELINE configs[2]: PV-MCTS self-play, `n_games` lockstep games per GPU,
+    `n_sims` playouts per move, SLPolicy + Value with random-init weights
+    (Chainer-default LeCunNormal, seed 0), reference constants lmbda=0.5,
+    c_puct=1, n_thr=15, both colours search.  One leaf-eval = one playout
+    (value net + rollout at the leaf; the policy net runs on expansions).
+    Default: a bounded sample of the first `n_turns` turns; --mcts-full plays
+    the games to the end and reports games/s."""
+    from iago_amd import engine, network, ops
+    w, b = shipped_rollout_weights()
+    torch.manual_seed(0)
+    policy = network.SLPolicy().cuda().eval()
+    value = network.Value().cuda().eval()
+    m = engine.BatchedMCTS(n_games, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0,
+                           n_thr=15, capacity=8192, seed=7, game_id_base=rank * n_games)
+    eng = engine.SelfPlayEngine(m, max_turns=(128 if full_games else n_turns))
+    m.warmup()                 # MIOpen kernel selection for every batch bucket
+    eng.play(2, record=False)  # allocator, code objects
+    m.n_leaf_evals = m.n_policy_evals = 0
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    res = eng.play(n_sims, record=True)
+    gathered = None
+    if dist is not None and full_games:
+        from iago_amd.dist import gather_tuples
+        gathered = gather_tuples(res.tuples())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stats = torch.tensor([dt, m.n_leaf_evals, m.n_policy_evals], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tm = stats[:1].clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats)
+        stats[0] = tm[0]
+    dt, leaf, pol = (float(x) for x in stats.tolist())
+    flops = leaf * 122_994_944 + pol * 122_847_232  # SURVEY.md 8(d): Value / SLPolicy per eval
+    out = {"leaf_evals_per_sec": leaf / dt, "leaf_evals": int(leaf), "policy_evals": int(pol),
+           "seconds": dt, "turns_played": res.n_turns, "sims_per_move": n_sims,
+           "games_per_gpu": n_games, "full_games": bool(full_games),
+           "net_tflops_fp32": flops / dt / 1e12,
+           "config": "BASELINE configs[2]: PV-MCTS %d sims/move, %d games per GPU, SLPolicy+Value "
+                     "random init fp32, lmbda=0.5 c_puct=1 n_thr=15" % (n_sims, n_games),
+           "tree_bytes_per_gpu": m.tree.bytes()}
+    if full_games:
+        out["games_per_sec"] = world * n_games / dt
+        if gathered is not None:
+            out["gathered_tuples"] = int(gathered["z"].numel())
+    return out
+
+
 def measured_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes, if any."""
     path = os.path.join(ROOT, "profiles", "rollout_traffic.json")
@@ -99,6 +153,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mcts-games", type=int, default=1024)
+    ap.add_argument("--mcts-sims", type=int, default=100)
+    ap.add_argument("--mcts-turns", type=int, default=2,
+                    help="turns of the bounded PV-MCTS sample (0 = skip the leg)")
+    ap.add_argument("--mcts-full", action="store_true", help="play the PV-MCTS games to the end")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,6 +230,11 @@ def main():
     dt = float(tmax.item())
     board_steps = int(steps_total.item())
 
+    mcts = None
+    if args.mcts_turns > 0 or args.mcts_full:
+        mcts = mcts_leg(args.mcts_games, args.mcts_sims, args.mcts_turns, args.mcts_full, world,
+                        rank, dist)
+
     if rank == 0:
         games = world * K * B
         alg_bytes_per_launch = BYTES_PER_BOARD_STEP * board_steps / (world * K)
@@ -192,6 +256,8 @@ def main():
                          "kernel": "rollout_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch},
         }
+        if mcts is not None:
+            line["mcts"] = mcts
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, b)
         print(json.dumps(line), flush=True)

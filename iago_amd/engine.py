@@ -118,12 +118,35 @@ class BatchedMCTS(object):
         self.v = torch.zeros(n_games, dtype=torch.float32, **kw)
         self.move = torch.zeros(n_games, dtype=torch.int8, **kw)
         self.visits = torch.zeros((n_games, 64), dtype=torch.int32, **kw)
+        self._policy_in = torch.zeros((max(n_games, 16), 2, 8, 8), dtype=torch.float32, **kw)
         self.sim_counter = 0          # Philox stream id: one per simulation
         self.n_leaf_evals = 0
         self.n_policy_evals = 0
         self.rollout_hook = None
         self._rollout_out = ops.RolloutResult()
         self._rollout_out.z = self.z
+
+    def _bucket(self, n):
+        """Smallest power-of-two batch >= n (min 16), capped at the pool size."""
+        b = 16
+        while b < n:
+            b *= 2
+        return min(b, self._policy_in.shape[0])
+
+    def warmup(self):
+        """Run the nets once per batch shape the search will use."""
+        with torch.no_grad():
+            b = 16
+            while True:
+                nb = min(b, self._policy_in.shape[0])
+                if self.policy_fn is not None:
+                    self.policy_fn(self._policy_in[:nb])
+                if nb == self._policy_in.shape[0]:
+                    break
+                b *= 2
+            if self.value_fn is not None and self.lmbda < 1.0:
+                self.value_fn(self.planes)
+        torch.cuda.synchronize()
 
     # -- one simulation = MCTS.playout for every active game (MCTS.py:105-133)
     def _select(self, own, opp, active, from_root):
@@ -139,7 +162,12 @@ class BatchedMCTS(object):
         idx = torch.nonzero(self.needs_expand & active).reshape(-1)  # host sync: usually small
         if idx.numel() > 0:
             games = idx.to(torch.int32)
-            sub_planes = ops.encode_planes(self.cur_own[idx], self.cur_opp[idx])
+            n_exp = int(idx.numel())
+            # MIOpen picks (and on first sight searches for) a kernel per input
+            # shape: run the policy net on a few fixed bucket sizes only
+            nb = self._bucket(n_exp)
+            sub_planes = self._policy_in[:nb]
+            ops.encode_planes(self.cur_own[idx], self.cur_opp[idx], out=sub_planes[:n_exp])
             with torch.no_grad():
                 probs = self.policy_fn(sub_planes).to(torch.float32).contiguous()
             self.n_policy_evals += int(idx.numel())

@@ -209,3 +209,31 @@ class GameEnv(object):
 
     def __call__(self):
         return orc.judge(self.state, 1)
+
+
+def selfplay_game(mcts, n_sims, handicap=None):
+    """One PV-MCTS self-play game in the turn structure of game.py:117-142,253-255
+    with BOTH colours driven by MCTS.get_move (the reference drives colour 2
+    only; colour 1 is a human or the SL policy): a side with a legal move
+    searches, plays the most visited child and advances the tree
+    (game.py:112-113); a side without one passes and advances the tree with -1
+    (game.py:136-140).  Returns (moves per turn, z from colour 1's view, state)."""
+    state = orc.initial_state(handicap)
+    stone_num, pass_flg, moves = 4, False, []
+    while stone_num < 64:
+        for color in (1, 2):
+            acts = orc.legal_actions(state, color)
+            if len(acts) > 0:
+                a = mcts.get_move(state, color, n_sims)
+                mcts.update_with_move(a)
+                orc.place_stone(state, a, color)
+                stone_num += 1
+                pass_flg = False
+                moves.append(a)
+            else:
+                if pass_flg:
+                    stone_num = 64
+                pass_flg = True
+                mcts.update_with_move(-1)
+                moves.append(-1)
+    return moves, orc.judge(state, 1), state

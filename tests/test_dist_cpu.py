@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard the games and
+all-gather their finished tuples (iago_amd.dist), as bench.py / the self-play
+engine do over RCCL on the GPUs."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from iago_amd.dist import gather_tuples, shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_games():
+    for n, world in [(8192, 8), (10, 3), (5, 8), (0, 2), (4096, 1)]:
+        spans = [shard_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        for a, b in zip(spans, spans[1:]):
+            assert a[1] == b[0]
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_games = 11
+        lo, hi = shard_range(n_games)
+        # ragged: every game contributes (game id + 1) % 4 tuples
+        rows = [(g, k) for g in range(lo, hi) for k in range((g + 1) % 4)]
+        own = torch.tensor([g * 1000 + k for g, k in rows], dtype=torch.int64)
+        pi = torch.tensor([[g + k + c for c in range(64)] for g, k in rows],
+                          dtype=torch.int32).reshape(-1, 64)
+        z = torch.tensor([(g % 3) - 1 for g, k in rows], dtype=torch.int8)
+        out = gather_tuples(dict(own=own, pi=pi, z=z))
+        q.put((rank, out["own"].tolist(), out["pi"].sum().item(), out["z"].tolist(),
+               tuple(out["pi"].shape)))
+        # an empty shard on one rank must work too
+        e = gather_tuples(dict(x=torch.arange(3 if rank == 0 else 0, dtype=torch.float32)))
+        q.put((rank, e["x"].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_tuples_world2_gloo():
+    world, port = 2, 29000 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows = [(g, k) for g in range(11) for k in range((g + 1) % 4)]
+    want_own = [g * 1000 + k for g, k in rows]
+    want_z = [(g % 3) - 1 for g, k in rows]
+    full = [x for x in got if len(x) == 5]
+    assert len(full) == 2
+    for rank, own, pisum, z, shape in full:
+        assert own == want_own and z == want_z
+        assert shape == (len(rows), 64)
+        assert pisum == sum(g + k + c for g, k in rows for c in range(64))
+    for x in got:
+        if len(x) == 2:
+            assert x[1] == [0.0, 1.0, 2.0]
+
+
+def test_gather_tuples_single_process_is_identity():
+    t = dict(a=torch.arange(5), b=torch.ones(5, 3))
+    out = gather_tuples(t)
+    assert out["a"] is t["a"] and out["b"] is t["b"]
