@@ -12,7 +12,7 @@ SO_PATH = os.path.join(HERE, "libiago_hip.so")
 
 IAGO_OK = 0
 IAGO_MAX_TURNS = 128
-IAGO_ROLLOUT_TABLE_FLOATS = 3 * 2 * 256 * 8
+IAGO_ROLLOUT_TABLE_FLOATS = 3 * 2 * 256 * 8 + 256 * 8 + 64 + 4
 TRACE_PASS = 0xFF
 
 # every symbol include/iago_hip.h declares (tests/test_abi.py checks the list
@@ -34,10 +34,10 @@ class IagoError(RuntimeError):
 class RolloutArgs(C.Structure):
     _fields_ = [
         ("own", C.c_void_p), ("opp", C.c_void_p), ("n", C.c_int64),
-        ("table", C.c_void_p), ("bias", C.c_void_p), ("uniforms", C.c_void_p),
+        ("table", C.c_void_p), ("uniforms", C.c_void_p),
         ("seed", C.c_uint64), ("id_base", C.c_uint32), ("stream_id", C.c_uint32),
         ("z", C.c_void_p), ("final_own", C.c_void_p), ("final_opp", C.c_void_p),
-        ("n_turns", C.c_void_p), ("trace", C.c_void_p), ("uniform_policy", C.c_int),
+        ("n_turns", C.c_void_p), ("trace", C.c_void_p), ("log_form", C.c_int),
     ]
 
 
@@ -85,7 +85,7 @@ def lib():
     L.iago_judge.argtypes = [vp, vp, vp, i64, vp]
     L.iago_sample_moves.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
                                     i64, vp]
-    L.iago_rollout_build_table.argtypes = [vp, vp]
+    L.iago_rollout_build_table.argtypes = [vp, vp, vp]
     L.iago_rollout.argtypes = [C.POINTER(RolloutArgs), vp]
     tp = C.POINTER(MctsTree)
     L.iago_mcts_reset.argtypes = [tp, vp, vp]

@@ -112,17 +112,26 @@ __device__ __forceinline__ uint64_t to_lane(uint64_t x, const Lane8 &L)
 // Legal moves of `own` (reference: game.py:210-235).  o, p are own/opp in the
 // lane orientation.  Each lane floods its direction through contiguous
 // opponent stones (<= 6 of them fit on a ray) and lands on an empty cell.
+// Written on 32-bit halves so that every flood step is v_lshlrev_b32 +
+// v_alignbit_b32 + 2 x v_and_or_b32 (the shift is 1..9, never >= 32).
 __device__ __forceinline__ uint64_t group8_legal(uint64_t o, uint64_t p, const Lane8 &L)
 {
-    const uint64_t pm = p & L.mask;
-    uint64_t t = (o << L.s) & pm;
-    t |= (t << L.s) & pm;
-    t |= (t << L.s) & pm;
-    t |= (t << L.s) & pm;
-    t |= (t << L.s) & pm;
-    t |= (t << L.s) & pm;
-    uint64_t mv = (t << L.s) & ~(o | p) & L.mask;
-    return group8_or(to_lane(mv, L));
+    const uint32_t s = L.s, rs = 32u - L.s;
+    const uint32_t ml = (uint32_t)L.mask, mh = (uint32_t)(L.mask >> 32);
+    const uint32_t ol = (uint32_t)o, oh = (uint32_t)(o >> 32);
+    const uint32_t pl = (uint32_t)p, ph = (uint32_t)(p >> 32);
+    const uint32_t pml = pl & ml, pmh = ph & mh;
+    uint32_t tl = (ol << s) & pml;
+    uint32_t th = __builtin_amdgcn_alignbit(oh, ol, rs) & pmh;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const uint32_t nl = tl << s, nh = __builtin_amdgcn_alignbit(th, tl, rs);
+        tl = (nl & pml) | tl;
+        th = (nh & pmh) | th;
+    }
+    const uint32_t el = ~(ol | pl) & ml, eh = ~(oh | ph) & mh; // empty cells, wrap-masked
+    const uint32_t vl = (tl << s) & el, vh = __builtin_amdgcn_alignbit(th, tl, rs) & eh;
+    return group8_or(to_lane(((uint64_t)vh << 32) | vl, L));
 }
 
 // Ray masks: ray[k][pos] = cells strictly beyond `pos` in the direction with

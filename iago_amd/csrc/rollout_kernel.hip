@@ -6,25 +6,29 @@
 //
 // Mapping: 8 lanes per board (othello_dev.hpp).  Per turn, per board:
 //   1. legal moves: direction-per-lane flood fill, DPP OR-reduce;
-//   2. RolloutPolicy logits (network.py:59-64: conv3x3 2->1, pad 1, + bias[64]):
-//      lane r produces the 8 logits of board row r as
+//   2. RolloutPolicy (network.py:59-64: conv3x3 2->1, pad 1, + bias[64], softmax):
+//      lane r evaluates the 8 cells of board row r.  The conv is linear in the
+//      0/1 planes, so a row's 8 logits are
 //        bias[r][:] + sum over the 3 input rows (r-1, r, r+1) and the 2 planes of
 //        T[ky][plane][row byte][:]
-//      where T (48 KiB, staged once per block in LDS) holds, for every possible
-//      8-cell row pattern, that row's contribution to 8 adjacent outputs -- the
-//      conv is linear in the 0/1 planes, so 6 table rows (12 ds_read_b128) replace
-//      144 multiply-adds;
-//   3. masked softmax over the legal cells, inverse-CDF sampling in cell order
-//      (numpy.random.choice semantics, mcts_self_play.py:103-106): per-lane
-//      running sums, a 3-step DPP scan across the 8 rows, and the sampled cell
-//      is the number of cells whose CDF is <= u * total;
+//      with T precomputed for all 256 row patterns and staged in LDS.  In the
+//      default PRODUCT form the table holds exp() of those contributions, so
+//      the unnormalised softmax numerators are a product of 7 factors: no
+//      v_exp_f32, no max pass (the host checks the dynamic range and selects
+//      the LOG form -- sum, max, exp2 -- when a product could under/overflow);
+//   3. masked inverse-CDF sampling in cell order (numpy.random.choice
+//      semantics, mcts_self_play.py:103-106): illegal cells are zeroed with a
+//      0/1 multiplier row from LDS, per-lane running sums, a 3-step DPP scan
+//      across the 8 rows; the sampled cell index is the number of cells whose
+//      CDF is <= u * total;
 //   4. flips: direction-per-lane carry propagation against LDS ray masks;
 //   5. pass / double pass / full board bookkeeping in the reference's
 //      paired-turn loop (mcts_self_play.py:25-29,124-134).
 // Uniforms come from Philox4x32-10: the 8 lanes of a group generate 8 counter
-// blocks (32 turns) at once; turn t uses word t&3 of counter t>>2, fetched with
-// one ds_bpermute.  HBM traffic is 16 B in + 1 B out per game (+ optional
-// trace / final boards); everything else stays in VGPRs/LDS.
+// blocks (32 turns) at once; turn t uses word t&3 of counter t>>2; the 4 words
+// of a counter are fetched with 4 back-to-back ds_bpermute every 4 turns.
+// HBM traffic is 16 B in + 1 B out per game (+ optional trace / final boards);
+// everything else stays in VGPRs/LDS.
 #include "abi_common.hpp"
 #include "othello_dev.hpp"
 
@@ -34,15 +38,22 @@ using namespace iago;
 
 namespace {
 
-constexpr int TBL_FLOATS = IAGO_ROLLOUT_TABLE_FLOATS; // [3][2][256][8]
+// blob layout (floats), see iago_rollout_build_table
+constexpr int OFF_E = 0;                       // E[ky][plane][half][byte][4]
+constexpr int N_E = 3 * 2 * 2 * 256 * 4;       // 12288
+constexpr int OFF_LM = OFF_E + N_E;            // LM[half][byte][4]: 1.0 / 0.0 per legal bit
+constexpr int N_LM = 2 * 256 * 4;              // 2048
+constexpr int OFF_BIAS = OFF_LM + N_LM;        // 64
+constexpr int OFF_MODE = OFF_BIAS + 64;        // 1.0 = product form, 0.0 = log form
+static_assert(OFF_MODE + 4 == IAGO_ROLLOUT_TABLE_FLOATS, "blob size");
+constexpr int LDS_FLOATS = N_E + N_LM;
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct RolloutParams {
     const uint64_t *own;
     const uint64_t *opp;
     int64_t n;
-    const float *table;
-    const float *bias;
+    const float *blob;
     const float *uniforms;
     uint32_t key0, key1, id_base, stream_id;
     int8_t *z;
@@ -50,21 +61,169 @@ struct RolloutParams {
     uint64_t *final_opp;
     uint8_t *n_turns;
     uint8_t *trace;
-    int uniform_policy;
 };
 
 __device__ __forceinline__ float4 lds_f4(const float *p) { return *(const float4 *)p; }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct Row8 {
+    f2 a, b, c, d; // cells (0,1) (2,3) (4,5) (6,7)
+};
+__device__ __forceinline__ void mul8(Row8 &e, const float4 lo, const float4 hi)
+{
+    e.a *= (f2){lo.x, lo.y};
+    e.b *= (f2){lo.z, lo.w};
+    e.c *= (f2){hi.x, hi.y};
+    e.d *= (f2){hi.z, hi.w};
+}
+__device__ __forceinline__ void add8(Row8 &e, const float4 lo, const float4 hi)
+{
+    e.a += (f2){lo.x, lo.y};
+    e.b += (f2){lo.z, lo.w};
+    e.c += (f2){hi.x, hi.y};
+    e.d += (f2){hi.z, hi.w};
+}
+
+// Per-board state carried across turns (replicated in the 8 lanes of the group).
+struct Game {
+    uint64_t own, opp; // own = side to move
+    uint32_t stones;   // stone_num (mcts_self_play.py:15)
+    uint32_t nt;       // turns played
+    bool pass_flg, done;
+};
+
+template <bool PRODUCT>
+__device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t t,
+                                          const Lane8 &L, const float *tbl, const uint64_t *ray,
+                                          const float (&bias)[8], const uint32_t sh_r,
+                                          const uint32_t sh_l, const RolloutParams &P,
+                                          const int64_t b)
+{
+    const uint32_t r = L.l8;
+    // ---- table rows of this lane's 3x8 window: issue the LDS reads first
+    const uint32_t wo = ((uint32_t)(G.own >> sh_r) << sh_l) & 0xFFFFFFu; // own: plane 1
+    const uint32_t wp = ((uint32_t)(G.opp >> sh_r) << sh_l) & 0xFFFFFFu; // opp: plane 0
+    float4 ta[6], tb[6];
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+        const uint32_t bp = (wp >> (8 * ky)) & 0xFFu;
+        const uint32_t bo = (wo >> (8 * ky)) & 0xFFu;
+        const float *tp = tbl + OFF_E + ((ky * 2 + 0) * 2) * 1024 + bp * 4;
+        const float *to = tbl + OFF_E + ((ky * 2 + 1) * 2) * 1024 + bo * 4;
+        ta[2 * ky] = lds_f4(tp);
+        tb[2 * ky] = lds_f4(tp + 1024);
+        ta[2 * ky + 1] = lds_f4(to);
+        tb[2 * ky + 1] = lds_f4(to + 1024);
+    }
+
+    // ---- legal moves of the side to move
+    const uint64_t o = to_lane(G.own, L), p = to_lane(G.opp, L);
+    const uint64_t legal = group8_legal(o, p, L);
+    const bool has = legal != 0ull;
+    const uint32_t lr = (uint32_t)(legal >> (8u * r)) & 0xFFu;
+    const float4 lm0 = lds_f4(tbl + OFF_LM + lr * 4), lm1 = lds_f4(tbl + OFF_LM + 1024 + lr * 4);
+
+    // ---- unnormalised probabilities e[x] of row r, zero on illegal cells
+    Row8 E;
+    E.a = (f2){bias[0], bias[1]};
+    E.b = (f2){bias[2], bias[3]};
+    E.c = (f2){bias[4], bias[5]};
+    E.d = (f2){bias[6], bias[7]};
+    if (PRODUCT) {
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            mul8(E, ta[k], tb[k]);
+        mul8(E, lm0, lm1);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            add8(E, ta[k], tb[k]);
+    }
+    float e[8] = {E.a.x, E.a.y, E.b.x, E.b.y, E.c.x, E.c.y, E.d.x, E.d.y};
+    if (!PRODUCT) {
+        const float lmv[8] = {lm0.x, lm0.y, lm0.z, lm0.w, lm1.x, lm1.y, lm1.z, lm1.w};
+        float m = -INFINITY;
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            e[x] = (lmv[x] != 0.0f) ? e[x] : -INFINITY;
+            m = fmaxf(m, e[x]);
+        }
+        m = group8_max(m);
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+            e[x] = (lmv[x] != 0.0f) ? __builtin_amdgcn_exp2f((e[x] - m) * LOG2E) : 0.0f;
+    }
+
+    // ---- inverse-CDF sample in cell order
+    float c[8];
+    c[0] = e[0];
+#pragma unroll
+    for (int x = 1; x < 8; x++)
+        c[x] = c[x - 1] + e[x];
+    float start, total;
+    group8_scan(c[7], r, start, total);
+    // u * total is rounded BEFORE the subtraction (no FMA contraction): the oracle's
+    // floor(u * n) for the uniform policy is reproduced bit for bit
+    float thr;
+    {
+#pragma clang fp contract(off)
+        const float ut = u * total;
+        thr = ut - start;
+    }
+    // cnt = #cells with c[x] <= thr: funnel the sign bits of thr - c[x] (set iff
+    // c[x] > thr; thr - c == +0 on equality) into one word, one v_alignbit each
+    uint32_t over = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+        over = __builtin_amdgcn_alignbit(over, __builtin_bit_cast(uint32_t, thr - c[x]), 31);
+    uint32_t cnt = 8u - (uint32_t)__popc(over & 0xFFu);
+    cnt = group8_add(cnt);
+    uint32_t action = cnt;
+    // Rounding can leave the count one cell off a legal one (or at 64): take
+    // the next legal cell, else the last one.  Rare, so branch per wave.
+    const bool bad = has && (cnt > 63u || ((legal >> (cnt & 63u)) & 1ull) == 0ull);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+        const uint64_t rem = (cnt < 64u) ? (legal & (~0ull << cnt)) : 0ull;
+        const uint32_t fix =
+            rem ? (uint32_t)__builtin_ctzll(rem) : (63u - (uint32_t)__builtin_clzll(legal | 1ull));
+        action = bad ? fix : action;
+    }
+    action &= 63u;
+
+    // ---- flips and board update (branch-free)
+    const uint64_t f = group8_flips(o, p, action, L, ray);
+    const bool live_turn = !G.done;
+    const bool play = has && live_turn;
+    const bool passing = !has && live_turn;
+    const uint64_t fm = play ? f : 0ull;
+    const uint64_t bit = (uint64_t)(play ? 1u : 0u) << action;
+    const uint64_t nown = G.own | fm | bit;
+    const uint64_t nopp = G.opp & ~fm;
+    G.stones += play ? 1u : 0u;
+    G.stones = (passing && G.pass_flg) ? 64u : G.stones; // double pass (mcts_self_play.py:131-133)
+    G.pass_flg = live_turn ? passing : G.pass_flg;
+    if (P.trace && live_turn && r == 0u)
+        P.trace[(int64_t)t * P.n + b] = play ? (uint8_t)action : (uint8_t)IAGO_TRACE_PASS;
+    // The other side moves next.  Finished boards keep swapping too: `done` is
+    // only raised, and the turn loop only left, after an odd turn, so a finished
+    // board is swapped an even number of times and ends in its final orientation.
+    G.own = nopp;
+    G.opp = nown;
+    G.nt += live_turn ? 1u : 0u;
+    // `while stone_num < 64` is evaluated once per pair of turns (mcts_self_play.py:26-28)
+    if (t & 1u)
+        G.done = G.done || G.stones >= 64u;
+}
+
+template <bool PRODUCT>
 __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
 {
-    __shared__ __attribute__((aligned(16))) float tbl[TBL_FLOATS];
+    __shared__ __attribute__((aligned(16))) float tbl[LDS_FLOATS];
     __shared__ uint64_t ray[RAY_TABLE_WORDS];
-
-    const bool use_net = P.uniform_policy == 0;
-    if (use_net) {
-        const float4 *src = (const float4 *)P.table;
+    {
+        const float4 *src = (const float4 *)P.blob;
         float4 *dst = (float4 *)tbl;
-        for (uint32_t i = threadIdx.x; i < (uint32_t)(TBL_FLOATS / 4); i += blockDim.x)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(LDS_FLOATS / 4); i += blockDim.x)
             dst[i] = src[i];
     }
     fill_ray_table(ray);
@@ -76,18 +235,18 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
     const uint32_t r = L.l8;
     const bool live = b < P.n;
 
-    uint64_t own = live ? P.own[b] : 0ull;
-    uint64_t opp = live ? P.opp[b] : 0ull;
-    uint32_t stones = (uint32_t)__popcll(own | opp);
-    bool pass_flg = false;
-    bool done = !live || stones >= 64u; // `while stone_num < 64` (mcts_self_play.py:26)
-    uint32_t nt = 0;
+    Game G;
+    G.own = live ? P.own[b] : 0ull;
+    G.opp = live ? P.opp[b] : 0ull;
+    G.stones = (uint32_t)__popcll(G.own | G.opp);
+    G.pass_flg = false;
+    G.done = !live || G.stones >= 64u; // `while stone_num < 64` (mcts_self_play.py:26)
+    G.nt = 0;
 
-    // this lane's 8 biases (row r of bias2/b)
-    float bias[8];
+    float bias[8]; // this lane's row of bias2/b (exp'ed in product form)
 #pragma unroll
     for (int x = 0; x < 8; x++)
-        bias[x] = use_net ? P.bias[r * 8 + x] : 0.0f;
+        bias[x] = P.blob[OFF_BIAS + r * 8 + x];
 
     // window of rows r-1, r, r+1 as 24 bits: (x >> sh_r) << sh_l
     const uint32_t sh_r = r ? 8u * (r - 1u) : 0u;
@@ -97,124 +256,47 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
     uint32_t rw[4] = {0, 0, 0, 0};
     const uint32_t lane = threadIdx.x & 63u;
 
-    for (uint32_t t = 0; t < (uint32_t)IAGO_MAX_TURNS; t++) {
-        // ---- uniform for this turn
-        float u;
+    for (uint32_t t4 = 0; t4 < (uint32_t)IAGO_MAX_TURNS; t4 += 4) {
+        float u4[4];
         if (P.uniforms) {
-            u = live ? P.uniforms[(int64_t)t * P.n + b] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                u4[k] = live ? P.uniforms[(int64_t)(t4 + k) * P.n + b] : 0.0f;
         } else {
-            if ((t & 31u) == 0u) {
+            if ((t4 & 31u) == 0u) {
                 rw[0] = rid;
-                rw[1] = (t >> 2) + r;
+                rw[1] = (t4 >> 2) + r;
                 rw[2] = P.stream_id;
                 rw[3] = 0u;
                 philox4x32_10(rw, P.key0, P.key1);
             }
-            const uint32_t k = t & 3u; // wave-uniform
-            const uint32_t mine = (k == 0u) ? rw[0] : (k == 1u) ? rw[1] : (k == 2u) ? rw[2] : rw[3];
-            const uint32_t src = (lane & ~7u) + ((t >> 2) & 7u);
-            const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)mine);
-            u = (float)(w >> 8) * (1.0f / 16777216.0f);
-        }
-
-        // ---- legal moves of the side to move
-        const uint64_t o = to_lane(own, L), p = to_lane(opp, L);
-        const uint64_t legal = group8_legal(o, p, L);
-        const bool has = legal != 0ull;
-
-        // ---- RolloutPolicy logits of row r
-        float l[8];
+            const int src = (int)(((lane & ~7u) + ((t4 >> 2) & 7u)) << 2);
 #pragma unroll
-        for (int x = 0; x < 8; x++)
-            l[x] = bias[x];
-        if (use_net) {
-            const uint32_t wo = ((uint32_t)(own >> sh_r) << sh_l) & 0xFFFFFFu;
-            const uint32_t wp = ((uint32_t)(opp >> sh_r) << sh_l) & 0xFFFFFFu;
-#pragma unroll
-            for (int ky = 0; ky < 3; ky++) {
-                const uint32_t bo = (wo >> (8 * ky)) & 0xFFu; // own stones: plane 1
-                const uint32_t bp = (wp >> (8 * ky)) & 0xFFu; // opp stones: plane 0
-                const float *tp = tbl + ((ky * 2 + 0) * 256 + bp) * 8;
-                const float *to = tbl + ((ky * 2 + 1) * 256 + bo) * 8;
-                const float4 a0 = lds_f4(tp), a1 = lds_f4(tp + 4);
-                const float4 c0 = lds_f4(to), c1 = lds_f4(to + 4);
-                l[0] += a0.x; l[1] += a0.y; l[2] += a0.z; l[3] += a0.w;
-                l[4] += a1.x; l[5] += a1.y; l[6] += a1.z; l[7] += a1.w;
-                l[0] += c0.x; l[1] += c0.y; l[2] += c0.z; l[3] += c0.w;
-                l[4] += c1.x; l[5] += c1.y; l[6] += c1.z; l[7] += c1.w;
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rw[k]);
+                u4[k] = (float)(w >> 8) * (1.0f / 16777216.0f);
             }
         }
-
-        // ---- masked softmax + inverse-CDF sample
-        const uint32_t lr = (uint32_t)(legal >> (8u * r)) & 0xFFu;
-        float m = -INFINITY;
-#pragma unroll
-        for (int x = 0; x < 8; x++) {
-            l[x] = ((lr >> x) & 1u) ? l[x] : -INFINITY;
-            m = fmaxf(m, l[x]);
-        }
-        m = group8_max(m);
-        float c[8];
-        float acc = 0.0f;
-#pragma unroll
-        for (int x = 0; x < 8; x++) {
-            const float e = ((lr >> x) & 1u) ? __builtin_amdgcn_exp2f((l[x] - m) * LOG2E) : 0.0f;
-            acc += e;
-            c[x] = acc;
-        }
-        float start, total;
-        group8_scan(acc, r, start, total);
-        const float thr = u * total;
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int x = 0; x < 8; x++)
-            cnt += ((start + c[x]) <= thr) ? 1u : 0u;
-        cnt = group8_add(cnt);
-        // first legal cell at or above the sampled index; the last legal cell if
-        // rounding pushed the threshold past the total
-        const uint64_t rem = (cnt < 64u) ? (legal & (~0ull << cnt)) : 0ull;
-        const uint32_t action =
-            rem ? (uint32_t)__builtin_ctzll(rem) : (63u - (uint32_t)__builtin_clzll(legal | 1ull));
-
-        // ---- flips and board update
-        const uint64_t f = group8_flips(o, p, action & 63u, L, ray);
-        const bool play = has && !done;
-        if (play) {
-            const uint64_t bit = 1ull << (action & 63u);
-            own = own | f | bit;
-            opp = opp & ~f;
-            stones += 1u;
-            pass_flg = false;
-        } else if (!done) {
-            if (pass_flg)
-                stones = 64u; // double pass ends the game (mcts_self_play.py:131-133)
-            pass_flg = true;
-        }
-        if (!done) {
-            if (P.trace && r == 0u)
-                P.trace[(int64_t)t * P.n + b] = play ? (uint8_t)action : (uint8_t)IAGO_TRACE_PASS;
-            const uint64_t tmp = own; // the other side moves next
-            own = opp;
-            opp = tmp;
-            nt += 1u;
-        }
-        // `while stone_num < 64` is evaluated once per pair of turns
-        if (t & 1u)
-            done = done || stones >= 64u;
-        if (__builtin_amdgcn_ballot_w64(!done) == 0ull)
+        play_turn<PRODUCT>(G, u4[0], t4 + 0, L, tbl, ray, bias, sh_r, sh_l, P, b);
+        play_turn<PRODUCT>(G, u4[1], t4 + 1, L, tbl, ray, bias, sh_r, sh_l, P, b);
+        if (__builtin_amdgcn_ballot_w64(!G.done) == 0ull)
+            break;
+        play_turn<PRODUCT>(G, u4[2], t4 + 2, L, tbl, ray, bias, sh_r, sh_l, P, b);
+        play_turn<PRODUCT>(G, u4[3], t4 + 3, L, tbl, ray, bias, sh_r, sh_l, P, b);
+        if (__builtin_amdgcn_ballot_w64(!G.done) == 0ull)
             break;
     }
 
     if (live && r == 0u) {
         // nt is even: `own` is the side that was to move at the leaf again
-        const int d = __popcll(own) - __popcll(opp);
+        const int d = __popcll(G.own) - __popcll(G.opp);
         P.z[b] = (int8_t)((d > 0) - (d < 0));
         if (P.final_own)
-            P.final_own[b] = own;
+            P.final_own[b] = G.own;
         if (P.final_opp)
-            P.final_opp[b] = opp;
+            P.final_opp[b] = G.opp;
         if (P.n_turns)
-            P.n_turns[b] = (uint8_t)nt;
+            P.n_turns[b] = (uint8_t)G.nt;
     }
 }
 
@@ -222,25 +304,64 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
 
 extern "C" {
 
-int iago_rollout_build_table(const float *w18, float *table)
+int iago_rollout_build_table(const float *w18, const float *b64, float *blob)
 {
-    if (!w18 || !table)
+    if (!blob || (w18 && !b64))
         return iago_fail(IAGO_ERR_INVALID, "iago_rollout_build_table: null pointer");
-    // T[ky][plane][byte][x] = sum_kx W[plane][ky][kx] * bit(byte, x + kx - 1)
+    // T[ky][plane][byte][x] = sum_kx W[plane][ky][kx] * bit(byte, x + kx - 1), float32
+    // accumulation in kx order; w18 == NULL: uniform policy (all contributions 0)
+    static thread_local float T[3][2][256][8];
+    double tmax[3][2], tmin[3][2];
+    for (int ky = 0; ky < 3; ky++)
+        for (int pl = 0; pl < 2; pl++) {
+            tmax[ky][pl] = -1e300;
+            tmin[ky][pl] = 1e300;
+            for (int byte = 0; byte < 256; byte++)
+                for (int x = 0; x < 8; x++) {
+                    float acc = 0.0f;
+                    for (int kx = 0; kx < 3 && w18; kx++) {
+                        const int xx = x + kx - 1;
+                        if (xx >= 0 && xx <= 7 && ((byte >> xx) & 1))
+                            acc += w18[pl * 9 + ky * 3 + kx];
+                    }
+                    T[ky][pl][byte][x] = acc;
+                    if (acc > tmax[ky][pl]) tmax[ky][pl] = acc;
+                    if (acc < tmin[ky][pl]) tmin[ky][pl] = acc;
+                }
+        }
+    double lmax = -1e300, lmin = 1e300;
+    for (int x = 0; x < 64; x++) {
+        const double bv = w18 ? (double)b64[x] : 0.0;
+        if (bv > lmax) lmax = bv;
+        if (bv < lmin) lmin = bv;
+    }
+    for (int ky = 0; ky < 3; ky++)
+        for (int pl = 0; pl < 2; pl++) {
+            lmax += tmax[ky][pl];
+            lmin += tmin[ky][pl];
+        }
+    // Product form needs every partial product of the 7 factors inside float32's
+    // normal range: with the shift spread evenly the largest full product is 1
+    // and the smallest exp(lmin - lmax).
+    const bool product = std::isfinite(lmax) && std::isfinite(lmin) && (lmax - lmin) < 60.0;
+    const double shift = product ? -lmax / 7.0 : 0.0;
     for (int ky = 0; ky < 3; ky++)
         for (int pl = 0; pl < 2; pl++)
             for (int byte = 0; byte < 256; byte++)
                 for (int x = 0; x < 8; x++) {
-                    float acc = 0.0f;
-                    for (int kx = 0; kx < 3; kx++) {
-                        const int xx = x + kx - 1;
-                        if (xx < 0 || xx > 7)
-                            continue;
-                        if ((byte >> xx) & 1)
-                            acc += w18[pl * 9 + ky * 3 + kx];
-                    }
-                    table[((ky * 2 + pl) * 256 + byte) * 8 + x] = acc;
+                    const float tv = T[ky][pl][byte][x];
+                    const float v = product ? (float)exp((double)tv + shift) : tv;
+                    blob[OFF_E + (((ky * 2 + pl) * 2 + (x >> 2)) * 256 + byte) * 4 + (x & 3)] = v;
                 }
+    for (int byte = 0; byte < 256; byte++)
+        for (int x = 0; x < 8; x++)
+            blob[OFF_LM + ((x >> 2) * 256 + byte) * 4 + (x & 3)] = ((byte >> x) & 1) ? 1.0f : 0.0f;
+    for (int x = 0; x < 64; x++) {
+        const float bv = w18 ? b64[x] : 0.0f;
+        blob[OFF_BIAS + x] = product ? (float)exp((double)bv + shift) : bv;
+    }
+    blob[OFF_MODE] = product ? 1.0f : 0.0f;
+    blob[OFF_MODE + 1] = blob[OFF_MODE + 2] = blob[OFF_MODE + 3] = 0.0f;
     return IAGO_OK;
 }
 
@@ -252,18 +373,17 @@ int iago_rollout(const iago_rollout_args *a, void *stream)
         return iago_fail(IAGO_ERR_INVALID, "iago_rollout: n out of range");
     if (a->n == 0)
         return IAGO_OK;
-    if (!a->own || !a->opp || !a->z)
-        return iago_fail(IAGO_ERR_INVALID, "iago_rollout: own/opp/z must not be null");
-    if (!a->uniform_policy && (!a->table || !a->bias))
-        return iago_fail(IAGO_ERR_INVALID, "iago_rollout: table/bias required unless uniform_policy");
-    if (a->table && ((uintptr_t)a->table & 15u))
+    if (!a->own || !a->opp || !a->z || !a->table)
+        return iago_fail(IAGO_ERR_INVALID, "iago_rollout: own/opp/z/table must not be null");
+    if ((uintptr_t)a->table & 15u)
         return iago_fail(IAGO_ERR_INVALID, "iago_rollout: table must be 16-byte aligned");
+    if (a->log_form != 0 && a->log_form != 1)
+        return iago_fail(IAGO_ERR_INVALID, "iago_rollout: log_form must be 0 or 1");
     RolloutParams P;
     P.own = a->own;
     P.opp = a->opp;
     P.n = a->n;
-    P.table = a->table;
-    P.bias = a->bias;
+    P.blob = a->table;
     P.uniforms = a->uniforms;
     P.key0 = (uint32_t)a->seed;
     P.key1 = (uint32_t)(a->seed >> 32);
@@ -274,14 +394,17 @@ int iago_rollout(const iago_rollout_args *a, void *stream)
     P.final_opp = a->final_opp;
     P.n_turns = a->n_turns;
     P.trace = a->trace;
-    P.uniform_policy = a->uniform_policy;
     // 8 lanes per board; 4 waves (32 boards) per block share one staging of the
-    // 48 KiB table.  The kernel is latency-bound per wave, so 4 waves on the 4
+    // 56 KiB of tables.  The kernel is latency-bound per wave, so 4 waves on the 4
     // SIMDs of one CU run as fast as on 4 CUs.
     const int64_t threads = a->n * 8;
     const int block = (threads >= 256) ? 256 : 64;
     const unsigned grid = (unsigned)((threads + block - 1) / block);
-    hipLaunchKernelGGL(rollout_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, P);
+    if (a->log_form)
+        hipLaunchKernelGGL(rollout_kernel<false>, dim3(grid), dim3(block), 0, (hipStream_t)stream,
+                           P);
+    else
+        hipLaunchKernelGGL(rollout_kernel<true>, dim3(grid), dim3(block), 0, (hipStream_t)stream, P);
     return iago_check_launch("iago_rollout");
 }
 

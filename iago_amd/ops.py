@@ -101,18 +101,32 @@ def sample_moves(probs, legal, uniforms=None, seed=0, id_base=0, step=0, stream_
 
 class RolloutWeights(object):
     """Device-resident RolloutPolicy parameters (network.py:49-64) in the form
-    the rollout kernel consumes: the 48 KiB row table and the 64 biases."""
+    the rollout kernel consumes (the table blob of iago_rollout_build_table).
+    w = None builds the uniform policy."""
 
-    def __init__(self, w, b, device="cuda"):
-        w = np.ascontiguousarray(np.asarray(w, dtype=np.float32).reshape(18))
-        b = np.ascontiguousarray(np.asarray(b, dtype=np.float32).reshape(64))
-        table = np.empty(IAGO_ROLLOUT_TABLE_FLOATS, dtype=np.float32)
-        check(_lib.lib().iago_rollout_build_table(C.c_void_p(w.ctypes.data),
-                                                  C.c_void_p(table.ctypes.data)),
+    def __init__(self, w=None, b=None, device="cuda"):
+        blob = np.empty(IAGO_ROLLOUT_TABLE_FLOATS, dtype=np.float32)
+        if w is None:
+            self.w = self.b = None
+            wp = bp = None
+        else:
+            self.w = np.ascontiguousarray(np.asarray(w, dtype=np.float32).reshape(18))
+            self.b = np.ascontiguousarray(np.asarray(b, dtype=np.float32).reshape(64))
+            wp, bp = C.c_void_p(self.w.ctypes.data), C.c_void_p(self.b.ctypes.data)
+        check(_lib.lib().iago_rollout_build_table(wp, bp, C.c_void_p(blob.ctypes.data)),
               "iago_rollout_build_table")
-        self.w, self.b = w, b
-        self.table = torch.from_numpy(table).to(device)
-        self.bias = torch.from_numpy(b).to(device)
+        self.log_form = 0 if blob[-4] == 1.0 else 1
+        self.table = torch.from_numpy(blob).to(device)
+
+
+_UNIFORM = {}
+
+
+def uniform_weights(device="cuda"):
+    key = str(device)
+    if key not in _UNIFORM:
+        _UNIFORM[key] = RolloutWeights(None, None, device)
+    return _UNIFORM[key]
 
 
 class RolloutResult(object):
@@ -146,12 +160,10 @@ def rollout(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=Non
     a.own = _dev(own, torch.int64, "own")
     a.opp = _dev(opp, torch.int64, "opp")
     a.n = n
-    if weights is not None:
-        a.table = _dev(weights.table, torch.float32, "table")
-        a.bias = _dev(weights.bias, torch.float32, "bias")
-        a.uniform_policy = 0
-    else:
-        a.uniform_policy = 1
+    if weights is None:
+        weights = uniform_weights(dev)
+    a.table = _dev(weights.table, torch.float32, "table")
+    a.log_form = weights.log_form
     if uniforms is not None:
         if tuple(uniforms.shape) != (IAGO_MAX_TURNS, n):
             raise ValueError("uniforms must have shape (%d, n)" % IAGO_MAX_TURNS)

@@ -48,7 +48,7 @@ typedef enum iago_status {
 #define IAGO_PASS (-1)          /* pass action, game.py:181 */
 #define IAGO_TRACE_PASS 0xFF    /* pass marker in uint8 action traces */
 #define IAGO_MAX_TURNS 128      /* upper bound on turns of one game (<= 124) */
-#define IAGO_ROLLOUT_TABLE_FLOATS (3 * 2 * 256 * 8)
+#define IAGO_ROLLOUT_TABLE_FLOATS (3 * 2 * 256 * 8 + 256 * 8 + 64 + 4)
 
 IAGO_API int iago_abi_version(void);
 IAGO_API const char *iago_last_error(void);
@@ -119,18 +119,25 @@ IAGO_API int iago_sample_moves(const float *probs, const uint64_t *legal, const 
 /*
  * Host helper: expand RolloutPolicy parameters (network.py:49-64; conv1/W
  * (1,2,3,3) as 18 floats, channel 0 = opponent plane, channel 1 = side to
- * move) into the row-lookup tables the rollout kernel stages in LDS.
- * w18, table are HOST pointers; table has IAGO_ROLLOUT_TABLE_FLOATS floats
- * and is then copied to the device by the caller.
+ * move; bias2/b as 64 floats) into the table blob the rollout kernel stages in
+ * LDS.  w18, b64, blob are HOST pointers; blob has IAGO_ROLLOUT_TABLE_FLOATS
+ * floats and is then copied to the device by the caller.  w18 == NULL builds
+ * the uniform policy (every legal move equally likely).
+ * Layout: E[3 ky][2 plane][2 half][256 row byte][4] row-pattern contributions
+ * to 8 adjacent outputs; LM[2 half][256][4] 1.0/0.0 legal-cell multipliers;
+ * bias[64]; mode[4].  mode[0] == 1: PRODUCT form (E and bias hold exp() of the
+ * contributions, shifted so that the largest softmax numerator is 1), chosen
+ * when the logit range is < 60 so that no partial product leaves float32's
+ * range; mode[0] == 0: LOG form (raw sums; the kernel does max / exp2).  Pass
+ * log_form = (mode[0] == 0) to iago_rollout.
  */
-IAGO_API int iago_rollout_build_table(const float *w18, float *table);
+IAGO_API int iago_rollout_build_table(const float *w18, const float *b64, float *blob);
 
 typedef struct iago_rollout_args {
     const uint64_t *own;     /* [n] side to move at the leaf */
     const uint64_t *opp;     /* [n] */
     int64_t n;
-    const float *table;      /* device, from iago_rollout_build_table */
-    const float *bias;       /* device, 64 floats (bias2/b) */
+    const float *table;      /* device copy of the blob from iago_rollout_build_table */
     const float *uniforms;   /* optional device [IAGO_MAX_TURNS][n] float32 in [0,1); NULL = Philox */
     uint64_t seed;           /* Philox4x32-10 key */
     uint32_t id_base;        /* rollout b draws from counter (id_base + b, turn/4, stream, 0) */
@@ -140,7 +147,7 @@ typedef struct iago_rollout_args {
     uint64_t *final_opp;     /* optional [n] */
     uint8_t *n_turns;        /* optional [n]: turns played (passes included) */
     uint8_t *trace;          /* optional [IAGO_MAX_TURNS][n]: action per turn, 0xFF = pass */
-    int uniform_policy;      /* 1: ignore table/bias, every legal move equally likely */
+    int log_form;            /* 0: blob is in PRODUCT form, 1: LOG form (see above) */
 } iago_rollout_args;
 
 /*
