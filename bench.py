@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--large-boards", type=int, default=1 << 20,
+                    help="extra occupancy datapoint: boards in one launch (0 = skip)")
     ap.add_argument("--mcts-games", type=int, default=1024)
     ap.add_argument("--mcts-sims", type=int, default=100)
     ap.add_argument("--mcts-turns", type=int, default=2,
@@ -230,6 +232,32 @@ def main():
     dt = float(tmax.item())
     board_steps = int(steps_total.item())
 
+    # the same kernel with the chip full (not the headline config): occupancy evidence
+    large = None
+    if args.large_boards > 0 and rank == 0:
+        LB = args.large_boards
+        lown = torch.full((LB,), START_OWN, dtype=torch.int64, device="cuda")
+        lopp = torch.full((LB,), START_OPP, dtype=torch.int64, device="cuda")
+        lout = ops.RolloutResult()
+        lout.z = torch.empty(LB, dtype=torch.int8, device="cuda")
+        lout.n_turns = torch.empty(LB, dtype=torch.uint8, device="cuda")
+        for k in range(3):
+            ops.rollout(lown, lopp, weights, seed=1, id_base=0, stream_id=k, out=lout)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        LK = 10
+        for k in range(LK):
+            ops.rollout(lown, lopp, weights, seed=2, id_base=0, stream_id=k, out=lout)
+        e1.record()
+        torch.cuda.synchronize()
+        lms = e0.elapsed_time(e1) / LK
+        lsteps = int(lout.n_turns.to(torch.int64).sum().item())
+        large = {"boards": LB, "kernel_ms": lms, "games_per_sec": LB / (lms * 1e-3),
+                 "board_steps_per_sec": lsteps / (lms * 1e-3),
+                 "hbm_frac": BYTES_PER_BOARD_STEP * lsteps / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del lown, lopp, lout
+
     mcts = None
     if args.mcts_turns > 0 or args.mcts_full:
         mcts = mcts_leg(args.mcts_games, args.mcts_sims, args.mcts_turns, args.mcts_full, world,
@@ -256,6 +284,8 @@ def main():
                          "kernel": "rollout_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch},
         }
+        if large is not None:
+            line["large_batch"] = large
         if mcts is not None:
             line["mcts"] = mcts
         if not args.no_cpu_baseline:

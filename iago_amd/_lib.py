@@ -12,7 +12,7 @@ SO_PATH = os.path.join(HERE, "libiago_hip.so")
 
 IAGO_OK = 0
 IAGO_MAX_TURNS = 128
-IAGO_ROLLOUT_TABLE_FLOATS = 3 * 2 * 256 * 8 + 256 * 8 + 64 + 4
+IAGO_ROLLOUT_TABLE_FLOATS = 3 * 2 * 256 * 8 + 64 + 4
 TRACE_PASS = 0xFF
 
 # every symbol include/iago_hip.h declares (tests/test_abi.py checks the list

@@ -69,9 +69,6 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(
     int32_t *__restrict__ cur_node, uint64_t *__restrict__ cur_own, uint64_t *__restrict__ cur_opp,
     uint8_t *__restrict__ needs_expand, uint64_t *__restrict__ legal_out)
 {
-    __shared__ uint64_t ray[RAY_TABLE_WORDS];
-    fill_ray_table(ray);
-    __syncthreads();
 
     const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int64_t g = gtid >> 3;
@@ -114,7 +111,7 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(
         const int a = descending ? (int)T.action[base + child] : -1;
         // GameFunctions.place_stone(state, action, c); c = 3 - c  (MCTS.py:131-132)
         const uint64_t f =
-            group8_flips(to_lane(own, L), to_lane(opp, L), (uint32_t)a & 63u, L, ray);
+            group8_flips(to_lane(own, L), to_lane(opp, L), (uint32_t)a & 63u, L);
         if (descending) {
             uint64_t no = own, np_ = opp;
             if (a >= 0) {

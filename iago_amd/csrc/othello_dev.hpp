@@ -85,21 +85,41 @@ __device__ __forceinline__ uint64_t rev64(uint64_t x) { return __builtin_bitreve
 
 // Per-lane constants of the group-of-8 decomposition.
 struct Lane8 {
-    uint32_t l8;   // lane index inside the group, 0..7
-    uint32_t s;    // left-shift of this lane's direction: 1, 7, 8, 9
-    uint64_t mask; // destination mask that kills A/H-file wrap-around
-    bool rev;      // lanes 4..7 work on the bit-reversed board
+    uint32_t l8;    // lane index inside the group, 0..7
+    uint32_t s;     // left-shift of this lane's direction: 1, 7, 8, 9
+    uint64_t mask;  // destination mask that kills A/H-file wrap-around
+    uint64_t base;  // ray of this direction from cell 0, without cell 0 (see ray_mask)
+    uint32_t ca, cx; // column-mask recipe of ray_mask
+    bool rev;       // lanes 4..7 work on the bit-reversed board
 };
 
 __device__ __forceinline__ Lane8 make_lane8(uint32_t tid)
 {
     Lane8 L;
     L.l8 = tid & 7u;
-    uint32_t k = L.l8 & 3u;
-    L.s = (k == 0) ? 1u : (6u + k); // 1,7,8,9
+    const uint32_t k = L.l8 & 3u; // 0: E (+1), 1: SW (+7), 2: S (+8), 3: SE (+9)
+    L.s = (k == 0) ? 1u : (6u + k);
     L.mask = (k == 1) ? ~FILE_H : ((k == 2) ? ~0ull : ~FILE_A);
+    L.base = (k == 0)   ? 0x00000000000000FEull
+             : (k == 1) ? 0x0002040810204080ull
+             : (k == 2) ? 0x0101010101010100ull
+                        : 0x8040201008040200ull;
+    // columns a ray cell may have: E, SE: > col(pos); SW: < col(pos); S: any
+    L.ca = (k == 1) ? 0xFFu : ((k == 2) ? 0u : 0xFEu);
+    L.cx = (k == 0 || k == 3) ? 0u : 0xFFu;
     L.rev = L.l8 >= 4u;
     return L;
+}
+
+// Cells strictly beyond `pl` (a cell index in the LANE's orientation) along the
+// lane's direction, up to the board edge: the direction's ray from cell 0
+// shifted to pl, with the cells that wrapped around the A/H files removed by a
+// column mask ((ca << col) ^ cx, replicated to the 8 rows with v_perm_b32).
+__device__ __forceinline__ uint64_t ray_mask(const Lane8 &L, uint32_t pl)
+{
+    const uint32_t m8 = (L.ca << (pl & 7u)) ^ L.cx;
+    const uint32_t m32 = __builtin_amdgcn_perm(m8, m8, 0u); // byte 0 of m8 in all 4 bytes
+    return (L.base << pl) & (((uint64_t)m32 << 32) | m32);
 }
 
 // Board in the lane's own orientation.
@@ -134,40 +154,15 @@ __device__ __forceinline__ uint64_t group8_legal(uint64_t o, uint64_t p, const L
     return group8_or(to_lane(((uint64_t)vh << 32) | vl, L));
 }
 
-// Ray masks: ray[k][pos] = cells strictly beyond `pos` in the direction with
-// left shift s_k (k = 0..3 -> 1, 7, 8, 9), stopping at the board edge.
-__device__ __forceinline__ uint64_t make_ray(uint32_t k, uint32_t pos)
-{
-    int dr = (k == 0) ? 0 : 1;
-    int dc = (k == 0) ? 1 : ((k == 1) ? -1 : ((k == 2) ? 0 : 1));
-    int r = (int)(pos >> 3) + dr, c = (int)(pos & 7) + dc;
-    uint64_t m = 0;
-    while (r >= 0 && r < 8 && c >= 0 && c < 8) {
-        m |= 1ull << (r * 8 + c);
-        r += dr;
-        c += dc;
-    }
-    return m;
-}
-constexpr int RAY_TABLE_WORDS = 4 * 64;
-
-// Fill a [4][64] ray table in LDS (call from every thread of the block, then barrier).
-__device__ __forceinline__ void fill_ray_table(uint64_t *ray)
-{
-    for (uint32_t i = threadIdx.x; i < (uint32_t)RAY_TABLE_WORDS; i += blockDim.x)
-        ray[i] = make_ray(i >> 6, i & 63u);
-}
-
 // Stones flipped by `own` playing at `pos` (reference: game.py:180-207, no
 // legality check).  Each lane resolves its ray with one carry propagation:
 // adding 1 to (opp | ~ray) ripples through the contiguous opponent stones next
 // to `pos` and stops on the first ray cell that is not an opponent stone; the
 // run is flipped iff that cell holds an own stone.
 __device__ __forceinline__ uint64_t group8_flips(uint64_t o, uint64_t p, uint32_t pos,
-                                                 const Lane8 &L, const uint64_t *ray)
+                                                 const Lane8 &L)
 {
-    const uint32_t pl = L.rev ? 63u - pos : pos;
-    const uint64_t M = ray[(L.l8 & 3u) * 64u + pl];
+    const uint64_t M = ray_mask(L, L.rev ? 63u - pos : pos);
     const uint64_t x = p | ~M;
     const uint64_t t = x + 1ull;
     const uint64_t cand = (t ^ x) & M & p;

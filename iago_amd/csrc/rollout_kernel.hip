@@ -17,11 +17,11 @@
 //      v_exp_f32, no max pass (the host checks the dynamic range and selects
 //      the LOG form -- sum, max, exp2 -- when a product could under/overflow);
 //   3. masked inverse-CDF sampling in cell order (numpy.random.choice
-//      semantics, mcts_self_play.py:103-106): illegal cells are zeroed with a
-//      0/1 multiplier row from LDS, per-lane running sums, a 3-step DPP scan
+//      semantics, mcts_self_play.py:103-106): illegal cells are zeroed with
+//      bit-field masks, per-lane running sums, a 3-step DPP scan
 //      across the 8 rows; the sampled cell index is the number of cells whose
 //      CDF is <= u * total;
-//   4. flips: direction-per-lane carry propagation against LDS ray masks;
+//   4. flips: direction-per-lane carry propagation against computed ray masks;
 //   5. pass / double pass / full board bookkeeping in the reference's
 //      paired-turn loop (mcts_self_play.py:25-29,124-134).
 // Uniforms come from Philox4x32-10: the 8 lanes of a group generate 8 counter
@@ -41,12 +41,10 @@ namespace {
 // blob layout (floats), see iago_rollout_build_table
 constexpr int OFF_E = 0;                       // E[ky][plane][half][byte][4]
 constexpr int N_E = 3 * 2 * 2 * 256 * 4;       // 12288
-constexpr int OFF_LM = OFF_E + N_E;            // LM[half][byte][4]: 1.0 / 0.0 per legal bit
-constexpr int N_LM = 2 * 256 * 4;              // 2048
-constexpr int OFF_BIAS = OFF_LM + N_LM;        // 64
+constexpr int OFF_BIAS = OFF_E + N_E;          // 64
 constexpr int OFF_MODE = OFF_BIAS + 64;        // 1.0 = product form, 0.0 = log form
 static_assert(OFF_MODE + 4 == IAGO_ROLLOUT_TABLE_FLOATS, "blob size");
-constexpr int LDS_FLOATS = N_E + N_LM;
+constexpr int LDS_FLOATS = N_E; // the legal-cell multipliers are computed on the VALU
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct RolloutParams {
@@ -84,17 +82,37 @@ __device__ __forceinline__ void add8(Row8 &e, const float4 lo, const float4 hi)
     e.d += (f2){hi.z, hi.w};
 }
 
+#ifdef EXP_STAMPS
+#define STAMP(i)                                                                      \
+    do {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        unsigned long long t_;                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        G.seg[i] += t_ - G.last;                                                      \
+        G.last = t_;                                                                  \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 // Per-board state carried across turns (replicated in the 8 lanes of the group).
 struct Game {
     uint64_t own, opp; // own = side to move
     uint32_t stones;   // stone_num (mcts_self_play.py:15)
     uint32_t nt;       // turns played
-    bool pass_flg, done;
+    // pass_flg / done as 0/1 integers in VGPRs: the per-turn bookkeeping stays on
+    // the VALU (compare results routed through SGPR masks and SALU logic cost a
+    // VALU->SALU->VALU round trip per term)
+    uint32_t pass_flg, done;
+#ifdef EXP_STAMPS
+    unsigned long long seg[6], last;
+#endif
 };
 
 template <bool PRODUCT>
 __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t t,
-                                          const Lane8 &L, const float *tbl, const uint64_t *ray,
+                                          const Lane8 &L, const float *tbl,
                                           const float (&bias)[8], const uint32_t sh_r,
                                           const uint32_t sh_l, const RolloutParams &P,
                                           const int64_t b)
@@ -106,8 +124,13 @@ __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t
     float4 ta[6], tb[6];
 #pragma unroll
     for (int ky = 0; ky < 3; ky++) {
+#ifdef EXP_CONST_E
+        const uint32_t bp = (wp >> (8 * ky)) & 0x1u;
+        const uint32_t bo = (wo >> (8 * ky)) & 0x1u;
+#else
         const uint32_t bp = (wp >> (8 * ky)) & 0xFFu;
         const uint32_t bo = (wo >> (8 * ky)) & 0xFFu;
+#endif
         const float *tp = tbl + OFF_E + ((ky * 2 + 0) * 2) * 1024 + bp * 4;
         const float *to = tbl + OFF_E + ((ky * 2 + 1) * 2) * 1024 + bo * 4;
         ta[2 * ky] = lds_f4(tp);
@@ -116,13 +139,14 @@ __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t
         tb[2 * ky + 1] = lds_f4(to + 1024);
     }
 
+    STAMP(0); // window + E-read issue
     // ---- legal moves of the side to move
     const uint64_t o = to_lane(G.own, L), p = to_lane(G.opp, L);
     const uint64_t legal = group8_legal(o, p, L);
-    const bool has = legal != 0ull;
+    const uint32_t has = min(1u, (uint32_t)legal | (uint32_t)(legal >> 32)); // 0/1
     const uint32_t lr = (uint32_t)(legal >> (8u * r)) & 0xFFu;
-    const float4 lm0 = lds_f4(tbl + OFF_LM + lr * 4), lm1 = lds_f4(tbl + OFF_LM + 1024 + lr * 4);
 
+    STAMP(1); // movegen + LM issue
     // ---- unnormalised probabilities e[x] of row r, zero on illegal cells
     Row8 E;
     E.a = (f2){bias[0], bias[1]};
@@ -133,25 +157,32 @@ __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t
 #pragma unroll
         for (int k = 0; k < 6; k++)
             mul8(E, ta[k], tb[k]);
-        mul8(E, lm0, lm1);
     } else {
 #pragma unroll
         for (int k = 0; k < 6; k++)
             add8(E, ta[k], tb[k]);
     }
     float e[8] = {E.a.x, E.a.y, E.b.x, E.b.y, E.c.x, E.c.y, E.d.x, E.d.y};
-    if (!PRODUCT) {
-        const float lmv[8] = {lm0.x, lm0.y, lm0.z, lm0.w, lm1.x, lm1.y, lm1.z, lm1.w};
+    // legality of the row's cells as all-ones / zero words (v_bfe_i32 of one bit)
+    uint32_t lmask[8];
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+        lmask[x] = (uint32_t)((int32_t)(lr << (31 - x)) >> 31);
+    if (PRODUCT) {
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+            e[x] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, e[x]) & lmask[x]);
+    } else {
         float m = -INFINITY;
 #pragma unroll
         for (int x = 0; x < 8; x++) {
-            e[x] = (lmv[x] != 0.0f) ? e[x] : -INFINITY;
+            e[x] = lmask[x] ? e[x] : -INFINITY;
             m = fmaxf(m, e[x]);
         }
         m = group8_max(m);
 #pragma unroll
         for (int x = 0; x < 8; x++)
-            e[x] = (lmv[x] != 0.0f) ? __builtin_amdgcn_exp2f((e[x] - m) * LOG2E) : 0.0f;
+            e[x] = lmask[x] ? __builtin_amdgcn_exp2f((e[x] - m) * LOG2E) : 0.0f;
     }
 
     // ---- inverse-CDF sample in cell order
@@ -181,7 +212,7 @@ __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t
     uint32_t action = cnt;
     // Rounding can leave the count one cell off a legal one (or at 64): take
     // the next legal cell, else the last one.  Rare, so branch per wave.
-    const bool bad = has && (cnt > 63u || ((legal >> (cnt & 63u)) & 1ull) == 0ull);
+    const bool bad = (has != 0u) && (cnt > 63u || ((legal >> (cnt & 63u)) & 1ull) == 0ull);
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
         const uint64_t rem = (cnt < 64u) ? (legal & (~0ull << cnt)) : 0ull;
         const uint32_t fix =
@@ -190,18 +221,22 @@ __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t
     }
     action &= 63u;
 
+    STAMP(3); // cumsum, scan, count, fix-up
     // ---- flips and board update (branch-free)
-    const uint64_t f = group8_flips(o, p, action, L, ray);
-    const bool live_turn = !G.done;
-    const bool play = has && live_turn;
-    const bool passing = !has && live_turn;
-    const uint64_t fm = play ? f : 0ull;
-    const uint64_t bit = (uint64_t)(play ? 1u : 0u) << action;
+    const uint64_t f = group8_flips(o, p, action, L);
+    STAMP(4); // flips
+    const uint32_t live_turn = G.done ^ 1u;
+    const uint32_t play = has & live_turn;
+    const uint32_t passing = (has ^ 1u) & live_turn;
+    const uint32_t pm = 0u - play; // all ones iff a stone is placed
+    const uint64_t fm = f & (((uint64_t)pm << 32) | pm);
+    const uint64_t bit = (uint64_t)play << action;
     const uint64_t nown = G.own | fm | bit;
     const uint64_t nopp = G.opp & ~fm;
-    G.stones += play ? 1u : 0u;
-    G.stones = (passing && G.pass_flg) ? 64u : G.stones; // double pass (mcts_self_play.py:131-133)
-    G.pass_flg = live_turn ? passing : G.pass_flg;
+    // stone_num += 1 on a move; a second consecutive pass sets it to 64
+    // (mcts_self_play.py:126-133); stones never exceeds 64 otherwise
+    G.stones = max(G.stones + play, (passing & G.pass_flg) << 6);
+    G.pass_flg = (G.pass_flg & G.done) | passing;
     if (P.trace && live_turn && r == 0u)
         P.trace[(int64_t)t * P.n + b] = play ? (uint8_t)action : (uint8_t)IAGO_TRACE_PASS;
     // The other side moves next.  Finished boards keep swapping too: `done` is
@@ -209,24 +244,23 @@ __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t
     // board is swapped an even number of times and ends in its final orientation.
     G.own = nopp;
     G.opp = nown;
-    G.nt += live_turn ? 1u : 0u;
+    G.nt += live_turn;
     // `while stone_num < 64` is evaluated once per pair of turns (mcts_self_play.py:26-28)
     if (t & 1u)
-        G.done = G.done || G.stones >= 64u;
+        G.done |= G.stones >> 6;
+    STAMP(5); // update
 }
 
 template <bool PRODUCT>
 __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
 {
     __shared__ __attribute__((aligned(16))) float tbl[LDS_FLOATS];
-    __shared__ uint64_t ray[RAY_TABLE_WORDS];
     {
         const float4 *src = (const float4 *)P.blob;
         float4 *dst = (float4 *)tbl;
         for (uint32_t i = threadIdx.x; i < (uint32_t)(LDS_FLOATS / 4); i += blockDim.x)
             dst[i] = src[i];
     }
-    fill_ray_table(ray);
     __syncthreads();
 
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,9 +273,14 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
     G.own = live ? P.own[b] : 0ull;
     G.opp = live ? P.opp[b] : 0ull;
     G.stones = (uint32_t)__popcll(G.own | G.opp);
-    G.pass_flg = false;
-    G.done = !live || G.stones >= 64u; // `while stone_num < 64` (mcts_self_play.py:26)
+    G.pass_flg = 0u;
+    G.done = (!live || G.stones >= 64u) ? 1u : 0u; // `while stone_num < 64` (mcts_self_play.py:26)
     G.nt = 0;
+#ifdef EXP_STAMPS
+    for (int i = 0; i < 6; i++)
+        G.seg[i] = 0;
+    G.last = __builtin_amdgcn_s_memtime();
+#endif
 
     float bias[8]; // this lane's row of bias2/b (exp'ed in product form)
 #pragma unroll
@@ -277,13 +316,13 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
                 u4[k] = (float)(w >> 8) * (1.0f / 16777216.0f);
             }
         }
-        play_turn<PRODUCT>(G, u4[0], t4 + 0, L, tbl, ray, bias, sh_r, sh_l, P, b);
-        play_turn<PRODUCT>(G, u4[1], t4 + 1, L, tbl, ray, bias, sh_r, sh_l, P, b);
-        if (__builtin_amdgcn_ballot_w64(!G.done) == 0ull)
+        play_turn<PRODUCT>(G, u4[0], t4 + 0, L, tbl, bias, sh_r, sh_l, P, b);
+        play_turn<PRODUCT>(G, u4[1], t4 + 1, L, tbl, bias, sh_r, sh_l, P, b);
+        if (__builtin_amdgcn_ballot_w64(G.done == 0u) == 0ull)
             break;
-        play_turn<PRODUCT>(G, u4[2], t4 + 2, L, tbl, ray, bias, sh_r, sh_l, P, b);
-        play_turn<PRODUCT>(G, u4[3], t4 + 3, L, tbl, ray, bias, sh_r, sh_l, P, b);
-        if (__builtin_amdgcn_ballot_w64(!G.done) == 0ull)
+        play_turn<PRODUCT>(G, u4[2], t4 + 2, L, tbl, bias, sh_r, sh_l, P, b);
+        play_turn<PRODUCT>(G, u4[3], t4 + 3, L, tbl, bias, sh_r, sh_l, P, b);
+        if (__builtin_amdgcn_ballot_w64(G.done == 0u) == 0ull)
             break;
     }
 
@@ -297,6 +336,12 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
             P.final_opp[b] = G.opp;
         if (P.n_turns)
             P.n_turns[b] = (uint8_t)G.nt;
+#ifdef EXP_STAMPS
+        if (P.final_own && P.final_opp) { // diagnostic build: segment cycle sums, 21 bits each
+            P.final_own[b] = (G.seg[0] & 0x1FFFFF) | ((G.seg[1] & 0x1FFFFF) << 21) | ((G.seg[2] & 0x1FFFFF) << 42);
+            P.final_opp[b] = (G.seg[3] & 0x1FFFFF) | ((G.seg[4] & 0x1FFFFF) << 21) | ((G.seg[5] & 0x1FFFFF) << 42);
+        }
+#endif
     }
 }
 
@@ -353,9 +398,6 @@ int iago_rollout_build_table(const float *w18, const float *b64, float *blob)
                     const float v = product ? (float)exp((double)tv + shift) : tv;
                     blob[OFF_E + (((ky * 2 + pl) * 2 + (x >> 2)) * 256 + byte) * 4 + (x & 3)] = v;
                 }
-    for (int byte = 0; byte < 256; byte++)
-        for (int x = 0; x < 8; x++)
-            blob[OFF_LM + ((x >> 2) * 256 + byte) * 4 + (x & 3)] = ((byte >> x) & 1) ? 1.0f : 0.0f;
     for (int x = 0; x < 64; x++) {
         const float bv = w18 ? b64[x] : 0.0f;
         blob[OFF_BIAS + x] = product ? (float)exp((double)bv + shift) : bv;

@@ -29,9 +29,6 @@ __global__ __launch_bounds__(BLOCK) void apply_moves_kernel(uint64_t *__restrict
                                                             const int8_t *__restrict__ action,
                                                             int64_t n)
 {
-    __shared__ uint64_t ray[RAY_TABLE_WORDS];
-    fill_ray_table(ray);
-    __syncthreads();
     const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int64_t b = gtid >> 3;
     const Lane8 L = make_lane8(threadIdx.x);
@@ -39,7 +36,7 @@ __global__ __launch_bounds__(BLOCK) void apply_moves_kernel(uint64_t *__restrict
     const uint64_t o = live ? own[b] : 0ull, p = live ? opp[b] : 0ull;
     const int a = live ? (int)action[b] : -1;
     const uint32_t pos = (uint32_t)a & 63u;
-    const uint64_t f = group8_flips(to_lane(o, L), to_lane(p, L), pos, L, ray);
+    const uint64_t f = group8_flips(to_lane(o, L), to_lane(p, L), pos, L);
     if (live && L.l8 == 0 && a >= 0) {
         const uint64_t bit = 1ull << pos;
         own[b] = o | f | bit;

@@ -10,6 +10,14 @@ import torch
 import torch.distributed as dist
 
 
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def shard_range(n_games, rank=None, world=None):
     """Contiguous block of global game ids owned by `rank`: [lo, hi)."""
     if world is None:

@@ -1,0 +1,165 @@
+"""REINFORCE self-play training (src/train_rl.py:13-88) on the GPU engine.
+
+One "set" = 2N = 64 games of the learner (colour 1) against an opponent drawn
+from the pool of earlier checkpoints; odd games give colour 2 an extra stone on
+one of (2,4),(3,5),(4,2),(5,3) (src/train_rl.py:41-47).  The update reproduces
+the reference's loss exactly, including its quirk: `pred` is already a softmax
+output and `F.softmax_cross_entropy(pred, y)` applies log-softmax to it again
+(src/train_rl.py:61-64), loss = mean(CE_i * z_i).  Optimiser: Chainer's Adam
+with the WeightDecay(5e-4) hook (src/train_rl.py:24-26); Chainer is not in the
+reference tree (unpinned, readme.md:13), so `ChainerAdam` restates its published
+update rule -- PARITY UNPINNED, see DESIGN.md.
+
+Multi-GPU (BASELINE configs[4]): the games of a set shard over the ranks, the
+recorded (state, action, z) tuples are all-gathered (iago_amd.dist) and every
+rank applies the identical update -- no gradient all-reduce.
+"""
+import glob
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import dist as idist
+from . import engine, network, ops, rl_self_play
+
+
+class ChainerAdam(object):
+    """chainer.optimizers.Adam(alpha=1e-3, beta1=0.9, beta2=0.999, eps=1e-8) +
+    optimizer_hooks.WeightDecay(rate) as called at src/train_rl.py:24-26,66.
+
+    Chainer's rule (v4+, from its documentation): the hook adds rate*w to every
+    gradient (biases included) before the update; then per parameter
+        m += (1-beta1)(g - m);  v += (1-beta2)(g*g - v)
+        w -= alpha_t * m / (sqrt(v) + eps),
+        alpha_t = alpha * sqrt(1 - beta2^t) / (1 - beta1^t).
+    State layout of `state_dict_npz` follows serializers.save_npz(optimizer):
+    't', 'epoch', '<param path>/t', '<param path>/m', '<param path>/v'.
+    """
+
+    def __init__(self, model, alpha=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4):
+        self.model = model
+        self.alpha, self.beta1, self.beta2, self.eps, self.wd = alpha, beta1, beta2, eps, weight_decay
+        self.t = 0
+        self.state = {n: (torch.zeros_like(p), torch.zeros_like(p))
+                      for n, p in model.named_parameters()}
+
+    @torch.no_grad()
+    def update(self):
+        self.t += 1
+        a_t = self.alpha * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
+        for n, p in self.model.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad + self.wd * p
+            m, v = self.state[n]
+            m.add_((g - m) * (1.0 - self.beta1))
+            v.add_((g * g - v) * (1.0 - self.beta2))
+            p.sub_(a_t * m / (v.sqrt() + self.eps))
+
+    def state_dict_npz(self):
+        out = {"t": np.asarray(self.t, np.int64), "epoch": np.asarray(0, np.int64)}
+        keys = {id(p): k for k, p in self.model._npz_map().items()}
+        for n, p in self.model.named_parameters():
+            k = keys[id(p)]
+            m, v = self.state[n]
+            out[k + "/t"] = np.asarray(self.t, np.int64)
+            out[k + "/m"] = m.detach().cpu().numpy()
+            out[k + "/v"] = v.detach().cpu().numpy()
+        return out
+
+    def save_npz(self, path):
+        np.savez(path, **self.state_dict_npz())
+
+    def load_npz(self, path):
+        src = np.load(path)
+        self.t = int(src["t"])
+        keys = {id(p): k for k, p in self.model._npz_map().items()}
+        for n, p in self.model.named_parameters():
+            k = keys[id(p)]
+            m, v = self.state[n]
+            m.copy_(torch.from_numpy(src[k + "/m"]))
+            v.copy_(torch.from_numpy(src[k + "/v"]))
+        return self
+
+
+def reinforce_loss(model, own, opp, actions, rewards):
+    """src/train_rl.py:55-64.  own/opp: recorded learner positions (own = the
+    learner = mover); the reference rebuilds planes [x==1, x==2] from the
+    colour-swapped boards, which is exactly encode_planes(own, opp)."""
+    x = ops.encode_planes(own, opp)
+    pred = model(x)                                                  # softmax probabilities
+    c = F.cross_entropy(pred, actions.to(torch.int64), reduction="none")  # log-softmax AGAIN
+    return torch.mean(c * rewards.to(torch.float32))
+
+
+class ReinforceTrainer(object):
+    """The loop of src/train_rl.py:28-81 with the reference's constants."""
+
+    def __init__(self, model1, pool_dir=None, N=32, seed=0, alpha=1e-3, device="cuda"):
+        self.model1 = model1.to(device)
+        self.opt = ChainerAdam(self.model1, alpha=alpha)
+        self.N, self.seed, self.device = N, seed, device
+        self.pool_dir = pool_dir
+        self.rs = np.random.RandomState(seed)
+        self.models, self.cnt, self.set_index = 1, 0, 0
+        self.log = []
+
+    def pick_opponent(self):
+        """np.random.choice(glob('../models/RL/*.npz')) (src/train_rl.py:33-37)."""
+        paths = sorted(glob.glob(os.path.join(self.pool_dir, "*.npz"))) if self.pool_dir else []
+        m2 = network.SLPolicy()
+        if paths:
+            m2.load_npz(paths[self.rs.randint(len(paths))])
+        else:
+            m2.load_npz(self.model1.npz_dict())  # self-play against the current weights
+        return m2.to(self.device).eval()
+
+    def play_set(self, model2):
+        """2N games; odd games carry the handicap stone (src/train_rl.py:41-47).
+        Games shard over the ranks; returns the gathered tuples of the whole set."""
+        n_total = 2 * self.N
+        lo, hi = idist.shard_range(n_total)
+        cells = np.array(engine.HANDICAP_CELLS)[self.rs.randint(4, size=n_total)]
+        hc = np.where(np.arange(n_total) % 2 == 1, np.uint64(1) << cells.astype(np.uint64),
+                      np.uint64(0)).astype(np.uint64)
+        self.model1.eval()
+        r = rl_self_play.play_batch(self.model1, model2, hi - lo,
+                                    handicap=ops.bits_to_tensor(hc[lo:hi], self.device),
+                                    seed=self.seed, game_id_base=self.set_index * n_total + lo)
+        valid = (r["action"] >= 0)                       # (T1, B): the learner moved
+        z = r["z"].reshape(1, -1).expand_as(r["action"])
+        tup = idist.gather_tuples(dict(own=r["own"][valid], opp=r["opp"][valid],
+                                       action=r["action"][valid], z=z[valid]))
+        wins = idist.gather_tuples(dict(win=(r["z"] == 1).to(torch.int8)))["win"]
+        return tup, int(wins.sum().item())
+
+    def step(self):
+        """One set + one update; returns dict(rate, loss, saved)."""
+        model2 = self.pick_opponent()
+        tup, result = self.play_set(model2)
+        self.model1.train()
+        for p in self.model1.parameters():
+            p.grad = None
+        loss = reinforce_loss(self.model1, tup["own"], tup["opp"], tup["action"], tup["z"])
+        loss.backward()
+        self.opt.update()
+        rate = result / (2 * self.N)
+        saved = False
+        if rate > 0.5:                                             # src/train_rl.py:71-72
+            self.cnt += 1
+        if self.cnt > 4 * math.sqrt(self.models) and rate > 0.6:  # src/train_rl.py:73-79
+            if self.pool_dir and idist.rank() == 0:
+                self.model1.save_npz(os.path.join(self.pool_dir, "model%d.npz" % self.models))
+                os.makedirs(os.path.join(self.pool_dir, "optimizers"), exist_ok=True)
+                self.opt.save_npz(os.path.join(self.pool_dir, "optimizers", "%d.npz" % self.models))
+            self.models += 1
+            self.cnt = 0
+            saved = True
+        self.set_index += 1
+        out = dict(rate=rate, loss=float(loss.item()), saved=saved, n_tuples=int(tup["z"].numel()),
+                   stop=rate < 0.2)                                # src/train_rl.py:80-81
+        self.log.append(out)
+        return out

@@ -48,7 +48,7 @@ typedef enum iago_status {
 #define IAGO_PASS (-1)          /* pass action, game.py:181 */
 #define IAGO_TRACE_PASS 0xFF    /* pass marker in uint8 action traces */
 #define IAGO_MAX_TURNS 128      /* upper bound on turns of one game (<= 124) */
-#define IAGO_ROLLOUT_TABLE_FLOATS (3 * 2 * 256 * 8 + 256 * 8 + 64 + 4)
+#define IAGO_ROLLOUT_TABLE_FLOATS (3 * 2 * 256 * 8 + 64 + 4)
 
 IAGO_API int iago_abi_version(void);
 IAGO_API const char *iago_last_error(void);
@@ -124,8 +124,7 @@ IAGO_API int iago_sample_moves(const float *probs, const uint64_t *legal, const 
  * floats and is then copied to the device by the caller.  w18 == NULL builds
  * the uniform policy (every legal move equally likely).
  * Layout: E[3 ky][2 plane][2 half][256 row byte][4] row-pattern contributions
- * to 8 adjacent outputs; LM[2 half][256][4] 1.0/0.0 legal-cell multipliers;
- * bias[64]; mode[4].  mode[0] == 1: PRODUCT form (E and bias hold exp() of the
+ * to 8 adjacent outputs; bias[64]; mode[4].  mode[0] == 1: PRODUCT form (E and bias hold exp() of the
  * contributions, shifted so that the largest softmax numerator is 1), chosen
  * when the logit range is < 60 so that no partial product leaves float32's
  * range; mode[0] == 0: LOG form (raw sums; the kernel does max / exp2).  Pass
