@@ -99,9 +99,11 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
     m = engine.BatchedMCTS(n_games, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0,
                            n_thr=15, capacity=8192, seed=7, game_id_base=rank * n_games)
     eng = engine.SelfPlayEngine(m, max_turns=(128 if full_games else n_turns))
+    m.enable_stats()
     m.warmup()                 # MIOpen kernel selection for every batch bucket
     eng.play(2, record=False)  # allocator, code objects
     m.n_leaf_evals = m.n_policy_evals = 0
+    m.stats.zero_()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -129,12 +131,52 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
            "net_tflops_fp32": flops / dt / 1e12,
            "config": "BASELINE configs[2]: PV-MCTS %d sims/move, %d games per GPU, SLPolicy+Value "
                      "random init fp32, lmbda=0.5 c_puct=1 n_thr=15" % (n_sims, n_games),
-           "tree_bytes_per_gpu": m.tree.bytes()}
+           "tree_pool_bytes_per_gpu": m.tree.bytes(), "tree_traffic_rank0": m.tree_bytes()}
     if full_games:
         out["games_per_sec"] = world * n_games / dt
         if gathered is not None:
             out["gathered_tuples"] = int(gathered["z"].numel())
     return out
+
+
+def mcts_cpu_baseline(n_sims=600):
+    """The reference's own algorithm for the PV-MCTS leg on ONE host core: the
+    oracle's restatement of MCTS.playout (oracle/mcts_py.py) with float32
+    torch-CPU SLPolicy / Value (B = 1 calls, one thread, like the reference's
+    Chainer calls) and the C oracle's rollout; same constants as the GPU leg."""
+    from iago_amd import network
+    from oracle import mcts_py
+    from oracle import oracle as orc
+    w, b = shipped_rollout_weights()
+    torch.manual_seed(0)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        policy, value = network.SLPolicy().eval(), network.Value().eval()
+        counter = [0]
+
+        def pol(x):
+            with torch.no_grad():
+                return policy(torch.from_numpy(x)).numpy().reshape(64)
+
+        def val(x):
+            with torch.no_grad():
+                return value(torch.from_numpy(x)).numpy().reshape(1)[0]
+
+        def roll(state, color):
+            counter[0] += 1
+            return orc.simulate(state, color, w, b, seed=3, game_id=counter[0])[0]
+
+        m = mcts_py.MCTS(pol, val, roll, lmbda=0.5, c_puct=1, n_thr=15)
+        m.get_move(orc.initial_state(), 1, 5)  # warm-up
+        t0 = time.perf_counter()
+        m.get_move(orc.initial_state(), 1, n_sims)
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthreads)
+    return {"value": n_sims / dt, "unit": "leaf-evals/s", "cores": 1, "kind": "port",
+            "sample": "%d playouts of one game from the start position, oracle/mcts_py.py + "
+                      "torch-CPU fp32 nets (1 thread) + C rollout, %.1f s" % (n_sims, dt)}
 
 
 def measured_traffic():
@@ -157,9 +199,9 @@ def main():
                     help="extra occupancy datapoint: boards in one launch (0 = skip)")
     ap.add_argument("--mcts-games", type=int, default=1024)
     ap.add_argument("--mcts-sims", type=int, default=100)
-    ap.add_argument("--mcts-turns", type=int, default=2,
-                    help="turns of the bounded PV-MCTS sample (0 = skip the leg)")
-    ap.add_argument("--mcts-full", action="store_true", help="play the PV-MCTS games to the end")
+    ap.add_argument("--mcts-turns", type=int, default=-1,
+                    help="PV-MCTS leg: -1 = play the games to the end (default), N > 0 = a bounded "
+                         "sample of the first N turns, 0 = skip the leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,9 +301,9 @@ def main():
         del lown, lopp, lout
 
     mcts = None
-    if args.mcts_turns > 0 or args.mcts_full:
-        mcts = mcts_leg(args.mcts_games, args.mcts_sims, args.mcts_turns, args.mcts_full, world,
-                        rank, dist)
+    if args.mcts_turns != 0:
+        mcts = mcts_leg(args.mcts_games, args.mcts_sims, max(args.mcts_turns, 0),
+                        args.mcts_turns < 0, world, rank, dist)
 
     if rank == 0:
         games = world * K * B
@@ -290,6 +332,8 @@ def main():
             line["mcts"] = mcts
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, b)
+            if mcts is not None:
+                mcts["cpu_baseline"] = mcts_cpu_baseline()
         print(json.dumps(line), flush=True)
     barrier()
     if dist is not None:

@@ -90,7 +90,7 @@ def lib():
     tp = C.POINTER(MctsTree)
     L.iago_mcts_reset.argtypes = [tp, vp, vp]
     L.iago_mcts_select.argtypes = [tp, vp, vp, vp, C.c_float, C.c_int32, C.c_int, vp, vp, vp, vp,
-                                   vp, vp]
+                                   vp, vp, vp]
     L.iago_mcts_expand.argtypes = [tp, vp, i64, vp, vp, vp, vp]
     L.iago_leaf_values.argtypes = [vp, vp, C.c_float, vp, i64, vp]
     L.iago_mcts_backup.argtypes = [tp, vp, vp, vp, vp]

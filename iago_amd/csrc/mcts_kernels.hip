@@ -67,8 +67,10 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(
     Tree T, const uint64_t *__restrict__ root_own, const uint64_t *__restrict__ root_opp,
     const uint8_t *__restrict__ active, float c_puct, int n_thr, int from_root,
     int32_t *__restrict__ cur_node, uint64_t *__restrict__ cur_own, uint64_t *__restrict__ cur_opp,
-    uint8_t *__restrict__ needs_expand, uint64_t *__restrict__ legal_out)
+    uint8_t *__restrict__ needs_expand, uint64_t *__restrict__ legal_out,
+    int32_t *__restrict__ stats)
 {
+    int st_levels = 0, st_children = 0;
 
     const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int64_t g = gtid >> 3;
@@ -91,6 +93,8 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(
             break;
         const int k = descending ? (int)T.n_children[base + node] : 0;
         const int pn = descending ? T.n_visits[base + node] : 0;
+        st_levels += descending ? 1 : 0;
+        st_children += k;
         const double sq = sqrt((double)pn); // np.sqrt(parent.n_visits), MCTS.py:49
         double best_v = -INFINITY;
         int best_i = 0x7fffffff;
@@ -133,6 +137,10 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(
         const bool ne = T.first_child[base + node] < 0 && T.n_visits[base + node] >= n_thr;
         needs_expand[g] = ne ? 1 : 0;
         legal_out[g] = legal;
+        if (stats) {
+            stats[2 * g] += st_levels;
+            stats[2 * g + 1] += st_children;
+        }
     }
 }
 
@@ -304,7 +312,7 @@ int iago_mcts_reset(const iago_mcts_tree *tree, const uint8_t *mask, void *strea
 int iago_mcts_select(const iago_mcts_tree *tree, const uint64_t *root_own, const uint64_t *root_opp,
                      const uint8_t *active, float c_puct, int32_t n_thr, int from_root,
                      int32_t *cur_node, uint64_t *cur_own, uint64_t *cur_opp, uint8_t *needs_expand,
-                     uint64_t *legal, void *stream)
+                     uint64_t *legal, int32_t *stats, void *stream)
 {
     if (check_tree(tree, "iago_mcts_select: bad tree"))
         return IAGO_ERR_INVALID;
@@ -318,7 +326,7 @@ int iago_mcts_select(const iago_mcts_tree *tree, const uint64_t *root_own, const
         return IAGO_OK;
     hipLaunchKernelGGL(select_kernel, dim3(grid_for(tree->n_games * 8)), dim3(BLOCK), 0,
                        (hipStream_t)stream, *tree, root_own, root_opp, active, c_puct, n_thr,
-                       from_root, cur_node, cur_own, cur_opp, needs_expand, legal);
+                       from_root, cur_node, cur_own, cur_opp, needs_expand, legal, stats);
     return iago_check_launch("iago_mcts_select");
 }
 

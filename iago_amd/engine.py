@@ -119,6 +119,7 @@ class BatchedMCTS(object):
         self.move = torch.zeros(n_games, dtype=torch.int8, **kw)
         self.visits = torch.zeros((n_games, 64), dtype=torch.int32, **kw)
         self._policy_in = torch.zeros((max(n_games, 16), 2, 8, 8), dtype=torch.float32, **kw)
+        self.stats = None             # optional (n_games, 2) int32: levels, children scored
         self.sim_counter = 0          # Philox stream id: one per simulation
         self.n_leaf_evals = 0
         self.n_policy_evals = 0
@@ -154,7 +155,8 @@ class BatchedMCTS(object):
         check(L.iago_mcts_select(self.tree.ref(), _p(own), _p(opp), _p(active), self.c_puct,
                                  self.n_thr, 1 if from_root else 0, _p(self.cur_node),
                                  _p(self.cur_own), _p(self.cur_opp), _p(self.needs_expand),
-                                 _p(self.legal), _stream()), "iago_mcts_select")
+                                 _p(self.legal), _p(self.stats) if self.stats is not None else None,
+                                 _stream()), "iago_mcts_select")
 
     def simulate(self, own, opp, active, n_active=None):
         L = _lib.lib()
@@ -207,6 +209,19 @@ class BatchedMCTS(object):
         if int(self.tree.overflow.sum().item()) != 0:
             raise _lib.IagoError("MCTS node pool exhausted: raise `capacity` (%d nodes per game)"
                                  % self.tree.capacity)
+
+    def enable_stats(self):
+        self.stats = torch.zeros((self.n_games, 2), dtype=torch.int32, device=self.cur_own.device)
+
+    def tree_bytes(self):
+        """Algorithmic bytes moved on the tree arrays so far:
+        select reads first_child/n_children/n_visits (9 B) per level and
+        (n, Q, P) = 12 B per child scored + 1 B action; backup reads and writes
+        (n, Q) and reads parent = 20 B per level (+ the leaf itself)."""
+        lv, ch = (int(x) for x in self.stats.to(torch.int64).sum(dim=0).tolist())
+        sel = 10 * lv + 12 * ch + 8 * self.n_leaf_evals
+        bak = 20 * (lv + self.n_leaf_evals)
+        return {"select": sel, "backup": bak, "levels": lv, "children_scored": ch}
 
     def best_move(self, active=None, want_visits=True):
         """argmax visit count of the root's children, first wins (MCTS.py:147)."""

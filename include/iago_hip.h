@@ -208,12 +208,15 @@ IAGO_API int iago_mcts_reset(const iago_mcts_tree *tree, const uint8_t *mask, vo
  *   cur_node/cur_own/cur_opp: the leaf and its position (own = side to move),
  *   needs_expand: 1 iff leaf.n_visits >= n_thr (MCTS.py:109),
  *   legal: the leaf's legal-move mask (game.py:210-235) when needs_expand.
+ * stats (optional, int32 [n_games][2]): ACCUMULATES per game the levels
+ * descended and the children scored by this call -- the harness turns them
+ * into the algorithmic bytes of the tree arrays.
  */
 IAGO_API int iago_mcts_select(const iago_mcts_tree *tree, const uint64_t *root_own,
                               const uint64_t *root_opp, const uint8_t *active, float c_puct,
                               int32_t n_thr, int from_root, int32_t *cur_node, uint64_t *cur_own,
                               uint64_t *cur_opp, uint8_t *needs_expand, uint64_t *legal,
-                              void *stream);
+                              int32_t *stats, void *stream);
 
 /*
  * Expand the leaves listed in `games` (int32 game ids, n_expand of them):

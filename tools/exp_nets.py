@@ -15,8 +15,13 @@ torch.manual_seed(0)
 v = network.Value().cuda().eval()
 x = (torch.rand(B,2,8,8,device='cuda')>0.5).float()
 FL = 122.99e6*B
+network.Block.fused_inference=False
 with torch.no_grad():
     t=bench(v,x); print('default NCHW fp32: %.3f ms  %.1f TF'%(t,FL/t/1e9))
+    network.Block.fused_inference=True
+    t=bench(v,x); print('fused conv+bias+relu: %.3f ms  %.1f TF'%(t,FL/t/1e9))
+    network.Block.fused_inference=False
+    a0=v(x); network.Block.fused_inference=True; a1=v(x); print('fused vs unfused max diff', (a0-a1).abs().max().item()); network.Block.fused_inference=False
     torch.backends.cudnn.benchmark=True
     t=bench(v,x); print('benchmark=True: %.3f ms  %.1f TF'%(t,FL/t/1e9))
     v2 = network.Value().cuda().eval().to(memory_format=torch.channels_last)
