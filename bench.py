@@ -111,8 +111,7 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
     res = eng.play(n_sims, record=True)
     gathered = None
     if dist is not None and full_games:
-        from iago_amd.dist import gather_tuples
-        gathered = gather_tuples(res.tuples())
+            gathered = gather_tuples(res.tuples())
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -212,23 +211,30 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (any N)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     from iago_amd import ops
-    from iago_amd.dist import gather_tuples
 
     B, K, W = args.boards, args.steps, args.warmup
     w, b = shipped_rollout_weights()
     weights = ops.RolloutWeights(w, b)
     own = torch.full((B,), START_OWN, dtype=torch.int64, device="cuda")
     opp = torch.full((B,), START_OPP, dtype=torch.int64, device="cuda")
-    # the round's finished tuples, resident in HBM: K steps x B games
-    z = torch.empty((K, B), dtype=torch.int8, device="cuda")
-    fo = torch.empty((K, B), dtype=torch.int64, device="cuda")
-    fp = torch.empty((K, B), dtype=torch.int64, device="cuda")
-    nt = torch.empty((K, B), dtype=torch.uint8, device="cuda")
+    # the round's finished tuples, resident in HBM: K steps x B games, as views of ONE
+    # byte buffer so that the all-gather needs no packing pass and no host sync
+    n = K * B
+    roundbuf = torch.empty(n * 18, dtype=torch.uint8, device="cuda")
+    fo = roundbuf[0:8 * n].view(torch.int64).view(K, B)
+    fp = roundbuf[8 * n:16 * n].view(torch.int64).view(K, B)
+    z = roundbuf[16 * n:17 * n].view(torch.int8).view(K, B)
+    nt = roundbuf[17 * n:18 * n].view(K, B)
+    gathered = torch.empty(world * n * 18, dtype=torch.uint8, device="cuda") if world > 1 or \
+        "RANK" in os.environ else None
     outs = []
     for k in range(K):
         r = ops.RolloutResult()
@@ -255,10 +261,9 @@ def main():
     for k in range(K):
         step(k, k)
     ev1.record()
-    gathered = None
     if dist is not None:
-        gathered = gather_tuples(dict(z=z.view(-1), final_own=fo.view(-1), final_opp=fp.view(-1),
-                                      n_turns=nt.view(-1)))
+        # every rank contributes the same K x B tuples: one collective, no host sync
+        dist.all_gather_into_tensor(gathered, roundbuf)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -270,7 +275,8 @@ def main():
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(steps_total)
-        assert gathered["z"].numel() == world * K * B
+        mine = gathered[rank * n * 18:(rank + 1) * n * 18]
+        assert torch.equal(mine, roundbuf)
     dt = float(tmax.item())
     board_steps = int(steps_total.item())
 
@@ -318,7 +324,7 @@ def main():
                                    "rollout-policy-only playouts from the start position, "
                                    "shipped RolloutPolicy weights" % B,
                        "boards_per_gpu": B, "games_per_step": world * B,
-                       "tuple_allgather": "rccl" if world > 1 else "none"},
+                       "tuple_allgather": "rccl" if dist is not None else "none"},
             "board_steps_per_sec": board_steps / dt,
             "board_steps_per_game": board_steps / games,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -39,7 +39,7 @@ def gather_tuples(fields, group=None):
     (payloads are MBs: latency-, not bandwidth-bound on 7 x 153 GB/s xGMI links).
     """
     names = sorted(fields)
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return {k: fields[k] for k in names}
     world = dist.get_world_size(group)
     first = fields[names[0]]
