@@ -8,17 +8,24 @@ Workload (BASELINE.json configs[1]): per GPU, 4096 parallel Othello boards from
 the standard start position are played to the end by the fused HIP rollout
 kernel with the reference's shipped RolloutPolicy weights (82 floats, kept as
 golden data in tests/golden/simulate.json) -- rollout-policy-only self-play.
-One step = one launch = 4096 finished games per GPU.  With N > 1 every rank
-plays its own 4096-board shard (weak scaling, Philox streams keyed by the
-global game id) and the finished (final boards, z, turns) tuples of the whole
-round are all-gathered over RCCL inside the timed region.
+One step = one launch = 4096 finished games per GPU.  Steps are independent
+batches; they are issued round-robin on 16 HIP streams so that several launches
+overlap on the chip (a 4096-board launch is 512 waves: one wave on half of the
+SIMDs).  With N > 1 every rank plays its own 4096-board shard (weak scaling,
+Philox streams keyed by the global game id) and the finished (final boards, z,
+turns) tuples of the whole round are all-gathered over RCCL inside the timed
+region, as one collective on the round's tuple buffer.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the rollout kernel against the
 HBM roof with SURVEY.md section 8(d)'s algorithmic bytes (33 B per board-step);
 `cpu_baseline` times the CPU oracle (oracle/, a C port of the reference's
 Python loops) on the host cores over a bounded sample of the same workload.
+Extra objects: `large_batch` (the same kernel at 1M boards in one launch),
+`mcts` (BASELINE configs[2]: PV-MCTS 100 sims/move, 1024 games, played to the
+end: leaf-evals/s and games/s, with its own 1-core CPU baseline).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -190,9 +197,11 @@ def measured_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
+    ap.add_argument("--streams", type=int, default=16,
+                    help="HIP streams the independent steps are issued on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--large-boards", type=int, default=1 << 20,
                     help="extra occupancy datapoint: boards in one launch (0 = skip)")
@@ -218,7 +227,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    from iago_amd import ops
+    from iago_amd import _lib, ops
 
     B, K, W = args.boards, args.steps, args.warmup
     w, b = shipped_rollout_weights()
@@ -241,26 +250,51 @@ def main():
         r.z, r.final_own, r.final_opp, r.n_turns = z[k], fo[k], fp[k], nt[k]
         outs.append(r)
 
-    def step(k, slot):
+    # Steps are independent batches: they are issued round-robin on S HIP streams
+    # so that S launches (S x 512 waves) overlap on the chip.  Every launch is
+    # marshalled before the timed region; issuing one costs a single ctypes call.
+    S = max(1, args.streams)
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    sptr = [ctypes.c_void_p(st.cuda_stream) for st in streams]
+
+    def prepare(k, slot):
         # global game id = ((step * world) + rank) * B + board: results do not depend on N
-        ops.rollout(own, opp, weights, seed=2024, id_base=((k * world + rank) * B) & 0xFFFFFFFF,
-                    out=outs[slot])
+        return ops.rollout_prepare(own, opp, weights, seed=2024,
+                                   id_base=((k * world + rank) * B) & 0xFFFFFFFF, out=outs[slot])
+
+    warm = [prepare(1_000_000 + k, k % K) for k in range(W)]
+    timed = [prepare(k, k) for k in range(K)]
+    SAMPLE = 32  # every 32nd launch is bracketed by an event pair on its own stream
+    evs = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for k in range(0, K, SAMPLE)}
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for k in range(W):
-        step(1_000_000 + k, k % K)
+    rc = 0
+    for k, p in enumerate(warm):
+        rc |= p.launch(sptr[k % S])
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    main = torch.cuda.current_stream()
+    span0, span1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
-    for k in range(K):
-        step(k, k)
-    ev1.record()
+    span0.record(main)
+    for st in streams:
+        st.wait_stream(main)
+    for k, p in enumerate(timed):
+        j = k % S
+        e = evs.get(k)
+        if e is not None:
+            e[0].record(streams[j])
+        rc |= p.launch(sptr[j])
+        if e is not None:
+            e[1].record(streams[j])
+    for st in streams:
+        main.wait_stream(st)
+    span1.record(main)
     if dist is not None:
         # every rank contributes the same K x B tuples: one collective, no host sync
         dist.all_gather_into_tensor(gathered, roundbuf)
@@ -268,7 +302,11 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K
+    if rc != 0:
+        raise SystemExit("iago_rollout failed: %s" % _lib.lib().iago_last_error())
+    # average duration of ONE launch (start -> end on its own stream, S launches in flight)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in evs.values()) / len(evs)
+    span_ms = span0.elapsed_time(span1)  # GPU time of the K launches together
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     steps_total = nt.to(torch.int64).sum().reshape(1)
@@ -314,7 +352,11 @@ def main():
     if rank == 0:
         games = world * K * B
         alg_bytes_per_launch = BYTES_PER_BOARD_STEP * board_steps / (world * K)
+        # roofline of the dominant kernel.  `achieved` follows the contract: algorithmic
+        # bytes of a launch / that launch's duration (agrees with rocprofv3's average).
+        # With S launches overlapping, the chip as a whole moves `aggregate_achieved`.
         achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        aggregate = alg_bytes_per_launch * K / (span_ms * 1e-3) / 1e9
         line = {
             "metric": "self-play games/sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
@@ -324,13 +366,17 @@ def main():
                                    "rollout-policy-only playouts from the start position, "
                                    "shipped RolloutPolicy weights" % B,
                        "boards_per_gpu": B, "games_per_step": world * B,
-                       "tuple_allgather": "rccl" if dist is not None else "none"},
+                       "tuple_allgather": "rccl" if dist is not None else "none",
+                       "hip_streams": S},
             "board_steps_per_sec": board_steps / dt,
             "board_steps_per_game": board_steps / games,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "kernel": "rollout_kernel", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "launches_in_flight": kernel_ms * K / span_ms,
+                         "aggregate_achieved": aggregate,
+                         "aggregate_frac": aggregate / HBM_PEAK_GBS},
         }
         if large is not None:
             line["large_batch"] = large

@@ -136,14 +136,22 @@ class RolloutResult(object):
         self.z = self.final_own = self.final_opp = self.n_turns = self.trace = None
 
 
-def rollout(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=None,
-            want_final=False, want_turns=False, want_trace=False, out=None):
-    """Simulate(state)(color) for every board (mcts_self_play.py:9-134).
+class PreparedRollout(object):
+    """A fully marshalled iago_rollout call: `launch(stream)` costs one ctypes
+    call.  Holds references to every tensor the launch touches."""
+    __slots__ = ("args", "ref", "result", "_keep", "_fn")
 
-    weights=None plays uniformly random legal moves.  `uniforms`
-    (IAGO_MAX_TURNS, n) float32 replaces the Philox stream (parity tests).
-    `out` may be a RolloutResult with preallocated tensors to reuse.
-    """
+    def launch(self, stream_ptr=None):
+        """Enqueue on `stream_ptr` (a hipStream_t as int / c_void_p; None =
+        torch's current stream); returns the iago status code."""
+        if stream_ptr is None:
+            stream_ptr = _stream()
+        return self._fn(self.ref, stream_ptr)
+
+
+def rollout_prepare(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=None,
+                    want_final=False, want_turns=False, want_trace=False, out=None):
+    """Marshal a rollout launch once (see `rollout` for the arguments)."""
     n = own.numel()
     res = out if out is not None else RolloutResult()
     dev = own.device
@@ -156,12 +164,12 @@ def rollout(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=Non
         res.n_turns = torch.empty(n, dtype=torch.uint8, device=dev)
     if want_trace and res.trace is None:
         res.trace = torch.full((IAGO_MAX_TURNS, n), 0xFE, dtype=torch.uint8, device=dev)
+    if weights is None:
+        weights = uniform_weights(dev)
     a = RolloutArgs()
     a.own = _dev(own, torch.int64, "own")
     a.opp = _dev(opp, torch.int64, "opp")
     a.n = n
-    if weights is None:
-        weights = uniform_weights(dev)
     a.table = _dev(weights.table, torch.float32, "table")
     a.log_form = weights.log_form
     if uniforms is not None:
@@ -179,5 +187,22 @@ def rollout(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=Non
         a.n_turns = _dev(res.n_turns, torch.uint8, "n_turns")
     if res.trace is not None:
         a.trace = _dev(res.trace, torch.uint8, "trace")
-    check(_lib.lib().iago_rollout(C.byref(a), _stream()), "iago_rollout")
-    return res
+    p = PreparedRollout()
+    p.args, p.ref, p.result = a, C.byref(a), res
+    p._keep = (own, opp, weights, uniforms)
+    p._fn = _lib.lib().iago_rollout
+    return p
+
+
+def rollout(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=None,
+            want_final=False, want_turns=False, want_trace=False, out=None):
+    """Simulate(state)(color) for every board (mcts_self_play.py:9-134).
+
+    weights=None plays uniformly random legal moves.  `uniforms`
+    (IAGO_MAX_TURNS, n) float32 replaces the Philox stream (parity tests).
+    `out` may be a RolloutResult with preallocated tensors to reuse.
+    """
+    p = rollout_prepare(own, opp, weights, seed, id_base, stream_id, uniforms, want_final,
+                        want_turns, want_trace, out)
+    check(p.launch(), "iago_rollout")
+    return p.result
