@@ -55,7 +55,7 @@ def test_uniform_policy_bit_exact(ops, n, seed, id_base):
         assert z[b] == oz
 
 
-def replay_check(own, opp, z, fo, fp, nt, tr, w, bvec, uniform_of):
+def replay_check(own, opp, z, fo, fp, nt, tr, w, bvec, uniform_of, masked_logit_softmax=False):
     """Replay GPU traces through the oracle rules; returns (#sampled, #exact)."""
     sampled = exact = 0
     for b in range(len(own)):
@@ -67,8 +67,17 @@ def replay_check(own, opp, z, fo, fp, nt, tr, w, bvec, uniform_of):
                 a = -1 if tr[t, b] == 0xFF else int(tr[t, b])
                 if acts:
                     assert a in acts, (b, t, a, acts)
-                    prob, _ = orc.rollout_policy(orc.make_state_var(s, c), w, bvec)
-                    p = orc.masked_probs(prob, acts)
+                    prob, logits = orc.rollout_policy(orc.make_state_var(s, c), w, bvec)
+                    if masked_logit_softmax:
+                        # weights so extreme that the reference's own softmax-then-mask
+                        # underflows to 0/0 (it raises there): float64 softmax over the
+                        # legal cells of the oracle's float32 logits instead
+                        lg = np.full(64, -np.inf)
+                        lg[acts] = logits[acts].astype(np.float64)
+                        p = np.exp(lg - lg.max())
+                        p /= p.sum()
+                    else:
+                        p = orc.masked_probs(prob, acts)
                     u = uniform_of(b, t)
                     cdf = np.cumsum(p)
                     lo = cdf[a - 1] if a > 0 else 0.0
@@ -170,3 +179,50 @@ def test_full_size_properties(ops):
         r4 = ops.rollout(own, opp, weights, seed=43, want_final=True)
         torch.cuda.synchronize()
         assert not torch.equal(r1.final_own, r4.final_own)
+
+
+def test_log_form_rollout_replay(ops):
+    """Weights whose logit range exceeds the product form's float32 budget make
+    the host pick the LOG form (max / exp2 in the kernel); same replay parity."""
+    rs = np.random.RandomState(3)
+    w = (12.0 * rs.randn(18)).astype(np.float32)
+    bvec = (5.0 * rs.randn(64)).astype(np.float32)
+    weights = ops.RolloutWeights(w, bvec)
+    assert weights.log_form == 1
+    small = ops.RolloutWeights(0.1 * w, bvec)
+    assert small.log_form == 0
+    n, seed = 200, 21
+    own, opp = random_positions(n, seed=8)
+    out = run(ops, own, opp, weights, seed=seed, id_base=5)
+    sampled, exact = replay_check(own, opp, *out, w, bvec,
+                                  lambda b, t: orc.uniform(seed, 5 + b, t, 0),
+                                  masked_logit_softmax=True)
+    assert sampled > 3000 and exact >= sampled - 2
+
+
+def test_sample_moves_bit_exact(ops):
+    """iago_sample_moves == oracle masked_probs + choice_cdf (float64, cell order)."""
+    rs = np.random.RandomState(12)
+    n = 3000
+    own, opp = random_positions(n, seed=31)
+    legal = ops.legal_moves(ops.bits_to_tensor(own), ops.bits_to_tensor(opp))
+    probs = rs.dirichlet(np.ones(64) * 0.3, size=n).astype(np.float32)
+    u = rs.random_sample(n)
+    got = ops.sample_moves(torch.from_numpy(probs).cuda(), legal,
+                           uniforms=torch.from_numpy(u).cuda()).cpu().numpy()
+    lb = ops.tensor_to_bits(legal)
+    for i in range(n):
+        acts = [a for a in range(64) if (int(lb[i]) >> a) & 1]
+        if not acts:
+            assert got[i] == -1
+            continue
+        want = orc.choice_cdf(orc.masked_probs(probs[i], acts), u[i])
+        assert got[i] == want, i
+    # Philox path: the uniform of (seed, id_base + b, step)
+    got2 = ops.sample_moves(torch.from_numpy(probs).cuda(), legal, seed=9, id_base=100,
+                            step=7).cpu().numpy()
+    for i in range(0, n, 37):
+        acts = [a for a in range(64) if (int(lb[i]) >> a) & 1]
+        if acts:
+            want = orc.choice_cdf(orc.masked_probs(probs[i], acts), orc.uniform(9, 100 + i, 7))
+            assert got2[i] == want
