@@ -185,6 +185,33 @@ def mcts_cpu_baseline(n_sims=600):
                       "torch-CPU fp32 nets (1 thread) + C rollout, %.1f s" % (n_sims, dt)}
 
 
+def reinforce_leg(n_iters, world, rank, dist):
+    """BASELINE configs[4] in miniature: `n_iters` iterations of the REINFORCE loop
+    (src/train_rl.py:28-81): one set of 2N = 64 SLPolicy-vs-SLPolicy games sharded
+    over the ranks, all-gather of the (state, action, z) tuples, one update on
+    every rank.  Random-init SLPolicy (seed 0), opponent = the current weights."""
+    from iago_amd import network
+    from iago_amd.train_rl import ReinforceTrainer
+    torch.manual_seed(0)
+    tr = ReinforceTrainer(network.SLPolicy(), pool_dir=None, N=32, seed=rank)
+    tr.step()  # warm-up: MIOpen forward/backward kernel selection
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    tuples = 0
+    for _ in range(n_iters):
+        tuples += tr.step()["n_tuples"]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    return {"iters_per_sec": n_iters / dt, "games_per_sec": 64 * n_iters / dt,
+            "tuples_per_iter": tuples / n_iters, "iters": n_iters,
+            "config": "64 policy-vs-policy games per set (SLPolicy, random init, fp32) + "
+                      "double-softmax REINFORCE update, ChainerAdam + WD 5e-4"}
+
+
 def measured_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes, if any."""
     path = os.path.join(ROOT, "profiles", "rollout_traffic.json")
@@ -205,6 +232,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--large-boards", type=int, default=1 << 20,
                     help="extra occupancy datapoint: boards in one launch (0 = skip)")
+    ap.add_argument("--train-iters", type=int, default=3,
+                    help="REINFORCE iterations of the training leg (0 = skip)")
     ap.add_argument("--mcts-games", type=int, default=1024)
     ap.add_argument("--mcts-sims", type=int, default=100)
     ap.add_argument("--mcts-turns", type=int, default=-1,
@@ -349,6 +378,8 @@ def main():
         mcts = mcts_leg(args.mcts_games, args.mcts_sims, max(args.mcts_turns, 0),
                         args.mcts_turns < 0, world, rank, dist)
 
+    train = reinforce_leg(args.train_iters, world, rank, dist) if args.train_iters > 0 else None
+
     if rank == 0:
         games = world * K * B
         alg_bytes_per_launch = BYTES_PER_BOARD_STEP * board_steps / (world * K)
@@ -382,6 +413,8 @@ def main():
             line["large_batch"] = large
         if mcts is not None:
             line["mcts"] = mcts
+        if train is not None:
+            line["reinforce"] = train
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, b)
             if mcts is not None:

@@ -85,14 +85,27 @@ class ChainerAdam(object):
         return self
 
 
-def reinforce_loss(model, own, opp, actions, rewards):
+def reinforce_loss(model, own, opp, actions, rewards, pad_to=None):
     """src/train_rl.py:55-64.  own/opp: recorded learner positions (own = the
     learner = mover); the reference rebuilds planes [x==1, x==2] from the
-    colour-swapped boards, which is exactly encode_planes(own, opp)."""
-    x = ops.encode_planes(own, opp)
+    colour-swapped boards, which is exactly encode_planes(own, opp).
+
+    pad_to: round the batch up to a multiple of it with zero-reward rows (they
+    add exactly 0 to the loss and its gradient; the mean still divides by the
+    true count) so that MIOpen sees a handful of batch shapes instead of a new
+    one -- and a new kernel search -- every set."""
+    n = own.numel()
+    if pad_to and n % pad_to:
+        extra = pad_to - n % pad_to
+        own = torch.cat([own, own[:1].expand(extra)])
+        opp = torch.cat([opp, opp[:1].expand(extra)])
+        actions = torch.cat([actions, actions[:1].expand(extra)])
+        rewards = torch.cat([rewards, torch.zeros(extra, dtype=rewards.dtype,
+                                                  device=rewards.device)])
+    x = ops.encode_planes(own.contiguous(), opp.contiguous())
     pred = model(x)                                                  # softmax probabilities
     c = F.cross_entropy(pred, actions.to(torch.int64), reduction="none")  # log-softmax AGAIN
-    return torch.mean(c * rewards.to(torch.float32))
+    return torch.sum(c * rewards.to(torch.float32)) / n              # F.mean(c * r)
 
 
 class ReinforceTrainer(object):
@@ -143,7 +156,8 @@ class ReinforceTrainer(object):
         self.model1.train()
         for p in self.model1.parameters():
             p.grad = None
-        loss = reinforce_loss(self.model1, tup["own"], tup["opp"], tup["action"], tup["z"])
+        loss = reinforce_loss(self.model1, tup["own"], tup["opp"], tup["action"], tup["z"],
+                              pad_to=512)
         loss.backward()
         self.opt.update()
         rate = result / (2 * self.N)

@@ -151,3 +151,70 @@ def test_pool_overflow_is_reported(eng):
     p = torch.full((1,), 0x0000001008000000, dtype=torch.int64, device="cuda")
     with pytest.raises(_lib.IagoError):
         m.search(o, p, torch.ones(1, dtype=torch.uint8, device="cuda"), 20)
+
+
+def test_full_size_tree_invariants(eng):
+    """BASELINE configs[2] size: 1024 games x 100 playouts from the start position
+    with the real (random-init) nets.  Size-independent properties of the
+    reference's algorithm on the device trees: visit conservation at the root
+    and at every expanded node, parent/child links, priors, action order,
+    determinism for a fixed seed, and agreement of best_move with the stored
+    visit counts."""
+    engine, ops = eng
+    from iago_amd import network
+    g = __import__("tests.conftest", fromlist=["load_json"]).load_json("simulate.json")
+    torch.manual_seed(0)
+    policy, value = network.SLPolicy().cuda().eval(), network.Value().cuda().eval()
+    G, n_sims, n_thr, cap = 1024, 100, 15, 1024
+    w = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    own = torch.full((G,), engine.START_OWN, dtype=torch.int64, device="cuda")
+    opp = torch.full((G,), engine.START_OPP, dtype=torch.int64, device="cuda")
+    act = torch.ones(G, dtype=torch.uint8, device="cuda")
+
+    def run():
+        m = engine.BatchedMCTS(G, policy, value, w, lmbda=0.5, c_puct=1.0, n_thr=n_thr,
+                               capacity=cap, seed=3)
+        m.search(own, opp, act, n_sims)
+        return m
+
+    m = run()
+    T = m.tree
+    nn = T.n_nodes.cpu().numpy()
+    par = T.parent.cpu().numpy().reshape(G, cap)
+    fc = T.first_child.cpu().numpy().reshape(G, cap)
+    nc = T.n_children.cpu().numpy().reshape(G, cap)
+    nv = T.n_visits.cpu().numpy().reshape(G, cap)
+    q = T.q.cpu().numpy().reshape(G, cap)
+    pr = T.p.cpu().numpy().reshape(G, cap)
+    ac = T.action.cpu().numpy().reshape(G, cap)
+    assert int(T.overflow.sum().item()) == 0
+    assert np.all(T.root.cpu().numpy() == 0) and np.all(par[:, 0] == -1)
+    assert np.all(nv[:, 0] == n_sims)                    # every playout passes through the root
+    move, visits = m.best_move(act)
+    move, visits = move.cpu().numpy(), visits.cpu().numpy()
+    for gi in range(0, G, 7):
+        n = nn[gi]
+        assert 5 <= n <= cap
+        for i in range(n):
+            if fc[gi, i] >= 0:
+                k, c0 = nc[gi, i], fc[gi, i]
+                kids = slice(c0, c0 + k)
+                assert np.all(par[gi, kids] == i)
+                assert np.all(np.diff(ac[gi, kids].astype(int)) > 0)          # ascending actions
+                # a node is evaluated itself exactly n_thr times before it expands
+                assert nv[gi, i] == n_thr + nv[gi, kids].sum(), (gi, i)
+                assert np.all(pr[gi, kids] > 0.1 - 1e-7) and np.all(pr[gi, kids] <= 1.1 + 1e-6)
+            else:
+                assert nv[gi, i] < n_thr or i == 0 or nv[gi, i] == n_thr      # unexpanded leaf
+        assert np.all(np.abs(q[gi, :n]) <= 0.5 * np.abs(q[gi, :n]).max() + 1.0)
+        kids = slice(fc[gi, 0], fc[gi, 0] + nc[gi, 0])
+        assert nc[gi, 0] == 4 and list(ac[gi, kids]) == [19, 26, 37, 44]      # the 4 opening moves
+        assert visits[gi, ac[gi, kids]].tolist() == nv[gi, kids].tolist()
+        assert move[gi] == ac[gi, kids][np.argmax(nv[gi, kids])]
+    # all 1024 games start identically; their trees differ only through the rollouts' RNG
+    assert len({int(x) for x in nn}) > 1
+    m2 = run()
+    for f in ("n_visits", "q", "p", "action", "first_child"):
+        a, b = getattr(m.tree, f), getattr(m2.tree, f)
+        used = torch.arange(cap, device="cuda").reshape(1, cap) < m.tree.n_nodes.reshape(G, 1)
+        assert torch.equal(a.reshape(G, cap)[used], b.reshape(G, cap)[used]), f
