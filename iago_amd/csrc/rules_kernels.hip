@@ -118,6 +118,24 @@ __global__ __launch_bounds__(BLOCK) void sample_moves_kernel(
     action[b] = (int8_t)idx; // 64 would mean NaN probabilities: the reference raises there
 }
 
+
+// Block epilogue: one float4 per thread, 16 threads per (board, channel) plane.
+__global__ __launch_bounds__(BLOCK) void bias_relu_kernel(float4 *__restrict__ x,
+                                                          const float *__restrict__ bias,
+                                                          int64_t n4, int channels)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n4)
+        return;
+    const float b = bias[(i >> 4) % channels];
+    float4 v = x[i];
+    v.x = fmaxf(v.x + b, 0.0f);
+    v.y = fmaxf(v.y + b, 0.0f);
+    v.z = fmaxf(v.z + b, 0.0f);
+    v.w = fmaxf(v.w + b, 0.0f);
+    x[i] = v;
+}
+
 inline unsigned grid_for(int64_t threads) { return (unsigned)((threads + BLOCK - 1) / BLOCK); }
 
 } // namespace
@@ -184,6 +202,20 @@ int iago_sample_moves(const float *probs, const uint64_t *legal, const double *u
                        probs, legal, uniforms, (uint32_t)seed, (uint32_t)(seed >> 32), id_base,
                        step, stream_id, action, n);
     return iago_check_launch("iago_sample_moves");
+}
+
+int iago_bias_relu(float *x, const float *bias, int64_t n, int32_t channels, void *stream)
+{
+    if (n < 0 || channels < 1 || (n > 0 && (!x || !bias)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_bias_relu: null pointer or bad size");
+    if ((uintptr_t)x & 15u)
+        return iago_fail(IAGO_ERR_INVALID, "iago_bias_relu: x must be 16-byte aligned");
+    if (n == 0)
+        return IAGO_OK;
+    const int64_t n4 = n * channels * 16;
+    hipLaunchKernelGGL(bias_relu_kernel, dim3(grid_for(n4)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (float4 *)x, bias, n4, (int)channels);
+    return iago_check_launch("iago_bias_relu");
 }
 
 } // extern "C"

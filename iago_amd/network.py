@@ -28,6 +28,13 @@ class Block(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, ksize, padding=pad)
 
     def forward(self, x):
+        if (x.is_cuda and not torch.is_grad_enabled() and x.shape[-1] == 8 and x.shape[-2] == 8
+                and x.dtype == torch.float32 and self.conv.bias is not None):
+            # inference on the GPU: MIOpen convolution without bias + one fused
+            # bias/ReLU pass (HIP) instead of PyTorch's two elementwise kernels
+            from . import ops
+            y = F.conv2d(x, self.conv.weight, None, padding=self.conv.padding)
+            return ops.bias_relu_(y.contiguous(), self.conv.bias)
         return F.relu(self.conv(x))
 
 

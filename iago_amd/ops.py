@@ -82,6 +82,16 @@ def judge(own, opp):
     return out
 
 
+def bias_relu_(x, bias):
+    """In place max(x + bias[c], 0) on a (n, C, 8, 8) float32 tensor: the epilogue
+    of network.Block (network.py:9-13) as one pass."""
+    if x.dim() != 4 or x.shape[2] != 8 or x.shape[3] != 8:
+        raise ValueError("x must be (n, C, 8, 8)")
+    check(_lib.lib().iago_bias_relu(_dev(x, torch.float32, "x"), _dev(bias, torch.float32, "bias"),
+                                    x.shape[0], x.shape[1], _stream()), "iago_bias_relu")
+    return x
+
+
 def sample_moves(probs, legal, uniforms=None, seed=0, id_base=0, step=0, stream_id=0):
     """Masked inverse-CDF sampling (src/rl_self_play.py:111-122); int8 actions,
     -1 where there is no legal move.  uniforms: optional float64 (n,)."""

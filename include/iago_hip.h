@@ -160,6 +160,18 @@ typedef struct iago_rollout_args {
 IAGO_API int iago_rollout(const iago_rollout_args *args, void *stream);
 
 
+/* ------------------------------------------------------------------- nets */
+
+/*
+ * In place x[b][c][:] = max(x[b][c][:] + bias[c], 0) on a float32 NCHW tensor
+ * with 8x8 planes (hw = 64): the bias + ReLU epilogue of Block.__call__
+ * (network.py:9-13: Convolution2D with bias, then F.relu) as ONE pass, for the
+ * inference path of the PyTorch modules (MIOpen's convolution is called
+ * without bias; PyTorch would otherwise run a bias-add and a ReLU kernel).
+ * x: [n][channels][64] floats, 16-byte aligned; bias: [channels].
+ */
+IAGO_API int iago_bias_relu(float *x, const float *bias, int64_t n, int32_t channels, void *stream);
+
 /* ------------------------------------------------------------------- MCTS */
 
 /*
