@@ -130,6 +130,8 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(
     }
     // leaf: expansion test (MCTS.py:109) and its legal moves (MCTS.py:111)
     const uint64_t legal = group8_legal(to_lane(own, L), to_lane(opp, L), L);
+    if (live && L.l8 == 0 && descending && T.first_child[base + node] >= 0)
+        T.overflow[g] = 1; // path longer than MAX_DEPTH: reported like a full pool
     if (live && L.l8 == 0) {
         cur_node[g] = node;
         cur_own[g] = own;

@@ -82,6 +82,9 @@ __device__ __forceinline__ void add8(Row8 &e, const float4 lo, const float4 hi)
     e.d += (f2){hi.z, hi.w};
 }
 
+// Diagnostic build only (-DEXP_STAMPS, tools/exp_stamps.py): s_memtime stamps at the
+// segment boundaries of a turn; the sums leave through final_own/final_opp.  Never
+// defined in the shipped library.
 #ifdef EXP_STAMPS
 #define STAMP(i)                                                                      \
     do {                                                                              \
@@ -124,13 +127,8 @@ __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t
     float4 ta[6], tb[6];
 #pragma unroll
     for (int ky = 0; ky < 3; ky++) {
-#ifdef EXP_CONST_E
-        const uint32_t bp = (wp >> (8 * ky)) & 0x1u;
-        const uint32_t bo = (wo >> (8 * ky)) & 0x1u;
-#else
         const uint32_t bp = (wp >> (8 * ky)) & 0xFFu;
         const uint32_t bo = (wo >> (8 * ky)) & 0xFFu;
-#endif
         const float *tp = tbl + OFF_E + ((ky * 2 + 0) * 2) * 1024 + bp * 4;
         const float *to = tbl + OFF_E + ((ky * 2 + 1) * 2) * 1024 + bo * 4;
         ta[2 * ky] = lds_f4(tp);

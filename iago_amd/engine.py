@@ -207,8 +207,8 @@ class BatchedMCTS(object):
         for _ in range(n_sims):
             self.simulate(own, opp, active, n_active)
         if int(self.tree.overflow.sum().item()) != 0:
-            raise _lib.IagoError("MCTS node pool exhausted: raise `capacity` (%d nodes per game)"
-                                 % self.tree.capacity)
+            raise _lib.IagoError("MCTS node pool exhausted (or a search path deeper than 512): "
+                                 "raise `capacity` (%d nodes per game)" % self.tree.capacity)
 
     def enable_stats(self):
         self.stats = torch.zeros((self.n_games, 2), dtype=torch.int32, device=self.cur_own.device)

@@ -55,6 +55,10 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
             if bool(done.all().item()):
                 break
     p1, p2 = (own, opp) if t % 2 == 0 else (opp, own)
+    if bool((torch.stack(rec_act) > 63).any().item()):
+        # iago_sample_moves returns 64 when no cell's CDF exceeds u: NaN probabilities.
+        # numpy.random.choice raises here in the reference (src/rl_self_play.py:122)
+        raise ValueError("probabilities contain NaN")
     return dict(own=torch.stack(rec_own), opp=torch.stack(rec_opp), action=torch.stack(rec_act),
                 z=ops.judge(p1, p2), final_p1=p1, final_p2=p2, n_turns=t)
 

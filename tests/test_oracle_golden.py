@@ -120,8 +120,7 @@ def test_env(golden_json):
 
         env = mcts_py.GameEnv(opp, c["uniforms"])
         for s in c["steps"]:
-            obs, r, done, info = env.step(s["action"]) if s["action"] in \
-                orc.legal_actions(env.state, 1) or not orc.legal_actions(env.state, 1) else (None,) * 4
+            obs, r, done, info = env.step(s["action"])  # fixtures only hold legal agent actions
             assert orc.state_to_bits(env.state) == (s["p1"], s["p2"])
             assert (done, r, env.stone_num, env.pass_flg) == (s["done"], s["reward"],
                                                               s["stone_num"], s["pass_flg"])
