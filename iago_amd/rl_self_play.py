@@ -28,6 +28,7 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
     pass_flg = torch.zeros(B, dtype=torch.bool, device=device)
     done = torch.zeros(B, dtype=torch.bool, device=device)
     rec_own, rec_opp, rec_act = [], [], []
+    nan_seen = torch.zeros((), dtype=torch.bool, device=device)
     t = 0
     while t < ops.IAGO_MAX_TURNS:
         color = 1 if t % 2 == 0 else 2
@@ -39,6 +40,7 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
         a = ops.sample_moves(probs.to(torch.float32).contiguous(),
                              torch.where(active, legal, torch.zeros_like(legal)), uniforms=u,
                              seed=seed, id_base=game_id_base, step=t)
+        nan_seen = nan_seen | (a > 63).any()
         if color == 1:
             rec_own.append(own.clone())
             rec_opp.append(opp.clone())
@@ -55,7 +57,7 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
             if bool(done.all().item()):
                 break
     p1, p2 = (own, opp) if t % 2 == 0 else (opp, own)
-    if bool((torch.stack(rec_act) > 63).any().item()):
+    if bool(nan_seen.item()):
         # iago_sample_moves returns 64 when no cell's CDF exceeds u: NaN probabilities.
         # numpy.random.choice raises here in the reference (src/rl_self_play.py:122)
         raise ValueError("probabilities contain NaN")
