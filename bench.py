@@ -212,13 +212,34 @@ def reinforce_leg(n_iters, world, rank, dist):
                       "double-softmax REINFORCE update, ChainerAdam + WD 5e-4"}
 
 
-def measured_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes, if any."""
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2  # wave64 VALU instructions/ns: 1024 SIMD-32s, 2 cycles each
+
+
+def measured_pmc():
+    """Per-launch figures from the committed rocprofv3 --pmc passes (profiles/), if any."""
     path = os.path.join(ROOT, "profiles", "rollout_traffic.json")
     if os.path.exists(path):
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    return None
+            return json.load(f)
+    return {}
+
+
+def measured_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes, if any."""
+    return measured_pmc().get("hbm_bytes_per_launch")
+
+
+def valu_utilisation(boards, seconds):
+    """What really bounds the kernel: wave-level VALU instructions (PMC count per
+    board from profiles/, the instruction stream does not depend on the batch) over
+    the chip's issue peak.  None without a committed PMC profile."""
+    pmc = measured_pmc()
+    if "valu_insts_per_launch" not in pmc:
+        return None
+    per_board = pmc["valu_insts_per_launch"] / pmc["boards_per_launch"]
+    achieved = per_board * boards / seconds / 1e9
+    return {"valu_insts_per_board": per_board, "achieved_ginst_per_s": achieved,
+            "peak_ginst_per_s": VALU_PEAK_GINST, "frac": achieved / VALU_PEAK_GINST}
 
 
 def main():
@@ -370,7 +391,8 @@ def main():
         lsteps = int(lout.n_turns.to(torch.int64).sum().item())
         large = {"boards": LB, "kernel_ms": lms, "games_per_sec": LB / (lms * 1e-3),
                  "board_steps_per_sec": lsteps / (lms * 1e-3),
-                 "hbm_frac": BYTES_PER_BOARD_STEP * lsteps / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                 "hbm_frac": BYTES_PER_BOARD_STEP * lsteps / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "valu": valu_utilisation(LB, lms * 1e-3)}
         del lown, lopp, lout
 
     mcts = None
@@ -407,7 +429,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "launches_in_flight": kernel_ms * K / span_ms,
                          "aggregate_achieved": aggregate,
-                         "aggregate_frac": aggregate / HBM_PEAK_GBS},
+                         "aggregate_frac": aggregate / HBM_PEAK_GBS,
+                         "valu": valu_utilisation(K * B, span_ms * 1e-3)},
         }
         if large is not None:
             line["large_batch"] = large

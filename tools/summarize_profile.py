@@ -53,10 +53,15 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     summary["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KiB per launch; FETCH_SIZE doubled per "
                                "the gfx950 correction for 16 B/lane reads (the 48 KiB table staging "
                                "is float4 loads; board loads are 8 B/lane and uncalibrated)")
+    extra = {}
+    if "SQ_INSTS_VALU" in pmc and "Grid_Size" in pmc.get("_dispatch", {}):
+        # wave-level VALU instructions of one launch and the boards it played (8 lanes each)
+        extra = {"valu_insts_per_launch": pmc["SQ_INSTS_VALU"]["mean"],
+                 "boards_per_launch": int(pmc["_dispatch"]["Grid_Size"]) // 8}
     with open(os.path.join(out, "rollout_traffic.json"), "w") as f:
-        json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kib": fetch_kb,
-                   "write_size_kib": write_kb, "profile": tag,
-                   "note": summary["traffic_note"]}, f, indent=1)
+        json.dump(dict({"hbm_bytes_per_launch": hbm, "fetch_size_kib": fetch_kb,
+                        "write_size_kib": write_kb, "profile": tag,
+                        "note": summary["traffic_note"]}, **extra), f, indent=1)
 with open(os.path.join(out, "%s_pmc_summary.json" % tag), "w") as f:
     json.dump(summary, f, indent=1)
 print(json.dumps(summary, indent=1)[:3000])
