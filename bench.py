@@ -80,6 +80,9 @@ def cpu_baseline(w, b, budget_s=10.0):
             steps = sum(f.result()[1] for f in futs)
         return time.perf_counter() - t0, steps
 
+    t0 = time.perf_counter()
+    orc.simulate_batch(s0, 1, w, b, 0, 1_000_000, 2000)
+    one_core = 2000 / (time.perf_counter() - t0)
     probe_t, _ = run(100, 5_000_000)
     n_each = max(100, min(200_000, int(100 * budget_s / probe_t)))
     dt, steps = run(n_each, 10_000_000)
@@ -87,7 +90,7 @@ def cpu_baseline(w, b, budget_s=10.0):
     return {"value": games / dt, "unit": "games/s", "cores": cores, "kind": "port",
             "sample": "%d rollout-policy games from the start position (%d per thread, "
                       "oracle/othello_oracle.c, %.1f s)" % (games, n_each, dt),
-            "board_steps_per_game": steps / games}
+            "board_steps_per_game": steps / games, "one_core_games_per_sec": one_core}
 
 
 def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
