@@ -20,7 +20,7 @@ TRACE_PASS = 0xFF
 SYMBOLS = [
     "iago_abi_version", "iago_last_error", "iago_device_count",
     "iago_legal_moves", "iago_apply_moves", "iago_encode_planes", "iago_judge",
-    "iago_sample_moves", "iago_bias_relu",
+    "iago_sample_moves", "iago_augment8", "iago_bias_relu",
     "iago_rollout_build_table", "iago_rollout",
     "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_leaf_values",
     "iago_mcts_backup", "iago_mcts_best_move", "iago_mcts_advance_root",
@@ -85,6 +85,7 @@ def lib():
     L.iago_judge.argtypes = [vp, vp, vp, i64, vp]
     L.iago_sample_moves.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
                                     i64, vp]
+    L.iago_augment8.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
     L.iago_bias_relu.argtypes = [vp, vp, i64, C.c_int32, vp]
     L.iago_rollout_build_table.argtypes = [vp, vp, vp]
     L.iago_rollout.argtypes = [C.POINTER(RolloutArgs), vp]

@@ -136,6 +136,50 @@ __global__ __launch_bounds__(BLOCK) void bias_relu_kernel(float4 *__restrict__ x
     x[i] = v;
 }
 
+
+// Board symmetries on a bitboard (bit a = row*8+col).
+__device__ __forceinline__ uint64_t bb_transpose(uint64_t x) // (y,x) -> (x,y)
+{
+    uint64_t t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;
+    x ^= t ^ (t << 7);
+    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull;
+    x ^= t ^ (t << 14);
+    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull;
+    x ^= t ^ (t << 28);
+    return x;
+}
+// np.rot90 (counter-clockwise): (y,x) -> (7-x, y) = transpose, then flip the rows
+__device__ __forceinline__ uint64_t bb_rot90(uint64_t x) { return __builtin_bswap64(bb_transpose(x)); }
+__device__ __forceinline__ int act_rot90(int a) { return a < 0 ? a : (7 - (a & 7)) * 8 + (a >> 3); }
+__device__ __forceinline__ int act_transpose(int a) { return a < 0 ? a : (a & 7) * 8 + (a >> 3); }
+
+__global__ __launch_bounds__(BLOCK) void augment8_kernel(
+    const uint64_t *__restrict__ own, const uint64_t *__restrict__ opp,
+    const int8_t *__restrict__ action, uint64_t *__restrict__ own_out,
+    uint64_t *__restrict__ opp_out, int8_t *__restrict__ action_out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    uint64_t o = own[i], p = opp[i];
+    int a = (int)action[i];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k == 4) { // load.py:64-68
+            o = bb_transpose(o);
+            p = bb_transpose(p);
+            a = act_transpose(a);
+        } else if (k > 0) { // load.py:58-63,69-74
+            o = bb_rot90(o);
+            p = bb_rot90(p);
+            a = act_rot90(a);
+        }
+        own_out[k * n + i] = o;
+        opp_out[k * n + i] = p;
+        action_out[k * n + i] = (int8_t)a;
+    }
+}
+
 inline unsigned grid_for(int64_t threads) { return (unsigned)((threads + BLOCK - 1) / BLOCK); }
 
 } // namespace
@@ -216,6 +260,18 @@ int iago_bias_relu(float *x, const float *bias, int64_t n, int32_t channels, voi
     hipLaunchKernelGGL(bias_relu_kernel, dim3(grid_for(n4)), dim3(BLOCK), 0, (hipStream_t)stream,
                        (float4 *)x, bias, n4, (int)channels);
     return iago_check_launch("iago_bias_relu");
+}
+
+int iago_augment8(const uint64_t *own, const uint64_t *opp, const int8_t *action, uint64_t *own_out,
+                  uint64_t *opp_out, int8_t *action_out, int64_t n, void *stream)
+{
+    if (n < 0 || (n > 0 && (!own || !opp || !action || !own_out || !opp_out || !action_out)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_augment8: null pointer or negative n");
+    if (n == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(augment8_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, own,
+                       opp, action, own_out, opp_out, action_out, n);
+    return iago_check_launch("iago_augment8");
 }
 
 } // extern "C"

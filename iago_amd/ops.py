@@ -82,6 +82,20 @@ def judge(own, opp):
     return out
 
 
+def augment8(own, opp, action):
+    """8-fold dihedral augmentation in the reference's order (load.py:56-74):
+    returns (8, n) own, opp (int64) and action (int8)."""
+    n = own.numel()
+    oo = torch.empty((8, n), dtype=torch.int64, device=own.device)
+    po = torch.empty((8, n), dtype=torch.int64, device=own.device)
+    ao = torch.empty((8, n), dtype=torch.int8, device=own.device)
+    check(_lib.lib().iago_augment8(_dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp"),
+                                   _dev(action, torch.int8, "action"), _dev(oo, torch.int64, "o"),
+                                   _dev(po, torch.int64, "p"), _dev(ao, torch.int8, "a"), n,
+                                   _stream()), "iago_augment8")
+    return oo, po, ao
+
+
 def bias_relu_(x, bias):
     """In place max(x + bias[c], 0) on a (n, C, 8, 8) float32 tensor: the epilogue
     of network.Block (network.py:9-13) as one pass."""

@@ -114,6 +114,17 @@ IAGO_API int iago_sample_moves(const float *probs, const uint64_t *legal, const 
                                uint64_t seed, uint32_t id_base, uint32_t step, uint32_t stream_id,
                                int8_t *action, int64_t n, void *stream);
 
+/*
+ * The 8-fold dihedral augmentation of a (position, action) data set, in the
+ * reference's order (load.py:56-74): variant 0 = identity, 1..3 = successive
+ * np.rot90 (counter-clockwise, (y,x) -> (7-x, y), load.rotate load.py:12-16),
+ * 4 = transpose of variant 3 (load.transpose load.py:18-22), 5..7 = three more
+ * rotations.  own/opp/action: [n]; outputs [8][n]; action -1 stays -1.
+ */
+IAGO_API int iago_augment8(const uint64_t *own, const uint64_t *opp, const int8_t *action,
+                           uint64_t *own_out, uint64_t *opp_out, int8_t *action_out, int64_t n,
+                           void *stream);
+
 /* ---------------------------------------------------------------- rollout */
 
 /*

@@ -96,6 +96,7 @@ import game as ref_game  # noqa: E402
 import mcts_self_play as ref_sim  # noqa: E402
 import rl_env as ref_env  # noqa: E402
 import rl_self_play as ref_rl  # noqa: E402
+import load as ref_load  # noqa: E402  (pure numpy; main() is not run)
 
 gf = ref_game.GameFunctions
 
@@ -632,15 +633,50 @@ def sampling():
     return np.array(ps), np.array(us), np.array(idx, np.int64)
 
 
+# ------------------------------------------------------ 8. augmentation
+def augment(recs):
+    """The 8-fold dihedral augmentation of load.py:56-71 on sample positions,
+    with the reference's own action maps load.rotate / load.transpose and the
+    numpy calls of its main()."""
+    idx = np.linspace(0, len(recs) - 1, 40).astype(int)
+    states = np.zeros((len(idx), 8, 8))
+    actions = np.zeros(len(idx))
+    for k, i in enumerate(idx):
+        p1, p2, legal = int(recs[i, 0]), int(recs[i, 1]), int(recs[i, 3])
+        for a in range(64):
+            states[k, a // 8, a % 8] = 1 if (p1 >> a) & 1 else (2 if (p2 >> a) & 1 else 0)
+        acts = [a for a in range(64) if (legal >> a) & 1]
+        actions[k] = acts[k % len(acts)] if acts else 27
+    S, A = states, actions
+    for i in range(3):                                   # load.py:58-63
+        states = np.rot90(states, k=1, axes=(1, 2))
+        S = np.concatenate([S, states], axis=0)
+        actions = ref_load.rotate(actions)
+        A = np.concatenate([A, actions], axis=0)
+    states = states.transpose(0, 2, 1)                   # load.py:64-68
+    S = np.concatenate([S, states], axis=0)
+    actions = ref_load.transpose(actions)
+    A = np.concatenate([A, actions], axis=0)
+    for i in range(3):                                   # load.py:69-74
+        states = np.rot90(states, k=1, axes=(1, 2))
+        S = np.concatenate([S, states], axis=0)
+        actions = ref_load.rotate(actions)
+        A = np.concatenate([A, actions], axis=0)
+    bits = np.array([to_bits(st) for st in S], dtype=np.uint64)
+    return bits.reshape(8, len(idx), 2), A.reshape(8, len(idx)).astype(np.int64)
+
+
 def main():
     check_choice_restatement()
     recs, games = rules_traces()
     names, boards, legal, place, order = rules_edge()
     pidx, pl = planes(recs)
     ps, us, idx = sampling()
+    aug_bits, aug_act = augment(recs)
     np.savez_compressed(os.path.join(OUT, "rules.npz"), trace=recs, games=games,
                         edge_boards=boards, edge_legal=legal, edge_place=place,
-                        planes_idx=pidx, planes=pl, samp_p=ps, samp_u=us, samp_idx=idx)
+                        planes_idx=pidx, planes=pl, samp_p=ps, samp_u=us, samp_idx=idx,
+                        aug_bits=aug_bits, aug_act=aug_act)
     with open(os.path.join(OUT, "order.json"), "w") as f:
         json.dump(dict(names=names, order=order), f)
     with open(os.path.join(OUT, "simulate.json"), "w") as f:

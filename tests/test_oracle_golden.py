@@ -210,3 +210,14 @@ def test_mcts_rollouts_replay(golden_json):
     g = golden_json("mcts.json")
     for c in g["cases"]:
         assert set(c["zs"]) <= {-1, 0, 1}
+
+
+def test_augment8(golden_rules):
+    from oracle import augment_np
+    bits, act = golden_rules["aug_bits"], golden_rules["aug_act"]
+    states = np.stack([st(b[0], b[1]) for b in bits[0]])
+    S, A = augment_np.augment8(states, act[0])
+    assert np.array_equal(A, act)
+    for k in range(8):
+        for i in range(bits.shape[1]):
+            assert orc.state_to_bits(S[k, i]) == (int(bits[k, i, 0]), int(bits[k, i, 1]))

@@ -146,3 +146,34 @@ def test_full_size_symmetry_property(ops):
     assert np.all((a2[moved] & a[moved]) == a[moved])
     flips = b[moved] & ~b2[moved]
     assert np.all(flips != 0)
+
+
+def test_augment8_golden_and_oracle(ops, golden_rules):
+    """iago_augment8 against the vectors recorded from load.py's own functions
+    and against the numpy restatement on a large random batch."""
+    from oracle import augment_np
+    bits, act = golden_rules["aug_bits"], golden_rules["aug_act"]
+    o, p, a = ops.augment8(T(ops, bits[0, :, 0]), T(ops, bits[0, :, 1]),
+                           torch.from_numpy(act[0].astype(np.int8)).cuda())
+    assert np.array_equal(ops.tensor_to_bits(o).reshape(8, -1), bits[:, :, 0])
+    assert np.array_equal(ops.tensor_to_bits(p).reshape(8, -1), bits[:, :, 1])
+    assert np.array_equal(a.cpu().numpy(), act.astype(np.int8))
+    n = 5000
+    own, opp = random_positions(n, seed=41)
+    rs = np.random.RandomState(2)
+    acts = rs.randint(-1, 64, size=n).astype(np.int8)
+    o, p, a = ops.augment8(T(ops, own), T(ops, opp), torch.from_numpy(acts).cuda())
+    states = np.stack([state_of(own[i], opp[i]) for i in range(n)])
+    S, A = augment_np.augment8(states, np.maximum(acts, 0))
+    ob, pb, ab = ops.tensor_to_bits(o).reshape(8, n), ops.tensor_to_bits(p).reshape(8, n), a.cpu().numpy()
+    for k in range(8):
+        for i in range(0, n, 50):
+            assert orc.state_to_bits(S[k, i]) == (int(ob[k, i]), int(pb[k, i]))
+        ok = acts >= 0
+        assert np.array_equal(ab[k][ok], A[k][ok].astype(np.int8))
+        assert np.all(ab[k][~ok] == -1)
+    # the 8 variants of a position have the same number of stones and legal moves
+    lm = ops.tensor_to_bits(ops.legal_moves(o.reshape(-1), p.reshape(-1))).reshape(8, n)
+    pop = np.vectorize(lambda v: bin(int(v)).count("1"))
+    mob = pop(lm[:, :400])
+    assert np.all(mob == mob[0:1])
