@@ -107,7 +107,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
     policy = network.SLPolicy().cuda().eval()
     value = network.Value().cuda().eval()
     m = engine.BatchedMCTS(n_games, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0,
-                           n_thr=15, capacity=8192, seed=7, game_id_base=rank * n_games)
+                           n_thr=15, capacity=engine.suggest_capacity(n_sims, 15), seed=7,
+                           game_id_base=rank * n_games)
     eng = engine.SelfPlayEngine(m, max_turns=(128 if full_games else n_turns))
     m.enable_stats()
     m.warmup()                 # MIOpen kernel selection for every batch bucket
@@ -140,7 +141,9 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
            "net_tflops_fp32": flops / dt / 1e12,
            "config": "BASELINE configs[2]: PV-MCTS %d sims/move, %d games per GPU, SLPolicy+Value "
                      "random init fp32, lmbda=0.5 c_puct=1 n_thr=15" % (n_sims, n_games),
-           "tree_pool_bytes_per_gpu": m.tree.bytes(), "tree_traffic_rank0": m.tree_bytes()}
+           "tree_pool_bytes_per_gpu": m.tree.bytes(), "tree_traffic_rank0": m.tree_bytes(),
+           "tree_nodes_used_max": int(m.tree.n_nodes.max().item()),
+           "tree_capacity": m.tree.capacity}
     if full_games:
         out["games_per_sec"] = world * n_games / dt
         if gathered is not None:

@@ -30,6 +30,17 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def suggest_capacity(n_sims, n_thr=15, moves=64, branching=12):
+    """Nodes per game that a whole self-play game needs without pool compaction:
+    every expansion adds ~`branching` children, a search adds at most
+    n_sims / n_thr + 1 expansions, abandoned siblings are never reclaimed."""
+    per_move = (n_sims // max(n_thr, 1) + 1) * branching
+    cap = 1024
+    while cap < per_move * moves:
+        cap *= 2
+    return cap
+
+
 class TreePool(object):
     """Device memory of the per-game search trees (iago_mcts_tree)."""
 
