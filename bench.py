@@ -99,8 +99,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
     (Chainer-default LeCunNormal, seed 0), reference constants lmbda=0.5,
     c_puct=1, n_thr=15, both colours search.  One leaf-eval = one playout
     (value net + rollout at the leaf; the policy net runs on expansions).
-    Default: a bounded sample of the first `n_turns` turns; --mcts-full plays
-    the games to the end and reports games/s."""
+    By default the games are played to the end (games/s); --mcts-turns N > 0
+    times a bounded sample of the first N turns instead."""
     from iago_amd import engine, network, ops
     w, b = shipped_rollout_weights()
     torch.manual_seed(0)
@@ -122,7 +122,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
     res = eng.play(n_sims, record=True)
     gathered = None
     if dist is not None and full_games:
-            gathered = gather_tuples(res.tuples())
+        from iago_amd.dist import gather_tuples
+        gathered = gather_tuples(res.tuples())
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
