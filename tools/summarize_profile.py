@@ -20,8 +20,12 @@ out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+rocprof_avg_ns = None
 if stats:
     rows = list(csv.reader(open(stats[0])))
+    for r in rows[1:]:
+        if kern in r[0]:
+            rocprof_avg_ns = float(r[3])
     with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w") as f:
         w = csv.writer(f)
         for r in rows:
@@ -54,10 +58,12 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                                "the gfx950 correction for 16 B/lane reads (the 48 KiB table staging "
                                "is float4 loads; board loads are 8 B/lane and uncalibrated)")
     extra = {}
+    if rocprof_avg_ns is not None:
+        extra["rocprof_kernel_avg_ms"] = rocprof_avg_ns / 1e6
     if "SQ_INSTS_VALU" in pmc and "Grid_Size" in pmc.get("_dispatch", {}):
         # wave-level VALU instructions of one launch and the boards it played (8 lanes each)
-        extra = {"valu_insts_per_launch": pmc["SQ_INSTS_VALU"]["mean"],
-                 "boards_per_launch": int(pmc["_dispatch"]["Grid_Size"]) // 8}
+        extra.update({"valu_insts_per_launch": pmc["SQ_INSTS_VALU"]["mean"],
+                      "boards_per_launch": int(pmc["_dispatch"]["Grid_Size"]) // 8})
     with open(os.path.join(out, "rollout_traffic.json"), "w") as f:
         json.dump(dict({"hbm_bytes_per_launch": hbm, "fetch_size_kib": fetch_kb,
                         "write_size_kib": write_kb, "profile": tag,
