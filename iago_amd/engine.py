@@ -105,7 +105,7 @@ class BatchedMCTS(object):
     policy_fn(planes) -> (L,64) probabilities, value_fn(planes) -> (L,) values,
     planes = (L,2,8,8) float32 CUDA tensor (GameFunctions.make_state_var
     layout).  rollout_weights: ops.RolloutWeights (None = uniform random
-    rollouts).  rollout_hook(z) lets tests record / replace rollout results.
+    rollouts).  rollout_hook(engine) runs after every rollout launch (tests record `engine.z`).
     """
 
     def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
