@@ -389,22 +389,28 @@ int iago_rollout_build_table(const float *w18, const float *b64, float *blob)
             lmax += tmax[ky][pl];
             lmin += tmin[ky][pl];
         }
-    // Product form needs every partial product of the 7 factors inside float32's
-    // normal range: with the shift spread evenly the largest full product is 1
-    // and the smallest exp(lmin - lmax).
+    // Product form: every factor is shifted by ITS OWN maximum, so each factor is in
+    // (0, 1], the full product is exp(logit - lmax) <= 1 and no partial product can
+    // overflow; the smallest partial product is >= exp(-(lmax - lmin)), kept normal
+    // by the range test.  (Softmax is shift-invariant, so the shifts cancel.)
     const bool product = std::isfinite(lmax) && std::isfinite(lmin) && (lmax - lmin) < 60.0;
-    const double shift = product ? -lmax / 7.0 : 0.0;
+    double bmax = -1e300;
+    for (int x = 0; x < 64; x++)
+        if (w18 && (double)b64[x] > bmax)
+            bmax = (double)b64[x];
+    if (!w18)
+        bmax = 0.0;
     for (int ky = 0; ky < 3; ky++)
         for (int pl = 0; pl < 2; pl++)
             for (int byte = 0; byte < 256; byte++)
                 for (int x = 0; x < 8; x++) {
                     const float tv = T[ky][pl][byte][x];
-                    const float v = product ? (float)exp((double)tv + shift) : tv;
+                    const float v = product ? (float)exp((double)tv - tmax[ky][pl]) : tv;
                     blob[OFF_E + (((ky * 2 + pl) * 2 + (x >> 2)) * 256 + byte) * 4 + (x & 3)] = v;
                 }
     for (int x = 0; x < 64; x++) {
         const float bv = w18 ? b64[x] : 0.0f;
-        blob[OFF_BIAS + x] = product ? (float)exp((double)bv + shift) : bv;
+        blob[OFF_BIAS + x] = product ? (float)exp((double)bv - bmax) : bv;
     }
     blob[OFF_MODE] = product ? 1.0f : 0.0f;
     blob[OFF_MODE + 1] = blob[OFF_MODE + 2] = blob[OFF_MODE + 3] = 0.0f;

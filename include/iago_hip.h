@@ -136,7 +136,7 @@ IAGO_API int iago_augment8(const uint64_t *own, const uint64_t *opp, const int8_
  * the uniform policy (every legal move equally likely).
  * Layout: E[3 ky][2 plane][2 half][256 row byte][4] row-pattern contributions
  * to 8 adjacent outputs; bias[64]; mode[4].  mode[0] == 1: PRODUCT form (E and bias hold exp() of the
- * contributions, shifted so that the largest softmax numerator is 1), chosen
+ * contributions, each factor shifted by its own maximum so that all lie in (0,1]), chosen
  * when the logit range is < 60 so that no partial product leaves float32's
  * range; mode[0] == 0: LOG form (raw sums; the kernel does max / exp2).  Pass
  * log_form = (mode[0] == 0) to iago_rollout.

@@ -64,3 +64,36 @@ def test_invalid_arguments_are_reported(so):
     assert b"iago_legal_moves" in L.iago_last_error()
     assert L.iago_legal_moves(None, None, None, 0, None) == 0
     assert L.iago_rollout(None, None) == -1
+
+
+def test_rollout_table_builder_host_side(so):
+    """iago_rollout_build_table runs on the host: product form keeps every factor in
+    (0, 1] whatever the common offset of the logits, the uniform policy is all ones,
+    and a wide logit range selects the log form."""
+    import ctypes as C
+    import numpy as np
+    L = _lib.lib()
+    n = _lib.IAGO_ROLLOUT_TABLE_FLOATS
+    rs = np.random.RandomState(0)
+
+    def build(w, b):
+        blob = np.empty(n, np.float32)
+        wp = C.c_void_p(w.ctypes.data) if w is not None else None
+        bp = C.c_void_p(b.ctypes.data) if b is not None else None
+        assert L.iago_rollout_build_table(wp, bp, C.c_void_p(blob.ctypes.data)) == 0
+        return blob
+
+    w = rs.randn(18).astype(np.float32)
+    for offset in (0.0, 500.0, -3000.0):
+        b = (rs.randn(64) + offset).astype(np.float32)
+        blob = build(w, b)
+        assert blob[-4] == 1.0                       # product form
+        body = blob[:-4]
+        assert np.all(np.isfinite(body)) and body.min() > 0.0 and body.max() == 1.0
+        # bias factors: exp(b - max b)
+        assert np.allclose(body[-64:], np.exp(b.astype(np.float64) - b.max()), rtol=1e-6)
+    uni = build(None, None)
+    assert np.all(uni[:-4] == 1.0) and uni[-4] == 1.0
+    wide = build((12 * rs.randn(18)).astype(np.float32), (5 * rs.randn(64)).astype(np.float32))
+    assert wide[-4] == 0.0                           # log form: raw sums
+    assert L.iago_rollout_build_table(C.c_void_p(w.ctypes.data), None, None) == -1

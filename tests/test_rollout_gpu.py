@@ -226,3 +226,17 @@ def test_sample_moves_bit_exact(ops):
         if acts:
             want = orc.choice_cdf(orc.masked_probs(probs[i], acts), orc.uniform(9, 100 + i, 7))
             assert got2[i] == want
+
+
+def test_product_form_with_large_common_offset(ops):
+    """Softmax is shift-invariant: biases offset by +500 (product form, factors
+    shifted by their own maxima) replay against the oracle like any other net."""
+    rs = np.random.RandomState(8)
+    w = rs.randn(18).astype(np.float32)
+    bvec = (0.5 * rs.randn(64) + 500.0).astype(np.float32)
+    weights = ops.RolloutWeights(w, bvec)
+    assert weights.log_form == 0
+    own, opp = random_positions(150, seed=17)
+    out = run(ops, own, opp, weights, seed=2, id_base=40)
+    sampled, exact = replay_check(own, opp, *out, w, bvec, lambda b, t: orc.uniform(2, 40 + b, t, 0))
+    assert sampled > 2000 and exact >= sampled - 2
