@@ -306,6 +306,10 @@ class SelfPlayEngine(object):
             m.search(own, opp, active, n_sims)
             move, visits = m.best_move(active)
             mv = torch.where(active.bool(), move, torch.full_like(move, -1))
+            if bool((mv == -2).any().item()):
+                # what max() over an empty children dict raises in MCTS.get_move (MCTS.py:147)
+                raise ValueError("a searched root has no children: n_sims is below the "
+                                 "expansion threshold n_thr")
             if record:
                 res.own[t], res.opp[t], res.valid[t], res.move[t] = own, opp, active, mv
                 res.pi[t] = visits * active.reshape(B, 1).to(torch.int32)
