@@ -145,6 +145,10 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
            "seconds": dt, "turns_played": res.n_turns, "sims_per_move": n_sims,
            "games_per_gpu": n_games, "full_games": bool(full_games),
            "net_tflops_fp32": flops / dt / 1e12,
+           # the convolutions bound this leg: fp32 matrix/vector peak 157.3 TFLOP/s (MI355X)
+           "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12 / world, "peak": 157.3,
+                        "unit": "TFLOP/s", "frac": flops / dt / 1e12 / world / 157.3,
+                        "flops_per_leaf_eval": 122_994_944, "flops_per_policy_eval": 122_847_232},
            "config": "BASELINE configs[2]: PV-MCTS %d sims/move, %d games per GPU, SLPolicy+Value "
                      "random init fp32, lmbda=0.5 c_puct=1 n_thr=15" % (n_sims, n_games),
            "tree_pool_bytes_per_gpu": m.tree.bytes(), "tree_traffic_rank0": m.tree_bytes(),
