@@ -117,7 +117,7 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
     eng = engine.SelfPlayEngine(m, max_turns=(128 if full_games else n_turns))
     m.enable_stats()
     m.warmup()                 # MIOpen kernel selection for every batch bucket
-    eng.play(2, record=False)  # allocator, code objects
+    engine.SelfPlayEngine(m, max_turns=4).play(16, record=False)  # allocator, code objects
     m.n_leaf_evals = m.n_policy_evals = 0
     m.stats.zero_()
     torch.cuda.synchronize()
