@@ -29,7 +29,8 @@ class Block(nn.Module):
 
     def forward(self, x):
         if (x.is_cuda and not torch.is_grad_enabled() and x.shape[-1] == 8 and x.shape[-2] == 8
-                and x.dtype == torch.float32 and self.conv.bias is not None):
+                and x.dtype == torch.float32 and self.conv.bias is not None
+                and not torch.is_autocast_enabled()):
             # inference on the GPU: MIOpen convolution without bias + one fused
             # bias/ReLU pass (HIP) instead of PyTorch's two elementwise kernels
             from . import ops
