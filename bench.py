@@ -201,6 +201,28 @@ def mcts_cpu_baseline(n_sims=600):
                       "torch-CPU fp32 nets (1 thread) + C rollout, %.1f s" % (n_sims, dt)}
 
 
+def mcts_b1_leg(n_sims=200):
+    """Serving mode of game.py:112-113: ONE game, MCTS.get_move with a simulation
+    budget (the reference spends 10 s per move at ~100 playouts/s on one core)."""
+    from iago_amd import MCTS as mcts_mod
+    from iago_amd import boards, network, ops
+    w, b = shipped_rollout_weights()
+    torch.manual_seed(0)
+    m = mcts_mod.MCTS(policy_net=network.SLPolicy().cuda().eval(),
+                      value_net=network.Value().cuda().eval(),
+                      rollout_weights=ops.RolloutWeights(w, b), n_sims=n_sims, capacity=65536)
+    state = boards.initial_state()
+    m._m.warmup()
+    m.get_move(state, 1)  # warm-up move (also fills the root)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    a = m.get_move(state, 1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"playouts_per_sec": n_sims / dt, "ms_per_playout": dt / n_sims * 1e3,
+            "sims": n_sims, "move": int(a)}
+
+
 def reinforce_leg(n_iters, world, rank, dist):
     """BASELINE configs[4] in miniature: `n_iters` iterations of the REINFORCE loop
     (src/train_rl.py:28-81): one set of 2N = 64 SLPolicy-vs-SLPolicy games sharded
@@ -417,6 +439,7 @@ def main():
                         args.mcts_turns < 0, world, rank, dist)
 
     train = reinforce_leg(args.train_iters, world, rank, dist) if args.train_iters > 0 else None
+    b1 = mcts_b1_leg() if (mcts is not None and rank == 0) else None
 
     if rank == 0:
         games = world * K * B
@@ -460,6 +483,8 @@ def main():
             line["mcts"] = mcts
         if train is not None:
             line["reinforce"] = train
+        if b1 is not None:
+            line["mcts_single_game"] = b1
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, b)
             if mcts is not None:
