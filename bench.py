@@ -8,13 +8,15 @@ Workload (BASELINE.json configs[1]): per GPU, 4096 parallel Othello boards from
 the standard start position are played to the end by the fused HIP rollout
 kernel with the reference's shipped RolloutPolicy weights (82 floats, kept as
 golden data in tests/golden/simulate.json) -- rollout-policy-only self-play.
-One step = one launch = 4096 finished games per GPU.  Steps are independent
-batches; they are issued round-robin on 32 HIP streams (16 hardware queues) so that
-several launches overlap on the chip (a 4096-board launch is 512 waves: one wave on half of the
-SIMDs).  With N > 1 every rank plays its own 4096-board shard (weak scaling,
-Philox streams keyed by the global game id) and the finished (final boards, z,
-turns) tuples of the whole round are all-gathered over RCCL inside the timed
-region, as one collective on the round's tuple buffer.
+One step = 4096 finished games per GPU.  Steps are independent batches: by default
+64 consecutive steps share one kernel launch (262,144 boards), which the library
+plays with its lane-per-board rollout kernel; `--steps-per-launch 1` issues every
+step as its own launch of the 8-lanes-per-board kernel, overlapped on 32 HIP
+streams / 16 hardware queues (a single 4096-board launch is only 512 waves).
+With N > 1 every rank plays its own 4096-board shard (weak scaling, Philox streams
+keyed by a rank-major global game id) and the finished (final boards, z, turns)
+tuples of the whole round are all-gathered over RCCL inside the timed region, as
+one collective on the round's tuple buffer.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the rollout kernel against the
 HBM roof with SURVEY.md section 8(d)'s algorithmic bytes (33 B per board-step);
@@ -286,6 +288,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
+    ap.add_argument("--steps-per-launch", type=int, default=64,
+                    help="consecutive steps played by one kernel launch (1 = one launch per "
+                         "step, overlapped on --streams HIP streams)")
     ap.add_argument("--streams", type=int, default=32,
                     help="HIP streams the independent steps are issued on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -320,49 +325,52 @@ def main():
     B, K, W = args.boards, args.steps, args.warmup
     w, b = shipped_rollout_weights()
     weights = ops.RolloutWeights(w, b)
-    own = torch.full((B,), START_OWN, dtype=torch.int64, device="cuda")
-    opp = torch.full((B,), START_OPP, dtype=torch.int64, device="cuda")
+    # G consecutive steps share one launch (G x B boards): with >= 32768 boards the
+    # library plays them with the lane-per-board kernel, which needs ~40 % fewer
+    # wave-instructions per board but 8x more boards in flight to fill the chip.
+    # G = 1 issues every step as its own launch, overlapped on S HIP streams.
+    G = max(1, min(args.steps_per_launch, K))
+    own = torch.full((G * B,), START_OWN, dtype=torch.int64, device="cuda")
+    opp = torch.full((G * B,), START_OPP, dtype=torch.int64, device="cuda")
     # the round's finished tuples, resident in HBM: K steps x B games, as views of ONE
     # byte buffer so that the all-gather needs no packing pass and no host sync
     n = K * B
     roundbuf = torch.empty(n * 18, dtype=torch.uint8, device="cuda")
-    fo = roundbuf[0:8 * n].view(torch.int64).view(K, B)
-    fp = roundbuf[8 * n:16 * n].view(torch.int64).view(K, B)
-    z = roundbuf[16 * n:17 * n].view(torch.int8).view(K, B)
-    nt = roundbuf[17 * n:18 * n].view(K, B)
+    fo = roundbuf[0:8 * n].view(torch.int64)
+    fp = roundbuf[8 * n:16 * n].view(torch.int64)
+    z = roundbuf[16 * n:17 * n].view(torch.int8)
+    nt = roundbuf[17 * n:18 * n]
     gathered = torch.empty(world * n * 18, dtype=torch.uint8, device="cuda") if world > 1 or \
         "RANK" in os.environ else None
-    outs = []
-    for k in range(K):
-        r = ops.RolloutResult()
-        r.z, r.final_own, r.final_opp, r.n_turns = z[k], fo[k], fp[k], nt[k]
-        outs.append(r)
 
-    # Steps are independent batches: they are issued round-robin on S HIP streams
-    # so that S launches (S x 512 waves) overlap on the chip.  Every launch is
-    # marshalled before the timed region; issuing one costs a single ctypes call.
-    S = max(1, args.streams)
+    S = max(1, args.streams) if G == 1 else 1
     streams = [torch.cuda.Stream() for _ in range(S)]
     sptr = [ctypes.c_void_p(st.cuda_stream) for st in streams]
 
-    def prepare(k, slot):
-        # global game id = ((step * world) + rank) * B + board: results do not depend on N
-        return ops.rollout_prepare(own, opp, weights, seed=2024,
-                                   id_base=((k * world + rank) * B) & 0xFFFFFFFF, out=outs[slot])
+    def prepare(k0, g, id_step):
+        """One launch playing steps k0 .. k0+g-1 into their slots of the round buffer.
+        Global game id = (rank * 2^20 + step) * B + board (rank-major, so that the ids
+        of consecutive steps of a rank are contiguous)."""
+        r = ops.RolloutResult()
+        lo, hi = k0 * B, (k0 + g) * B
+        r.z, r.final_own, r.final_opp, r.n_turns = z[lo:hi], fo[lo:hi], fp[lo:hi], nt[lo:hi]
+        return ops.rollout_prepare(own[:g * B], opp[:g * B], weights, seed=2024,
+                                   id_base=((rank * (1 << 20) + id_step) * B) & 0xFFFFFFFF, out=r)
 
-    warm = [prepare(1_000_000 + k, k % K) for k in range(W)]
-    timed = [prepare(k, k) for k in range(K)]
-    SAMPLE = 32  # every 32nd launch is bracketed by an event pair on its own stream
-    evs = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for k in range(0, K, SAMPLE)}
+    warm = [prepare(0, min(G, K), 500_000 + k) for k in range(0, W, G)]
+    timed = [prepare(k, min(G, K - k), k) for k in range(0, K, G)]
+    n_launches = len(timed)
+    SAMPLE = 32 if G == 1 else 1  # launches bracketed by an event pair on their stream
+    evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for i in range(0, n_launches, SAMPLE)}
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
     rc = 0
-    for k, p in enumerate(warm):
-        rc |= p.launch(sptr[k % S])
+    for i, p in enumerate(warm):
+        rc |= p.launch(sptr[i % S])
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -372,9 +380,9 @@ def main():
     span0.record(main)
     for st in streams:
         st.wait_stream(main)
-    for k, p in enumerate(timed):
-        j = k % S
-        e = evs.get(k)
+    for i, p in enumerate(timed):
+        j = i % S
+        e = evs.get(i)
         if e is not None:
             e[0].record(streams[j])
         rc |= p.launch(sptr[j])
@@ -392,12 +400,14 @@ def main():
     dt = time.perf_counter() - t0
     if rc != 0:
         raise SystemExit("iago_rollout failed: %s" % _lib.lib().iago_last_error())
-    # average duration of ONE launch (start -> end on its own stream, S launches in flight)
-    kernel_ms = sum(a.elapsed_time(b) for a, b in evs.values()) / len(evs)
+    # average duration of ONE launch (start -> end on its own stream)
+    full = [i for i in evs if timed[i].args.n == G * B] or list(evs)
+    kernel_ms = sum(evs[i][0].elapsed_time(evs[i][1]) for i in full) / len(full)
     span_ms = span0.elapsed_time(span1)  # GPU time of the K launches together
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     steps_total = nt.to(torch.int64).sum().reshape(1)
+    launch_steps = G  # steps per (full) launch
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(steps_total)
@@ -443,7 +453,7 @@ def main():
 
     if rank == 0:
         games = world * K * B
-        alg_bytes_per_launch = BYTES_PER_BOARD_STEP * board_steps / (world * K)
+        alg_bytes_per_launch = BYTES_PER_BOARD_STEP * board_steps / (world * K) * launch_steps
         # Roofline of the dominant kernel.  One launch moves `alg_bytes_per_launch`
         # (algorithmic) in `kernel_ms`: an event pair brackets the launch's slot on its
         # stream = execution + queueing behind the other streams' launches (rocprofv3's
@@ -454,7 +464,7 @@ def main():
         #          = bytes of the K launches / GPU span of the timed region,
         # which is also value x bytes per game.
         per_launch = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        achieved = alg_bytes_per_launch * K / (span_ms * 1e-3) / 1e9
+        achieved = alg_bytes_per_launch * (K / launch_steps) / (span_ms * 1e-3) / 1e9
         line = {
             "metric": "self-play games/sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
@@ -465,14 +475,16 @@ def main():
                                    "shipped RolloutPolicy weights" % B,
                        "boards_per_gpu": B, "games_per_step": world * B,
                        "tuple_allgather": "rccl" if dist is not None else "none",
-                       "hip_streams": S},
+                       "steps_per_launch": G, "hip_streams": S},
             "board_steps_per_sec": board_steps / dt,
             "board_steps_per_game": board_steps / games,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "kernel": "rollout_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "rollout_lpb_kernel" if G * B >= 32768 else "rollout_kernel",
+                         "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "launches_in_flight": kernel_ms * K / span_ms,
+                         "launches_in_flight": kernel_ms * (K / launch_steps) / span_ms,
+                         "boards_per_launch": launch_steps * B,
                          "per_launch_achieved": per_launch,
                          "rocprof_kernel_avg_ms": measured_pmc().get("rocprof_kernel_avg_ms"),
                          "valu": valu_utilisation(K * B, span_ms * 1e-3)},

@@ -12,7 +12,8 @@ SO_PATH = os.path.join(HERE, "libiago_hip.so")
 
 IAGO_OK = 0
 IAGO_MAX_TURNS = 128
-IAGO_ROLLOUT_TABLE_FLOATS = 3 * 2 * 256 * 8 + 64 + 4
+IAGO_ROLLOUT_TABLE_FLOATS = 3 * 2 * 256 * 8 + 64 + 4 + 2 * 512
+ROLLOUT_MODE_INDEX = 3 * 2 * 256 * 8 + 64  # blob[mode] == 1.0: product form
 TRACE_PASS = 0xFF
 
 # every symbol include/iago_hip.h declares (tests/test_abi.py checks the list
@@ -38,6 +39,7 @@ class RolloutArgs(C.Structure):
         ("seed", C.c_uint64), ("id_base", C.c_uint32), ("stream_id", C.c_uint32),
         ("z", C.c_void_p), ("final_own", C.c_void_p), ("final_opp", C.c_void_p),
         ("n_turns", C.c_void_p), ("trace", C.c_void_p), ("log_form", C.c_int),
+        ("throughput_hint", C.c_int),
     ]
 
 

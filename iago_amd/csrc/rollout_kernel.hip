@@ -31,6 +31,7 @@
 // everything else stays in VGPRs/LDS.
 #include "abi_common.hpp"
 #include "othello_dev.hpp"
+#include "rollout_blob.hpp"
 
 #include <math.h>
 
@@ -38,12 +39,6 @@ using namespace iago;
 
 namespace {
 
-// blob layout (floats), see iago_rollout_build_table
-constexpr int OFF_E = 0;                       // E[ky][plane][half][byte][4]
-constexpr int N_E = 3 * 2 * 2 * 256 * 4;       // 12288
-constexpr int OFF_BIAS = OFF_E + N_E;          // 64
-constexpr int OFF_MODE = OFF_BIAS + 64;        // 1.0 = product form, 0.0 = log form
-static_assert(OFF_MODE + 4 == IAGO_ROLLOUT_TABLE_FLOATS, "blob size");
 constexpr int LDS_FLOATS = N_E; // the legal-cell multipliers are computed on the VALU
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -351,6 +346,9 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
 
 } // namespace
 
+// defined in rollout_lpb_kernel.hip
+void iago_launch_rollout_lpb(const iago_rollout_args *a, void *stream);
+
 extern "C" {
 
 int iago_rollout_build_table(const float *w18, const float *b64, float *blob)
@@ -414,6 +412,22 @@ int iago_rollout_build_table(const float *w18, const float *b64, float *blob)
     }
     blob[OFF_MODE] = product ? 1.0f : 0.0f;
     blob[OFF_MODE + 1] = blob[OFF_MODE + 2] = blob[OFF_MODE + 3] = 0.0f;
+    // per-cell tables of the lane-per-board kernel: all 9 taps of one plane at once,
+    // float32 accumulation in (ky, kx) order, each table shifted by its own maximum
+    for (int pl = 0; pl < 2; pl++) {
+        float ct[512];
+        double cmax = -1e300;
+        for (int idx = 0; idx < 512; idx++) {
+            float acc = 0.0f;
+            for (int k = 0; k < 9 && w18; k++)
+                if ((idx >> k) & 1)
+                    acc += w18[pl * 9 + k];
+            ct[idx] = acc;
+            if (acc > cmax) cmax = acc;
+        }
+        for (int idx = 0; idx < 512; idx++)
+            blob[OFF_CT + pl * 512 + idx] = product ? (float)exp((double)ct[idx] - cmax) : ct[idx];
+    }
     return IAGO_OK;
 }
 
@@ -429,8 +443,9 @@ int iago_rollout(const iago_rollout_args *a, void *stream)
         return iago_fail(IAGO_ERR_INVALID, "iago_rollout: own/opp/z/table must not be null");
     if ((uintptr_t)a->table & 15u)
         return iago_fail(IAGO_ERR_INVALID, "iago_rollout: table must be 16-byte aligned");
-    if (a->log_form != 0 && a->log_form != 1)
-        return iago_fail(IAGO_ERR_INVALID, "iago_rollout: log_form must be 0 or 1");
+    if ((a->log_form != 0 && a->log_form != 1) ||
+        (a->throughput_hint != 0 && a->throughput_hint != 1))
+        return iago_fail(IAGO_ERR_INVALID, "iago_rollout: log_form / throughput_hint must be 0 or 1");
     RolloutParams P;
     P.own = a->own;
     P.opp = a->opp;
@@ -456,6 +471,12 @@ int iago_rollout(const iago_rollout_args *a, void *stream)
     const int block = (threads >= 256) ? 256 : 64;
     const int64_t n_groups = (threads + block - 1) / block;
     const unsigned grid = (unsigned)(n_groups < 0x7fffffffll ? n_groups : 0x7fffffffll);
+    // Lane-per-board kernel (rollout_lpb_kernel.hip) when throughput matters more than
+    // this launch's latency; it implements the product form only.
+    if (!a->log_form && (a->throughput_hint || a->n >= 32768)) {
+        iago_launch_rollout_lpb(a, stream);
+        return iago_check_launch("iago_rollout");
+    }
     if (a->log_form)
         hipLaunchKernelGGL(rollout_kernel<false>, dim3(grid), dim3(block), 0, (hipStream_t)stream,
                            P);

@@ -1,0 +1,298 @@
+// rollout_lpb_kernel.hip -- the leaf rollout with ONE LANE PER BOARD.
+//
+// Same contract and results as rollout_kernel.hip (iago_rollout, replacing
+// Simulate(state)(color), mcts_self_play.py:9-134); chosen by the launcher when
+// the caller keeps the chip full (throughput_hint) or the batch alone does.
+//
+// Why a second kernel.  The 8-lanes-per-board kernel minimises the latency of a
+// small batch (8x the waves, direction- and row-parallel work) but pays for it
+// with cross-lane traffic (bit-reversed orientations, DPP reductions), with
+// logits for all 64 cells through 1.5 KB of LDS gathers per board-turn (the LDS
+// pipe saturates at 12 waves/CU), and ~27 wave-instructions per board-turn.
+// Here a lane owns its board:
+//   * legal moves: 8 constant-shift floods on the lane's two u64;
+//   * the rollout policy is evaluated ONLY at the legal cells (8.5 on average):
+//     the softmax numerator of a cell is bias[c] * CT[0][opp 3x3 pattern] *
+//     CT[1][own 3x3 pattern] -- two 4-byte LDS reads from 512-entry tables;
+//   * the running sums of the legal cells stay in registers (one slot per legal
+//     move, the loop leaves when no lane of the wave has a move left), the
+//     sampled slot is the number of sums <= u * total, its cell comes from a
+//     packed byte array;
+//   * flips: the 4 rays towards higher bits by carry propagation on the board,
+//     the 4 others on the bit-reversed board;
+//   * Philox: the lane draws the 4 uniforms of turns 4k..4k+3 itself.
+// ~17 wave-instructions per board-turn and almost no LDS traffic.
+#include "abi_common.hpp"
+#include "othello_dev.hpp"
+#include "rollout_blob.hpp"
+
+using namespace iago;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int SLOTS = 34; // an Othello position has at most 33 legal moves
+
+struct LpbParams {
+    const uint64_t *own;
+    const uint64_t *opp;
+    int64_t n;
+    const float *blob;
+    const float *uniforms;
+    uint32_t key0, key1, id_base, stream_id;
+    int8_t *z;
+    uint64_t *final_own;
+    uint64_t *final_opp;
+    uint8_t *n_turns;
+    uint8_t *trace;
+};
+
+template <int S>
+__device__ __forceinline__ uint64_t moves_up(uint64_t own, uint64_t opp, uint64_t empty, uint64_t m)
+{
+    const uint64_t pm = opp & m;
+    uint64_t t = (own << S) & pm;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+        t |= (t << S) & pm;
+    return (t << S) & empty & m;
+}
+template <int S>
+__device__ __forceinline__ uint64_t moves_down(uint64_t own, uint64_t opp, uint64_t empty,
+                                               uint64_t m)
+{
+    const uint64_t pm = opp & m;
+    uint64_t t = (own >> S) & pm;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+        t |= (t >> S) & pm;
+    return (t >> S) & empty & m;
+}
+
+// game.py:210-235 on one lane; the masks are the DESTINATION files a shifted stone may
+// not land on (A/H-file wrap-around)
+__device__ __forceinline__ uint64_t legal_moves_1(uint64_t own, uint64_t opp)
+{
+    const uint64_t e = ~(own | opp);
+    return moves_up<1>(own, opp, e, ~FILE_A) | moves_up<7>(own, opp, e, ~FILE_H) |
+           moves_up<8>(own, opp, e, ~0ull) | moves_up<9>(own, opp, e, ~FILE_A) |
+           moves_down<1>(own, opp, e, ~FILE_H) | moves_down<7>(own, opp, e, ~FILE_A) |
+           moves_down<8>(own, opp, e, ~0ull) | moves_down<9>(own, opp, e, ~FILE_H);
+}
+
+// Flips along the ray of direction K (0: +1, 1: +7, 2: +8, 3: +9) from `pos`:
+// othello_dev.hpp's ray_mask / carry trick with compile-time direction constants.
+template <int K>
+__device__ __forceinline__ uint64_t flips_up(uint64_t o, uint64_t p, uint32_t pos)
+{
+    constexpr uint64_t base = (K == 0)   ? 0x00000000000000FEull
+                              : (K == 1) ? 0x0002040810204080ull
+                              : (K == 2) ? 0x0101010101010100ull
+                                         : 0x8040201008040200ull;
+    uint64_t M = base << pos;
+    if (K != 2) {
+        constexpr uint32_t ca = (K == 1) ? 0xFFu : 0xFEu, cx = (K == 1) ? 0xFFu : 0u;
+        const uint32_t m8 = (ca << (pos & 7u)) ^ cx;
+        const uint32_t m32 = __builtin_amdgcn_perm(m8, m8, 0u);
+        M &= ((uint64_t)m32 << 32) | m32;
+    }
+    const uint64_t x = p | ~M;
+    const uint64_t t = x + 1ull;
+    return ((t & M & o) != 0ull) ? ((t ^ x) & M & p) : 0ull;
+}
+
+// game.py:180-207 on one lane (no legality check)
+__device__ __forceinline__ uint64_t flips_1(uint64_t own, uint64_t opp, uint32_t pos)
+{
+    const uint64_t f = flips_up<0>(own, opp, pos) | flips_up<1>(own, opp, pos) |
+                       flips_up<2>(own, opp, pos) | flips_up<3>(own, opp, pos);
+    const uint64_t ro = rev64(own), rp = rev64(opp);
+    const uint32_t rpos = 63u - pos;
+    const uint64_t g = flips_up<0>(ro, rp, rpos) | flips_up<1>(ro, rp, rpos) |
+                       flips_up<2>(ro, rp, rpos) | flips_up<3>(ro, rp, rpos);
+    return f | rev64(g);
+}
+
+// 9-bit pattern of the 3x3 neighbourhood of cell (r, x): bit 3*ky + kx = cell
+// (r + ky - 1, x + kx - 1), zero outside the board.  sh_r / sh_l bring rows r-1..r+1
+// to bits 0..23 (as in rollout_kernel.hip); cm removes the column that wrapped.
+__device__ __forceinline__ uint32_t pattern9(uint64_t b, uint32_t sh_r, uint32_t sh_l, uint32_t x,
+                                             uint32_t cm)
+{
+    const uint32_t w = (((uint32_t)(b >> sh_r) << sh_l) & 0xFFFFFFu) << 1; // cell x-1 at bit x
+    const uint32_t q = (w >> x) & cm;
+    return (q & 7u) | (((q >> 8) & 7u) << 3) | (((q >> 16) & 7u) << 6);
+}
+
+// Per-turn sampling state.  The slot arrays are only ever indexed with compile-time
+// constants (template recursion instead of loops with early exits), so they live in
+// registers.
+struct Slots {
+    float cdf[SLOTS];
+    uint32_t cells[(SLOTS + 3) / 4]; // 4 cell indices per word
+    uint64_t rem;                    // legal cells not yet visited
+    float acc;                       // running sum
+    int filled;                      // wave-uniform number of slots written
+};
+
+template <int J>
+__device__ __forceinline__ void fill_slots(Slots &S, uint64_t own, uint64_t opp, const float *ct,
+                                           const float *be)
+{
+    if constexpr (J < SLOTS) {
+        if (__builtin_amdgcn_ballot_w64(S.rem != 0ull) == 0ull)
+            return; // no lane of the wave has a legal cell left
+        const bool valid = S.rem != 0ull;
+        const uint32_t c = valid ? (uint32_t)__builtin_ctzll(S.rem) : 0u;
+        S.rem &= S.rem - 1ull;
+        const uint32_t r = c >> 3, x = c & 7u;
+        const uint32_t sh_r = r ? 8u * (r - 1u) : 0u, sh_l = r ? 0u : 8u;
+        const uint32_t cm =
+            0x070707u & ~((x == 0u) ? 0x010101u : 0u) & ~((x == 7u) ? 0x040404u : 0u);
+        const uint32_t io = pattern9(own, sh_r, sh_l, x, cm);
+        const uint32_t ip = pattern9(opp, sh_r, sh_l, x, cm);
+        // plane 0 = opponent of the side to move, plane 1 = side to move (game.py:168-174)
+        const float e = be[c] * ct[ip] * ct[512 + io];
+        S.acc += valid ? e : 0.0f;
+        S.cdf[J] = S.acc;
+        S.cells[J >> 2] |= c << (8 * (J & 3));
+        S.filled = J + 1;
+        fill_slots<J + 1>(S, own, opp, ct, be);
+    }
+}
+
+template <int J>
+__device__ __forceinline__ uint32_t count_slots(const Slots &S, float thr)
+{
+    if constexpr (J < SLOTS) {
+        if (J >= S.filled)
+            return 0u;
+        return ((S.cdf[J] <= thr) ? 1u : 0u) + count_slots<J + 1>(S, thr);
+    } else {
+        return 0u;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
+{
+    __shared__ float ct[N_CT]; // [plane][512]
+    __shared__ float be[64];   // exp'ed biases
+    for (uint32_t i = threadIdx.x; i < (uint32_t)N_CT; i += BLOCK)
+        ct[i] = P.blob[OFF_CT + i];
+    if (threadIdx.x < 64)
+        be[threadIdx.x] = P.blob[OFF_BIAS + threadIdx.x];
+    __syncthreads();
+
+    const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = b < P.n;
+    uint64_t own = live ? P.own[b] : 0ull; // side to move
+    uint64_t opp = live ? P.opp[b] : 0ull;
+    uint32_t stones = (uint32_t)__popcll(own | opp);
+    uint32_t pass_flg = 0u, nt = 0u;
+    uint32_t done = (!live || stones >= 64u) ? 1u : 0u; // `while stone_num < 64`
+    const uint32_t rid = P.id_base + (uint32_t)b;
+    uint32_t rw[4] = {0, 0, 0, 0};
+
+    for (uint32_t t = 0; t < (uint32_t)IAGO_MAX_TURNS; t++) {
+        // ---- uniform of this turn: word t&3 of Philox counter (rid, t>>2, stream, 0)
+        float u;
+        if (P.uniforms) {
+            u = live ? P.uniforms[(int64_t)t * P.n + b] : 0.0f;
+        } else {
+            if ((t & 3u) == 0u) {
+                rw[0] = rid;
+                rw[1] = t >> 2;
+                rw[2] = P.stream_id;
+                rw[3] = 0u;
+                philox4x32_10(rw, P.key0, P.key1);
+            }
+            const uint32_t k = t & 3u; // wave-uniform
+            const uint32_t w = (k == 0u) ? rw[0] : (k == 1u) ? rw[1] : (k == 2u) ? rw[2] : rw[3];
+            u = (float)(w >> 8) * (1.0f / 16777216.0f);
+        }
+
+        const uint64_t legal = legal_moves_1(own, opp);
+        const uint32_t has = min(1u, (uint32_t)legal | (uint32_t)(legal >> 32));
+
+        // ---- softmax numerators of the legal cells, running sums in slot order
+        Slots S;
+#pragma unroll
+        for (int i = 0; i < (SLOTS + 3) / 4; i++)
+            S.cells[i] = 0u;
+        S.rem = done ? 0ull : legal;
+        S.acc = 0.0f;
+        S.filled = 0;
+        fill_slots<0>(S, own, opp, ct, be);
+        // ---- inverse CDF (mcts_self_play.py:103-106): slot = #sums <= u * total
+        float thr;
+        {
+#pragma clang fp contract(off)
+            thr = u * S.acc; // rounded before any comparison: bit-exact uniform policy
+        }
+        uint32_t slot = count_slots<0>(S, thr);
+        const uint32_t nlegal = (uint32_t)__popcll(legal);
+        slot = min(slot, nlegal ? nlegal - 1u : 0u); // rounding past the total: last legal cell
+        uint32_t word = S.cells[0];
+#pragma unroll
+        for (int i = 1; i < (SLOTS + 3) / 4; i++)
+            word = ((slot >> 2) == (uint32_t)i) ? S.cells[i] : word;
+        const uint32_t action = (word >> (8u * (slot & 3u))) & 63u;
+
+        // ---- flips, board update, pass / termination bookkeeping (branch-free)
+        const uint64_t f = flips_1(own, opp, action);
+        const uint32_t live_turn = done ^ 1u;
+        const uint32_t play = has & live_turn;
+        const uint32_t passing = (has ^ 1u) & live_turn;
+        const uint32_t pm = 0u - play;
+        const uint64_t fm = f & (((uint64_t)pm << 32) | pm);
+        const uint64_t bit = (uint64_t)play << action;
+        const uint64_t nown = own | fm | bit;
+        const uint64_t nopp = opp & ~fm;
+        stones = max(stones + play, (passing & pass_flg) << 6); // mcts_self_play.py:126-133
+        pass_flg = (pass_flg & done) | passing;
+        if (P.trace && live_turn)
+            P.trace[(int64_t)t * P.n + b] = play ? (uint8_t)action : (uint8_t)IAGO_TRACE_PASS;
+        own = nopp; // the other side moves next (finished boards swap an even number of times)
+        opp = nown;
+        nt += live_turn;
+        if (t & 1u) { // `while stone_num < 64` once per pair of turns
+            done |= stones >> 6;
+            if (__builtin_amdgcn_ballot_w64(done == 0u) == 0ull)
+                break;
+        }
+    }
+
+    if (live) {
+        const int d = __popcll(own) - __popcll(opp);
+        P.z[b] = (int8_t)((d > 0) - (d < 0));
+        if (P.final_own)
+            P.final_own[b] = own;
+        if (P.final_opp)
+            P.final_opp[b] = opp;
+        if (P.n_turns)
+            P.n_turns[b] = (uint8_t)nt;
+    }
+}
+
+} // namespace
+
+void iago_launch_rollout_lpb(const iago_rollout_args *a, void *stream)
+{
+    LpbParams P;
+    P.own = a->own;
+    P.opp = a->opp;
+    P.n = a->n;
+    P.blob = a->table;
+    P.uniforms = a->uniforms;
+    P.key0 = (uint32_t)a->seed;
+    P.key1 = (uint32_t)(a->seed >> 32);
+    P.id_base = a->id_base;
+    P.stream_id = a->stream_id;
+    P.z = a->z;
+    P.final_own = a->final_own;
+    P.final_opp = a->final_opp;
+    P.n_turns = a->n_turns;
+    P.trace = a->trace;
+    const unsigned grid = (unsigned)((a->n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(rollout_lpb_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, P);
+}

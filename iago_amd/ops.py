@@ -139,7 +139,7 @@ class RolloutWeights(object):
             wp, bp = C.c_void_p(self.w.ctypes.data), C.c_void_p(self.b.ctypes.data)
         check(_lib.lib().iago_rollout_build_table(wp, bp, C.c_void_p(blob.ctypes.data)),
               "iago_rollout_build_table")
-        self.log_form = 0 if blob[-4] == 1.0 else 1
+        self.log_form = 0 if blob[_lib.ROLLOUT_MODE_INDEX] == 1.0 else 1
         self.table = torch.from_numpy(blob).to(device)
 
 
@@ -174,7 +174,8 @@ class PreparedRollout(object):
 
 
 def rollout_prepare(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=None,
-                    want_final=False, want_turns=False, want_trace=False, out=None):
+                    want_final=False, want_turns=False, want_trace=False, out=None,
+                    throughput_hint=False):
     """Marshal a rollout launch once (see `rollout` for the arguments)."""
     n = own.numel()
     res = out if out is not None else RolloutResult()
@@ -196,6 +197,7 @@ def rollout_prepare(own, opp, weights=None, seed=0, id_base=0, stream_id=0, unif
     a.n = n
     a.table = _dev(weights.table, torch.float32, "table")
     a.log_form = weights.log_form
+    a.throughput_hint = 1 if throughput_hint else 0
     if uniforms is not None:
         if tuple(uniforms.shape) != (IAGO_MAX_TURNS, n):
             raise ValueError("uniforms must have shape (%d, n)" % IAGO_MAX_TURNS)
@@ -219,14 +221,17 @@ def rollout_prepare(own, opp, weights=None, seed=0, id_base=0, stream_id=0, unif
 
 
 def rollout(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=None,
-            want_final=False, want_turns=False, want_trace=False, out=None):
+            want_final=False, want_turns=False, want_trace=False, out=None,
+            throughput_hint=False):
     """Simulate(state)(color) for every board (mcts_self_play.py:9-134).
 
     weights=None plays uniformly random legal moves.  `uniforms`
     (IAGO_MAX_TURNS, n) float32 replaces the Philox stream (parity tests).
     `out` may be a RolloutResult with preallocated tensors to reuse.
+    throughput_hint: the caller overlaps this launch with others (see
+    iago_rollout_args.throughput_hint).
     """
     p = rollout_prepare(own, opp, weights, seed, id_base, stream_id, uniforms, want_final,
-                        want_turns, want_trace, out)
+                        want_turns, want_trace, out, throughput_hint)
     check(p.launch(), "iago_rollout")
     return p.result

@@ -48,7 +48,7 @@ typedef enum iago_status {
 #define IAGO_PASS (-1)          /* pass action, game.py:181 */
 #define IAGO_TRACE_PASS 0xFF    /* pass marker in uint8 action traces */
 #define IAGO_MAX_TURNS 128      /* upper bound on turns of one game (<= 124) */
-#define IAGO_ROLLOUT_TABLE_FLOATS (3 * 2 * 256 * 8 + 64 + 4)
+#define IAGO_ROLLOUT_TABLE_FLOATS (3 * 2 * 256 * 8 + 64 + 4 + 2 * 512)
 
 IAGO_API int iago_abi_version(void);
 IAGO_API const char *iago_last_error(void);
@@ -135,7 +135,8 @@ IAGO_API int iago_augment8(const uint64_t *own, const uint64_t *opp, const int8_
  * floats and is then copied to the device by the caller.  w18 == NULL builds
  * the uniform policy (every legal move equally likely).
  * Layout: E[3 ky][2 plane][2 half][256 row byte][4] row-pattern contributions
- * to 8 adjacent outputs; bias[64]; mode[4].  mode[0] == 1: PRODUCT form (E and bias hold exp() of the
+ * to 8 adjacent outputs; bias[64]; mode[4]; CT[2 plane][512] per-cell contributions
+ * indexed by the 3x3 neighbourhood pattern (used by the lane-per-board kernel).  mode[0] == 1: PRODUCT form (E and bias hold exp() of the
  * contributions, each factor shifted by its own maximum so that all lie in (0,1]), chosen
  * when the logit range is < 60 so that no partial product leaves float32's
  * range; mode[0] == 0: LOG form (raw sums; the kernel does max / exp2).  Pass
@@ -158,6 +159,10 @@ typedef struct iago_rollout_args {
     uint8_t *n_turns;        /* optional [n]: turns played (passes included) */
     uint8_t *trace;          /* optional [IAGO_MAX_TURNS][n]: action per turn, 0xFF = pass */
     int log_form;            /* 0: blob is in PRODUCT form, 1: LOG form (see above) */
+    int throughput_hint;     /* 1: the caller keeps the chip full with other launches
+                                (overlapping streams): use the lane-per-board kernel, which
+                                trades this launch's latency for ~half the work per board;
+                                also chosen automatically for n >= 32768 */
 } iago_rollout_args;
 
 /*

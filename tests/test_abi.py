@@ -87,13 +87,15 @@ def test_rollout_table_builder_host_side(so):
     for offset in (0.0, 500.0, -3000.0):
         b = (rs.randn(64) + offset).astype(np.float32)
         blob = build(w, b)
-        assert blob[-4] == 1.0                       # product form
-        body = blob[:-4]
+        mode = _lib.ROLLOUT_MODE_INDEX
+        assert blob[mode] == 1.0                     # product form
+        body = np.concatenate([blob[:mode], blob[mode + 4:]])
         assert np.all(np.isfinite(body)) and body.min() > 0.0 and body.max() == 1.0
         # bias factors: exp(b - max b)
-        assert np.allclose(body[-64:], np.exp(b.astype(np.float64) - b.max()), rtol=1e-6)
+        assert np.allclose(blob[mode - 64:mode], np.exp(b.astype(np.float64) - b.max()), rtol=1e-6)
     uni = build(None, None)
-    assert np.all(uni[:-4] == 1.0) and uni[-4] == 1.0
+    mode = _lib.ROLLOUT_MODE_INDEX
+    assert np.all(uni[:mode] == 1.0) and uni[mode] == 1.0 and np.all(uni[mode + 4:] == 1.0)
     wide = build((12 * rs.randn(18)).astype(np.float32), (5 * rs.randn(64)).astype(np.float32))
-    assert wide[-4] == 0.0                           # log form: raw sums
+    assert wide[mode] == 0.0                         # log form: raw sums
     assert L.iago_rollout_build_table(C.c_void_p(w.ctypes.data), None, None) == -1

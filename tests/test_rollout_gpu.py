@@ -240,3 +240,85 @@ def test_product_form_with_large_common_offset(ops):
     out = run(ops, own, opp, weights, seed=2, id_base=40)
     sampled, exact = replay_check(own, opp, *out, w, bvec, lambda b, t: orc.uniform(2, 40 + b, t, 0))
     assert sampled > 2000 and exact >= sampled - 2
+
+
+# ------------------------------------------------- lane-per-board kernel (throughput_hint)
+@pytest.mark.parametrize("n,seed,id_base", [(1, 1, 0), (65, 2, 5), (700, 3, 1000)])
+def test_lpb_uniform_policy_bit_exact(ops, n, seed, id_base):
+    own, opp = random_positions(n, seed=seed)
+    own[: n // 3] = 0x0000000810000000
+    opp[: n // 3] = 0x0000001008000000
+    z, fo, fp, nt, tr = run(ops, own, opp, None, seed=seed, id_base=id_base, throughput_hint=True)
+    for b in range(n):
+        oz, final, otr = orc.random_playout(state_of(own[b], opp[b]), 1, seed=seed,
+                                            game_id=id_base + b)
+        assert trace_list(tr, b, nt[b]) == otr, b
+        assert (int(fo[b]), int(fp[b])) == orc.state_to_bits(final), b
+        assert z[b] == oz
+
+
+@pytest.mark.parametrize("which", ["random", "shipped", "offset"])
+def test_lpb_policy_rollout_replay(ops, which):
+    g = load_json("simulate.json")
+    if which == "random":
+        w, bvec = g["w"], g["b"]
+    elif which == "shipped":
+        w, bvec = g["shipped_w"], g["shipped_b"]
+    else:
+        rs = np.random.RandomState(8)
+        w = rs.randn(18).astype(np.float32)
+        bvec = (0.5 * rs.randn(64) - 700.0).astype(np.float32)
+    weights = ops.RolloutWeights(w, bvec)
+    n, seed, id_base, stream = 500, 12, 78, 4
+    own, opp = random_positions(n, seed=6)
+    own[:150] = 0x0000000810000000
+    opp[:150] = 0x0000001008000000
+    out = run(ops, own, opp, weights, seed=seed, id_base=id_base, stream_id=stream,
+              throughput_hint=True)
+    sampled, exact = replay_check(own, opp, *out, w, bvec,
+                                  lambda b, t: orc.uniform(seed, id_base + b, t, stream))
+    assert sampled > 8000 and exact >= sampled - 3, (sampled, exact)
+
+
+def test_lpb_golden_simulate_and_edges(ops, golden_rules):
+    g = load_json("simulate.json")
+    for wi in (0, 1):
+        w, bvec = (g["w"], g["b"]) if wi == 0 else (g["shipped_w"], g["shipped_b"])
+        weights = ops.RolloutWeights(w, bvec)
+        cases = [c for c in g["cases"] if c["weights"] == wi]
+        n = len(cases)
+        own = np.array([c["p1"] if c["color"] == 1 else c["p2"] for c in cases], np.uint64)
+        opp = np.array([c["p2"] if c["color"] == 1 else c["p1"] for c in cases], np.uint64)
+        us = np.zeros((MAXT, n), np.float32)
+        for i, c in enumerate(cases):
+            us[:len(c["uniforms"]), i] = c["uniforms"]
+        z, fo, fp, nt, tr = run(ops, own, opp, weights, uniforms=torch.from_numpy(us).cuda(),
+                                throughput_hint=True)
+        for i, c in enumerate(cases):
+            assert trace_list(tr, i, nt[i]) == c["trace"], i
+            assert z[i] == c["z"]
+    boards = golden_rules["edge_boards"]
+    own = np.concatenate([boards[:, 0], boards[:, 1]])
+    opp = np.concatenate([boards[:, 1], boards[:, 0]])
+    z, fo, fp, nt, tr = run(ops, own, opp, None, seed=9, throughput_hint=True)
+    for b in range(len(own)):
+        oz, final, otr = orc.random_playout(state_of(own[b], opp[b]), 1, seed=9, game_id=b)
+        assert trace_list(tr, b, nt[b]) == otr
+        assert (int(fo[b]), int(fp[b])) == orc.state_to_bits(final) and z[b] == oz
+
+
+def test_lpb_agrees_with_8lane_kernel_statistically(ops):
+    """Both kernels sample the same distribution from the same uniforms: their games
+    coincide except where float32 rounding of the two factorizations lands on
+    different sides of a CDF boundary."""
+    g = load_json("simulate.json")
+    weights = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    n = 4096
+    own = torch.full((n,), 0x0000000810000000, dtype=torch.int64, device="cuda")
+    opp = torch.full((n,), 0x0000001008000000, dtype=torch.int64, device="cuda")
+    a = ops.rollout(own, opp, weights, seed=5, want_final=True)
+    b = ops.rollout(own, opp, weights, seed=5, want_final=True, throughput_hint=True)
+    torch.cuda.synchronize()
+    same = (a.final_own == b.final_own) & (a.final_opp == b.final_opp)
+    assert float(same.float().mean()) > 0.995
+    assert torch.equal(ops.judge(b.final_own, b.final_opp), b.z)

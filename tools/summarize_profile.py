@@ -14,7 +14,7 @@ import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
-kern = sys.argv[3] if len(sys.argv) > 3 else "rollout_kernel"
+kern = sys.argv[3] if len(sys.argv) > 3 else "rollout_lpb_kernel"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -62,8 +62,10 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         extra["rocprof_kernel_avg_ms"] = rocprof_avg_ns / 1e6
     if "SQ_INSTS_VALU" in pmc and "Grid_Size" in pmc.get("_dispatch", {}):
         # wave-level VALU instructions of one launch and the boards it played (8 lanes each)
+        lanes_per_board = 1 if "lpb" in kern else 8
         extra.update({"valu_insts_per_launch": pmc["SQ_INSTS_VALU"]["mean"],
-                      "boards_per_launch": int(pmc["_dispatch"]["Grid_Size"]) // 8})
+                      "boards_per_launch": int(pmc["_dispatch"]["Grid_Size"]) // lanes_per_board,
+                      "kernel": kern})
     with open(os.path.join(out, "rollout_traffic.json"), "w") as f:
         json.dump(dict({"hbm_bytes_per_launch": hbm, "fetch_size_kib": fetch_kb,
                         "write_size_kib": write_kb, "profile": tag,
