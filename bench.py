@@ -9,7 +9,7 @@ the standard start position are played to the end by the fused HIP rollout
 kernel with the reference's shipped RolloutPolicy weights (82 floats, kept as
 golden data in tests/golden/simulate.json) -- rollout-policy-only self-play.
 One step = 4096 finished games per GPU.  Steps are independent batches: by default
-64 consecutive steps share one kernel launch (262,144 boards), which the library
+256 consecutive steps share one kernel launch (1,048,576 boards), which the library
 plays with its lane-per-board rollout kernel; `--steps-per-launch 1` issues every
 step as its own launch of the 8-lanes-per-board kernel, overlapped on 32 HIP
 streams / 16 hardware queues (a single 4096-board launch is only 512 waves).
@@ -288,7 +288,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
-    ap.add_argument("--steps-per-launch", type=int, default=64,
+    ap.add_argument("--steps-per-launch", type=int, default=256,
                     help="consecutive steps played by one kernel launch (1 = one launch per "
                          "step, overlapped on --streams HIP streams)")
     ap.add_argument("--streams", type=int, default=32,
