@@ -105,7 +105,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
     `n_sims` playouts per move, SLPolicy + Value with random-init weights
     (Chainer-default LeCunNormal, seed 0), reference constants lmbda=0.5,
     c_puct=1, n_thr=15, both colours search.  One leaf-eval = one playout
-    (value net + rollout at the leaf; the policy net runs on expansions).
+    (value net + rollout at the leaf; the policy net runs on expansions).  The fixed
+    tail of a playout and the next descent replay as one hipGraph launch.
     By default the games are played to the end (games/s); --mcts-turns N > 0
     times a bounded sample of the first N turns instead."""
     from iago_amd import engine, network, ops
@@ -115,7 +116,7 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
     value = network.Value().cuda().eval()
     m = engine.BatchedMCTS(n_games, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0,
                            n_thr=15, capacity=engine.suggest_capacity(n_sims, 15), seed=7,
-                           game_id_base=rank * n_games)
+                           game_id_base=rank * n_games, use_graph=True)
     eng = engine.SelfPlayEngine(m, max_turns=(128 if full_games else n_turns))
     m.enable_stats()
     m.warmup()                 # MIOpen kernel selection for every batch bucket
@@ -212,7 +213,8 @@ def mcts_b1_leg(n_sims=200):
     torch.manual_seed(0)
     m = mcts_mod.MCTS(policy_net=network.SLPolicy().cuda().eval(),
                       value_net=network.Value().cuda().eval(),
-                      rollout_weights=ops.RolloutWeights(w, b), n_sims=n_sims, capacity=65536)
+                      rollout_weights=ops.RolloutWeights(w, b), n_sims=n_sims, capacity=65536,
+                      use_graph=True)
     state = boards.initial_state()
     m._m.warmup()
     m.get_move(state, 1)  # warm-up move (also fills the root)
@@ -222,7 +224,7 @@ def mcts_b1_leg(n_sims=200):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"playouts_per_sec": n_sims / dt, "ms_per_playout": dt / n_sims * 1e3,
-            "sims": n_sims, "move": int(a)}
+            "sims": n_sims, "move": int(a), "hipgraph": True}
 
 
 def reinforce_leg(n_iters, world, rank, dist):

@@ -16,7 +16,8 @@ from . import boards, engine, ops
 class MCTS(object):
 
     def __init__(self, lmbda=0.5, c_puct=1, n_thr=15, time_limit=10, policy_net=None,
-                 value_net=None, rollout_weights=None, n_sims=None, capacity=65536, seed=0):
+                 value_net=None, rollout_weights=None, n_sims=None, capacity=65536, seed=0,
+                 use_graph=False):
         if policy_net is None or (value_net is None and lmbda < 1):
             raise ValueError("policy_net / value_net are required (the reference loads "
                              "./models/sl_model.npz and ./models/value_model.npz here)")
@@ -24,7 +25,8 @@ class MCTS(object):
         self.n_sims = n_sims
         self.policy_net, self.value_net = policy_net, value_net
         self._m = engine.BatchedMCTS(1, policy_net, value_net, rollout_weights, lmbda=lmbda,
-                                     c_puct=c_puct, n_thr=n_thr, capacity=capacity, seed=seed)
+                                     c_puct=c_puct, n_thr=n_thr, capacity=capacity, seed=seed,
+                                     use_graph=use_graph)
         self._one = torch.ones(1, dtype=torch.uint8, device="cuda")
 
     def get_move(self, state, color):

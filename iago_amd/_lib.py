@@ -37,6 +37,7 @@ class RolloutArgs(C.Structure):
         ("own", C.c_void_p), ("opp", C.c_void_p), ("n", C.c_int64),
         ("table", C.c_void_p), ("uniforms", C.c_void_p),
         ("seed", C.c_uint64), ("id_base", C.c_uint32), ("stream_id", C.c_uint32),
+        ("stream_id_dev", C.c_void_p),
         ("z", C.c_void_p), ("final_own", C.c_void_p), ("final_opp", C.c_void_p),
         ("n_turns", C.c_void_p), ("trace", C.c_void_p), ("log_form", C.c_int),
         ("throughput_hint", C.c_int),

@@ -49,6 +49,7 @@ struct RolloutParams {
     const float *blob;
     const float *uniforms;
     uint32_t key0, key1, id_base, stream_id;
+    const uint32_t *stream_id_dev;
     int8_t *z;
     uint64_t *final_own;
     uint64_t *final_opp;
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
     const Lane8 L = make_lane8(threadIdx.x);
     const uint32_t r = L.l8;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stream_id = P.stream_id + (P.stream_id_dev ? *P.stream_id_dev : 0u);
 
     float bias[8]; // this lane's row of bias2/b (exp'ed in product form)
 #pragma unroll
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
                 if ((t4 & 31u) == 0u) {
                     rw[0] = rid;
                     rw[1] = (t4 >> 2) + r;
-                    rw[2] = P.stream_id;
+                    rw[2] = stream_id;
                     rw[3] = 0u;
                     philox4x32_10(rw, P.key0, P.key1);
                 }
@@ -456,6 +458,7 @@ int iago_rollout(const iago_rollout_args *a, void *stream)
     P.key1 = (uint32_t)(a->seed >> 32);
     P.id_base = a->id_base;
     P.stream_id = a->stream_id;
+    P.stream_id_dev = a->stream_id_dev;
     P.z = a->z;
     P.final_own = a->final_own;
     P.final_opp = a->final_opp;

@@ -40,6 +40,7 @@ struct LpbParams {
     const float *blob;
     const float *uniforms;
     uint32_t key0, key1, id_base, stream_id;
+    const uint32_t *stream_id_dev;
     int8_t *z;
     uint64_t *final_own;
     uint64_t *final_opp;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
     uint32_t pass_flg = 0u, nt = 0u;
     uint32_t done = (!live || stones >= 64u) ? 1u : 0u; // `while stone_num < 64`
     const uint32_t rid = P.id_base + (uint32_t)b;
+    const uint32_t stream_id = P.stream_id + (P.stream_id_dev ? *P.stream_id_dev : 0u);
     uint32_t rw[4] = {0, 0, 0, 0};
 
     for (uint32_t t = 0; t < (uint32_t)IAGO_MAX_TURNS; t++) {
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
             if ((t & 3u) == 0u) {
                 rw[0] = rid;
                 rw[1] = t >> 2;
-                rw[2] = P.stream_id;
+                rw[2] = stream_id;
                 rw[3] = 0u;
                 philox4x32_10(rw, P.key0, P.key1);
             }
@@ -288,6 +290,7 @@ void iago_launch_rollout_lpb(const iago_rollout_args *a, void *stream)
     P.key1 = (uint32_t)(a->seed >> 32);
     P.id_base = a->id_base;
     P.stream_id = a->stream_id;
+    P.stream_id_dev = a->stream_id_dev;
     P.z = a->z;
     P.final_own = a->final_own;
     P.final_opp = a->final_opp;

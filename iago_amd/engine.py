@@ -109,7 +109,7 @@ class BatchedMCTS(object):
     """
 
     def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
-                 n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda"):
+                 n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         self.n_games = n_games
@@ -131,6 +131,11 @@ class BatchedMCTS(object):
         self.visits = torch.zeros((n_games, 64), dtype=torch.int32, **kw)
         self._policy_in = torch.zeros((max(n_games, 16), 2, 8, 8), dtype=torch.float32, **kw)
         self.stats = None             # optional (n_games, 2) int32: levels, children scored
+        self.use_graph, self._graph = bool(use_graph), None
+        self._g_own = torch.zeros(n_games, dtype=torch.int64, **kw)
+        self._g_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
+        self._g_active = torch.zeros(n_games, dtype=torch.uint8, **kw)
+        self._sim_dev = torch.zeros(1, dtype=torch.int32, **kw)  # Philox stream id on the device
         self.sim_counter = 0          # Philox stream id: one per simulation
         self.n_leaf_evals = 0
         self.n_policy_evals = 0
@@ -169,35 +174,40 @@ class BatchedMCTS(object):
                                  _p(self.legal), _p(self.stats) if self.stats is not None else None,
                                  _stream()), "iago_mcts_select")
 
-    def simulate(self, own, opp, active, n_active=None):
+    def _expand_pending(self, own, opp, active):
+        """Expansion branch of MCTS.playout (MCTS.py:109-121) for the games whose
+        cursor sits on a leaf with n_visits >= n_thr.  One host sync."""
         L = _lib.lib()
-        self._select(own, opp, active, True)
         idx = torch.nonzero(self.needs_expand & active).reshape(-1)  # host sync: usually small
-        if idx.numel() > 0:
-            games = idx.to(torch.int32)
-            n_exp = int(idx.numel())
-            # MIOpen picks (and on first sight searches for) a kernel per input
-            # shape: run the policy net on a few fixed bucket sizes only
-            nb = self._bucket(n_exp)
-            sub_planes = self._policy_in[:nb]
-            ops.encode_planes(self.cur_own[idx], self.cur_opp[idx], out=sub_planes[:n_exp])
-            with torch.no_grad():
-                probs = self.policy_fn(sub_planes).to(torch.float32).contiguous()
-            self.n_policy_evals += int(idx.numel())
-            check(L.iago_mcts_expand(self.tree.ref(), _p(games), games.numel(), _p(self.cur_node),
-                                     _p(self.legal), _p(probs), _stream()), "iago_mcts_expand")
-            sub_active = torch.zeros_like(active)
-            sub_active[idx] = 1
-            self._select(own, opp, sub_active, False)  # MCTS.py:121: recurse into the same node
-        # leaf evaluation (MCTS.py:123-127)
+        if idx.numel() == 0:
+            return
+        games = idx.to(torch.int32)
+        n_exp = int(idx.numel())
+        # MIOpen picks (and on first sight searches for) a kernel per input
+        # shape: run the policy net on a few fixed bucket sizes only
+        nb = self._bucket(n_exp)
+        sub_planes = self._policy_in[:nb]
+        ops.encode_planes(self.cur_own[idx], self.cur_opp[idx], out=sub_planes[:n_exp])
+        with torch.no_grad():
+            probs = self.policy_fn(sub_planes).to(torch.float32).contiguous()
+        self.n_policy_evals += n_exp
+        check(L.iago_mcts_expand(self.tree.ref(), _p(games), games.numel(), _p(self.cur_node),
+                                 _p(self.legal), _p(probs), _stream()), "iago_mcts_expand")
+        sub_active = torch.zeros_like(active)
+        sub_active[idx] = 1
+        self._select(own, opp, sub_active, False)  # MCTS.py:121: recurse into the same node
+
+    def _evaluate_and_backup(self, active, stream_id=0, stream_id_dev=None):
+        """Leaf evaluation (MCTS.py:123-127) and Node.update_recursive."""
+        L = _lib.lib()
         if self.lmbda < 1.0:
             ops.encode_planes(self.cur_own, self.cur_opp, out=self.planes)
             with torch.no_grad():
                 self.v = self.value_fn(self.planes).to(torch.float32).contiguous()
         if self.lmbda > 0.0:
             ops.rollout(self.cur_own, self.cur_opp, self.rollout_weights, seed=self.seed,
-                        id_base=self.game_id_base, stream_id=self.sim_counter,
-                        out=self._rollout_out)
+                        id_base=self.game_id_base, stream_id=stream_id,
+                        stream_id_dev=stream_id_dev, out=self._rollout_out)
             if self.rollout_hook is not None:
                 self.rollout_hook(self)
         check(L.iago_leaf_values(_p(self.v) if self.lmbda < 1.0 else None,
@@ -205,8 +215,42 @@ class BatchedMCTS(object):
                                  _p(self.leaf_value), self.n_games, _stream()), "iago_leaf_values")
         check(L.iago_mcts_backup(self.tree.ref(), _p(active), _p(self.cur_node),
                                  _p(self.leaf_value), _stream()), "iago_mcts_backup")
+
+    def simulate(self, own, opp, active, n_active=None):
+        """One MCTS.playout for every active game (eager launches)."""
+        self._select(own, opp, active, True)
+        self._expand_pending(own, opp, active)
+        self._evaluate_and_backup(active, stream_id=self.sim_counter)
         self.sim_counter = (self.sim_counter + 1) & 0xFFFFFFFF
         if n_active is not None:
+            self.n_leaf_evals += n_active
+
+    # -- hipGraph mode: the fixed tail of a playout (planes, value net, rollout, leaf
+    # mix, backup) and the NEXT playout's descent are captured once and replayed with
+    # a single launch; only the expansion test stays on the host.  Pays off for small
+    # batches, where a playout is ~25 short launches (single-game serving mode).
+    def _capture(self):
+        if self.rollout_hook is not None:
+            raise ValueError("rollout_hook is not available in graph mode")
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._evaluate_and_backup(self._g_active, stream_id=0, stream_id_dev=self._sim_dev)
+            self._sim_dev.add_(1)
+            self._select(self._g_own, self._g_opp, self._g_active, True)
+
+    def _search_graph(self, own, opp, active, n_sims, n_active):
+        self._g_own.copy_(own)
+        self._g_opp.copy_(opp)
+        self._g_active.copy_(active)
+        self._sim_dev.fill_(self.sim_counter - (1 << 32) if self.sim_counter >= (1 << 31)
+                            else self.sim_counter)
+        self._select(self._g_own, self._g_opp, self._g_active, True)
+        for _ in range(n_sims):
+            self._expand_pending(self._g_own, self._g_opp, self._g_active)
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+            self.sim_counter = (self.sim_counter + 1) & 0xFFFFFFFF
             self.n_leaf_evals += n_active
 
     def search(self, own, opp, active, n_sims):
@@ -215,8 +259,11 @@ class BatchedMCTS(object):
         n_active = int(active.sum().item())
         if n_active == 0:
             return
-        for _ in range(n_sims):
-            self.simulate(own, opp, active, n_active)
+        if self.use_graph:
+            self._search_graph(own, opp, active, n_sims, n_active)
+        else:
+            for _ in range(n_sims):
+                self.simulate(own, opp, active, n_active)
         if int(self.tree.overflow.sum().item()) != 0:
             raise _lib.IagoError("MCTS node pool exhausted (or a search path deeper than 512): "
                                  "raise `capacity` (%d nodes per game)" % self.tree.capacity)

@@ -175,7 +175,7 @@ class PreparedRollout(object):
 
 def rollout_prepare(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=None,
                     want_final=False, want_turns=False, want_trace=False, out=None,
-                    throughput_hint=False):
+                    throughput_hint=False, stream_id_dev=None):
     """Marshal a rollout launch once (see `rollout` for the arguments)."""
     n = own.numel()
     res = out if out is not None else RolloutResult()
@@ -205,6 +205,8 @@ def rollout_prepare(own, opp, weights=None, seed=0, id_base=0, stream_id=0, unif
     a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     a.id_base = int(id_base) & 0xFFFFFFFF
     a.stream_id = int(stream_id) & 0xFFFFFFFF
+    if stream_id_dev is not None:  # int32 CUDA tensor with one element, added on the device
+        a.stream_id_dev = _dev(stream_id_dev, torch.int32, "stream_id_dev")
     a.z = _dev(res.z, torch.int8, "z")
     if res.final_own is not None:
         a.final_own = _dev(res.final_own, torch.int64, "final_own")
@@ -215,14 +217,14 @@ def rollout_prepare(own, opp, weights=None, seed=0, id_base=0, stream_id=0, unif
         a.trace = _dev(res.trace, torch.uint8, "trace")
     p = PreparedRollout()
     p.args, p.ref, p.result = a, C.byref(a), res
-    p._keep = (own, opp, weights, uniforms)
+    p._keep = (own, opp, weights, uniforms, stream_id_dev)
     p._fn = _lib.lib().iago_rollout
     return p
 
 
 def rollout(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=None,
             want_final=False, want_turns=False, want_trace=False, out=None,
-            throughput_hint=False):
+            throughput_hint=False, stream_id_dev=None):
     """Simulate(state)(color) for every board (mcts_self_play.py:9-134).
 
     weights=None plays uniformly random legal moves.  `uniforms`
@@ -232,6 +234,6 @@ def rollout(own, opp, weights=None, seed=0, id_base=0, stream_id=0, uniforms=Non
     iago_rollout_args.throughput_hint).
     """
     p = rollout_prepare(own, opp, weights, seed, id_base, stream_id, uniforms, want_final,
-                        want_turns, want_trace, out, throughput_hint)
+                        want_turns, want_trace, out, throughput_hint, stream_id_dev)
     check(p.launch(), "iago_rollout")
     return p.result

@@ -153,6 +153,9 @@ typedef struct iago_rollout_args {
     uint64_t seed;           /* Philox4x32-10 key */
     uint32_t id_base;        /* rollout b draws from counter (id_base + b, turn/4, stream, 0) */
     uint32_t stream_id;
+    const uint32_t *stream_id_dev; /* optional device word added to stream_id when the kernel
+                                starts: lets a captured hipGraph replay the launch with a
+                                new Philox stream (the caller bumps the word on the stream) */
     int8_t *z;               /* [n] result from the leaf side-to-move's view */
     uint64_t *final_own;     /* optional [n]: final stones of the leaf side to move */
     uint64_t *final_opp;     /* optional [n] */

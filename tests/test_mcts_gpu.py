@@ -218,3 +218,40 @@ def test_full_size_tree_invariants(eng):
         a, b = getattr(m.tree, f), getattr(m2.tree, f)
         used = torch.arange(cap, device="cuda").reshape(1, cap) < m.tree.n_nodes.reshape(G, 1)
         assert torch.equal(a.reshape(G, cap)[used], b.reshape(G, cap)[used]), f
+
+
+def test_graph_mode_equals_eager(eng):
+    """hipGraph replay of the playout tail (planes, value net, rollout, leaf mix,
+    backup, next descent) builds the same trees as eager launches."""
+    engine, ops = eng
+    from iago_amd import network
+    g = __import__("tests.conftest", fromlist=["load_json"]).load_json("simulate.json")
+    torch.manual_seed(1)
+    policy, value = network.SLPolicy().cuda().eval(), network.Value().cuda().eval()
+    w = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    G = 8
+    own, opp = random_positions(G, seed=3)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    act = torch.ones(G, dtype=torch.uint8, device="cuda")
+    act[2] = 0
+    trees = []
+    for use_graph in (False, True):
+        m = engine.BatchedMCTS(G, policy, value, w, n_thr=3, capacity=1024, seed=9,
+                               use_graph=use_graph)
+        m.warmup()
+        m.search(o, p, act, 25)
+        m.search(o, p, act, 15)          # second search replays the captured graph
+        mv = m.best_move(act)[0].cpu().numpy().copy()
+        trees.append((m.tree.n_visits.cpu(), m.tree.q.cpu(), m.tree.p.cpu(), m.tree.action.cpu(),
+                      m.tree.n_nodes.cpu(), mv, m.n_leaf_evals, m.sim_counter))
+    a, b = trees
+    assert torch.equal(a[4], b[4]) and a[6] == b[6] and a[7] == b[7]
+    used = torch.arange(1024).reshape(1, 1024) < a[4].reshape(G, 1)
+    for k in (0, 3):   # visit counts and actions: identical trees
+        assert torch.equal(a[k].reshape(G, 1024)[used], b[k].reshape(G, 1024)[used]), k
+    # Q and P come through MIOpen, which may pick another algorithm (no workspace) under
+    # stream capture: equal within the nets' 1e-5 parity tolerance, not bit for bit
+    for k in (1, 2):
+        assert torch.allclose(a[k].reshape(G, 1024)[used], b[k].reshape(G, 1024)[used],
+                              rtol=0, atol=1e-5), k
+    assert np.array_equal(a[5], b[5])
