@@ -70,57 +70,76 @@ __device__ __forceinline__ uint64_t moves_down(uint64_t own, uint64_t opp, uint6
     return (t >> S) & empty & m;
 }
 
+// Moves towards the east (+1) for all 8 rows at once by carry propagation: adding the
+// opponent stones that have an own stone on their west to the inner-column opponent
+// mask ripples through each such run and sets the cell just past it.
+__device__ __forceinline__ uint64_t moves_east(uint64_t own, uint64_t opp, uint64_t empty)
+{
+    const uint64_t inner = opp & 0x7E7E7E7E7E7E7E7Eull; // a run never wraps: no col 0 / 7
+    const uint64_t start = (own << 1) & inner;
+    return (start + inner) & ~inner & empty;
+}
+
 // game.py:210-235 on one lane; the masks are the DESTINATION files a shifted stone may
-// not land on (A/H-file wrap-around)
-__device__ __forceinline__ uint64_t legal_moves_1(uint64_t own, uint64_t opp)
+// not land on (A/H-file wrap-around).  ro / rp: the bit-reversed boards (west = east
+// of the reversed board).
+__device__ __forceinline__ uint64_t legal_moves_1(uint64_t own, uint64_t opp, uint64_t ro,
+                                                  uint64_t rp)
 {
     const uint64_t e = ~(own | opp);
-    return moves_up<1>(own, opp, e, ~FILE_A) | moves_up<7>(own, opp, e, ~FILE_H) |
-           moves_up<8>(own, opp, e, ~0ull) | moves_up<9>(own, opp, e, ~FILE_A) |
-           moves_down<1>(own, opp, e, ~FILE_H) | moves_down<7>(own, opp, e, ~FILE_A) |
+    return moves_east(own, opp, e) | rev64(moves_east(ro, rp, rev64(e))) |
+           moves_up<7>(own, opp, e, ~FILE_H) | moves_up<8>(own, opp, e, ~0ull) |
+           moves_up<9>(own, opp, e, ~FILE_A) | moves_down<7>(own, opp, e, ~FILE_A) |
            moves_down<8>(own, opp, e, ~0ull) | moves_down<9>(own, opp, e, ~FILE_H);
 }
 
 // Flips along the ray of direction K (0: +1, 1: +7, 2: +8, 3: +9) from `pos`:
 // othello_dev.hpp's ray_mask / carry trick with compile-time direction constants.
+// gt / lt: the columns right / left of pos, replicated to all rows.
 template <int K>
-__device__ __forceinline__ uint64_t flips_up(uint64_t o, uint64_t p, uint32_t pos)
+__device__ __forceinline__ uint64_t flips_up(uint64_t o, uint64_t p, uint32_t pos, uint64_t gt,
+                                             uint64_t lt)
 {
     constexpr uint64_t base = (K == 0)   ? 0x00000000000000FEull
                               : (K == 1) ? 0x0002040810204080ull
                               : (K == 2) ? 0x0101010101010100ull
                                          : 0x8040201008040200ull;
     uint64_t M = base << pos;
-    if (K != 2) {
-        constexpr uint32_t ca = (K == 1) ? 0xFFu : 0xFEu, cx = (K == 1) ? 0xFFu : 0u;
-        const uint32_t m8 = (ca << (pos & 7u)) ^ cx;
-        const uint32_t m32 = __builtin_amdgcn_perm(m8, m8, 0u);
-        M &= ((uint64_t)m32 << 32) | m32;
-    }
+    if (K == 1)
+        M &= lt;
+    else if (K != 2)
+        M &= gt;
     const uint64_t x = p | ~M;
     const uint64_t t = x + 1ull;
     return ((t & M & o) != 0ull) ? ((t ^ x) & M & p) : 0ull;
 }
 
-// game.py:180-207 on one lane (no legality check)
-__device__ __forceinline__ uint64_t flips_1(uint64_t own, uint64_t opp, uint32_t pos)
+__device__ __forceinline__ uint64_t flips_4(uint64_t o, uint64_t p, uint32_t pos)
 {
-    const uint64_t f = flips_up<0>(own, opp, pos) | flips_up<1>(own, opp, pos) |
-                       flips_up<2>(own, opp, pos) | flips_up<3>(own, opp, pos);
-    const uint64_t ro = rev64(own), rp = rev64(opp);
-    const uint32_t rpos = 63u - pos;
-    const uint64_t g = flips_up<0>(ro, rp, rpos) | flips_up<1>(ro, rp, rpos) |
-                       flips_up<2>(ro, rp, rpos) | flips_up<3>(ro, rp, rpos);
-    return f | rev64(g);
+    const uint32_t c = pos & 7u;
+    const uint32_t g8 = 0xFEu << c, l8 = (0xFFu << c) ^ 0xFFu;
+    const uint32_t g32 = __builtin_amdgcn_perm(g8, g8, 0u), l32 = __builtin_amdgcn_perm(l8, l8, 0u);
+    const uint64_t gt = ((uint64_t)g32 << 32) | g32, lt = ((uint64_t)l32 << 32) | l32;
+    return flips_up<0>(o, p, pos, gt, lt) | flips_up<1>(o, p, pos, gt, lt) |
+           flips_up<2>(o, p, pos, gt, lt) | flips_up<3>(o, p, pos, gt, lt);
+}
+
+// game.py:180-207 on one lane (no legality check)
+__device__ __forceinline__ uint64_t flips_1(uint64_t own, uint64_t opp, uint64_t ro, uint64_t rp,
+                                            uint32_t pos)
+{
+    return flips_4(own, opp, pos) | rev64(flips_4(ro, rp, 63u - pos));
 }
 
 // 9-bit pattern of the 3x3 neighbourhood of cell (r, x): bit 3*ky + kx = cell
 // (r + ky - 1, x + kx - 1), zero outside the board.  sh_r / sh_l bring rows r-1..r+1
 // to bits 0..23 (as in rollout_kernel.hip); cm removes the column that wrapped.
-__device__ __forceinline__ uint32_t pattern9(uint64_t b, uint32_t sh_r, uint32_t sh_l, uint32_t x,
+__device__ __forceinline__ uint32_t pattern9(uint64_t b, uint32_t sh_r, uint32_t sh_l1, uint32_t x,
                                              uint32_t cm)
 {
-    const uint32_t w = (((uint32_t)(b >> sh_r) << sh_l) & 0xFFFFFFu) << 1; // cell x-1 at bit x
+    // rows r-1.. at bit 1 (cell x-1 at bit x); bits of rows beyond r+1 either fall off
+    // the 32-bit word or land above bit 18, or on bit 18 for x = 7 where cm clears it
+    const uint32_t w = (uint32_t)(b >> sh_r) << sh_l1;
     const uint32_t q = (w >> x) & cm;
     return (q & 7u) | (((q >> 8) & 7u) << 3) | (((q >> 16) & 7u) << 6);
 }
@@ -147,11 +166,11 @@ __device__ __forceinline__ void fill_slots(Slots &S, uint64_t own, uint64_t opp,
         const uint32_t c = valid ? (uint32_t)__builtin_ctzll(S.rem) : 0u;
         S.rem &= S.rem - 1ull;
         const uint32_t r = c >> 3, x = c & 7u;
-        const uint32_t sh_r = r ? 8u * (r - 1u) : 0u, sh_l = r ? 0u : 8u;
+        const uint32_t sh_r = r ? 8u * (r - 1u) : 0u, sh_l1 = r ? 1u : 9u;
         const uint32_t cm =
             0x070707u & ~((x == 0u) ? 0x010101u : 0u) & ~((x == 7u) ? 0x040404u : 0u);
-        const uint32_t io = pattern9(own, sh_r, sh_l, x, cm);
-        const uint32_t ip = pattern9(opp, sh_r, sh_l, x, cm);
+        const uint32_t io = pattern9(own, sh_r, sh_l1, x, cm);
+        const uint32_t ip = pattern9(opp, sh_r, sh_l1, x, cm);
         // plane 0 = opponent of the side to move, plane 1 = side to move (game.py:168-174)
         const float e = be[c] * ct[ip] * ct[512 + io];
         S.acc += valid ? e : 0.0f;
@@ -213,7 +232,8 @@ __global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
             u = (float)(w >> 8) * (1.0f / 16777216.0f);
         }
 
-        const uint64_t legal = legal_moves_1(own, opp);
+        const uint64_t ro = rev64(own), rp = rev64(opp);
+        const uint64_t legal = legal_moves_1(own, opp, ro, rp);
         const uint32_t has = min(1u, (uint32_t)legal | (uint32_t)(legal >> 32));
 
         // ---- softmax numerators of the legal cells, running sums in slot order
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
         const uint32_t action = (word >> (8u * (slot & 3u))) & 63u;
 
         // ---- flips, board update, pass / termination bookkeeping (branch-free)
-        const uint64_t f = flips_1(own, opp, action);
+        const uint64_t f = flips_1(own, opp, ro, rp, action);
         const uint32_t live_turn = done ^ 1u;
         const uint32_t play = has & live_turn;
         const uint32_t passing = (has ^ 1u) & live_turn;
