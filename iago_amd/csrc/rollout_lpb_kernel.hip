@@ -131,17 +131,47 @@ __device__ __forceinline__ uint64_t flips_1(uint64_t own, uint64_t opp, uint64_t
     return flips_4(own, opp, pos) | rev64(flips_4(ro, rp, 63u - pos));
 }
 
-// 9-bit pattern of the 3x3 neighbourhood of cell (r, x): bit 3*ky + kx = cell
-// (r + ky - 1, x + kx - 1), zero outside the board.  sh_r / sh_l bring rows r-1..r+1
-// to bits 0..23 (as in rollout_kernel.hip); cm removes the column that wrapped.
-__device__ __forceinline__ uint32_t pattern9(uint64_t b, uint32_t sh_r, uint32_t sh_l1, uint32_t x,
-                                             uint32_t cm)
+// A board with a guard column between the rows and an empty row in front: cell (k, j)
+// at bit 10 + 9k + j of a 96-bit string.  The 3x3 neighbourhood of cell c = 8r + x is
+// then the 21-bit window at bit 9r + x with no wrap-around to mask (the guard bit is
+// column -1 of one row and column 8 of the previous one).
+struct Padded {
+    uint64_t w01; // bits 0..63
+    uint64_t w12; // bits 32..95
+};
+
+__device__ __forceinline__ uint64_t spread4(uint32_t h) // rows at bits 0, 9, 18, 27
 {
-    // rows r-1.. at bit 1 (cell x-1 at bit x); bits of rows beyond r+1 either fall off
-    // the 32-bit word or land above bit 18, or on bit 18 for x = 7 where cm clears it
-    const uint32_t w = (uint32_t)(b >> sh_r) << sh_l1;
-    const uint32_t q = (w >> x) & cm;
-    return (q & 7u) | (((q >> 8) & 7u) << 3) | (((q >> 16) & 7u) << 6);
+    uint64_t y = (uint64_t)(h & 0xFFFFu) | ((uint64_t)(h & 0xFFFF0000u) << 2);
+    return (y & 0x0003FC00FFull) | ((y & 0x03FC00FF00ull) << 1);
+}
+
+__device__ __forceinline__ Padded pad_board(uint64_t b)
+{
+    const uint64_t L = spread4((uint32_t)b) << 10;  // rows 0..3: bits 10..45
+    const uint64_t H = spread4((uint32_t)(b >> 32)); // rows 4..7: bits 46..81 of the string
+    Padded P;
+    P.w01 = L | (H << 46);
+    P.w12 = (L >> 32) | (H << 14);
+    return P;
+}
+
+// byte offset into a 512-entry float table of the 9-bit pattern (bit 3*ky + kx = cell
+// (r + ky - 1, x + kx - 1), zero outside the board) of the window at bit s = 9r + x
+__device__ __forceinline__ uint32_t pattern9_off(const Padded &T, uint32_t s, uint32_t s32)
+{
+    const uint32_t q = ((s < 32u) ? (uint32_t)(T.w01 >> s) : (uint32_t)(T.w12 >> s32)) & 0x1C0E07u;
+    // rows at bits 0, 9, 18 -> 12, 15, 18: the three partial products do not overlap
+    return (__umul24(q, 0x1041u) >> 10) & 0x7FCu;
+}
+
+// index of the lowest set bit; 31 for x = 0 (v_ffbl_b32 returns -1 then)
+__device__ __forceinline__ uint32_t lowest_bit(uint64_t x)
+{
+    uint32_t a, b;
+    asm("v_ffbl_b32 %0, %1" : "=v"(a) : "v"((uint32_t)x));
+    asm("v_ffbl_b32 %0, %1" : "=v"(b) : "v"((uint32_t)(x >> 32)));
+    return min(a, b + 32u);
 }
 
 // Per-turn sampling state.  The slot arrays are only ever indexed with compile-time
@@ -156,28 +186,25 @@ struct Slots {
 };
 
 template <int J>
-__device__ __forceinline__ void fill_slots(Slots &S, uint64_t own, uint64_t opp, const float *ct,
-                                           const float *be)
+__device__ __forceinline__ void fill_slots(Slots &S, const Padded &To, const Padded &Tp,
+                                           const char *ct, const float *be)
 {
     if constexpr (J < SLOTS) {
         if (__builtin_amdgcn_ballot_w64(S.rem != 0ull) == 0ull)
             return; // no lane of the wave has a legal cell left
         const bool valid = S.rem != 0ull;
-        const uint32_t c = valid ? (uint32_t)__builtin_ctzll(S.rem) : 0u;
+        const uint32_t c = lowest_bit(S.rem); // a lane without one reads cell 31's tables
         S.rem &= S.rem - 1ull;
-        const uint32_t r = c >> 3, x = c & 7u;
-        const uint32_t sh_r = r ? 8u * (r - 1u) : 0u, sh_l1 = r ? 1u : 9u;
-        const uint32_t cm =
-            0x070707u & ~((x == 0u) ? 0x010101u : 0u) & ~((x == 7u) ? 0x040404u : 0u);
-        const uint32_t io = pattern9(own, sh_r, sh_l1, x, cm);
-        const uint32_t ip = pattern9(opp, sh_r, sh_l1, x, cm);
+        const uint32_t s = c + (c >> 3), s32 = s - 32u;
+        const uint32_t io = pattern9_off(To, s, s32);
+        const uint32_t ip = pattern9_off(Tp, s, s32);
         // plane 0 = opponent of the side to move, plane 1 = side to move (game.py:168-174)
-        const float e = be[c] * ct[ip] * ct[512 + io];
+        const float e = be[c] * *(const float *)(ct + ip) * *(const float *)(ct + 2048 + io);
         S.acc += valid ? e : 0.0f;
         S.cdf[J] = S.acc;
         S.cells[J >> 2] |= c << (8 * (J & 3));
         S.filled = J + 1;
-        fill_slots<J + 1>(S, own, opp, ct, be);
+        fill_slots<J + 1>(S, To, Tp, ct, be);
     }
 }
 
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
         S.rem = done ? 0ull : legal;
         S.acc = 0.0f;
         S.filled = 0;
-        fill_slots<0>(S, own, opp, ct, be);
+        fill_slots<0>(S, pad_board(own), pad_board(opp), (const char *)ct, be);
         // ---- inverse CDF (mcts_self_play.py:103-106): slot = #sums <= u * total
         float thr;
         {
