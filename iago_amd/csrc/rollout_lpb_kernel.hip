@@ -174,24 +174,40 @@ __device__ __forceinline__ uint32_t lowest_bit(uint64_t x)
     return min(a, b + 32u);
 }
 
-// Per-turn sampling state.  The slot arrays are only ever indexed with compile-time
-// constants (template recursion instead of loops with early exits), so they live in
-// registers.
+// Per-turn sampling state.  One template instance per slot (recursion instead of a loop
+// with early exits): the running sum of a slot lives in a register of its own frame.
 struct Slots {
-    float cdf[SLOTS];
     uint32_t cells[(SLOTS + 3) / 4]; // 4 cell indices per word
     uint64_t rem;                    // legal cells not yet visited
     float acc;                       // running sum
-    int filled;                      // wave-uniform number of slots written
+    uint32_t thr;                    // bits of u * total
+    uint32_t above_lo, above_hi;     // one bit per visited slot: running sum > u * total
+    int filled;                      // wave-uniform number of slots visited
 };
 
+// mcts_self_play.py:103-106: the threshold of the inverse CDF, rounded before any
+// comparison so that the uniform policy stays bit-exact with numpy
+__device__ __forceinline__ void close_slots(Slots &S, float u, int filled)
+{
+#pragma clang fp contract(off)
+    const float thr = u * S.acc;
+    S.thr = __float_as_uint(thr);
+    S.above_lo = 0u;
+    S.above_hi = 0u;
+    S.filled = filled;
+}
+
+// Way down: softmax numerators of the legal cells in cell order, until no lane of the
+// wave has a cell left.  Way back up: compare each slot's running sum with u * total.
 template <int J>
 __device__ __forceinline__ void fill_slots(Slots &S, const Padded &To, const Padded &Tp,
-                                           const char *ct, const float *be)
+                                           const char *ct, const float *be, float u)
 {
     if constexpr (J < SLOTS) {
-        if (__builtin_amdgcn_ballot_w64(S.rem != 0ull) == 0ull)
-            return; // no lane of the wave has a legal cell left
+        if (__builtin_amdgcn_ballot_w64(S.rem != 0ull) == 0ull) {
+            close_slots(S, u, J);
+            return;
+        }
         const bool valid = S.rem != 0ull;
         const uint32_t c = lowest_bit(S.rem); // a lane without one reads cell 31's tables
         S.rem &= S.rem - 1ull;
@@ -201,22 +217,18 @@ __device__ __forceinline__ void fill_slots(Slots &S, const Padded &To, const Pad
         // plane 0 = opponent of the side to move, plane 1 = side to move (game.py:168-174)
         const float e = be[c] * *(const float *)(ct + ip) * *(const float *)(ct + 2048 + io);
         S.acc += valid ? e : 0.0f;
-        S.cdf[J] = S.acc;
+        const uint32_t sum = __float_as_uint(S.acc);
         S.cells[J >> 2] |= c << (8 * (J & 3));
-        S.filled = J + 1;
-        fill_slots<J + 1>(S, To, Tp, ct, be);
-    }
-}
-
-template <int J>
-__device__ __forceinline__ uint32_t count_slots(const Slots &S, float thr)
-{
-    if constexpr (J < SLOTS) {
-        if (J >= S.filled)
-            return 0u;
-        return ((S.cdf[J] <= thr) ? 1u : 0u) + count_slots<J + 1>(S, thr);
+        fill_slots<J + 1>(S, To, Tp, ct, be, u);
+        // both floats are >= 0: their bit patterns order like the values, and bit 31 of
+        // the difference says sum > thr; shifted into the slot bitmap (newest = bit 0)
+        const uint32_t d = S.thr - sum;
+        if (J < 32)
+            S.above_lo = __builtin_amdgcn_alignbit(S.above_lo, d, 31);
+        else
+            S.above_hi = __builtin_amdgcn_alignbit(S.above_hi, d, 31);
     } else {
-        return 0u;
+        close_slots(S, u, SLOTS);
     }
 }
 
@@ -270,15 +282,9 @@ __global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
             S.cells[i] = 0u;
         S.rem = done ? 0ull : legal;
         S.acc = 0.0f;
-        S.filled = 0;
-        fill_slots<0>(S, pad_board(own), pad_board(opp), (const char *)ct, be);
+        fill_slots<0>(S, pad_board(own), pad_board(opp), (const char *)ct, be, u);
         // ---- inverse CDF (mcts_self_play.py:103-106): slot = #sums <= u * total
-        float thr;
-        {
-#pragma clang fp contract(off)
-            thr = u * S.acc; // rounded before any comparison: bit-exact uniform policy
-        }
-        uint32_t slot = count_slots<0>(S, thr);
+        uint32_t slot = (uint32_t)S.filled - (uint32_t)__popc(S.above_lo) - (uint32_t)__popc(S.above_hi);
         const uint32_t nlegal = (uint32_t)__popcll(legal);
         slot = min(slot, nlegal ? nlegal - 1u : 0u); // rounding past the total: last legal cell
         uint32_t word = S.cells[0];
