@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libiago_hip.so")
+SO_PATH = os.environ.get("IAGO_HIP_LIB") or os.path.join(HERE, "libiago_hip.so")
 
 IAGO_OK = 0
 IAGO_MAX_TURNS = 128

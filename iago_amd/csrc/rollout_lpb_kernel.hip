@@ -30,7 +30,13 @@ using namespace iago;
 
 namespace {
 
-constexpr int BLOCK = 256;
+#ifndef IAGO_LPB_BLOCK
+#define IAGO_LPB_BLOCK 256
+#endif
+#ifndef IAGO_LPB_ATTR
+#define IAGO_LPB_ATTR
+#endif
+constexpr int BLOCK = IAGO_LPB_BLOCK;
 constexpr int SLOTS = 34; // an Othello position has at most 33 legal moves
 
 struct LpbParams {
@@ -48,70 +54,115 @@ struct LpbParams {
     uint8_t *trace;
 };
 
-template <int S>
-__device__ __forceinline__ uint64_t moves_up(uint64_t own, uint64_t opp, uint64_t empty, uint64_t m)
+// Bitwise function TT of three 64-bit words, one v_bitop3_b32 per half (truth table
+// with a = 0xF0, b = 0xCC, c = 0xAA).  Spelled out because it is full rate on gfx950 and
+// the compiler otherwise leaves `a | (b & c)` as two instructions per half.
+template <int TT>
+__device__ __forceinline__ uint64_t bitop64(uint64_t a, uint64_t b, uint64_t c)
 {
-    const uint64_t pm = opp & m;
-    uint64_t t = (own << S) & pm;
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-        t |= (t << S) & pm;
-    return (t << S) & empty & m;
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, TT);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32),
+                                                    (uint32_t)(c >> 32), TT);
+    return ((uint64_t)hi << 32) | lo;
 }
-template <int S>
-__device__ __forceinline__ uint64_t moves_down(uint64_t own, uint64_t opp, uint64_t empty,
-                                               uint64_t m)
+constexpr int TT_A_OR_BC = 0xF8;    // a | (b & c)
+constexpr int TT_ABC = 0x80;        // a & b & c
+constexpr int TT_A_OR_NBC = 0xF7;   // a | ~(b & c)
+constexpr int TT_A_NB_C = 0x20;     // a & ~b & c
+constexpr int TT_AB_NC = 0x40;      // a & b & ~c
+constexpr int TT_A_OR_B_OR_C = 0xFE; // a | b | c
+
+// Shift amounts the compiler cannot see through: a 64-bit shift by a VGPR amount is ONE
+// v_lshlrev_b64 / v_lshrrev_b64 (the issue cost of a single 32-bit left shift on
+// gfx950), while a constant amount gets split into v_alignbit_b32 + a 32-bit shift.
+struct ShiftAmounts {
+    uint32_t s1, s7, s8, s9;
+};
+__device__ __forceinline__ ShiftAmounts opaque_shift_amounts()
+{
+    ShiftAmounts A;
+    asm("v_mov_b32 %0, 1" : "=v"(A.s1));
+    asm("v_mov_b32 %0, 7" : "=v"(A.s7));
+    asm("v_mov_b32 %0, 8" : "=v"(A.s8));
+    asm("v_mov_b32 %0, 9" : "=v"(A.s9));
+    return A;
+}
+
+__device__ __forceinline__ uint64_t moves_up(uint64_t own, uint64_t opp, uint64_t empty, uint64_t m,
+                                             uint32_t sh)
 {
     const uint64_t pm = opp & m;
-    uint64_t t = (own >> S) & pm;
+    uint64_t t = (own << sh) & pm;
 #pragma unroll
     for (int i = 0; i < 5; i++)
-        t |= (t >> S) & pm;
-    return (t >> S) & empty & m;
+        t = bitop64<TT_A_OR_BC>(t, t << sh, pm);
+    return (t << sh) & (empty & m);
+}
+__device__ __forceinline__ uint64_t moves_down(uint64_t own, uint64_t opp, uint64_t empty,
+                                               uint64_t m, uint32_t sh)
+{
+    const uint64_t pm = opp & m;
+    uint64_t t = (own >> sh) & pm;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+        t = bitop64<TT_A_OR_BC>(t, t >> sh, pm);
+    return (t >> sh) & (empty & m);
 }
 
 // Moves towards the east (+1) for all 8 rows at once by carry propagation: adding the
 // opponent stones that have an own stone on their west to the inner-column opponent
 // mask ripples through each such run and sets the cell just past it.
-__device__ __forceinline__ uint64_t moves_east(uint64_t own, uint64_t opp, uint64_t empty)
+__device__ __forceinline__ uint64_t moves_east(uint64_t own, uint64_t opp, uint64_t empty,
+                                               uint32_t s1)
 {
     const uint64_t inner = opp & 0x7E7E7E7E7E7E7E7Eull; // a run never wraps: no col 0 / 7
-    const uint64_t start = (own << 1) & inner;
-    return (start + inner) & ~inner & empty;
+    const uint64_t start = (own << s1) & inner;
+    return bitop64<TT_AB_NC>(start + inner, empty, inner);
 }
 
 // game.py:210-235 on one lane; the masks are the DESTINATION files a shifted stone may
 // not land on (A/H-file wrap-around).  ro / rp: the bit-reversed boards (west = east
 // of the reversed board).
 __device__ __forceinline__ uint64_t legal_moves_1(uint64_t own, uint64_t opp, uint64_t ro,
-                                                  uint64_t rp)
+                                                  uint64_t rp, const ShiftAmounts &A)
 {
     const uint64_t e = ~(own | opp);
-    return moves_east(own, opp, e) | rev64(moves_east(ro, rp, rev64(e))) |
-           moves_up<7>(own, opp, e, ~FILE_H) | moves_up<8>(own, opp, e, ~0ull) |
-           moves_up<9>(own, opp, e, ~FILE_A) | moves_down<7>(own, opp, e, ~FILE_A) |
-           moves_down<8>(own, opp, e, ~0ull) | moves_down<9>(own, opp, e, ~FILE_H);
+    const uint64_t a = bitop64<TT_A_OR_B_OR_C>(moves_east(own, opp, e, A.s1),
+                                               rev64(moves_east(ro, rp, rev64(e), A.s1)),
+                                               moves_up(own, opp, e, ~FILE_H, A.s7));
+    const uint64_t b = bitop64<TT_A_OR_B_OR_C>(moves_up(own, opp, e, ~0ull, A.s8),
+                                               moves_up(own, opp, e, ~FILE_A, A.s9),
+                                               moves_down(own, opp, e, ~FILE_A, A.s7));
+    return bitop64<TT_A_OR_B_OR_C>(a, b, moves_down(own, opp, e, ~0ull, A.s8) |
+                                             moves_down(own, opp, e, ~FILE_H, A.s9));
 }
 
-// Flips along the ray of direction K (0: +1, 1: +7, 2: +8, 3: +9) from `pos`:
-// othello_dev.hpp's ray_mask / carry trick with compile-time direction constants.
-// gt / lt: the columns right / left of pos, replicated to all rows.
+// Adds the flips along the ray of direction K (0: +1, 1: +7, 2: +8, 3: +9) from `pos`
+// to `acc`: othello_dev.hpp's ray_mask / carry trick with compile-time direction
+// constants.  gt / lt: the columns right / left of pos, replicated to all rows.
 template <int K>
-__device__ __forceinline__ uint64_t flips_up(uint64_t o, uint64_t p, uint32_t pos, uint64_t gt,
-                                             uint64_t lt)
+__device__ __forceinline__ uint64_t flips_up(uint64_t acc, uint64_t o, uint64_t p, uint32_t pos,
+                                             uint64_t gt, uint64_t lt)
 {
     constexpr uint64_t base = (K == 0)   ? 0x00000000000000FEull
                               : (K == 1) ? 0x0002040810204080ull
                               : (K == 2) ? 0x0101010101010100ull
                                          : 0x8040201008040200ull;
-    uint64_t M = base << pos;
-    if (K == 1)
-        M &= lt;
-    else if (K != 2)
-        M &= gt;
-    const uint64_t x = p | ~M;
-    const uint64_t t = x + 1ull;
-    return ((t & M & o) != 0ull) ? ((t ^ x) & M & p) : 0ull;
+    const uint64_t M0 = base << pos;
+    const uint64_t side = (K == 1) ? lt : gt;
+    const uint64_t M = (K == 2) ? M0 : (M0 & side);
+    // x: every bit that lets a carry pass = opponent stones on the ray, everything off it
+    const uint64_t x = (K == 2) ? (p | ~M0) : bitop64<TT_A_OR_NBC>(p, M0, side);
+    const uint64_t t = x + 1ull;                  // the carry stops at the first ray cell not in p
+    const uint64_t of = bitop64<TT_ABC>(t, M, o); // that cell, if it is an own stone
+    const uint64_t run = bitop64<TT_A_NB_C>(x, t, M); // the opponent run the carry went through
+    // of is one bit or zero: all ones iff there is a bracketing own stone
+    const uint32_t z = (uint32_t)of | (uint32_t)(of >> 32);
+    const uint32_t ok = (uint32_t)((int32_t)(0u - z) >> 31);
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)acc, (uint32_t)run, ok, TT_A_OR_BC);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(acc >> 32), (uint32_t)(run >> 32),
+                                                    ok, TT_A_OR_BC);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 __device__ __forceinline__ uint64_t flips_4(uint64_t o, uint64_t p, uint32_t pos)
@@ -120,8 +171,10 @@ __device__ __forceinline__ uint64_t flips_4(uint64_t o, uint64_t p, uint32_t pos
     const uint32_t g8 = 0xFEu << c, l8 = (0xFFu << c) ^ 0xFFu;
     const uint32_t g32 = __builtin_amdgcn_perm(g8, g8, 0u), l32 = __builtin_amdgcn_perm(l8, l8, 0u);
     const uint64_t gt = ((uint64_t)g32 << 32) | g32, lt = ((uint64_t)l32 << 32) | l32;
-    return flips_up<0>(o, p, pos, gt, lt) | flips_up<1>(o, p, pos, gt, lt) |
-           flips_up<2>(o, p, pos, gt, lt) | flips_up<3>(o, p, pos, gt, lt);
+    uint64_t f = flips_up<0>(0ull, o, p, pos, gt, lt);
+    f = flips_up<1>(f, o, p, pos, gt, lt);
+    f = flips_up<2>(f, o, p, pos, gt, lt);
+    return flips_up<3>(f, o, p, pos, gt, lt);
 }
 
 // game.py:180-207 on one lane (no legality check)
@@ -232,7 +285,7 @@ __device__ __forceinline__ void fill_slots(Slots &S, const Padded &To, const Pad
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
+__global__ __launch_bounds__(BLOCK) IAGO_LPB_ATTR void rollout_lpb_kernel(LpbParams P)
 {
     __shared__ float ct[N_CT]; // [plane][512]
     __shared__ float be[64];   // exp'ed biases
@@ -252,6 +305,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
     const uint32_t rid = P.id_base + (uint32_t)b;
     const uint32_t stream_id = P.stream_id + (P.stream_id_dev ? *P.stream_id_dev : 0u);
     uint32_t rw[4] = {0, 0, 0, 0};
+    const ShiftAmounts SA = opaque_shift_amounts();
 
     for (uint32_t t = 0; t < (uint32_t)IAGO_MAX_TURNS; t++) {
         // ---- uniform of this turn: word t&3 of Philox counter (rid, t>>2, stream, 0)
@@ -272,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
         }
 
         const uint64_t ro = rev64(own), rp = rev64(opp);
-        const uint64_t legal = legal_moves_1(own, opp, ro, rp);
+        const uint64_t legal = legal_moves_1(own, opp, ro, rp, SA);
         const uint32_t has = min(1u, (uint32_t)legal | (uint32_t)(legal >> 32));
 
         // ---- softmax numerators of the legal cells, running sums in slot order
