@@ -1,0 +1,351 @@
+// conv_kernels.hip -- the 3x3 convolution + bias + ReLU of Block.__call__
+// (network.py:5-13) for 8x8 boards on the MFMA units, for the inference path of the
+// Value net (network.py:66-96), which is >95 % of the net evaluations of the PV-MCTS
+// loop (every playout evaluates one leaf, MCTS.py:110-131).
+//
+// Arithmetic: "split f16".  gfx950 has no reduced-precision fast path for f32 MFMA
+// inputs (v_mfma_f32_32x32x2_f32 runs at the VALU rate), but f16 MFMA is 16x faster.
+// Every f32 operand a is carried as two f16 numbers
+//     a_hi = f16(a),   a_lo = f16((a - a_hi) * 2^11)        (a = a_hi + a_lo * 2^-11,
+//                                                             22 significant bits)
+// and a product sum is three MFMAs into two f32 accumulators:
+//     main  += w_hi * x_hi
+//     cross += w_hi * x_lo + w_lo * x_hi                     result = main + cross * 2^-11
+// (the w_lo * x_lo term, 2^-22 relative, is dropped).  Accumulation is f32.  Measured
+// deviation of the whole Value forward from an f64 evaluation: 3.7e-7 with the shipped
+// weights (plain f32: 2.5e-7); tests/test_conv_gpu.py holds it to the 1e-5 bar.
+//
+// Activation format between layers ("split channel blocks"): two f16 tensors
+// hi[b][C/16][64][16] and lo[...] -- 16 input channels of one cell are 32 contiguous
+// bytes (one MFMA k-step of a lane pair), one channel block of a board 2 KB.
+//
+// Kernel: one workgroup = 4 boards x all 128 output channels, 4 waves = one wave per
+// SIMD, wave w owns board w: D[co][cell] as 4 x 2 tiles of v_mfma_f32_32x32x16_f16,
+// 2 x 128 accumulator registers.  The K loop runs over stages of (16 input channels) x
+// (one kernel row = 3 taps); the padded 10x10 planes of a channel block and the weights
+// of a stage are double-buffered in LDS (150 KB), the next stage's global loads are
+// issued before the current stage's MFMAs and written to LDS after them.
+#include "abi_common.hpp"
+
+#include <hip/hip_fp16.h>
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int TB = 4;           // boards per workgroup (= waves)
+constexpr int THREADS = 64 * TB;
+constexpr int COUT = 128;
+constexpr int ROW = 48;         // bytes per LDS row: 16 halfs + 16 B padding (conflict-free b128 reads)
+constexpr int PP = 100;         // padded 10x10 plane
+constexpr int X_HALF = TB * PP * ROW;          // one of hi / lo: 19,200 B
+constexpr int X_BUF = 2 * X_HALF;              // 38,400 B
+constexpr int W_HALF = 3 * COUT * ROW;         // 18,432 B
+constexpr int W_BUF = 2 * W_HALF;              // 36,864 B
+constexpr int LDS_BYTES = 2 * X_BUF + 2 * W_BUF; // 150,528 B
+constexpr int T_ROW = (COUT + 4) * 2;          // epilogue image: 132 halfs per cell
+constexpr int T_HALF = TB * 64 * T_ROW;        // 67,584 B
+static_assert(2 * T_HALF <= LDS_BYTES, "epilogue image must fit in the staging buffers");
+
+struct ConvParams {
+    const uint4 *x_hi; // [n][cin/16][64][16] f16
+    const uint4 *x_lo;
+    const uint4 *w_hi; // [cin/16][3][3][128][16] f16
+    const uint4 *w_lo;
+    const float *bias; // [128]
+    uint4 *y_hi;       // [n][8][64][16] f16
+    uint4 *y_lo;
+    int64_t n;
+    int32_t n_chunks; // cin / 16
+};
+
+__device__ __forceinline__ half8 lds_half8(const char *p)
+{
+    return *(const half8 *)p;
+}
+
+__global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
+{
+    extern __shared__ __align__(16) char lds[];
+    char *const xbuf = lds;
+    char *const wbuf = lds + 2 * X_BUF;
+
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int64_t b0 = (int64_t)blockIdx.x * TB;
+
+    // zero both X buffers once: the border cells of the padded planes stay zero
+    for (int i = tid; i < 2 * X_BUF / 16; i += THREADS)
+        ((uint4 *)xbuf)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    // ---- staging: which 16-byte pieces this thread moves
+    // X chunk: per hi/lo TB*64*2 = 512 pieces -> 2 per thread each for hi and lo
+    // piece e in [0,512): board = e >> 7, cell = (e >> 1) & 63, half-piece = e & 1
+    uint4 xr[4];
+    // W stage: per hi/lo 3*128*2 = 768 pieces -> 3 per thread each
+    uint4 wr[6];
+
+    auto load_x = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int e = tid + q * THREADS;
+            const int64_t b = b0 + (e >> 7);
+            const int64_t src = (b * P.n_chunks + chunk) * 128 + (e & 127); // in 16-B pieces
+            const bool ok = b < P.n;
+            xr[q] = ok ? P.x_hi[src] : make_uint4(0, 0, 0, 0);
+            xr[2 + q] = ok ? P.x_lo[src] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_x = [&](int buf) {
+        char *base = xbuf + buf * X_BUF;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int e = tid + q * THREADS;
+            const int board = e >> 7, cell = (e >> 1) & 63, hp = e & 1;
+            const int pp = ((cell >> 3) + 1) * 10 + (cell & 7) + 1;
+            const int off = (board * PP + pp) * ROW + hp * 16;
+            *(uint4 *)(base + off) = xr[q];
+            *(uint4 *)(base + X_HALF + off) = xr[2 + q];
+        }
+    };
+    auto load_w = [&](int stage) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int64_t src = (int64_t)stage * 768 + tid + q * THREADS;
+            wr[q] = P.w_hi[src];
+            wr[3 + q] = P.w_lo[src];
+        }
+    };
+    auto store_w = [&](int buf) {
+        char *base = wbuf + buf * W_BUF;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int e = tid + q * THREADS; // (kx, co, half-piece)
+            const int off = (e >> 1) * ROW + (e & 1) * 16;
+            *(uint4 *)(base + off) = wr[q];
+            *(uint4 *)(base + W_HALF + off) = wr[3 + q];
+        }
+    };
+
+    float16v acc_main[4][2], acc_cross[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                acc_main[i][j][v] = 0.0f;
+                acc_cross[i][j][v] = 0.0f;
+            }
+
+    load_x(0);
+    load_w(0);
+    store_x(0);
+    store_w(0);
+    __syncthreads();
+
+    const int n_stages = 3 * P.n_chunks;
+    // lane-constant parts of the operand addresses
+    const int a_off = r * ROW + h * 16;                                    // + (kx*128 + 32i) * ROW
+    const int b_off0 = (w * PP + (r >> 3) * 10 + (r & 7)) * ROW + h * 16;  // + ((4j + ky)*10 + kx) * ROW
+
+    for (int s = 0; s < n_stages; s++) {
+        const int chunk = s / 3, ky = s - 3 * chunk;
+        const bool more = s + 1 < n_stages;
+        const bool new_chunk = more && ky == 2;
+        if (more)
+            load_w(s + 1);
+        if (new_chunk)
+            load_x(chunk + 1);
+
+        const char *xb = xbuf + (chunk & 1) * X_BUF;
+        const char *wb = wbuf + (s & 1) * W_BUF;
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            half8 a_hi[4], a_lo[4], b_hi[2], b_lo[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int off = a_off + (kx * COUT + 32 * i) * ROW;
+                a_hi[i] = lds_half8(wb + off);
+                a_lo[i] = lds_half8(wb + W_HALF + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int off = b_off0 + ((4 * j + ky) * 10 + kx) * ROW;
+                b_hi[j] = lds_half8(xb + off);
+                b_lo[j] = lds_half8(xb + X_HALF + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc_main[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc_main[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc_cross[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_lo[j], acc_cross[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc_cross[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[i], b_hi[j], acc_cross[i][j], 0, 0, 0);
+        }
+
+        if (more)
+            store_w((s + 1) & 1);
+        if (new_chunk)
+            store_x((chunk + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, ReLU, split, transpose through LDS, coalesced stores
+    // D tile (i, j): lane holds cell 32j + r, channels 32i + 8(v>>2) + 4h + (v&3)
+    char *const t_hi = lds, *const t_lo = lds + T_HALF;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int co = 32 * i + 8 * q + 4 * h;
+                __half hi4[4], lo4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    float v = acc_main[i][j][4 * q + t] + acc_cross[i][j][4 * q + t] * (1.0f / 2048.0f) +
+                              P.bias[co + t];
+                    v = fminf(fmaxf(v, 0.0f), 65000.0f);
+                    const __half vh = __float2half_rn(v);
+                    hi4[t] = vh;
+                    lo4[t] = __float2half_rn((v - __half2float(vh)) * 2048.0f);
+                }
+                const int off = (w * 64 + 32 * j + r) * T_ROW + co * 2;
+                *(uint2 *)(t_hi + off) = *(const uint2 *)hi4;
+                *(uint2 *)(t_lo + off) = *(const uint2 *)lo4;
+            }
+    __syncthreads();
+    // output pieces: per hi/lo TB * 8 blocks * 64 cells * 2 = 4096 -> 16 per thread
+#pragma unroll 4
+    for (int q = 0; q < 16; q++) {
+        const int e = tid + q * THREADS; // (board, block, cell, half-piece) in output order
+        const int board = e >> 10, cb = (e >> 7) & 7, cell = (e >> 1) & 63, hp = e & 1;
+        const int64_t b = b0 + board;
+        if (b < P.n) {
+            const int off = (board * 64 + cell) * T_ROW + (cb * 16 + hp * 8) * 2;
+            const int64_t dst = b * 1024 + (e & 1023);
+            P.y_hi[dst] = *(const uint4 *)(t_hi + off);
+            P.y_lo[dst] = *(const uint4 *)(t_lo + off);
+        }
+    }
+}
+
+// float32 NCHW planes -> split channel blocks
+__global__ __launch_bounds__(256) void split_nchw_kernel(const float *x, __half *hi, __half *lo, int64_t n,
+                                                         int channels)
+{
+    // one thread per (board, block, cell, 8 channels): reads 8 floats (stride 64), writes 16 B + 16 B
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int nb = channels / 16;
+    const int64_t total = n * nb * 128;
+    if (t >= total)
+        return;
+    const int hp = (int)(t & 1), cell = (int)((t >> 1) & 63);
+    const int64_t bb = t >> 7; // board * nb + block
+    const int64_t b = bb / nb;
+    const int cb = (int)(bb - b * nb);
+    const float *src = x + (b * channels + cb * 16 + hp * 8) * 64 + cell;
+    __half h8[8], l8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float v = fminf(fmaxf(src[k * 64], -65000.0f), 65000.0f);
+        const __half vh = __float2half_rn(v);
+        h8[k] = vh;
+        l8[k] = __float2half_rn((v - __half2float(vh)) * 2048.0f);
+    }
+    ((uint4 *)hi)[t] = *(const uint4 *)h8;
+    ((uint4 *)lo)[t] = *(const uint4 *)l8;
+}
+
+// split channel blocks -> float32 NCHW planes
+__global__ __launch_bounds__(256) void merge_nchw_kernel(const __half *hi, const __half *lo, float *y, int64_t n,
+                                                         int channels)
+{
+    // one thread per (board, channel, cell): coalesced writes, 2-byte gathers (L2-resident)
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = n * channels * 64;
+    if (t >= total)
+        return;
+    const int cell = (int)(t & 63);
+    const int64_t bc = t >> 6;
+    const int64_t b = bc / channels;
+    const int c = (int)(bc - b * channels);
+    const int64_t src = ((b * (channels / 16) + (c >> 4)) * 64 + cell) * 16 + (c & 15);
+    y[t] = __half2float(hi[src]) + __half2float(lo[src]) * (1.0f / 2048.0f);
+}
+
+} // namespace
+
+extern "C" {
+
+int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, const float *bias,
+                       void *y_hi, void *y_lo, int64_t n, int32_t cin, int32_t cout, void *stream)
+{
+    if (n < 0 || cout != COUT || cin <= 0 || (cin % 16) != 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split: cout must be 128 and cin a multiple of 16");
+    if (n == 0)
+        return IAGO_OK;
+    if (!x_hi || !x_lo || !w_hi || !w_lo || !bias || !y_hi || !y_lo)
+        return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split: null pointer");
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void *)conv3x3_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess)
+            return iago_fail(IAGO_ERR_HIP, "iago_conv3x3_split: cannot reserve 147 KB of LDS");
+        configured = true;
+    }
+    ConvParams P;
+    P.x_hi = (const uint4 *)x_hi;
+    P.x_lo = (const uint4 *)x_lo;
+    P.w_hi = (const uint4 *)w_hi;
+    P.w_lo = (const uint4 *)w_lo;
+    P.bias = bias;
+    P.y_hi = (uint4 *)y_hi;
+    P.y_lo = (uint4 *)y_lo;
+    P.n = n;
+    P.n_chunks = cin / 16;
+    const unsigned grid = (unsigned)((n + TB - 1) / TB);
+    hipLaunchKernelGGL(conv3x3_split_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, P);
+    return iago_check_launch("iago_conv3x3_split");
+}
+
+int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels, void *stream)
+{
+    if (n < 0 || channels <= 0 || (channels % 16) != 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_split_nchw: channels must be a multiple of 16");
+    if (n == 0)
+        return IAGO_OK;
+    if (!x || !hi || !lo)
+        return iago_fail(IAGO_ERR_INVALID, "iago_split_nchw: null pointer");
+    const int64_t total = n * (channels / 16) * 128;
+    hipLaunchKernelGGL(split_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, (__half *)hi, (__half *)lo, n, channels);
+    return iago_check_launch("iago_split_nchw");
+}
+
+int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n, int32_t channels, void *stream)
+{
+    if (n < 0 || channels <= 0 || (channels % 16) != 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_merge_nchw: channels must be a multiple of 16");
+    if (n == 0)
+        return IAGO_OK;
+    if (!hi || !lo || !y)
+        return iago_fail(IAGO_ERR_INVALID, "iago_merge_nchw: null pointer");
+    const int64_t total = n * channels * 64;
+    hipLaunchKernelGGL(merge_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const __half *)hi, (const __half *)lo, y, n, channels);
+    return iago_check_launch("iago_merge_nchw");
+}
+
+} // extern "C"

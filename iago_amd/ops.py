@@ -106,6 +106,72 @@ def bias_relu_(x, bias):
     return x
 
 
+# ---- split-f16 convolution stack (csrc/conv_kernels.hip) --------------------------
+
+class SplitActs(object):
+    """Activations in split channel blocks: f16 tensors hi, lo of shape
+    (n, C/16, 64, 16); value = hi + lo * 2**-11 (include/iago_hip.h)."""
+
+    __slots__ = ("hi", "lo", "channels")
+
+    def __init__(self, hi, lo, channels):
+        self.hi, self.lo, self.channels = hi, lo, channels
+
+    @property
+    def n(self):
+        return self.hi.shape[0]
+
+
+def split_weights(weight):
+    """(cout, cin, 3, 3) float32 conv weight -> (w_hi, w_lo) f16 tensors
+    [cin/16][3][3][cout][16] as iago_conv3x3_split expects them."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or cin % 16 or cout != 128:
+        raise ValueError("split_weights: need a (128, 16k, 3, 3) weight")
+    w = weight.detach().to(torch.float32).permute(2, 3, 0, 1)          # ky, kx, co, ci
+    w = w.reshape(3, 3, cout, cin // 16, 16).permute(3, 0, 1, 2, 4).contiguous()
+    hi = w.to(torch.float16)
+    lo = ((w - hi.to(torch.float32)) * 2048.0).to(torch.float16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def split_nchw(x):
+    """(n, C, 8, 8) float32 -> SplitActs."""
+    n, c = x.shape[0], x.shape[1]
+    if x.dim() != 4 or x.shape[2] != 8 or x.shape[3] != 8 or c % 16:
+        raise ValueError("x must be (n, 16k, 8, 8)")
+    hi = torch.empty((n, c // 16, 64, 16), dtype=torch.float16, device=x.device)
+    lo = torch.empty_like(hi)
+    check(_lib.lib().iago_split_nchw(_dev(x, torch.float32, "x"), _dev(hi, torch.float16, "hi"),
+                                     _dev(lo, torch.float16, "lo"), n, c, _stream()), "iago_split_nchw")
+    return SplitActs(hi, lo, c)
+
+
+def merge_nchw(a):
+    """SplitActs -> (n, C, 8, 8) float32."""
+    y = torch.empty((a.n, a.channels, 8, 8), dtype=torch.float32, device=a.hi.device)
+    check(_lib.lib().iago_merge_nchw(_dev(a.hi, torch.float16, "hi"), _dev(a.lo, torch.float16, "lo"),
+                                     _dev(y, torch.float32, "y"), a.n, a.channels, _stream()),
+          "iago_merge_nchw")
+    return y
+
+
+def conv3x3_split(a, w_hi, w_lo, bias):
+    """relu(conv3x3(a, w) + bias) on SplitActs: Block.__call__ (network.py:9-13) on
+    the MFMA units in split-f16 arithmetic.  w_hi, w_lo from split_weights."""
+    cin = a.channels
+    if w_hi.shape != (cin // 16, 3, 3, 128, 16):
+        raise ValueError("weight blocks %s do not match %d input channels" % (tuple(w_hi.shape), cin))
+    hi = torch.empty((a.n, 8, 64, 16), dtype=torch.float16, device=a.hi.device)
+    lo = torch.empty_like(hi)
+    check(_lib.lib().iago_conv3x3_split(_dev(a.hi, torch.float16, "x_hi"), _dev(a.lo, torch.float16, "x_lo"),
+                                        _dev(w_hi, torch.float16, "w_hi"), _dev(w_lo, torch.float16, "w_lo"),
+                                        _dev(bias, torch.float32, "bias"),
+                                        _dev(hi, torch.float16, "y_hi"), _dev(lo, torch.float16, "y_lo"),
+                                        a.n, cin, 128, _stream()), "iago_conv3x3_split")
+    return SplitActs(hi, lo, 128)
+
+
 def sample_moves(probs, legal, uniforms=None, seed=0, id_base=0, step=0, stream_id=0):
     """Masked inverse-CDF sampling (src/rl_self_play.py:111-122); int8 actions,
     -1 where there is no legal move.  uniforms: optional float64 (n,)."""

@@ -191,6 +191,29 @@ IAGO_API int iago_rollout(const iago_rollout_args *args, void *stream);
  */
 IAGO_API int iago_bias_relu(float *x, const float *bias, int64_t n, int32_t channels, void *stream);
 
+/*
+ * The 3x3 convolution + bias + ReLU of Block.__call__ (network.py:5-13) on 8x8 boards
+ * for the inference path of the Value net (network.py:66-96; evaluated once per
+ * playout, MCTS.py:110-131), on the MFMA units in "split f16" arithmetic: every
+ * float32 operand a is carried as a_hi = f16(a), a_lo = f16((a - a_hi) * 2^11), a
+ * product sum is w_hi*x_hi + 2^-11 * (w_hi*x_lo + w_lo*x_hi) with float32
+ * accumulation (22-bit products; the whole Value forward stays within 1e-6 of the
+ * float32 one).
+ *
+ * Activations between layers are "split channel blocks": two f16 arrays
+ * hi, lo [n][channels/16][64 cells][16 channels].  iago_split_nchw /
+ * iago_merge_nchw convert from / to float32 NCHW [n][channels][8][8].
+ * Weights: two f16 arrays [cin/16][3][3][cout][16] (kernel row, kernel column, output
+ * channel, input channel within the block) split the same way; bias float32 [cout].
+ * cout must be 128, cin a multiple of 16.  All pointers 16-byte aligned.
+ */
+IAGO_API int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
+                                const float *bias, void *y_hi, void *y_lo, int64_t n, int32_t cin,
+                                int32_t cout, void *stream);
+IAGO_API int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels, void *stream);
+IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n, int32_t channels,
+                             void *stream);
+
 /* ------------------------------------------------------------------- MCTS */
 
 /*

@@ -1,0 +1,102 @@
+"""Split-f16 MFMA convolution (csrc/conv_kernels.hip) against float32 PyTorch:
+the Block of network.py:5-13 and the Value forward of network.py:66-96."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _boards(n, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = torch.rand(n, 64, generator=g)
+    own = (r < 0.3).float()
+    opp = ((r >= 0.3) & (r < 0.6)).float()
+    return torch.stack([opp, own], 1).reshape(n, 2, 8, 8)
+
+
+def test_split_merge_round_trip():
+    from iago_amd import ops
+    torch.manual_seed(1)
+    x = (torch.randn(7, 64, 8, 8) * torch.logspace(-3, 2, 64).view(1, 64, 1, 1)).cuda()
+    y = ops.merge_nchw(ops.split_nchw(x))
+    # 22 significant bits; values below the f16 normal range (6e-5) keep an absolute
+    # error of 2^-24 * 2^-11
+    excess = ((y - x).abs() - 2.0 ** -21 * x.abs()).max().item()
+    assert excess < 1e-10, excess
+
+
+@pytest.mark.parametrize("cin", [64, 128])
+@pytest.mark.parametrize("n", [1, 4, 5, 37])
+def test_integer_data_is_exact(cin, n):
+    """Small-integer operands are exact in f16 and their sums in f32: any slip in the
+    MFMA operand / accumulator lane maps, the padding or the tap order shows up as an
+    exact mismatch.  Asymmetric weights and inputs."""
+    from iago_amd import ops
+    g = torch.Generator().manual_seed(cin * 100 + n)
+    x = torch.randint(-3, 4, (n, cin, 8, 8), generator=g).float()
+    w = torch.randint(-2, 3, (128, cin, 3, 3), generator=g).float()
+    b = torch.randint(-5, 6, (128,), generator=g).float()
+    ref = F.relu(F.conv2d(x, w, b, padding=1))
+    w_hi, w_lo = ops.split_weights(w.cuda())
+    assert float(w_lo.abs().max()) == 0.0
+    y = ops.merge_nchw(ops.conv3x3_split(ops.split_nchw(x.cuda()), w_hi, w_lo, b.cuda()))
+    assert torch.equal(y.cpu(), ref)
+
+
+@pytest.mark.parametrize("cin", [64, 128])
+def test_random_data_matches_float32(cin):
+    from iago_amd import ops
+    torch.manual_seed(cin)
+    n = 33
+    x = torch.rand(n, cin, 8, 8) * 2.0
+    w = torch.randn(128, cin, 3, 3) / np.sqrt(9 * cin)
+    b = torch.randn(128) * 0.1
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    w_hi, w_lo = ops.split_weights(w.cuda())
+    y = ops.merge_nchw(ops.conv3x3_split(ops.split_nchw(x.cuda()), w_hi, w_lo, b.cuda()))
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < 2e-6 * float(ref.abs().max()), err
+
+
+@pytest.mark.parametrize("n", [16, 100, 1024])
+def test_value_forward_split_vs_float32(n):
+    """network.py:66-96 (train=False): the split-f16 stack against MIOpen float32 on
+    the GPU and against float64 on the CPU; tolerance = the 1e-5 parity bar."""
+    from iago_amd import network
+    torch.manual_seed(5)
+    m = network.Value().eval()
+    # random init gives outputs ~1e-2: scale the weights up to O(1) activations
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.6)
+    x = _boards(n, seed=n)
+    with torch.no_grad():
+        ref64 = m.double()(x.double()).float()
+        m.float()
+        mg = m.cuda()
+        mg.split_f16 = False
+        y32 = mg(x.cuda()).cpu()
+        mg.split_f16 = True
+        assert mg._use_split(x.cuda())
+        ys = mg(x.cuda()).cpu()
+    scale = float(ref64.abs().max())
+    assert (ys - ref64).abs().max().item() < 1e-5 * max(1.0, scale)
+    assert (ys - y32).abs().max().item() < 1e-5 * max(1.0, scale)
+    # the split path is as close to float64 as MIOpen's float32 within a small factor
+    assert (ys - ref64).abs().max().item() < 8 * max((y32 - ref64).abs().max().item(), 1e-7 * scale)
+
+
+def test_value_split_cache_follows_weight_updates():
+    from iago_amd import network
+    m = network.Value().eval().cuda()
+    x = _boards(32).cuda()
+    with torch.no_grad():
+        a = m(x).clone()
+        m.block5.conv.weight.mul_(0.5)
+        b = m(x)
+        m.split_f16 = False
+        c = m(x)
+    assert not torch.allclose(a, b)
+    assert torch.allclose(b, c, atol=1e-6)
