@@ -33,6 +33,7 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); // a 16-byte piece in registers
 
 constexpr int TB = 4;           // boards per workgroup (= waves)
 constexpr int THREADS = 64 * TB;
@@ -65,6 +66,57 @@ __device__ __forceinline__ half8 lds_half8(const char *p)
     return *(const half8 *)p;
 }
 
+// MFMA operand fragments of one k-step (one tap, 16 input channels) of a wave
+struct Frags {
+    half8 a_hi[4], a_lo[4]; // weights, 4 blocks of 32 output channels
+    half8 b_hi[2], b_lo[2]; // activations, 2 blocks of 32 cells
+};
+
+// global data on its way to LDS
+struct StagedW {
+    u32x4 w[6]; // 3 hi + 3 lo pieces of the weights of a stage
+};
+struct StagedX {
+    u32x4 x[4]; // 2 hi + 2 lo pieces of a channel block of the 4 boards
+};
+
+__device__ __forceinline__ void load_frags(Frags &F, const char *wb, const char *xb, int a_off, int b_off,
+                                           int kx)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int off = a_off + (kx * COUT + 32 * i) * ROW;
+        F.a_hi[i] = lds_half8(wb + off);
+        F.a_lo[i] = lds_half8(wb + W_HALF + off);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int off = b_off + (40 * j + kx) * ROW; // cells 32j.. are 4 rows further down
+        F.b_hi[j] = lds_half8(xb + off);
+        F.b_lo[j] = lds_half8(xb + X_HALF + off);
+    }
+}
+
+__device__ __forceinline__ void mfma_step(const Frags &F, float16v (&acc_main)[4][2],
+                                          float16v (&acc_cross)[4][2])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            acc_main[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[i], F.b_hi[j], acc_main[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            acc_cross[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[i], F.b_lo[j], acc_cross[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            acc_cross[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_lo[i], F.b_hi[j], acc_cross[i][j], 0, 0, 0);
+}
+
 __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
 {
     extern __shared__ __align__(16) char lds[];
@@ -80,52 +132,64 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
         ((uint4 *)xbuf)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
-    // ---- staging: which 16-byte pieces this thread moves
-    // X chunk: per hi/lo TB*64*2 = 512 pieces -> 2 per thread each for hi and lo
-    // piece e in [0,512): board = e >> 7, cell = (e >> 1) & 63, half-piece = e & 1
-    uint4 xr[4];
-    // W stage: per hi/lo 3*128*2 = 768 pieces -> 3 per thread each
-    uint4 wr[6];
+    // ---- staging: the 16-byte pieces this thread moves per stage
+    // X channel block: per hi/lo TB*64*2 = 512 pieces (board = e >> 7, cell = (e >> 1) & 63,
+    // half-piece = e & 1) -> 2 per thread; W stage: 3*128*2 = 768 pieces -> 3 per thread
+    int64_t x_src[2];
+    int x_dst[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int e = tid + q * THREADS;
+        // boards past the end of a ragged batch read the last board (their results are not stored)
+        const int64_t b = min(b0 + (e >> 7), P.n - 1);
+        x_src[q] = b * P.n_chunks * 128 + (e & 127); // + chunk * 128, in 16-B pieces
+        const int cell = (e >> 1) & 63;
+        x_dst[q] = ((e >> 7) * PP + ((cell >> 3) + 1) * 10 + (cell & 7) + 1) * ROW + (e & 1) * 16;
+    }
+    int w_dst[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int e = tid + q * THREADS; // (kx, co, half-piece)
+        w_dst[q] = (e >> 1) * ROW + (e & 1) * 16;
+    }
+    const int n_chunks = P.n_chunks, n_stages = 3 * n_chunks;
 
-    auto load_x = [&](int chunk) {
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int e = tid + q * THREADS;
-            const int64_t b = b0 + (e >> 7);
-            const int64_t src = (b * P.n_chunks + chunk) * 128 + (e & 127); // in 16-B pieces
-            const bool ok = b < P.n;
-            xr[q] = ok ? P.x_hi[src] : make_uint4(0, 0, 0, 0);
-            xr[2 + q] = ok ? P.x_lo[src] : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_x = [&](int buf) {
-        char *base = xbuf + buf * X_BUF;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int e = tid + q * THREADS;
-            const int board = e >> 7, cell = (e >> 1) & 63, hp = e & 1;
-            const int pp = ((cell >> 3) + 1) * 10 + (cell & 7) + 1;
-            const int off = (board * PP + pp) * ROW + hp * 16;
-            *(uint4 *)(base + off) = xr[q];
-            *(uint4 *)(base + X_HALF + off) = xr[2 + q];
-        }
-    };
-    auto load_w = [&](int stage) {
+    const u32x4 *const gw_hi = (const u32x4 *)P.w_hi + tid, *const gw_lo = (const u32x4 *)P.w_lo + tid;
+    const u32x4 *const gx_hi = (const u32x4 *)P.x_hi, *const gx_lo = (const u32x4 *)P.x_lo;
+    auto fetch_w = [=](int stage) {
+        StagedW G;
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            const int64_t src = (int64_t)stage * 768 + tid + q * THREADS;
-            wr[q] = P.w_hi[src];
-            wr[3 + q] = P.w_lo[src];
+            const int64_t src = (int64_t)stage * 768 + q * THREADS;
+            G.w[q] = gw_hi[src];
+            G.w[3 + q] = gw_lo[src];
         }
+        return G;
     };
-    auto store_w = [&](int buf) {
-        char *base = wbuf + buf * W_BUF;
+    auto fetch_x = [=](int chunk) {
+        StagedX G;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int64_t src = x_src[q] + (int64_t)chunk * 128;
+            G.x[q] = gx_hi[src];
+            G.x[2 + q] = gx_lo[src];
+        }
+        return G;
+    };
+    auto commit_w = [=](const StagedW &G, int wsel) {
+        char *wb = wbuf + wsel * W_BUF;
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            const int e = tid + q * THREADS; // (kx, co, half-piece)
-            const int off = (e >> 1) * ROW + (e & 1) * 16;
-            *(uint4 *)(base + off) = wr[q];
-            *(uint4 *)(base + W_HALF + off) = wr[3 + q];
+            *(u32x4 *)(wb + w_dst[q]) = G.w[q];
+            *(u32x4 *)(wb + W_HALF + w_dst[q]) = G.w[3 + q];
+        }
+    };
+    auto commit_x = [=](const StagedX &G, int xsel) {
+        char *xb = xbuf + xsel * X_BUF;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            *(u32x4 *)(xb + x_dst[q]) = G.x[q];
+            *(u32x4 *)(xb + X_HALF + x_dst[q]) = G.x[2 + q];
         }
     };
 
@@ -140,66 +204,53 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
                 acc_cross[i][j][v] = 0.0f;
             }
 
-    load_x(0);
-    load_w(0);
-    store_x(0);
-    store_w(0);
+    // lane-constant parts of the operand addresses
+    const int a_off = r * ROW + h * 16;                                  // + (kx*128 + 32i) * ROW
+    const int b_off0 = (w * PP + (r >> 3) * 10 + (r & 7)) * ROW + h * 16; // + ((4j + ky)*10 + kx) * ROW
+
+    commit_w(fetch_w(0), 0);
+    commit_x(fetch_x(0), 0);
     __syncthreads();
 
-    const int n_stages = 3 * P.n_chunks;
-    // lane-constant parts of the operand addresses
-    const int a_off = r * ROW + h * 16;                                    // + (kx*128 + 32i) * ROW
-    const int b_off0 = (w * PP + (r >> 3) * 10 + (r & 7)) * ROW + h * 16;  // + ((4j + ky)*10 + kx) * ROW
-
-    for (int s = 0; s < n_stages; s++) {
-        const int chunk = s / 3, ky = s - 3 * chunk;
-        const bool more = s + 1 < n_stages;
-        const bool new_chunk = more && ky == 2;
-        if (more)
-            load_w(s + 1);
-        if (new_chunk)
-            load_x(chunk + 1);
-
+    // One stage = one kernel row (3 taps) x 16 input channels; its three k-steps alternate
+    // between two fragment sets, the next k-step's LDS reads are issued before the
+    // current one's MFMAs.  Weights travel global -> registers two stages ahead (their
+    // L2 latency under 256 workgroups asking for the same lines is longer than a stage)
+    // and registers -> LDS before the third k-step of the stage before their use, whose
+    // MFMAs then run behind the barrier together with the first fragment reads of the
+    // next stage.  The next channel block of the boards is fetched in the first stage of
+    // a block and written in the last.
+    Frags F0, F1;
+    StagedW G0, G1 = fetch_w(min(1, n_stages - 1)); // Gt holds the weights of a stage of parity t
+    StagedX GX = fetch_x(0);
+    load_frags(F0, wbuf, xbuf, a_off, b_off0, 0);
+    auto stage = [&](int s, Frags &Fa, Frags &Fb, StagedW &Gthis, const StagedW &Gnext) {
+        const int chunk = s / 3, ky = s - 3 * chunk; // Fa holds k-step 0 of stage s
+        const int s1 = min(s + 1, n_stages - 1);
         const char *xb = xbuf + (chunk & 1) * X_BUF;
         const char *wb = wbuf + (s & 1) * W_BUF;
-#pragma unroll
-        for (int kx = 0; kx < 3; kx++) {
-            half8 a_hi[4], a_lo[4], b_hi[2], b_lo[2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int off = a_off + (kx * COUT + 32 * i) * ROW;
-                a_hi[i] = lds_half8(wb + off);
-                a_lo[i] = lds_half8(wb + W_HALF + off);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int off = b_off0 + ((4 * j + ky) * 10 + kx) * ROW;
-                b_hi[j] = lds_half8(xb + off);
-                b_lo[j] = lds_half8(xb + X_HALF + off);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    acc_main[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc_main[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    acc_cross[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_lo[j], acc_cross[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    acc_cross[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[i], b_hi[j], acc_cross[i][j], 0, 0, 0);
-        }
-
-        if (more)
-            store_w((s + 1) & 1);
-        if (new_chunk)
-            store_x((chunk + 1) & 1);
+        const int b_off = b_off0 + ky * 10 * ROW;
+        Gthis = fetch_w(min(s + 2, n_stages - 1));
+        if (ky == 0)
+            GX = fetch_x(min(chunk + 1, n_chunks - 1));
+        load_frags(Fb, wb, xb, a_off, b_off, 1);
+        mfma_step(Fa, acc_main, acc_cross);
+        load_frags(Fa, wb, xb, a_off, b_off, 2);
+        mfma_step(Fb, acc_main, acc_cross);
+        commit_w(Gnext, (s + 1) & 1);
+        if (ky == 2)
+            commit_x(GX, (chunk + 1) & 1);
         __syncthreads();
+        const int chunk1 = s1 / 3, ky1 = s1 - 3 * chunk1;
+        load_frags(Fb, wbuf + ((s + 1) & 1) * W_BUF, xbuf + (chunk1 & 1) * X_BUF, a_off,
+                   b_off0 + ky1 * 10 * ROW, 0);
+        mfma_step(Fa, acc_main, acc_cross);
+    };
+    for (int s = 0; s < n_stages; s += 2) { // n_stages is even (cin a multiple of 32)
+        stage(s, F0, F1, G0, G1);
+        stage(s + 1, F1, F0, G1, G0);
     }
+    __syncthreads();
 
     // ---- epilogue: bias, ReLU, split, transpose through LDS, coalesced stores
     // D tile (i, j): lane holds cell 32j + r, channels 32i + 8(v>>2) + 4h + (v&3)
@@ -292,8 +343,8 @@ extern "C" {
 int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, const float *bias,
                        void *y_hi, void *y_lo, int64_t n, int32_t cin, int32_t cout, void *stream)
 {
-    if (n < 0 || cout != COUT || cin <= 0 || (cin % 16) != 0)
-        return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split: cout must be 128 and cin a multiple of 16");
+    if (n < 0 || cout != COUT || cin <= 0 || (cin % 32) != 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split: cout must be 128 and cin a multiple of 32");
     if (n == 0)
         return IAGO_OK;
     if (!x_hi || !x_lo || !w_hi || !w_lo || !bias || !y_hi || !y_lo)

@@ -205,7 +205,7 @@ IAGO_API int iago_bias_relu(float *x, const float *bias, int64_t n, int32_t chan
  * iago_merge_nchw convert from / to float32 NCHW [n][channels][8][8].
  * Weights: two f16 arrays [cin/16][3][3][cout][16] (kernel row, kernel column, output
  * channel, input channel within the block) split the same way; bias float32 [cout].
- * cout must be 128, cin a multiple of 16.  All pointers 16-byte aligned.
+ * cout must be 128, cin a multiple of 32.  All pointers 16-byte aligned.
  */
 IAGO_API int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
                                 const float *bias, void *y_hi, void *y_lo, int64_t n, int32_t cin,
