@@ -47,7 +47,7 @@ constexpr int W_BUF = 2 * W_HALF;              // 36,864 B
 constexpr int LDS_BYTES = 2 * X_BUF + 2 * W_BUF; // 150,528 B
 constexpr int T_ROW = (COUT + 4) * 2;          // epilogue image: 132 halfs per cell
 constexpr int T_HALF = TB * 64 * T_ROW;        // 67,584 B
-static_assert(2 * T_HALF <= LDS_BYTES, "epilogue image must fit in the staging buffers");
+static_assert(2 * T_HALF + COUT * 4 <= LDS_BYTES, "epilogue image must fit in the staging buffers");
 
 struct ConvParams {
     const uint4 *x_hi; // [n][cin/16][64][16] f16
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
     const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int64_t b0 = (int64_t)blockIdx.x * TB;
 
+    const float my_bias = P.bias[tid & (COUT - 1)]; // parked in a register until the epilogue
     // zero both X buffers once: the border cells of the padded planes stay zero
     for (int i = tid; i < 2 * X_BUF / 16; i += THREADS)
         ((uint4 *)xbuf)[i] = make_uint4(0, 0, 0, 0);
@@ -214,47 +215,51 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
 
     // One stage = one kernel row (3 taps) x 16 input channels; its three k-steps alternate
     // between two fragment sets, the next k-step's LDS reads are issued before the
-    // current one's MFMAs.  Weights travel global -> registers two stages ahead (their
-    // L2 latency under 256 workgroups asking for the same lines is longer than a stage)
-    // and registers -> LDS before the third k-step of the stage before their use, whose
-    // MFMAs then run behind the barrier together with the first fragment reads of the
-    // next stage.  The next channel block of the boards is fetched in the first stage of
-    // a block and written in the last.
+    // current one's MFMAs.  The data of a stage (its weights and the channel block of the
+    // boards it reads) travel global -> registers two stages ahead (the L2 latency under
+    // 256 workgroups asking for the same lines is longer than a stage) and registers ->
+    // LDS before the third k-step of the stage before, whose MFMAs then run behind the
+    // barrier together with the first fragment reads of the next stage.  Every stage
+    // moves the same number of pieces (the channel block is re-written with identical
+    // bytes while it is in use): the vmcnt bookkeeping stays exact across the loop.
     Frags F0, F1;
-    StagedW G0, G1 = fetch_w(min(1, n_stages - 1)); // Gt holds the weights of a stage of parity t
-    StagedX GX = fetch_x(0);
+    StagedW W0, W1 = fetch_w(min(1, n_stages - 1)); // Wt / Xt: data of a stage of parity t
+    StagedX X0, X1 = fetch_x(0);
     load_frags(F0, wbuf, xbuf, a_off, b_off0, 0);
-    auto stage = [&](int s, Frags &Fa, Frags &Fb, StagedW &Gthis, const StagedW &Gnext) {
+    auto stage = [&](int s, Frags &Fa, Frags &Fb, StagedW &Wthis, StagedX &Xthis, const StagedW &Wnext,
+                     const StagedX &Xnext) {
         const int chunk = s / 3, ky = s - 3 * chunk; // Fa holds k-step 0 of stage s
-        const int s1 = min(s + 1, n_stages - 1);
+        const int s1 = min(s + 1, n_stages - 1), s2 = min(s + 2, n_stages - 1);
+        const int chunk1 = s1 / 3, ky1 = s1 - 3 * chunk1;
         const char *xb = xbuf + (chunk & 1) * X_BUF;
         const char *wb = wbuf + (s & 1) * W_BUF;
         const int b_off = b_off0 + ky * 10 * ROW;
-        Gthis = fetch_w(min(s + 2, n_stages - 1));
-        if (ky == 0)
-            GX = fetch_x(min(chunk + 1, n_chunks - 1));
+        Wthis = fetch_w(s2);
+        Xthis = fetch_x(s2 / 3);
         load_frags(Fb, wb, xb, a_off, b_off, 1);
         mfma_step(Fa, acc_main, acc_cross);
         load_frags(Fa, wb, xb, a_off, b_off, 2);
         mfma_step(Fb, acc_main, acc_cross);
-        commit_w(Gnext, (s + 1) & 1);
-        if (ky == 2)
-            commit_x(GX, (chunk + 1) & 1);
+        commit_w(Wnext, (s + 1) & 1);
+        commit_x(Xnext, chunk1 & 1);
         __syncthreads();
-        const int chunk1 = s1 / 3, ky1 = s1 - 3 * chunk1;
         load_frags(Fb, wbuf + ((s + 1) & 1) * W_BUF, xbuf + (chunk1 & 1) * X_BUF, a_off,
                    b_off0 + ky1 * 10 * ROW, 0);
         mfma_step(Fa, acc_main, acc_cross);
     };
     for (int s = 0; s < n_stages; s += 2) { // n_stages is even (cin a multiple of 32)
-        stage(s, F0, F1, G0, G1);
-        stage(s + 1, F1, F0, G1, G0);
+        stage(s, F0, F1, W0, X0, W1, X1);
+        stage(s + 1, F1, F0, W1, X1, W0, X0);
     }
     __syncthreads();
 
     // ---- epilogue: bias, ReLU, split, transpose through LDS, coalesced stores
     // D tile (i, j): lane holds cell 32j + r, channels 32i + 8(v>>2) + 4h + (v&3)
     char *const t_hi = lds, *const t_lo = lds + T_HALF;
+    float *const bias_lds = (float *)(lds + 2 * T_HALF);
+    if (tid < COUT)
+        bias_lds[tid] = my_bias;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     float v = acc_main[i][j][4 * q + t] + acc_cross[i][j][4 * q + t] * (1.0f / 2048.0f) +
-                              P.bias[co + t];
+                              bias_lds[co + t];
                     v = fminf(fmaxf(v, 0.0f), 65000.0f);
                     const __half vh = __float2half_rn(v);
                     hi4[t] = vh;

@@ -1,7 +1,8 @@
 """Value forward: split-f16 MFMA convolutions vs MIOpen float32, per batch size."""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from iago_amd import network, ops
 
 torch.manual_seed(0)
