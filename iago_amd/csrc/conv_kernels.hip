@@ -341,6 +341,137 @@ __global__ __launch_bounds__(256) void merge_nchw_kernel(const __half *hi, const
     y[t] = __half2float(hi[src]) + __half2float(lo[src]) * (1.0f / 2048.0f);
 }
 
+// ---- Value stem: block1 = 3x3 convolution 2 -> 64 + bias + ReLU (network.py:66-70),
+// float32 planes in, split channel blocks out.  K = 18: plain float32 FMAs.  One thread
+// per (board, channel block, half block, cell): 8 output channels of a cell.
+__global__ __launch_bounds__(256) void value_stem_kernel(const float *planes, const float *w, const float *bias,
+                                                         uint4 *y_hi, uint4 *y_lo, int64_t n)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * 512)
+        return;
+    const int cell = (int)(t & 63), grp = (int)((t >> 6) & 7); // grp = channel block * 2 + half: wave-uniform
+    const int64_t b = t >> 9;
+    const int y = cell >> 3, x = cell & 7;
+    const float *pl = planes + b * 128;
+    float in[18];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const int yy = y + ky - 1, xx = x + kx - 1;
+                const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
+                in[c * 9 + ky * 3 + kx] = ok ? pl[c * 64 + yy * 8 + xx] : 0.0f;
+            }
+    const int co0 = __builtin_amdgcn_readfirstlane(grp) * 8;
+    __half h8[8], l8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float *wk = w + (co0 + k) * 18; // [co][ci][ky][kx]
+        float acc = bias[co0 + k];
+#pragma unroll
+        for (int j = 0; j < 18; j++)
+            acc = fmaf(wk[j], in[j], acc);
+        const float v = fminf(fmaxf(acc, 0.0f), 65000.0f);
+        const __half vh = __float2half_rn(v);
+        h8[k] = vh;
+        l8[k] = __float2half_rn((v - __half2float(vh)) * 2048.0f);
+    }
+    const int64_t dst = ((b * 4 + (grp >> 1)) * 64 + cell) * 2 + (grp & 1);
+    y_hi[dst] = *(const uint4 *)h8;
+    y_lo[dst] = *(const uint4 *)l8;
+}
+
+// ---- Value head: block9 = 3x3 convolution 128 -> 1 + bias + ReLU, fc10 (64 -> 128, no
+// bias), fc11 (128 -> 1, no bias) (network.py:78-96 with train=False), split channel
+// blocks in, one float per board out.  One workgroup per board: wave q sums channel
+// blocks 2q and 2q+1, lane = cell; float32 FMAs on the exact values hi + lo * 2^-11.
+__device__ __forceinline__ void fma16(float &acc, const float *wrow, uint4 a, uint4 b)
+{
+    const __half2 *pa = (const __half2 *)&a, *pb = (const __half2 *)&b;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float2 fa = __half22float2(pa[k]), fb = __half22float2(pb[k]);
+        acc = fmaf(wrow[2 * k], fa.x, acc);
+        acc = fmaf(wrow[2 * k + 1], fa.y, acc);
+        acc = fmaf(wrow[8 + 2 * k], fb.x, acc);
+        acc = fmaf(wrow[8 + 2 * k + 1], fb.y, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void value_head_kernel(const uint4 *x_hi, const uint4 *x_lo, const float *w9,
+                                                         const float *b9, const float *w10, const float *w11,
+                                                         float *out, int64_t n)
+{
+    // padded 10x10 plane of 16-channel rows per block, hi and lo: 8 * 100 * 32 B each
+    constexpr int IMG = 8 * PP * 32;
+    __shared__ __align__(16) char img[2 * IMG];
+    __shared__ __align__(16) float w9s[9 * 128]; // [tap][channel]
+    __shared__ float part[4 * 64];
+    __shared__ float h9[64];
+    __shared__ float hid[128];
+    const int tid = threadIdx.x, q = tid >> 6, lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    for (int i = tid; i < 2 * IMG / 16; i += 256)
+        ((uint4 *)img)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 9 * 128; i += 256) {
+        const int tap = i >> 7, c = i & 127;
+        w9s[i] = w9[c * 9 + tap]; // [1][128][3][3]
+    }
+    __syncthreads();
+    // 1024 pieces per hi/lo: (block, cell, half)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int e = tid + k * 256;
+        const int cb = e >> 7, cell = (e >> 1) & 63, hp = e & 1;
+        const int off = ((cb * PP + ((cell >> 3) + 1) * 10 + (cell & 7) + 1) * 2 + hp) * 16;
+        *(uint4 *)(img + off) = x_hi[b * 1024 + e];
+        *(uint4 *)(img + IMG + off) = x_lo[b * 1024 + e];
+    }
+    __syncthreads();
+    const int y = lane >> 3, x = lane & 7;
+    float acc_hi = 0.0f, acc_lo = 0.0f;
+#pragma unroll
+    for (int cbi = 0; cbi < 2; cbi++) {
+        const int cb = 2 * q + cbi;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int pp = (y + tap / 3) * 10 + x + tap % 3;
+            const char *ph = img + (cb * PP + pp) * 32;
+            const float *wrow = w9s + tap * 128 + cb * 16;
+            fma16(acc_hi, wrow, *(const uint4 *)ph, *(const uint4 *)(ph + 16));
+            fma16(acc_lo, wrow, *(const uint4 *)(ph + IMG), *(const uint4 *)(ph + IMG + 16));
+        }
+    }
+    part[q * 64 + lane] = acc_hi + acc_lo * (1.0f / 2048.0f);
+    __syncthreads();
+    if (tid < 64)
+        h9[tid] = fmaxf(((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + b9[0], 0.0f);
+    __syncthreads();
+    if (tid < 128) { // fc10 row tid, then its fc11 term
+        const float4 *row = (const float4 *)(w10 + tid * 64);
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const float4 wv = row[c];
+            s = fmaf(wv.x, h9[4 * c], s);
+            s = fmaf(wv.y, h9[4 * c + 1], s);
+            s = fmaf(wv.z, h9[4 * c + 2], s);
+            s = fmaf(wv.w, h9[4 * c + 3], s);
+        }
+        hid[tid] = s * w11[tid];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float v = 0.0f;
+        for (int j = 0; j < 128; j++) // fixed order: the result does not depend on the launch shape
+            v += hid[j];
+        out[b] = v;
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -374,6 +505,34 @@ int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, con
     const unsigned grid = (unsigned)((n + TB - 1) / TB);
     hipLaunchKernelGGL(conv3x3_split_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, P);
     return iago_check_launch("iago_conv3x3_split");
+}
+
+int iago_value_stem(const float *planes, const float *w1, const float *b1, void *y_hi, void *y_lo, int64_t n,
+                    void *stream)
+{
+    if (n < 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_stem: negative n");
+    if (n == 0)
+        return IAGO_OK;
+    if (!planes || !w1 || !b1 || !y_hi || !y_lo)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_stem: null pointer");
+    hipLaunchKernelGGL(value_stem_kernel, dim3((unsigned)((n * 512 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, planes, w1, b1, (uint4 *)y_hi, (uint4 *)y_lo, n);
+    return iago_check_launch("iago_value_stem");
+}
+
+int iago_value_head(const void *x_hi, const void *x_lo, const float *w9, const float *b9, const float *w10,
+                    const float *w11, float *out, int64_t n, void *stream)
+{
+    if (n < 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_head: negative n");
+    if (n == 0)
+        return IAGO_OK;
+    if (!x_hi || !x_lo || !w9 || !b9 || !w10 || !w11 || !out)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_head: null pointer");
+    hipLaunchKernelGGL(value_head_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4 *)x_hi, (const uint4 *)x_lo, w9, b9, w10, w11, out, n);
+    return iago_check_launch("iago_value_head");
 }
 
 int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels, void *stream)

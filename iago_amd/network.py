@@ -160,9 +160,10 @@ class Value(nn.Module, _NpzMixin):
         self.fc11 = nn.Linear(128, 1, bias=False)
         self.reset_parameters_chainer()
 
-    # Inference on the GPU runs blocks 2..8 (>98 % of the FLOPs) through the split-f16
-    # MFMA convolution (csrc/conv_kernels.hip: 22-bit products, float32 accumulation,
-    # the whole forward within 1e-6 of the float32 one).  Set to False for MIOpen's
+    # Inference on the GPU runs through csrc/conv_kernels.hip: blocks 2..8 (>98 % of the
+    # FLOPs) as split-f16 MFMA convolutions (22-bit products, float32 accumulation),
+    # block1 and block9 + fc10 + fc11 as fused float32 kernels; the whole forward stays
+    # within 1e-6 of the float32 one.  Set to False for MIOpen's
     # float32 convolutions everywhere.
     split_f16 = True
     SPLIT_MIN_BATCH = 16
@@ -186,11 +187,12 @@ class Value(nn.Module, _NpzMixin):
     def forward(self, x):
         if self._use_split(x):
             from . import ops
-            a = ops.split_nchw(self.block1(x).contiguous())
+            a = ops.value_stem(x.contiguous(), self.block1.conv.weight, self.block1.conv.bias)
             for k in range(2, 9):
                 w_hi, w_lo = self._split_weights(k)
                 a = ops.conv3x3_split(a, w_hi, w_lo, getattr(self, "block%d" % k).conv.bias)
-            h = self.block9(ops.merge_nchw(a))
+            return ops.value_head(a, self.block9.conv.weight, self.block9.conv.bias,
+                                  self.fc10.weight, self.fc11.weight)
         else:
             h = x
             for k in range(1, 10):

@@ -156,6 +156,34 @@ def merge_nchw(a):
     return y
 
 
+def value_stem(planes, w1, b1):
+    """relu(conv3x3(planes, w1) + b1), 2 -> 64 channels (Value.block1, network.py:68-70):
+    float32 planes (n, 2, 8, 8) -> SplitActs with 64 channels."""
+    n = planes.shape[0]
+    if tuple(planes.shape[1:]) != (2, 8, 8) or tuple(w1.shape) != (64, 2, 3, 3):
+        raise ValueError("value_stem: planes (n,2,8,8) and w1 (64,2,3,3) expected")
+    hi = torch.empty((n, 4, 64, 16), dtype=torch.float16, device=planes.device)
+    lo = torch.empty_like(hi)
+    check(_lib.lib().iago_value_stem(_dev(planes, torch.float32, "planes"), _dev(w1, torch.float32, "w1"),
+                                     _dev(b1, torch.float32, "b1"), _dev(hi, torch.float16, "y_hi"),
+                                     _dev(lo, torch.float16, "y_lo"), n, _stream()), "iago_value_stem")
+    return SplitActs(hi, lo, 64)
+
+
+def value_head(a, w9, b9, w10, w11):
+    """Value.block9 + fc10 + fc11 with train=False (network.py:78-96) on SplitActs with
+    128 channels -> (n,) float32."""
+    if a.channels != 128 or tuple(w9.shape) != (1, 128, 3, 3) or tuple(w10.shape) != (128, 64) \
+            or tuple(w11.shape) != (1, 128):
+        raise ValueError("value_head: unexpected shapes")
+    out = torch.empty((a.n,), dtype=torch.float32, device=a.hi.device)
+    check(_lib.lib().iago_value_head(_dev(a.hi, torch.float16, "x_hi"), _dev(a.lo, torch.float16, "x_lo"),
+                                     _dev(w9, torch.float32, "w9"), _dev(b9, torch.float32, "b9"),
+                                     _dev(w10, torch.float32, "w10"), _dev(w11, torch.float32, "w11"),
+                                     _dev(out, torch.float32, "out"), a.n, _stream()), "iago_value_head")
+    return out
+
+
 def conv3x3_split(a, w_hi, w_lo, bias):
     """relu(conv3x3(a, w) + bias) on SplitActs: Block.__call__ (network.py:9-13) on
     the MFMA units in split-f16 arithmetic.  w_hi, w_lo from split_weights."""

@@ -210,6 +210,20 @@ IAGO_API int iago_bias_relu(float *x, const float *bias, int64_t n, int32_t chan
 IAGO_API int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
                                 const float *bias, void *y_hi, void *y_lo, int64_t n, int32_t cin,
                                 int32_t cout, void *stream);
+/*
+ * The ends of the Value net around the split-f16 convolutions, in float32 arithmetic:
+ * iago_value_stem: block1 = conv3x3 2 -> 64 + bias + ReLU (network.py:68-70) from the
+ *   float32 planes [n][2][8][8] of iago_encode_planes to split channel blocks
+ *   [n][4][64][16]; w1 [64][2][3][3], b1 [64] as the reference stores them.
+ * iago_value_head: block9 = conv3x3 128 -> 1 + bias + ReLU, fc10 (64 -> 128, no bias),
+ *   fc11 (128 -> 1, no bias) with train=False (network.py:78-96; MCTS.py:86), from
+ *   split channel blocks [n][8][64][16] to out [n]; w9 [1][128][3][3], b9 [1],
+ *   w10 [128][64], w11 [1][128].
+ */
+IAGO_API int iago_value_stem(const float *planes, const float *w1, const float *b1, void *y_hi, void *y_lo,
+                             int64_t n, void *stream);
+IAGO_API int iago_value_head(const void *x_hi, const void *x_lo, const float *w9, const float *b9,
+                             const float *w10, const float *w11, float *out, int64_t n, void *stream);
 IAGO_API int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels, void *stream);
 IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n, int32_t channels,
                              void *stream);

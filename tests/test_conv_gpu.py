@@ -100,3 +100,29 @@ def test_value_split_cache_follows_weight_updates():
         c = m(x)
     assert not torch.allclose(a, b)
     assert torch.allclose(b, c, atol=1e-6)
+
+
+def test_value_stem_and_head_match_float32():
+    from iago_amd import network, ops
+    torch.manual_seed(11)
+    m = network.Value().eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.6)
+        m.block1.conv.bias.normal_(0, 0.1)
+        m.block9.conv.bias.fill_(0.05)
+    x = _boards(37, seed=3)
+    with torch.no_grad():
+        ref1 = F.relu(m.block1.conv(x))
+        mg = m.cuda()
+        a = ops.value_stem(x.cuda(), mg.block1.conv.weight, mg.block1.conv.bias)
+        got1 = ops.merge_nchw(a).cpu()
+        assert (got1 - ref1).abs().max().item() < 2e-6 * float(ref1.abs().max())
+        h = torch.rand(37, 128, 8, 8) * 1.5
+        m.cpu()
+        r9 = F.relu(m.block9.conv(h)).reshape(-1, 64)
+        ref = m.fc11(m.fc10(r9)).reshape(-1)
+        mg = m.cuda()
+        got = ops.value_head(ops.split_nchw(h.cuda()), mg.block9.conv.weight, mg.block9.conv.bias,
+                             mg.fc10.weight, mg.fc11.weight).cpu()
+        assert (got - ref).abs().max().item() < 2e-6 * max(1.0, float(ref.abs().max()))
