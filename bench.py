@@ -100,7 +100,7 @@ def cpu_baseline(w, b, budget_s=10.0):
             "board_steps_per_game": steps / games, "one_core_games_per_sec": one_core}
 
 
-def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
+def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=False):
     """BASELINE configs[2]: PV-MCTS self-play, `n_games` lockstep games per GPU,
     `n_sims` playouts per move, SLPolicy + Value with random-init weights
     (Chainer-default LeCunNormal, seed 0), reference constants lmbda=0.5,
@@ -114,6 +114,7 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
     torch.manual_seed(0)
     policy = network.SLPolicy().cuda().eval()
     value = network.Value().cuda().eval()
+    value.split_f16 = not value_f32
     m = engine.BatchedMCTS(n_games, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0,
                            n_thr=15, capacity=engine.suggest_capacity(n_sims, 15), seed=7,
                            game_id_base=rank * n_games, use_graph=True)
@@ -147,11 +148,12 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
     out = {"leaf_evals_per_sec": leaf / dt, "leaf_evals": int(leaf), "policy_evals": int(pol),
            "seconds": dt, "turns_played": res.n_turns, "sims_per_move": n_sims,
            "games_per_gpu": n_games, "full_games": bool(full_games),
-           "net_tflops_fp32": flops / dt / 1e12,
-           # the convolutions bound this leg: fp32 matrix/vector peak 157.3 TFLOP/s (MI355X)
-           "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12 / world, "peak": 157.3,
-                        "unit": "TFLOP/s", "frac": flops / dt / 1e12 / world / 157.3,
-                        "flops_per_leaf_eval": 122_994_944, "flops_per_policy_eval": 122_847_232},
+           "net_tflops_fp32": flops / dt / 1e12,   # float32-equivalent FLOP/s of both nets
+           "value_conv": ("f32 (MIOpen)" if value_f32 else
+                          "split-f16 MFMA: f16 hi/lo operands, 3 MFMAs per product sum, f32 accumulation; "
+                          "Value forward within 1e-6 of the f32 one (tests/test_conv_gpu.py)"),
+           "policy_conv": "f32 (MIOpen)",
+           "roofline": _mcts_roofline(leaf, pol, dt, world, value_f32),
            "config": "BASELINE configs[2]: PV-MCTS %d sims/move, %d games per GPU, SLPolicy+Value "
                      "random init fp32, lmbda=0.5 c_puct=1 n_thr=15" % (n_sims, n_games),
            "tree_pool_bytes_per_gpu": m.tree.bytes(), "tree_traffic_rank0": m.tree_bytes(),
@@ -162,6 +164,22 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist):
         if gathered is not None:
             out["gathered_tuples"] = int(gathered["z"].numel())
     return out
+
+
+def _mcts_roofline(leaf, pol, dt, world, value_f32):
+    """The convolutions bound this leg.  f32 path: float32 matrix/vector peak 157.3
+    TFLOP/s.  Split-f16 path: the Value convolutions of blocks 2..8 (122.68 MFLOP per
+    evaluation) execute 3 f16 MFMAs per product sum against the dense f16 peak of
+    2,500 TFLOP/s (MI355X_MICROARCH.md)."""
+    if value_f32:
+        a = (leaf * 122_994_944 + pol * 122_847_232) / dt / 1e12 / world
+        return {"bound": "mfma", "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
+                "flops_per_leaf_eval": 122_994_944, "flops_per_policy_eval": 122_847_232}
+    a = leaf * 3 * 122_683_392 / dt / 1e12 / world
+    return {"bound": "mfma", "achieved": a, "peak": 2500.0, "unit": "TFLOP/s", "frac": a / 2500.0,
+            "dtype": "f16 MFMA operands (split f32), f32 accumulate",
+            "mfma_flops_per_leaf_eval": 3 * 122_683_392, "flops_per_leaf_eval": 122_994_944,
+            "flops_per_policy_eval": 122_847_232}
 
 
 def mcts_cpu_baseline(n_sims=600):
@@ -305,6 +323,9 @@ def main():
     ap.add_argument("--mcts-turns", type=int, default=-1,
                     help="PV-MCTS leg: -1 = play the games to the end (default), N > 0 = a bounded "
                          "sample of the first N turns, 0 = skip the leg")
+    ap.add_argument("--mcts-value-f32", action="store_true",
+                    help="PV-MCTS leg: MIOpen float32 convolutions for the Value net instead of the "
+                         "split-f16 MFMA kernels")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -448,7 +469,7 @@ def main():
     mcts = None
     if args.mcts_turns != 0:
         mcts = mcts_leg(args.mcts_games, args.mcts_sims, max(args.mcts_turns, 0),
-                        args.mcts_turns < 0, world, rank, dist)
+                        args.mcts_turns < 0, world, rank, dist, value_f32=args.mcts_value_f32)
 
     train = reinforce_leg(args.train_iters, world, rank, dist) if args.train_iters > 0 else None
     b1 = mcts_b1_leg() if (mcts is not None and rank == 0) else None
