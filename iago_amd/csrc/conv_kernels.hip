@@ -472,6 +472,177 @@ __global__ __launch_bounds__(256) void value_head_kernel(const uint4 *x_hi, cons
     }
 }
 
+// ---- float32 convolution for SMALL batches (the policy net on the expansions of a
+// playout, MCTS.py:109-121: a few dozen boards per call).  Exact float32 products on
+// v_mfma_f32_32x32x2_f32 (which runs at the VALU rate: 9.4 M MACs of one board and layer
+// are 74 k cycles of one CU), so a board is spread over 4 workgroups (32 output channels
+// each) and the K loop over the 4 waves of a workgroup (a quarter of the input channels
+// each, all 9 taps); partial sums meet in LDS.  float32 NCHW in and out, bias + ReLU fused.
+constexpr int F32_CO = 32;          // output channels per workgroup
+constexpr int F32_XPLANE = PP;      // padded plane, floats
+
+struct ConvF32Params {
+    const float *x;    // [n][cin][64]
+    const float4 *w;   // [4][9][cin][32]
+    const float *bias; // [128]
+    float *y;          // [n][128][64]
+    int32_t cin;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
+{
+    constexpr int CQ = CIN / 4;              // input channels per wave
+    constexpr int SLAB = CQ * F32_CO;        // floats of one (tap, wave) weight slab
+    extern __shared__ __align__(16) char lds[];
+    float *const xs = (float *)lds;                       // [CIN][100]
+    float *const ws = xs + CIN * F32_XPLANE;              // [4 waves][2][SLAB]
+    const int tid = threadIdx.x, q = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int64_t b = blockIdx.x >> 2;
+    const int cg = blockIdx.x & 3;
+
+    // weights of tap 0 on their way while the board is staged
+    const float4 *wsrc = P.w + ((int64_t)(cg * 9) * CIN + q * CQ) * (F32_CO / 4) + lane;
+    constexpr int WPIECES = SLAB / 4 / 64; // float4 pieces per lane and slab
+    float4 wreg[WPIECES];
+#pragma unroll
+    for (int k = 0; k < WPIECES; k++)
+        wreg[k] = wsrc[k * 64];
+
+    // ---- stage the board: zero the borders, copy the 8x8 interiors
+    for (int i = tid; i < CIN * 36; i += 256) {
+        const int c = i / 36, e = i - c * 36;
+        // border cells of a 10x10 plane: rows 0 and 9 (20 cells), columns 0 and 9 of rows 1..8
+        const int pp = e < 10 ? e : e < 20 ? 80 + e : (e - 20) < 8 ? (e - 19) * 10 : (e - 27) * 10 + 9;
+        xs[c * F32_XPLANE + pp] = 0.0f;
+    }
+    const float4 *xsrc = (const float4 *)(P.x + b * CIN * 64);
+    for (int i = tid; i < CIN * 16; i += 256) {
+        const float4 v = xsrc[i];
+        const int c = i >> 4, cell = (i & 15) * 4;
+        float *d = xs + c * F32_XPLANE + ((cell >> 3) + 1) * 10 + (cell & 7) + 1;
+        d[0] = v.x;
+        d[1] = v.y;
+        d[2] = v.z;
+        d[3] = v.w;
+    }
+    float *const wq = ws + q * 2 * SLAB;
+#pragma unroll
+    for (int k = 0; k < WPIECES; k++)
+        ((float4 *)wq)[k * 64 + lane] = wreg[k];
+    __syncthreads();
+
+    float16v acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int v = 0; v < 16; v++)
+            acc[j][v] = 0.0f;
+
+    // lane-constant operand offsets: A = W[k = 2t + h][co = r], B = X[ci = .. + 2t + h][cell]
+    const float *const xq = xs + (q * CQ + h) * F32_XPLANE + (r >> 3) * 10 + (r & 7);
+    for (int tap = 0; tap < 9; tap++) {
+        const int buf = tap & 1;
+        if (tap < 8) {
+#pragma unroll
+            for (int k = 0; k < WPIECES; k++)
+                wreg[k] = wsrc[(int64_t)(tap + 1) * CIN * (F32_CO / 4) + k * 64];
+        }
+        const float *wa = wq + buf * SLAB + h * F32_CO + r;
+        const float *xb = xq + (tap / 3) * 10 + tap % 3;
+#pragma unroll
+        for (int t = 0; t < CQ / 2; t++) {
+            const float a = wa[2 * t * F32_CO];
+            const float b0 = xb[2 * t * F32_XPLANE];
+            const float b1 = xb[2 * t * F32_XPLANE + 40];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        }
+        if (tap < 8) {
+            // the other buffer was last read in tap - 1 by this wave only: no barrier
+#pragma unroll
+            for (int k = 0; k < WPIECES; k++)
+                ((float4 *)(wq + (buf ^ 1) * SLAB))[k * 64 + lane] = wreg[k];
+        }
+    }
+    __syncthreads();
+
+    // ---- the four K-quarters meet in LDS: red[q][j][v][lane]
+    float *const red = (float *)lds;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int v = 0; v < 16; v++)
+            red[((q * 2 + j) * 16 + v) * 64 + lane] = acc[j][v];
+    __syncthreads();
+    // wave q finishes registers v = 4q .. 4q+3 of both tiles:
+    // channel 32 cg + 8 (v >> 2) + 4 h + (v & 3) = 32 cg + 8 q + 4 h + t, cell 32 j + r
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int v = 4 * q + t;
+            float s = 0.0f;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++)
+                s += red[((qq * 2 + j) * 16 + v) * 64 + lane];
+            const int co = 32 * cg + 8 * q + 4 * h + t;
+            P.y[(b * COUT + co) * 64 + 32 * j + r] = fmaxf(s + P.bias[co], 0.0f);
+        }
+}
+
+// float32 stem: conv3x3 2 -> 64 + bias + ReLU to float32 NCHW (SLPolicy.block1,
+// network.py:17-19); one thread per (board, channel, cell)
+__global__ __launch_bounds__(256) void stem_f32_kernel(const float *planes, const float *w, const float *bias,
+                                                       float *y, int64_t n)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * 4096)
+        return;
+    const int cell = (int)(t & 63), co = __builtin_amdgcn_readfirstlane((int)((t >> 6) & 63));
+    const int64_t b = t >> 12;
+    const int yy0 = cell >> 3, xx0 = cell & 7;
+    const float *pl = planes + b * 128;
+    const float *wk = w + co * 18;
+    float acc = bias[co];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const int yy = yy0 + ky - 1, xx = xx0 + kx - 1;
+                const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
+                acc = fmaf(wk[c * 9 + ky * 3 + kx], ok ? pl[c * 64 + yy * 8 + xx] : 0.0f, acc);
+            }
+    y[t] = fmaxf(acc, 0.0f);
+}
+
+// SLPolicy head: conv9 (1x1, 128 -> 1, no bias), bias10 (64), softmax (network.py:29-47);
+// one wave per board, lane = cell
+__global__ __launch_bounds__(64) void policy_head_kernel(const float *x, const float *w9, const float *b10,
+                                                         float *probs, int64_t n)
+{
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float *xb = x + b * COUT * 64 + lane;
+    float s = 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < COUT; c++)
+        s = fmaf(w9[c], xb[c * 64], s);
+    s += b10[lane];
+    float m = s;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        m = fmaxf(m, __shfl_xor(m, d, 64));
+    const float e = expf(s - m);
+    float z = e;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        z += __shfl_xor(z, d, 64);
+    probs[b * 64 + lane] = e / z;
+}
+
 } // namespace
 
 extern "C" {
@@ -533,6 +704,63 @@ int iago_value_head(const void *x_hi, const void *x_lo, const float *w9, const f
     hipLaunchKernelGGL(value_head_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,
                        (const uint4 *)x_hi, (const uint4 *)x_lo, w9, b9, w10, w11, out, n);
     return iago_check_launch("iago_value_head");
+}
+
+int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y, int64_t n, int32_t cin,
+                     int32_t cout, void *stream)
+{
+    if (n < 0 || cout != COUT || (cin != 64 && cin != 128))
+        return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_f32: cout must be 128 and cin 64 or 128");
+    if (n == 0)
+        return IAGO_OK;
+    if (!x || !w || !bias || !y)
+        return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_f32: null pointer");
+    if (n > (1 << 28))
+        return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_f32: batch too large");
+    ConvF32Params P;
+    P.x = x;
+    P.w = (const float4 *)w;
+    P.bias = bias;
+    P.y = y;
+    P.cin = cin;
+    const size_t lds = (size_t)(cin * F32_XPLANE + 4 * 2 * (cin / 4) * F32_CO) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void *)conv3x3_f32_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((128 * F32_XPLANE + 4 * 2 * 32 * F32_CO) * sizeof(float))) != hipSuccess)
+            return iago_fail(IAGO_ERR_HIP, "iago_conv3x3_f32: cannot reserve LDS");
+        configured = true;
+    }
+    if (cin == 128)
+        hipLaunchKernelGGL(conv3x3_f32_kernel<128>, dim3((unsigned)(n * 4)), dim3(256), lds, (hipStream_t)stream, P);
+    else
+        hipLaunchKernelGGL(conv3x3_f32_kernel<64>, dim3((unsigned)(n * 4)), dim3(256), lds, (hipStream_t)stream, P);
+    return iago_check_launch("iago_conv3x3_f32");
+}
+
+int iago_stem_f32(const float *planes, const float *w1, const float *b1, float *y, int64_t n, void *stream)
+{
+    if (n < 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_stem_f32: negative n");
+    if (n == 0)
+        return IAGO_OK;
+    if (!planes || !w1 || !b1 || !y)
+        return iago_fail(IAGO_ERR_INVALID, "iago_stem_f32: null pointer");
+    hipLaunchKernelGGL(stem_f32_kernel, dim3((unsigned)(n * 16)), dim3(256), 0, (hipStream_t)stream, planes, w1, b1,
+                       y, n);
+    return iago_check_launch("iago_stem_f32");
+}
+
+int iago_policy_head(const float *x, const float *w9, const float *b10, float *probs, int64_t n, void *stream)
+{
+    if (n < 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_policy_head: negative n");
+    if (n == 0)
+        return IAGO_OK;
+    if (!x || !w9 || !b10 || !probs)
+        return iago_fail(IAGO_ERR_INVALID, "iago_policy_head: null pointer");
+    hipLaunchKernelGGL(policy_head_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, x, w9, b10, probs, n);
+    return iago_check_launch("iago_policy_head");
 }
 
 int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels, void *stream)

@@ -121,8 +121,44 @@ class SLPolicy(nn.Module, _NpzMixin):
         h = self.conv9(h).reshape(-1, 64)
         return self.bias10(h)
 
+    # Small inference batches on the GPU (the expansions of a playout: a few dozen boards)
+    # run through the float32 matrix-unit kernels of csrc/conv_kernels.hip, which spread
+    # one board over four workgroups; larger batches through MIOpen.
+    F32_MAX_BATCH = 128
+
+    def _use_f32_kernels(self, x):
+        return (x.is_cuda and not self.training and not torch.is_grad_enabled()
+                and x.dtype == torch.float32 and 0 < x.shape[0] <= self.F32_MAX_BATCH
+                and not torch.is_autocast_enabled())
+
     def forward(self, x):
+        if self._use_f32_kernels(x):
+            from . import ops
+            h = _f32_trunk(self, x)
+            return ops.policy_head(h, self.conv9.weight.reshape(128), self.bias10.b)
         return F.softmax(self.logits(x), dim=1)
+
+
+def _f32_weights(module, k):
+    """Cached [4][9][cin][32] layout of block k's weight (ops.f32_weights)."""
+    from . import ops
+    w = getattr(module, "block%d" % k).conv.weight
+    cache = module.__dict__.setdefault("_f32_cache", {})
+    key = (w._version, w.data_ptr(), str(w.device))
+    hit = cache.get(k)
+    if hit is None or hit[0] != key:
+        hit = (key, ops.f32_weights(w))
+        cache[k] = hit
+    return hit[1]
+
+
+def _f32_trunk(module, x):
+    """blocks 1..8 of SLPolicy / Value in float32 on the matrix units (small batches)."""
+    from . import ops
+    h = ops.stem_f32(x.contiguous(), module.block1.conv.weight, module.block1.conv.bias)
+    for k in range(2, 9):
+        h = ops.conv3x3_f32(h, _f32_weights(module, k), getattr(module, "block%d" % k).conv.bias)
+    return h
 
 
 class RolloutPolicy(nn.Module, _NpzMixin):
@@ -193,6 +229,12 @@ class Value(nn.Module, _NpzMixin):
                 a = ops.conv3x3_split(a, w_hi, w_lo, getattr(self, "block%d" % k).conv.bias)
             return ops.value_head(a, self.block9.conv.weight, self.block9.conv.bias,
                                   self.fc10.weight, self.fc11.weight)
+        elif (self.split_f16 and x.is_cuda and not self.training and not torch.is_grad_enabled()
+              and x.dtype == torch.float32 and x.shape[0] > 0 and not torch.is_autocast_enabled()):
+            # small batches (single-game serving): float32 matrix-unit kernels
+            from . import ops
+            return ops.value_head(ops.split_nchw(_f32_trunk(self, x)), self.block9.conv.weight,
+                                  self.block9.conv.bias, self.fc10.weight, self.fc11.weight)
         else:
             h = x
             for k in range(1, 10):

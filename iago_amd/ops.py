@@ -200,6 +200,52 @@ def conv3x3_split(a, w_hi, w_lo, bias):
     return SplitActs(hi, lo, 128)
 
 
+# ---- float32 small-batch convolution stack (policy net on expansions) ----------------
+
+def f32_weights(weight):
+    """(128, cin, 3, 3) float32 conv weight -> [4][9][cin][32] as iago_conv3x3_f32 reads it."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or cout != 128 or cin not in (64, 128):
+        raise ValueError("f32_weights: need a (128, 64|128, 3, 3) weight")
+    w = weight.detach().to(torch.float32).permute(2, 3, 1, 0).reshape(9, cin, 4, 32)
+    return w.permute(2, 0, 1, 3).contiguous()
+
+
+def conv3x3_f32(x, w4, bias):
+    """relu(conv3x3(x, w) + bias) in float32 on the matrix units; x (n, cin, 8, 8)."""
+    n, cin = x.shape[0], x.shape[1]
+    if tuple(w4.shape) != (4, 9, cin, 32):
+        raise ValueError("weight layout %s does not match %d input channels" % (tuple(w4.shape), cin))
+    y = torch.empty((n, 128, 8, 8), dtype=torch.float32, device=x.device)
+    check(_lib.lib().iago_conv3x3_f32(_dev(x, torch.float32, "x"), _dev(w4, torch.float32, "w"),
+                                      _dev(bias, torch.float32, "bias"), _dev(y, torch.float32, "y"),
+                                      n, cin, 128, _stream()), "iago_conv3x3_f32")
+    return y
+
+
+def stem_f32(planes, w1, b1):
+    n = planes.shape[0]
+    if tuple(planes.shape[1:]) != (2, 8, 8) or tuple(w1.shape) != (64, 2, 3, 3):
+        raise ValueError("stem_f32: planes (n,2,8,8) and w1 (64,2,3,3) expected")
+    y = torch.empty((n, 64, 8, 8), dtype=torch.float32, device=planes.device)
+    check(_lib.lib().iago_stem_f32(_dev(planes, torch.float32, "planes"), _dev(w1, torch.float32, "w1"),
+                                   _dev(b1, torch.float32, "b1"), _dev(y, torch.float32, "y"), n,
+                                   _stream()), "iago_stem_f32")
+    return y
+
+
+def policy_head(x, w9, b10):
+    """softmax(conv1x1(x, w9) + b10) (network.py:29-47): x (n, 128, 8, 8) -> (n, 64)."""
+    n = x.shape[0]
+    if tuple(x.shape[1:]) != (128, 8, 8) or w9.numel() != 128 or b10.numel() != 64:
+        raise ValueError("policy_head: unexpected shapes")
+    probs = torch.empty((n, 64), dtype=torch.float32, device=x.device)
+    check(_lib.lib().iago_policy_head(_dev(x, torch.float32, "x"), _dev(w9.reshape(128), torch.float32, "w9"),
+                                      _dev(b10, torch.float32, "b10"), _dev(probs, torch.float32, "probs"),
+                                      n, _stream()), "iago_policy_head")
+    return probs
+
+
 def sample_moves(probs, legal, uniforms=None, seed=0, id_base=0, step=0, stream_id=0):
     """Masked inverse-CDF sampling (src/rl_self_play.py:111-122); int8 actions,
     -1 where there is no legal move.  uniforms: optional float64 (n,)."""

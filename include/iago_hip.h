@@ -224,6 +224,24 @@ IAGO_API int iago_value_stem(const float *planes, const float *w1, const float *
                              int64_t n, void *stream);
 IAGO_API int iago_value_head(const void *x_hi, const void *x_lo, const float *w9, const float *b9,
                              const float *w10, const float *w11, float *out, int64_t n, void *stream);
+/*
+ * float32 convolutions for SMALL batches: the policy net on the expansions of a playout
+ * (MCTS.py:109-121 evaluates SLPolicy on the few games whose leaf reached n_thr visits).
+ * Exact float32 products on the matrix units, one board spread over 4 workgroups.
+ * iago_conv3x3_f32: y = relu(conv3x3(x, w) + bias) (Block.__call__, network.py:9-13),
+ *   x [n][cin][8][8], y [n][128][8][8] float32; cin 64 or 128, cout 128; w re-laid as
+ *   [4 groups of 32 output channels][9 taps][cin][32] float32.
+ * iago_stem_f32: SLPolicy.block1, conv3x3 2 -> 64 + bias + ReLU, planes [n][2][8][8] ->
+ *   y [n][64][8][8]; w1 [64][2][3][3].
+ * iago_policy_head: conv9 (1x1, 128 -> 1, no bias) + bias10 + softmax (network.py:29-47):
+ *   x [n][128][8][8] -> probs [n][64]; w9 [128], b10 [64].
+ */
+IAGO_API int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y, int64_t n,
+                              int32_t cin, int32_t cout, void *stream);
+IAGO_API int iago_stem_f32(const float *planes, const float *w1, const float *b1, float *y, int64_t n,
+                           void *stream);
+IAGO_API int iago_policy_head(const float *x, const float *w9, const float *b10, float *probs, int64_t n,
+                              void *stream);
 IAGO_API int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels, void *stream);
 IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n, int32_t channels,
                              void *stream);

@@ -126,3 +126,67 @@ def test_value_stem_and_head_match_float32():
         got = ops.value_head(ops.split_nchw(h.cuda()), mg.block9.conv.weight, mg.block9.conv.bias,
                              mg.fc10.weight, mg.fc11.weight).cpu()
         assert (got - ref).abs().max().item() < 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("cin", [64, 128])
+@pytest.mark.parametrize("n", [1, 3, 64])
+def test_f32_conv_integer_data_is_exact(cin, n):
+    from iago_amd import ops
+    g = torch.Generator().manual_seed(cin + n)
+    x = torch.randint(-3, 4, (n, cin, 8, 8), generator=g).float()
+    w = torch.randint(-2, 3, (128, cin, 3, 3), generator=g).float()
+    b = torch.randint(-5, 6, (128,), generator=g).float()
+    ref = F.relu(F.conv2d(x, w, b, padding=1))
+    y = ops.conv3x3_f32(x.cuda(), ops.f32_weights(w.cuda()), b.cuda())
+    assert torch.equal(y.cpu(), ref)
+
+
+def test_f32_conv_random_data():
+    from iago_amd import ops
+    torch.manual_seed(2)
+    x = torch.rand(9, 128, 8, 8) * 2.0
+    w = torch.randn(128, 128, 3, 3) / np.sqrt(9 * 128)
+    b = torch.randn(128) * 0.1
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    y = ops.conv3x3_f32(x.cuda(), ops.f32_weights(w.cuda()), b.cuda())
+    assert (y.cpu().double() - ref).abs().max().item() < 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 128])
+def test_policy_small_batch_kernels_vs_miopen_and_float64(n):
+    """SLPolicy.__call__ (network.py:15-47) through stem_f32 / conv3x3_f32 / policy_head."""
+    from iago_amd import network
+    torch.manual_seed(9)
+    m = network.SLPolicy().eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.5)
+        m.bias10.b.normal_(0, 0.3)
+        m.block3.conv.bias.normal_(0, 0.1)
+    x = _boards(n, seed=40 + n)
+    with torch.no_grad():
+        ref64 = m.double()(x.double()).float()
+        m.float()
+        mg = m.cuda()
+        assert mg._use_f32_kernels(x.cuda())
+        got = mg(x.cuda()).cpu()
+        mg.F32_MAX_BATCH = 0
+        miopen = mg(x.cuda()).cpu()
+    assert (got - ref64).abs().max().item() < 1e-5
+    assert (got - miopen).abs().max().item() < 1e-5
+    assert torch.allclose(got.sum(1), torch.ones(n), atol=1e-5)
+
+
+def test_value_small_batch_uses_f32_kernels():
+    from iago_amd import network
+    torch.manual_seed(10)
+    m = network.Value().eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.6)
+    x = _boards(3, seed=77)
+    with torch.no_grad():
+        ref64 = m.double()(x.double()).float()
+        m.float()
+        got = m.cuda()(x.cuda()).cpu()
+    assert (got - ref64).abs().max().item() < 1e-5 * max(1.0, float(ref64.abs().max()))
