@@ -124,7 +124,7 @@ class SLPolicy(nn.Module, _NpzMixin):
     # Small inference batches on the GPU (the expansions of a playout: a few dozen boards)
     # run through the float32 matrix-unit kernels of csrc/conv_kernels.hip, which spread
     # one board over four workgroups; larger batches through MIOpen.
-    F32_MAX_BATCH = 128
+    F32_MAX_BATCH = 192
 
     def _use_f32_kernels(self, x):
         return (x.is_cuda and not self.training and not torch.is_grad_enabled()
@@ -202,7 +202,7 @@ class Value(nn.Module, _NpzMixin):
     # within 1e-6 of the float32 one.  Set to False for MIOpen's
     # float32 convolutions everywhere.
     split_f16 = True
-    SPLIT_MIN_BATCH = 16
+    SPLIT_MIN_BATCH = 192   # below: float32 matrix-unit kernels (126 us at <= 64 boards, 225 us at 128)
 
     def _split_weights(self, k):
         from . import ops
