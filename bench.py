@@ -100,7 +100,7 @@ def cpu_baseline(w, b, budget_s=10.0):
             "board_steps_per_game": steps / games, "one_core_games_per_sec": one_core}
 
 
-def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=False):
+def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=False, use_graph=True):
     """BASELINE configs[2]: PV-MCTS self-play, `n_games` lockstep games per GPU,
     `n_sims` playouts per move, SLPolicy + Value with random-init weights
     (Chainer-default LeCunNormal, seed 0), reference constants lmbda=0.5,
@@ -117,7 +117,7 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     value.split_f16 = not value_f32
     m = engine.BatchedMCTS(n_games, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0,
                            n_thr=15, capacity=engine.suggest_capacity(n_sims, 15), seed=7,
-                           game_id_base=rank * n_games, use_graph=True)
+                           game_id_base=rank * n_games, use_graph=use_graph)
     eng = engine.SelfPlayEngine(m, max_turns=(128 if full_games else n_turns))
     m.enable_stats()
     m.warmup()                 # MIOpen kernel selection for every batch bucket
@@ -323,6 +323,9 @@ def main():
     ap.add_argument("--mcts-turns", type=int, default=-1,
                     help="PV-MCTS leg: -1 = play the games to the end (default), N > 0 = a bounded "
                          "sample of the first N turns, 0 = skip the leg")
+    ap.add_argument("--mcts-eager", action="store_true",
+                    help="PV-MCTS leg: plain launches instead of the hipGraph tail (rocprofv3 does not "
+                         "attribute kernels launched from a graph)")
     ap.add_argument("--mcts-value-f32", action="store_true",
                     help="PV-MCTS leg: MIOpen float32 convolutions for the Value net instead of the "
                          "split-f16 MFMA kernels")
@@ -469,7 +472,8 @@ def main():
     mcts = None
     if args.mcts_turns != 0:
         mcts = mcts_leg(args.mcts_games, args.mcts_sims, max(args.mcts_turns, 0),
-                        args.mcts_turns < 0, world, rank, dist, value_f32=args.mcts_value_f32)
+                        args.mcts_turns < 0, world, rank, dist, value_f32=args.mcts_value_f32,
+                        use_graph=not args.mcts_eager)
 
     train = reinforce_leg(args.train_iters, world, rank, dist) if args.train_iters > 0 else None
     b1 = mcts_b1_leg() if (mcts is not None and rank == 0) else None
