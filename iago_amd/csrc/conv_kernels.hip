@@ -19,9 +19,10 @@
 // hi[b][C/16][64][16] and lo[...] -- 16 input channels of one cell are 32 contiguous
 // bytes (one MFMA k-step of a lane pair), one channel block of a board 2 KB.
 //
-// Kernel: one workgroup = 4 boards x all 128 output channels, 4 waves = one wave per
-// SIMD, wave w owns board w: D[co][cell] as 4 x 2 tiles of v_mfma_f32_32x32x16_f16,
-// 2 x 128 accumulator registers.  The K loop runs over stages of (16 input channels) x
+// Kernel: one workgroup = 4 boards x all 128 output channels; CS waves per board (1: one
+// wave per SIMD with the whole register file, 4 x 2 tiles of v_mfma_f32_32x32x16_f16 and
+// 2 x 128 accumulator registers per wave; 2, the default: two waves per SIMD, 2 x 2 tiles
+// each -- same speed at 1024 boards, no spills, shorter epilogue).  The K loop runs over stages of (16 input channels) x
 // (one kernel row = 3 taps); the padded 10x10 planes of a channel block and the weights
 // of a stage are double-buffered in LDS (150 KB), the next stage's global loads are
 // issued before the current stage's MFMAs and written to LDS after them.
@@ -35,8 +36,16 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); // a 16-byte piece in registers
 
-constexpr int TB = 4;           // boards per workgroup (= waves)
-constexpr int THREADS = 64 * TB;
+constexpr int TB = 4;           // boards per workgroup
+#ifndef IAGO_CONV_CS
+#define IAGO_CONV_CS 2
+#endif
+constexpr int CS = IAGO_CONV_CS; // waves per board: each owns 128 / CS output channels
+constexpr int NI = 4 / CS;       // 32-channel blocks per wave
+constexpr int THREADS = 64 * TB * CS;
+constexpr int XQ = 512 / THREADS;                 // X pieces per thread and hi/lo
+constexpr int WQ = (768 + THREADS - 1) / THREADS; // W pieces per thread and hi/lo (the last may repeat)
+static_assert(XQ * THREADS == 512 && (CS == 1 || CS == 2), "piece counts");
 constexpr int COUT = 128;
 constexpr int ROW = 48;         // bytes per LDS row: 16 halfs + 16 B padding (conflict-free b128 reads)
 constexpr int PP = 100;         // padded 10x10 plane
@@ -68,23 +77,23 @@ __device__ __forceinline__ half8 lds_half8(const char *p)
 
 // MFMA operand fragments of one k-step (one tap, 16 input channels) of a wave
 struct Frags {
-    half8 a_hi[4], a_lo[4]; // weights, 4 blocks of 32 output channels
+    half8 a_hi[NI], a_lo[NI]; // weights, NI blocks of 32 output channels
     half8 b_hi[2], b_lo[2]; // activations, 2 blocks of 32 cells
 };
 
 // global data on its way to LDS
 struct StagedW {
-    u32x4 w[6]; // 3 hi + 3 lo pieces of the weights of a stage
+    u32x4 w[2 * WQ]; // hi + lo pieces of the weights of a stage
 };
 struct StagedX {
-    u32x4 x[4]; // 2 hi + 2 lo pieces of a channel block of the 4 boards
+    u32x4 x[2 * XQ]; // hi + lo pieces of a channel block of the 4 boards
 };
 
 __device__ __forceinline__ void load_frags(Frags &F, const char *wb, const char *xb, int a_off, int b_off,
                                            int kx)
 {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NI; i++) {
         const int off = a_off + (kx * COUT + 32 * i) * ROW;
         F.a_hi[i] = lds_half8(wb + off);
         F.a_lo[i] = lds_half8(wb + W_HALF + off);
@@ -97,21 +106,21 @@ __device__ __forceinline__ void load_frags(Frags &F, const char *wb, const char 
     }
 }
 
-__device__ __forceinline__ void mfma_step(const Frags &F, float16v (&acc_main)[4][2],
-                                          float16v (&acc_cross)[4][2])
+__device__ __forceinline__ void mfma_step(const Frags &F, float16v (&acc_main)[NI][2],
+                                          float16v (&acc_cross)[NI][2])
 {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
             acc_main[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[i], F.b_hi[j], acc_main[i][j], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
             acc_cross[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[i], F.b_lo[j], acc_cross[i][j], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
             acc_cross[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_lo[i], F.b_hi[j], acc_cross[i][j], 0, 0, 0);
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
     char *const wbuf = lds + 2 * X_BUF;
 
     const int tid = threadIdx.x;
-    const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = (tid >> 6) & (TB - 1), cs = tid >> 8, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int64_t b0 = (int64_t)blockIdx.x * TB;
 
     const float my_bias = P.bias[tid & (COUT - 1)]; // parked in a register until the epilogue
@@ -135,11 +144,12 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
 
     // ---- staging: the 16-byte pieces this thread moves per stage
     // X channel block: per hi/lo TB*64*2 = 512 pieces (board = e >> 7, cell = (e >> 1) & 63,
-    // half-piece = e & 1) -> 2 per thread; W stage: 3*128*2 = 768 pieces -> 3 per thread
-    int64_t x_src[2];
-    int x_dst[2];
+    // half-piece = e & 1); W stage: 3*128*2 = 768 pieces (kx, co, half-piece).  With 512
+    // threads the upper half repeats its first W piece instead of branching.
+    int64_t x_src[XQ];
+    int x_dst[XQ];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < XQ; q++) {
         const int e = tid + q * THREADS;
         // boards past the end of a ragged batch read the last board (their results are not stored)
         const int64_t b = min(b0 + (e >> 7), P.n - 1);
@@ -147,56 +157,57 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
         const int cell = (e >> 1) & 63;
         x_dst[q] = ((e >> 7) * PP + ((cell >> 3) + 1) * 10 + (cell & 7) + 1) * ROW + (e & 1) * 16;
     }
-    int w_dst[3];
+    int w_piece[WQ], w_dst[WQ];
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-        const int e = tid + q * THREADS; // (kx, co, half-piece)
+    for (int q = 0; q < WQ; q++) {
+        const int e = (tid + q * THREADS < 768) ? tid + q * THREADS : tid;
+        w_piece[q] = e;
         w_dst[q] = (e >> 1) * ROW + (e & 1) * 16;
     }
     const int n_chunks = P.n_chunks, n_stages = 3 * n_chunks;
 
-    const u32x4 *const gw_hi = (const u32x4 *)P.w_hi + tid, *const gw_lo = (const u32x4 *)P.w_lo + tid;
+    const u32x4 *const gw_hi = (const u32x4 *)P.w_hi, *const gw_lo = (const u32x4 *)P.w_lo;
     const u32x4 *const gx_hi = (const u32x4 *)P.x_hi, *const gx_lo = (const u32x4 *)P.x_lo;
     auto fetch_w = [=](int stage) {
         StagedW G;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const int64_t src = (int64_t)stage * 768 + q * THREADS;
+        for (int q = 0; q < WQ; q++) {
+            const int64_t src = (int64_t)stage * 768 + w_piece[q];
             G.w[q] = gw_hi[src];
-            G.w[3 + q] = gw_lo[src];
+            G.w[WQ + q] = gw_lo[src];
         }
         return G;
     };
     auto fetch_x = [=](int chunk) {
         StagedX G;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < XQ; q++) {
             const int64_t src = x_src[q] + (int64_t)chunk * 128;
             G.x[q] = gx_hi[src];
-            G.x[2 + q] = gx_lo[src];
+            G.x[XQ + q] = gx_lo[src];
         }
         return G;
     };
     auto commit_w = [=](const StagedW &G, int wsel) {
         char *wb = wbuf + wsel * W_BUF;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
+        for (int q = 0; q < WQ; q++) {
             *(u32x4 *)(wb + w_dst[q]) = G.w[q];
-            *(u32x4 *)(wb + W_HALF + w_dst[q]) = G.w[3 + q];
+            *(u32x4 *)(wb + W_HALF + w_dst[q]) = G.w[WQ + q];
         }
     };
     auto commit_x = [=](const StagedX &G, int xsel) {
         char *xb = xbuf + xsel * X_BUF;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < XQ; q++) {
             *(u32x4 *)(xb + x_dst[q]) = G.x[q];
-            *(u32x4 *)(xb + X_HALF + x_dst[q]) = G.x[2 + q];
+            *(u32x4 *)(xb + X_HALF + x_dst[q]) = G.x[XQ + q];
         }
     };
 
-    float16v acc_main[4][2], acc_cross[4][2];
+    float16v acc_main[NI][2], acc_cross[NI][2];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
             }
 
     // lane-constant parts of the operand addresses
-    const int a_off = r * ROW + h * 16;                                  // + (kx*128 + 32i) * ROW
+    const int a_off = (cs * 32 * NI + r) * ROW + h * 16;                 // + (kx*128 + 32i) * ROW
     const int b_off0 = (w * PP + (r >> 3) * 10 + (r & 7)) * ROW + h * 16; // + ((4j + ky)*10 + kx) * ROW
 
     commit_w(fetch_w(0), 0);
@@ -261,12 +272,12 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
         bias_lds[tid] = my_bias;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int co = 32 * i + 8 * q + 4 * h;
+                const int co = 32 * (NI * cs + i) + 8 * q + 4 * h;
                 __half hi4[4], lo4[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -282,9 +293,9 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
                 *(uint2 *)(t_lo + off) = *(const uint2 *)lo4;
             }
     __syncthreads();
-    // output pieces: per hi/lo TB * 8 blocks * 64 cells * 2 = 4096 -> 16 per thread
+    // output pieces: per hi/lo TB * 8 blocks * 64 cells * 2 = 4096
 #pragma unroll 4
-    for (int q = 0; q < 16; q++) {
+    for (int q = 0; q < 4096 / THREADS; q++) {
         const int e = tid + q * THREADS; // (board, block, cell, half-piece) in output order
         const int board = e >> 10, cb = (e >> 7) & 7, cell = (e >> 1) & 63, hp = e & 1;
         const int64_t b = b0 + board;
