@@ -475,6 +475,13 @@ def main():
                         args.mcts_turns < 0, world, rank, dist, value_f32=args.mcts_value_f32,
                         use_graph=not args.mcts_eager)
 
+    if mcts is not None and not args.mcts_value_f32 and args.mcts_turns < 0:
+        # the same leg with MIOpen float32 convolutions for the Value net, on a bounded
+        # sample (first 4 turns), for comparison with the split-f16 kernels
+        ref = mcts_leg(args.mcts_games, args.mcts_sims, 4, False, world, rank, dist, value_f32=True)
+        mcts["value_f32_sample"] = {k: ref[k] for k in ("leaf_evals_per_sec", "leaf_evals", "seconds",
+                                                        "turns_played", "value_conv")}
+
     train = reinforce_leg(args.train_iters, world, rank, dist) if args.train_iters > 0 else None
     b1 = mcts_b1_leg() if (mcts is not None and rank == 0) else None
 
