@@ -20,7 +20,8 @@ TRACE_PASS = 0xFF
 # against the header and the built library)
 SYMBOLS = [
     "iago_abi_version", "iago_last_error", "iago_device_count",
-    "iago_legal_moves", "iago_apply_moves", "iago_encode_planes", "iago_judge",
+    "iago_legal_moves", "iago_apply_moves", "iago_encode_planes", "iago_encode_planes_indexed",
+    "iago_judge",
     "iago_sample_moves", "iago_augment8", "iago_bias_relu",
     "iago_conv3x3_split", "iago_split_nchw", "iago_merge_nchw", "iago_value_stem", "iago_value_head",
     "iago_conv3x3_f32", "iago_stem_f32", "iago_policy_head",

@@ -46,15 +46,18 @@ __global__ __launch_bounds__(BLOCK) void apply_moves_kernel(uint64_t *__restrict
 
 // One thread per float4 of the (n,2,8,8) tensor: 32 threads cover the 512 B
 // of one board, so a wave writes 1 KiB contiguous (fully coalesced stores).
+// index: optional gather list (row b of the output encodes board index[b]).
 __global__ __launch_bounds__(BLOCK) void encode_planes_kernel(const uint64_t *__restrict__ own,
                                                               const uint64_t *__restrict__ opp,
+                                                              const int64_t *__restrict__ index,
                                                               float4 *__restrict__ planes,
                                                               int64_t n)
 {
     const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const int64_t b = gtid >> 5;
-    if (b >= n)
+    const int64_t row = gtid >> 5;
+    if (row >= n)
         return;
+    const int64_t b = index ? index[row] : row;
     const uint32_t k = (uint32_t)gtid & 31u;
     // channel 0 = opponent of the side to move, channel 1 = side to move
     // (game.py:168-174: the colour-1 swap puts the mover in `state==2`)
@@ -219,8 +222,22 @@ int iago_encode_planes(const uint64_t *own, const uint64_t *opp, float *planes, 
     if (n == 0)
         return IAGO_OK;
     hipLaunchKernelGGL(encode_planes_kernel, dim3(grid_for(n * 32)), dim3(BLOCK), 0,
-                       (hipStream_t)stream, own, opp, (float4 *)planes, n);
+                       (hipStream_t)stream, own, opp, (const int64_t *)nullptr, (float4 *)planes, n);
     return iago_check_launch("iago_encode_planes");
+}
+
+int iago_encode_planes_indexed(const uint64_t *own, const uint64_t *opp, const int64_t *index, float *planes,
+                               int64_t n, void *stream)
+{
+    if (n < 0 || (n > 0 && (!own || !opp || !index || !planes)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_encode_planes_indexed: null pointer or negative n");
+    if (((uintptr_t)planes & 15u) != 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_encode_planes_indexed: planes must be 16-byte aligned");
+    if (n == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(encode_planes_kernel, dim3(grid_for(n * 32)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, own, opp, index, (float4 *)planes, n);
+    return iago_check_launch("iago_encode_planes_indexed");
 }
 
 int iago_judge(const uint64_t *own, const uint64_t *opp, int8_t *z, int64_t n, void *stream)

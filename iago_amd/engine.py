@@ -178,7 +178,8 @@ class BatchedMCTS(object):
         """Expansion branch of MCTS.playout (MCTS.py:109-121) for the games whose
         cursor sits on a leaf with n_visits >= n_thr.  One host sync."""
         L = _lib.lib()
-        idx = torch.nonzero(self.needs_expand & active).reshape(-1)  # host sync: usually small
+        pending = self.needs_expand & active
+        idx = torch.nonzero(pending).reshape(-1)  # host sync: usually small
         if idx.numel() == 0:
             return
         games = idx.to(torch.int32)
@@ -187,15 +188,13 @@ class BatchedMCTS(object):
         # shape: run the policy net on a few fixed bucket sizes only
         nb = self._bucket(n_exp)
         sub_planes = self._policy_in[:nb]
-        ops.encode_planes(self.cur_own[idx], self.cur_opp[idx], out=sub_planes[:n_exp])
+        ops.encode_planes_indexed(self.cur_own, self.cur_opp, idx, sub_planes)
         with torch.no_grad():
             probs = self.policy_fn(sub_planes).to(torch.float32).contiguous()
         self.n_policy_evals += n_exp
         check(L.iago_mcts_expand(self.tree.ref(), _p(games), games.numel(), _p(self.cur_node),
                                  _p(self.legal), _p(probs), _stream()), "iago_mcts_expand")
-        sub_active = torch.zeros_like(active)
-        sub_active[idx] = 1
-        self._select(own, opp, sub_active, False)  # MCTS.py:121: recurse into the same node
+        self._select(own, opp, pending, False)  # MCTS.py:121: recurse into the same node
 
     def _evaluate_and_backup(self, active, stream_id=0, stream_id_dev=None):
         """Leaf evaluation (MCTS.py:123-127) and Node.update_recursive."""

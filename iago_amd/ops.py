@@ -73,6 +73,18 @@ def encode_planes(own, opp, out=None):
     return out
 
 
+def encode_planes_indexed(own, opp, index, out):
+    """Planes of boards index[0..k) (int64 tensor) into out[:k] (game.py:168-174)."""
+    k = index.numel()
+    if out.numel() < k * 128:
+        raise ValueError("planes buffer is too small")
+    check(_lib.lib().iago_encode_planes_indexed(_dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp"),
+                                                _dev(index, torch.int64, "index"),
+                                                _dev(out, torch.float32, "planes"), k, _stream()),
+          "iago_encode_planes_indexed")
+    return out
+
+
 def judge(own, opp):
     """sign(#own - #opp) as int8 (mcts_self_play.py:113-121)."""
     n = own.numel()

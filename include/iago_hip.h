@@ -90,6 +90,10 @@ IAGO_API int iago_apply_moves(uint64_t *own, uint64_t *opp, const int8_t *action
  */
 IAGO_API int iago_encode_planes(const uint64_t *own, const uint64_t *opp, float *planes, int64_t n,
                        void *stream);
+/* The same for a gather list: row b of `planes` encodes board index[b] (int64; each in
+ * [0, number of boards)): the planes of the few games a playout expands (MCTS.py:109-113). */
+IAGO_API int iago_encode_planes_indexed(const uint64_t *own, const uint64_t *opp, const int64_t *index,
+                                        float *planes, int64_t n, void *stream);
 
 /*
  * z[b] = sign(popcount(own) - popcount(opp)) as int8.  Replaces

@@ -177,3 +177,17 @@ def test_augment8_golden_and_oracle(ops, golden_rules):
     pop = np.vectorize(lambda v: bin(int(v)).count("1"))
     mob = pop(lm[:, :400])
     assert np.all(mob == mob[0:1])
+
+
+@pytest.mark.gpu
+def test_encode_planes_indexed_matches_gather():
+    import torch
+    from iago_amd import ops
+    g = torch.Generator().manual_seed(3)
+    own = torch.randint(-2**62, 2**62, (97,), generator=g, dtype=torch.int64)
+    opp = torch.randint(-2**62, 2**62, (97,), generator=g, dtype=torch.int64) & ~own
+    idx = torch.tensor([5, 0, 96, 42, 42, 7], dtype=torch.int64)
+    out = torch.zeros(8, 2, 8, 8, device="cuda")
+    ops.encode_planes_indexed(own.cuda(), opp.cuda(), idx.cuda(), out)
+    want = ops.encode_planes(own[idx].cuda(), opp[idx].cuda())
+    assert torch.equal(out[:6], want) and float(out[6:].abs().sum()) == 0.0
