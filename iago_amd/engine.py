@@ -231,6 +231,13 @@ class BatchedMCTS(object):
     def _capture(self):
         if self.rollout_hook is not None:
             raise ValueError("rollout_hook is not available in graph mode")
+        if self.lmbda < 1.0:
+            # one eager evaluation first: lazy one-time setup (kernel attributes, MIOpen's
+            # choice for this shape, cached weight layouts) must not happen under capture
+            ops.encode_planes(self.cur_own, self.cur_opp, out=self.planes)
+            with torch.no_grad():
+                self.value_fn(self.planes)
+            torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._evaluate_and_backup(self._g_active, stream_id=0, stream_id_dev=self._sim_dev)
