@@ -24,7 +24,7 @@
 // 2 x 128 accumulator registers per wave; 2, the default: two waves per SIMD, 2 x 2 tiles
 // each -- same speed at 1024 boards, no spills, shorter epilogue).  The K loop runs over stages of (16 input channels) x
 // (one kernel row = 3 taps); the padded 10x10 planes of a channel block and the weights
-// of a stage are double-buffered in LDS (150 KB), the next stage's global loads are
+// of a stage are double-buffered in LDS (159 KB), the next stage's global loads are
 // issued before the current stage's MFMAs and written to LDS after them.
 #include "abi_common.hpp"
 
@@ -49,11 +49,20 @@ static_assert(XQ * THREADS == 512 && (CS == 1 || CS == 2), "piece counts");
 constexpr int COUT = 128;
 constexpr int ROW = 48;         // bytes per LDS row: 16 halfs + 16 B padding (conflict-free b128 reads)
 constexpr int PP = 100;         // padded 10x10 plane
-constexpr int X_HALF = TB * PP * ROW;          // one of hi / lo: 19,200 B
-constexpr int X_BUF = 2 * X_HALF;              // 38,400 B
+// Rows of the padded planes in the X buffers start at xrow(Y) = 24 (Y >> 1) + 10 (Y & 1)
+// (in 48-byte cell rows) instead of 10 Y: with the lane -> cell map of cell_of_lane() the
+// 16 lanes that one LDS cycle of a ds_read_b128 serves then always sit on 16 different
+// 4-bank groups, for every tap (xrow(Y + 2) = xrow(Y) + 24 = 8 mod 16).
+constexpr int XPP = 116;                       // cell rows per padded plane
+__host__ __device__ constexpr int xrow(int Y)
+{
+    return 24 * (Y >> 1) + 10 * (Y & 1);
+}
+constexpr int X_HALF = TB * XPP * ROW;         // one of hi / lo: 22,272 B
+constexpr int X_BUF = 2 * X_HALF;              // 44,544 B
 constexpr int W_HALF = 3 * COUT * ROW;         // 18,432 B
 constexpr int W_BUF = 2 * W_HALF;              // 36,864 B
-constexpr int LDS_BYTES = 2 * X_BUF + 2 * W_BUF; // 150,528 B
+constexpr int LDS_BYTES = 2 * X_BUF + 2 * W_BUF; // 162,816 B of 163,840
 constexpr int T_ROW = (COUT + 4) * 2;          // epilogue image: 132 halfs per cell
 constexpr int T_HALF = TB * 64 * T_ROW;        // 67,584 B
 static_assert(2 * T_HALF + COUT * 4 <= LDS_BYTES, "epilogue image must fit in the staging buffers");
@@ -89,8 +98,17 @@ struct StagedX {
     u32x4 x[2 * XQ]; // hi + lo pieces of a channel block of the 4 boards
 };
 
-__device__ __forceinline__ void load_frags(Frags &F, const char *wb, const char *xb, int a_off, int b_off,
-                                           int kx)
+// ds_read_b128 serves the lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (and the same
+// + 32) in separate LDS cycles.  Lane r of a 32-cell block holds board rows 0 and 2 of the
+// block in the first group and rows 1 and 3 in the second: (row << 3) | column.
+__device__ __forceinline__ int cell_of_lane(int r)
+{
+    return r < 4 ? r : r < 12 ? 8 + (r - 4) : r < 16 ? r - 8 : r < 20 ? 24 + (r - 16) : r < 28 ? 16 + (r - 20)
+                                                                                            : 24 + (r - 24);
+}
+
+__device__ __forceinline__ void load_frags(Frags &F, const char *wb, const char *xb, int a_off, int b_off0,
+                                           int b_off1, int kx)
 {
 #pragma unroll
     for (int i = 0; i < NI; i++) {
@@ -100,7 +118,7 @@ __device__ __forceinline__ void load_frags(Frags &F, const char *wb, const char 
     }
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        const int off = b_off + (40 * j + kx) * ROW; // cells 32j.. are 4 rows further down
+        const int off = (j ? b_off1 : b_off0) + kx * ROW;
         F.b_hi[j] = lds_half8(xb + off);
         F.b_lo[j] = lds_half8(xb + X_HALF + off);
     }
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
         const int64_t b = min(b0 + (e >> 7), P.n - 1);
         x_src[q] = b * P.n_chunks * 128 + (e & 127); // + chunk * 128, in 16-B pieces
         const int cell = (e >> 1) & 63;
-        x_dst[q] = ((e >> 7) * PP + ((cell >> 3) + 1) * 10 + (cell & 7) + 1) * ROW + (e & 1) * 16;
+        x_dst[q] = ((e >> 7) * XPP + xrow((cell >> 3) + 1) + (cell & 7) + 1) * ROW + (e & 1) * 16;
     }
     int w_piece[WQ], w_dst[WQ];
 #pragma unroll
@@ -218,7 +236,11 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
 
     // lane-constant parts of the operand addresses
     const int a_off = (cs * 32 * NI + r) * ROW + h * 16;                 // + (kx*128 + 32i) * ROW
-    const int b_off0 = (w * PP + (r >> 3) * 10 + (r & 7)) * ROW + h * 16; // + ((4j + ky)*10 + kx) * ROW
+    const int lane_cell = cell_of_lane(r); // (row << 3) | column within a 32-cell block
+    // B operand: padded cell (4j + row + ky, column + kx) of board w
+    auto b_off = [=](int j, int ky) {
+        return (w * XPP + xrow(4 * j + (lane_cell >> 3) + ky) + (lane_cell & 7)) * ROW + h * 16;
+    };
 
     commit_w(fetch_w(0), 0);
     commit_x(fetch_x(0), 0);
@@ -236,7 +258,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
     Frags F0, F1;
     StagedW W0, W1 = fetch_w(min(1, n_stages - 1)); // Wt / Xt: data of a stage of parity t
     StagedX X0, X1 = fetch_x(0);
-    load_frags(F0, wbuf, xbuf, a_off, b_off0, 0);
+    load_frags(F0, wbuf, xbuf, a_off, b_off(0, 0), b_off(1, 0), 0);
     auto stage = [&](int s, Frags &Fa, Frags &Fb, StagedW &Wthis, StagedX &Xthis, const StagedW &Wnext,
                      const StagedX &Xnext) {
         const int chunk = s / 3, ky = s - 3 * chunk; // Fa holds k-step 0 of stage s
@@ -244,18 +266,18 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
         const int chunk1 = s1 / 3, ky1 = s1 - 3 * chunk1;
         const char *xb = xbuf + (chunk & 1) * X_BUF;
         const char *wb = wbuf + (s & 1) * W_BUF;
-        const int b_off = b_off0 + ky * 10 * ROW;
+        const int bo0 = b_off(0, ky), bo1 = b_off(1, ky);
         Wthis = fetch_w(s2);
         Xthis = fetch_x(s2 / 3);
-        load_frags(Fb, wb, xb, a_off, b_off, 1);
+        load_frags(Fb, wb, xb, a_off, bo0, bo1, 1);
         mfma_step(Fa, acc_main, acc_cross);
-        load_frags(Fa, wb, xb, a_off, b_off, 2);
+        load_frags(Fa, wb, xb, a_off, bo0, bo1, 2);
         mfma_step(Fb, acc_main, acc_cross);
         commit_w(Wnext, (s + 1) & 1);
         commit_x(Xnext, chunk1 & 1);
         __syncthreads();
-        load_frags(Fb, wbuf + ((s + 1) & 1) * W_BUF, xbuf + (chunk1 & 1) * X_BUF, a_off,
-                   b_off0 + ky1 * 10 * ROW, 0);
+        load_frags(Fb, wbuf + ((s + 1) & 1) * W_BUF, xbuf + (chunk1 & 1) * X_BUF, a_off, b_off(0, ky1),
+                   b_off(1, ky1), 0);
         mfma_step(Fa, acc_main, acc_cross);
     };
     for (int s = 0; s < n_stages; s += 2) { // n_stages is even (cin a multiple of 32)
@@ -265,7 +287,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
     __syncthreads();
 
     // ---- epilogue: bias, ReLU, split, transpose through LDS, coalesced stores
-    // D tile (i, j): lane holds cell 32j + r, channels 32i + 8(v>>2) + 4h + (v&3)
+    // D tile (i, j): lane holds cell 32j + cell_of_lane(r), channels 32i + 8(v>>2) + 4h + (v&3)
     char *const t_hi = lds, *const t_lo = lds + T_HALF;
     float *const bias_lds = (float *)(lds + 2 * T_HALF);
     if (tid < COUT)
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
                     hi4[t] = vh;
                     lo4[t] = __float2half_rn((v - __half2float(vh)) * 2048.0f);
                 }
-                const int off = (w * 64 + 32 * j + r) * T_ROW + co * 2;
+                const int off = (w * 64 + 32 * j + lane_cell) * T_ROW + co * 2;
                 *(uint2 *)(t_hi + off) = *(const uint2 *)hi4;
                 *(uint2 *)(t_lo + off) = *(const uint2 *)lo4;
             }
@@ -671,7 +693,7 @@ int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, con
     if (!configured) {
         if (hipFuncSetAttribute((const void *)conv3x3_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
-            return iago_fail(IAGO_ERR_HIP, "iago_conv3x3_split: cannot reserve 147 KB of LDS");
+            return iago_fail(IAGO_ERR_HIP, "iago_conv3x3_split: cannot reserve 159 KB of LDS");
         configured = true;
     }
     ConvParams P;
