@@ -248,41 +248,43 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
 
     // One stage = one kernel row (3 taps) x 16 input channels; its three k-steps alternate
     // between two fragment sets, the next k-step's LDS reads are issued before the
-    // current one's MFMAs.  The data of a stage (its weights and the channel block of the
-    // boards it reads) travel global -> registers two stages ahead (the L2 latency under
-    // 256 workgroups asking for the same lines is longer than a stage) and registers ->
-    // LDS before the third k-step of the stage before, whose MFMAs then run behind the
-    // barrier together with the first fragment reads of the next stage.  Every stage
-    // moves the same number of pieces (the channel block is re-written with identical
-    // bytes while it is in use): the vmcnt bookkeeping stays exact across the loop.
+    // current one's MFMAs.  The data of stage s + 1 (its weights and the channel block of
+    // the boards it reads) are fetched global -> registers at the start of stage s - 1 and
+    // written registers -> LDS at the start of stage s, right AFTER the barrier that freed
+    // the other buffers (so the LDS writes run beside this stage's MFMAs instead of in
+    // front of a barrier), one register set; the third k-step's MFMAs run behind the
+    // closing barrier together with the first fragment reads of the next stage.  Every
+    // stage moves the same number of pieces (the channel block is re-written with
+    // identical bytes while it is in use): the vmcnt bookkeeping stays exact.
     Frags F0, F1;
-    StagedW W0, W1 = fetch_w(min(1, n_stages - 1)); // Wt / Xt: data of a stage of parity t
-    StagedX X0, X1 = fetch_x(0);
+    StagedW GW = fetch_w(min(1, n_stages - 1)); // in flight: the data of the NEXT stage
+    StagedX GX = fetch_x(0);
     load_frags(F0, wbuf, xbuf, a_off, b_off(0, 0), b_off(1, 0), 0);
-    auto stage = [&](int s, Frags &Fa, Frags &Fb, StagedW &Wthis, StagedX &Xthis, const StagedW &Wnext,
-                     const StagedX &Xnext) {
+    auto stage = [&](int s, Frags &Fa, Frags &Fb) {
         const int chunk = s / 3, ky = s - 3 * chunk; // Fa holds k-step 0 of stage s
         const int s1 = min(s + 1, n_stages - 1), s2 = min(s + 2, n_stages - 1);
         const int chunk1 = s1 / 3, ky1 = s1 - 3 * chunk1;
         const char *xb = xbuf + (chunk & 1) * X_BUF;
         const char *wb = wbuf + (s & 1) * W_BUF;
         const int bo0 = b_off(0, ky), bo1 = b_off(1, ky);
-        Wthis = fetch_w(s2);
-        Xthis = fetch_x(s2 / 3);
+        // the barrier that ended stage s - 1 freed the other buffers: write the data of
+        // stage s + 1 (fetched a stage ago) there and re-issue the loads for stage s + 2
+        commit_w(GW, (s + 1) & 1);
+        commit_x(GX, chunk1 & 1);
+        GW = fetch_w(s2);
+        GX = fetch_x(s2 / 3);
         load_frags(Fb, wb, xb, a_off, bo0, bo1, 1);
         mfma_step(Fa, acc_main, acc_cross);
         load_frags(Fa, wb, xb, a_off, bo0, bo1, 2);
         mfma_step(Fb, acc_main, acc_cross);
-        commit_w(Wnext, (s + 1) & 1);
-        commit_x(Xnext, chunk1 & 1);
         __syncthreads();
         load_frags(Fb, wbuf + ((s + 1) & 1) * W_BUF, xbuf + (chunk1 & 1) * X_BUF, a_off, b_off(0, ky1),
                    b_off(1, ky1), 0);
         mfma_step(Fa, acc_main, acc_cross);
     };
     for (int s = 0; s < n_stages; s += 2) { // n_stages is even (cin a multiple of 32)
-        stage(s, F0, F1, W0, X0, W1, X1);
-        stage(s + 1, F1, F0, W1, X1, W0, X0);
+        stage(s, F0, F1);
+        stage(s + 1, F1, F0);
     }
     __syncthreads();
 
