@@ -614,6 +614,70 @@ def mcts_traces():
     return dict(w=w.tolist(), b=b.tolist(), cases=cases)
 
 
+# ------------------------------------------------- 6b. game front-end
+class ScriptedMCTS(object):
+    """Stand-in for MCTS.MCTS behind game.Game: get_move picks a legal move from a hash
+    of the position, every call is logged (the front-end's call pattern is the fixture)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def get_move(self, state, color):
+        acts = gf.legal_actions(state, color)
+        p1, p2 = to_bits(state)
+        a = acts[(p1 * 31 + p2 * 17 + color) % len(acts)]
+        self.calls.append(["get_move", p1, p2, int(color), int(a)])
+        return a
+
+    def update_with_move(self, move):
+        self.calls.append(["update_with_move", int(move)])
+
+
+def frontend_traces():
+    """game.Game in auto mode (game.py:13-150, 236-262): ASCII board, prompts, gamelog
+    text and the MCTS call pattern, with stand-ins for the Chainer model and MCTS.MCTS
+    (Game.__init__ loads npz files through Chainer) and the recorded np.random.choice."""
+    import io
+    cases = []
+    real_choice = np.random.choice
+    try:
+        for g, start in enumerate([None, "pass1"]):
+            game = ref_game.Game.__new__(ref_game.Game)
+            game.p1, game.p2 = "IaGo(SLPolicy)", "IaGo(PV-MCTS)"   # game.py:19,25
+            game.model = FakePolicy(40 + g)
+            game.state = np.zeros([8, 8], dtype=np.float32)
+            game.state[4, 3] = game.state[3, 4] = 1
+            game.state[3, 3] = game.state[4, 4] = 2
+            if start is not None:
+                game.state = parse(EDGE_BOARDS[start])
+            game.stone_num = int(np.sum(game.state != 0))
+            game.play_num = 1
+            game.pass_flg = False
+            game.date = "2000-01-0%d-00-00" % (g + 1)
+            game.gamelog = "IaGo \n" + game.date + "\n"
+            game.mcts = ScriptedMCTS()
+            p1, p2 = to_bits(game.state)
+            rec = Recorder(7700 + g)
+            np.random.choice = rec
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                game.show()
+                while game.stone_num < 64:       # game.py:249-251
+                    game.turn(1, True)
+                    game.turn(2, True)
+                jd = game.judge()
+                print(jd)
+                game.gamelog += jd + "\n"
+            np.random.choice = real_choice
+            f1, f2 = to_bits(game.state)
+            cases.append(dict(p1=p1, p2=p2, salt=40 + g, date=game.date, us=rec.us, stdout=buf.getvalue(),
+                              gamelog=game.gamelog, calls=game.mcts.calls, final=[f1, f2],
+                              play_num=int(game.play_num)))
+    finally:
+        np.random.choice = real_choice
+    return dict(cases=cases)
+
+
 # ----------------------------------------------------------- 7. sampling
 def sampling():
     rs = np.random.RandomState(99)
@@ -689,6 +753,8 @@ def main():
         json.dump(node_math(), f)
     with open(os.path.join(OUT, "mcts.json"), "w") as f:
         json.dump(mcts_traces(), f)
+    with open(os.path.join(OUT, "frontend.json"), "w") as f:
+        json.dump(frontend_traces(), f)
     print("records:", len(recs), "games:", len(games), "edge boards:", len(names))
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
