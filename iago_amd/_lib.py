@@ -26,7 +26,8 @@ SYMBOLS = [
     "iago_conv3x3_split", "iago_split_nchw", "iago_merge_nchw", "iago_value_stem", "iago_value_head",
     "iago_conv3x3_f32", "iago_stem_f32", "iago_policy_head",
     "iago_rollout_build_table", "iago_rollout",
-    "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_leaf_values",
+    "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_mcts_pending",
+    "iago_leaf_values",
     "iago_mcts_backup", "iago_mcts_best_move", "iago_mcts_advance_root",
 ]
 

@@ -296,6 +296,50 @@ int check_tree(const Tree *t, const char *who)
     return IAGO_OK;
 }
 
+// The games whose cursor sits on a leaf due for expansion, in ascending order: one block
+// scans the flags in chunks of 1024 (ballot + prefix over the 16 waves).
+__global__ __launch_bounds__(1024) void pending_kernel(const uint8_t *__restrict__ needs_expand,
+                                                       const uint8_t *__restrict__ active, int n,
+                                                       uint8_t *__restrict__ pending,
+                                                       int64_t *__restrict__ index,
+                                                       int32_t *__restrict__ games, int32_t *__restrict__ count)
+{
+    __shared__ int wave_sum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0)
+        base = 0;
+    __syncthreads();
+    for (int g0 = 0; g0 < n; g0 += 1024) {
+        const int g = g0 + tid;
+        const bool p = g < n && needs_expand[g] != 0 && active[g] != 0;
+        if (g < n)
+            pending[g] = p ? 1 : 0;
+        const unsigned long long m = __ballot(p);
+        if (lane == 0)
+            wave_sum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; w++)
+            off += wave_sum[w];
+        if (p) {
+            const int k = off + __popcll(m & ((1ull << lane) - 1ull));
+            index[k] = g;
+            games[k] = g;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = base;
+            for (int w = 0; w < 16; w++)
+                t += wave_sum[w];
+            base = t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0)
+        *count = base;
+}
+
 } // namespace
 
 extern "C" {
@@ -345,6 +389,18 @@ int iago_mcts_expand(const iago_mcts_tree *tree, const int32_t *games, int64_t n
     hipLaunchKernelGGL(expand_kernel, dim3(grid_for(n_expand * 8)), dim3(BLOCK), 0,
                        (hipStream_t)stream, *tree, games, n_expand, cur_node, legal, probs);
     return iago_check_launch("iago_mcts_expand");
+}
+
+int iago_mcts_pending(const uint8_t *needs_expand, const uint8_t *active, int64_t n, uint8_t *pending,
+                      int64_t *index, int32_t *games, int32_t *count, void *stream)
+{
+    if (n < 0 || (n > 0 && (!needs_expand || !active || !pending || !index || !games || !count)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_pending: null pointer or negative n");
+    if (n > (1 << 24))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_pending: more than 2^24 games");
+    hipLaunchKernelGGL(pending_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, needs_expand, active,
+                       (int)n, pending, index, games, count);
+    return iago_check_launch("iago_mcts_pending");
 }
 
 int iago_leaf_values(const float *v, const int8_t *z, float lmbda, float *leaf_value, int64_t n,

@@ -122,6 +122,10 @@ class BatchedMCTS(object):
         self.cur_own = torch.zeros(n_games, dtype=torch.int64, **kw)
         self.cur_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
         self.needs_expand = torch.zeros(n_games, dtype=torch.uint8, **kw)
+        self._pending = torch.zeros(n_games, dtype=torch.uint8, **kw)
+        self._pend_idx = torch.zeros(n_games, dtype=torch.int64, **kw)
+        self._pend_games = torch.zeros(n_games, dtype=torch.int32, **kw)
+        self._pend_count = torch.zeros(1, dtype=torch.int32, **kw)
         self.legal = torch.zeros(n_games, dtype=torch.int64, **kw)
         self.leaf_value = torch.zeros(n_games, dtype=torch.float32, **kw)
         self.planes = torch.zeros((n_games, 2, 8, 8), dtype=torch.float32, **kw)
@@ -178,12 +182,13 @@ class BatchedMCTS(object):
         """Expansion branch of MCTS.playout (MCTS.py:109-121) for the games whose
         cursor sits on a leaf with n_visits >= n_thr.  One host sync."""
         L = _lib.lib()
-        pending = self.needs_expand & active
-        idx = torch.nonzero(pending).reshape(-1)  # host sync: usually small
-        if idx.numel() == 0:
+        check(L.iago_mcts_pending(_p(self.needs_expand), _p(active), self.n_games, _p(self._pending),
+                                  _p(self._pend_idx), _p(self._pend_games), _p(self._pend_count),
+                                  _stream()), "iago_mcts_pending")
+        n_exp = int(self._pend_count.item())  # the one host sync of a playout
+        if n_exp == 0:
             return
-        games = idx.to(torch.int32)
-        n_exp = int(idx.numel())
+        pending, idx, games = self._pending, self._pend_idx[:n_exp], self._pend_games[:n_exp]
         # MIOpen picks (and on first sight searches for) a kernel per input
         # shape: run the policy net on a few fixed bucket sizes only
         nb = self._bucket(n_exp)

@@ -323,6 +323,17 @@ IAGO_API int iago_mcts_expand(const iago_mcts_tree *tree, const int32_t *games, 
                               void *stream);
 
 /*
+ * The games a playout has to expand before it can go on (MCTS.py:109: the leaf reached
+ * n_thr visits): pending[g] = needs_expand[g] && active[g] (0/1), their ids in ascending
+ * order as index[] (int64) and games[] (int32, what iago_mcts_expand takes), *count =
+ * how many.  index / games must hold n entries.  One small launch in place of a mask,
+ * a stream compaction and a type conversion.
+ */
+IAGO_API int iago_mcts_pending(const uint8_t *needs_expand, const uint8_t *active, int64_t n,
+                               uint8_t *pending, int64_t *index, int32_t *games, int32_t *count,
+                               void *stream);
+
+/*
  * leaf_value = (1-lmbda)*v + lmbda*z in the reference's float32 arithmetic
  * (MCTS.py:123-125); v may be NULL when lmbda >= 1, z when lmbda <= 0.
  */

@@ -255,3 +255,25 @@ def test_graph_mode_equals_eager(eng):
         assert torch.allclose(a[k].reshape(G, 1024)[used], b[k].reshape(G, 1024)[used],
                               rtol=0, atol=1e-5), k
     assert np.array_equal(a[5], b[5])
+
+
+def test_pending_compaction():
+    """iago_mcts_pending: mask, ascending ids (int64 and int32) and count in one launch."""
+    import ctypes as C
+    import torch
+    from iago_amd import _lib
+    g = torch.Generator().manual_seed(4)
+    for n in (1, 63, 1024, 2500):
+        need = (torch.rand(n, generator=g) < 0.07).to(torch.uint8).cuda()
+        act = (torch.rand(n, generator=g) < 0.8).to(torch.uint8).cuda()
+        pend = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        idx = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+        games = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().iago_mcts_pending(p(need), p(act), n, p(pend), p(idx), p(games), p(cnt), None))
+        want = torch.nonzero(need & act).reshape(-1)
+        k = int(cnt.item())
+        assert k == want.numel()
+        assert torch.equal(idx[:k], want) and torch.equal(games[:k].long(), want)
+        assert torch.equal(pend, need & act)
