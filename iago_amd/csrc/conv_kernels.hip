@@ -22,10 +22,15 @@
 // Kernel: one workgroup = 4 boards x all 128 output channels; CS waves per board (1: one
 // wave per SIMD with the whole register file, 4 x 2 tiles of v_mfma_f32_32x32x16_f16 and
 // 2 x 128 accumulator registers per wave; 2, the default: two waves per SIMD, 2 x 2 tiles
-// each -- same speed at 1024 boards, no spills, shorter epilogue).  The K loop runs over stages of (16 input channels) x
-// (one kernel row = 3 taps); the padded 10x10 planes of a channel block and the weights
-// of a stage are double-buffered in LDS (159 KB), the next stage's global loads are
-// issued before the current stage's MFMAs and written to LDS after them.
+// each -- same speed at 1024 boards, no spills, shorter epilogue).  The K loop runs over
+// stages of (16 input channels) x (one kernel row = 3 taps); the padded 10x10 planes of a
+// channel block and the weights of a stage are double-buffered in LDS (159 KB); the data of
+// stage s + 1 are fetched into registers a stage ahead and written to LDS right after the
+// barrier that opens stage s.
+//
+// The same file holds the float32 kernels around it: the Value stem and head, and the
+// small-batch float32 stack (conv3x3_f32_kernel, stem_f32_kernel, policy_head_kernel) that
+// serves the policy net on the expansions of a playout and single-game play.
 #include "abi_common.hpp"
 
 #include <hip/hip_fp16.h>
