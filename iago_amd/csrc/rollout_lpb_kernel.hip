@@ -307,6 +307,7 @@ __global__ __launch_bounds__(BLOCK) IAGO_LPB_ATTR void rollout_lpb_kernel(LpbPar
     uint32_t rw[4] = {0, 0, 0, 0};
     const ShiftAmounts SA = opaque_shift_amounts();
 
+    Padded To = pad_board(own), Tp = pad_board(opp);
     for (uint32_t t = 0; t < (uint32_t)IAGO_MAX_TURNS; t++) {
         // ---- uniform of this turn: word t&3 of Philox counter (rid, t>>2, stream, 0)
         float u;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(BLOCK) IAGO_LPB_ATTR void rollout_lpb_kernel(LpbPar
             S.cells[i] = 0u;
         S.rem = done ? 0ull : legal;
         S.acc = 0.0f;
-        fill_slots<0>(S, pad_board(own), pad_board(opp), (const char *)ct, be, u);
+        fill_slots<0>(S, To, Tp, (const char *)ct, be, u);
         // ---- inverse CDF (mcts_self_play.py:103-106): slot = #sums <= u * total
         uint32_t slot = (uint32_t)S.filled - (uint32_t)__popc(S.above_lo) - (uint32_t)__popc(S.above_hi);
         const uint32_t nlegal = (uint32_t)__popcll(legal);
@@ -363,6 +364,15 @@ __global__ __launch_bounds__(BLOCK) IAGO_LPB_ATTR void rollout_lpb_kernel(LpbPar
             P.trace[(int64_t)t * P.n + b] = play ? (uint8_t)action : (uint8_t)IAGO_TRACE_PASS;
         own = nopp; // the other side moves next (finished boards swap an even number of times)
         opp = nown;
+        // the guard-column strings follow incrementally: only the changed cells are spread
+        {
+            const Padded D = pad_board(fm | bit);
+            const Padded oldTo = To;
+            To.w01 = Tp.w01 & ~D.w01; // new mover = old opponent minus the flipped stones
+            To.w12 = Tp.w12 & ~D.w12;
+            Tp.w01 = oldTo.w01 | D.w01;
+            Tp.w12 = oldTo.w12 | D.w12;
+        }
         nt += live_turn;
         if (t & 1u) { // `while stone_num < 64` once per pair of turns
             done |= stones >> 6;
