@@ -40,6 +40,7 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); // a 16-byte piece in registers
+typedef float f32x4 __attribute__((ext_vector_type(4)));        // (HIP's float4 / uint4 structs end up in scratch)
 
 constexpr int TB = 4;           // boards per workgroup
 #ifndef IAGO_CONV_CS
@@ -541,13 +542,23 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
     const int64_t b = blockIdx.x >> 2;
     const int cg = blockIdx.x & 3;
 
-    // weights of tap 0 on their way while the board is staged
-    const float4 *wsrc = P.w + ((int64_t)(cg * 9) * CIN + q * CQ) * (F32_CO / 4) + lane;
+    // weights of taps 0 and 1 and the whole board on their way before anything waits
+    const f32x4 *wsrc = (const f32x4 *)P.w + ((int64_t)(cg * 9) * CIN + q * CQ) * (F32_CO / 4) + lane;
     constexpr int WPIECES = SLAB / 4 / 64; // float4 pieces per lane and slab
-    float4 wreg[WPIECES];
+    constexpr int TAP = CIN * (F32_CO / 4); // float4 pieces between the slabs of two taps
+    f32x4 w0[WPIECES], wreg[WPIECES];
 #pragma unroll
     for (int k = 0; k < WPIECES; k++)
-        wreg[k] = wsrc[k * 64];
+        w0[k] = wsrc[k * 64];
+#pragma unroll
+    for (int k = 0; k < WPIECES; k++)
+        wreg[k] = wsrc[TAP + k * 64];
+    constexpr int XPIECES = CIN * 16 / 256; // float4 pieces of the board per thread
+    const f32x4 *xsrc = (const f32x4 *)(P.x + b * CIN * 64);
+    f32x4 xv[XPIECES];
+#pragma unroll
+    for (int k = 0; k < XPIECES; k++)
+        xv[k] = xsrc[tid + k * 256];
 
     // ---- stage the board: zero the borders, copy the 8x8 interiors
     for (int i = tid; i < CIN * 36; i += 256) {
@@ -556,20 +567,20 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
         const int pp = e < 10 ? e : e < 20 ? 80 + e : (e - 20) < 8 ? (e - 19) * 10 : (e - 27) * 10 + 9;
         xs[c * F32_XPLANE + pp] = 0.0f;
     }
-    const float4 *xsrc = (const float4 *)(P.x + b * CIN * 64);
-    for (int i = tid; i < CIN * 16; i += 256) {
-        const float4 v = xsrc[i];
-        const int c = i >> 4, cell = (i & 15) * 4;
-        float *d = xs + c * F32_XPLANE + ((cell >> 3) + 1) * 10 + (cell & 7) + 1;
-        d[0] = v.x;
-        d[1] = v.y;
-        d[2] = v.z;
-        d[3] = v.w;
-    }
     float *const wq = ws + q * 2 * SLAB;
 #pragma unroll
     for (int k = 0; k < WPIECES; k++)
-        ((float4 *)wq)[k * 64 + lane] = wreg[k];
+        ((f32x4 *)wq)[k * 64 + lane] = w0[k];
+#pragma unroll
+    for (int k = 0; k < XPIECES; k++) {
+        const int i = tid + k * 256;
+        const int c = i >> 4, cell = (i & 15) * 4;
+        float *d = xs + c * F32_XPLANE + ((cell >> 3) + 1) * 10 + (cell & 7) + 1;
+        d[0] = xv[k].x;
+        d[1] = xv[k].y;
+        d[2] = xv[k].z;
+        d[3] = xv[k].w;
+    }
     __syncthreads();
 
     float16v acc[2];
@@ -581,13 +592,24 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
 
     // lane-constant operand offsets: A = W[k = 2t + h][co = r], B = X[ci = .. + 2t + h][cell]
     const float *const xq = xs + (q * CQ + h) * F32_XPLANE + (r >> 3) * 10 + (r & 7);
+    // Tap t reads its weight slab from buffer t & 1.  At its start the slab of tap t + 1
+    // (in registers since tap t - 1) goes to the other buffer, which this wave alone read
+    // last in tap t - 1 (no barrier), and the loads of tap t + 2 are issued: a slab has a
+    // whole tap of MFMAs to arrive.
+#pragma unroll
     for (int tap = 0; tap < 9; tap++) {
         const int buf = tap & 1;
-        if (tap < 8) {
+        if (tap + 1 < 9) {
 #pragma unroll
             for (int k = 0; k < WPIECES; k++)
-                wreg[k] = wsrc[(int64_t)(tap + 1) * CIN * (F32_CO / 4) + k * 64];
+                ((f32x4 *)(wq + (buf ^ 1) * SLAB))[k * 64 + lane] = wreg[k];
         }
+        if (tap + 2 < 9) {
+#pragma unroll
+            for (int k = 0; k < WPIECES; k++)
+                wreg[k] = wsrc[(tap + 2) * TAP + k * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0); // the loads stay HERE, ahead of this tap's MFMAs
         const float *wa = wq + buf * SLAB + h * F32_CO + r;
         const float *xb = xq + (tap / 3) * 10 + tap % 3;
 #pragma unroll
@@ -597,12 +619,6 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
             const float b1 = xb[2 * t * F32_XPLANE + 40];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-        }
-        if (tap < 8) {
-            // the other buffer was last read in tap - 1 by this wave only: no barrier
-#pragma unroll
-            for (int k = 0; k < WPIECES; k++)
-                ((float4 *)(wq + (buf ^ 1) * SLAB))[k * 64 + lane] = wreg[k];
         }
     }
     __syncthreads();
