@@ -530,7 +530,10 @@ struct ConvF32Params {
     int32_t cin;
 };
 
-template <int CIN>
+// NJ = 2: a workgroup covers all 64 cells of its board (two 32-cell MFMA tiles per wave);
+// NJ = 1: half a board (rows 0-3 or 4-7), eight workgroups per board -- for batches so
+// small that four per board leave CUs idle.
+template <int CIN, int NJ>
 __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
 {
     constexpr int CQ = CIN / 4;              // input channels per wave
@@ -539,8 +542,10 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
     float *const xs = (float *)lds;                       // [CIN][100]
     float *const ws = xs + CIN * F32_XPLANE;              // [4 waves][2][SLAB]
     const int tid = threadIdx.x, q = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int64_t b = blockIdx.x >> 2;
-    const int cg = blockIdx.x & 3;
+    const unsigned wg = NJ == 2 ? blockIdx.x : blockIdx.x >> 1;
+    const int j0 = NJ == 2 ? 0 : (int)(blockIdx.x & 1); // first 32-cell tile of this workgroup
+    const int64_t b = wg >> 2;
+    const int cg = wg & 3;
 
     // weights of taps 0 and 1 and the whole board on their way before anything waits
     const f32x4 *wsrc = (const f32x4 *)P.w + ((int64_t)(cg * 9) * CIN + q * CQ) * (F32_CO / 4) + lane;
@@ -583,15 +588,15 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
     }
     __syncthreads();
 
-    float16v acc[2];
+    float16v acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
         for (int v = 0; v < 16; v++)
             acc[j][v] = 0.0f;
 
     // lane-constant operand offsets: A = W[k = 2t + h][co = r], B = X[ci = .. + 2t + h][cell]
-    const float *const xq = xs + (q * CQ + h) * F32_XPLANE + (r >> 3) * 10 + (r & 7);
+    const float *const xq = xs + (q * CQ + h) * F32_XPLANE + (4 * j0 + (r >> 3)) * 10 + (r & 7);
     // Tap t reads its weight slab from buffer t & 1.  At its start the slab of tap t + 1
     // (in registers since tap t - 1) goes to the other buffer, which this wave alone read
     // last in tap t - 1 (no barrier), and the loads of tap t + 2 are issued: a slab has a
@@ -615,10 +620,9 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
 #pragma unroll
         for (int t = 0; t < CQ / 2; t++) {
             const float a = wa[2 * t * F32_CO];
-            const float b0 = xb[2 * t * F32_XPLANE];
-            const float b1 = xb[2 * t * F32_XPLANE + 40];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[2 * t * F32_XPLANE + 40 * j], acc[j], 0, 0, 0);
         }
     }
     __syncthreads();
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
     // ---- the four K-quarters meet in LDS: red[q][j][v][lane]
     float *const red = (float *)lds;
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
         for (int v = 0; v < 16; v++)
             red[((q * 2 + j) * 16 + v) * 64 + lane] = acc[j][v];
@@ -634,7 +638,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
     // wave q finishes registers v = 4q .. 4q+3 of both tiles:
     // channel 32 cg + 8 (v >> 2) + 4 h + (v & 3) = 32 cg + 8 q + 4 h + t, cell 32 j + r
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int v = 4 * q + t;
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
             for (int qq = 0; qq < 4; qq++)
                 s += red[((qq * 2 + j) * 16 + v) * 64 + lane];
             const int co = 32 * cg + 8 * q + 4 * h + t;
-            P.y[(b * COUT + co) * 64 + 32 * j + r] = fmaxf(s + P.bias[co], 0.0f);
+            P.y[(b * COUT + co) * 64 + 32 * (j0 + j) + r] = fmaxf(s + P.bias[co], 0.0f);
         }
 }
 
@@ -780,17 +784,27 @@ int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y
     P.y = y;
     P.cin = cin;
     const size_t lds = (size_t)(cin * F32_XPLANE + 4 * 2 * (cin / 4) * F32_CO) * sizeof(float);
+    const int lds128 = (int)((128 * F32_XPLANE + 4 * 2 * 32 * F32_CO) * sizeof(float));
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void *)conv3x3_f32_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((128 * F32_XPLANE + 4 * 2 * 32 * F32_CO) * sizeof(float))) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv3x3_f32_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds128) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv3x3_f32_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds128) != hipSuccess)
             return iago_fail(IAGO_ERR_HIP, "iago_conv3x3_f32: cannot reserve LDS");
         configured = true;
     }
-    if (cin == 128)
-        hipLaunchKernelGGL(conv3x3_f32_kernel<128>, dim3((unsigned)(n * 4)), dim3(256), lds, (hipStream_t)stream, P);
+    // up to 32 boards: eight workgroups per board (half a board each) fill the CUs
+    const bool half = n <= 32;
+    const dim3 grid((unsigned)(n * (half ? 8 : 4)));
+    if (cin == 128 && half)
+        hipLaunchKernelGGL((conv3x3_f32_kernel<128, 1>), grid, dim3(256), lds, (hipStream_t)stream, P);
+    else if (cin == 128)
+        hipLaunchKernelGGL((conv3x3_f32_kernel<128, 2>), grid, dim3(256), lds, (hipStream_t)stream, P);
+    else if (half)
+        hipLaunchKernelGGL((conv3x3_f32_kernel<64, 1>), grid, dim3(256), lds, (hipStream_t)stream, P);
     else
-        hipLaunchKernelGGL(conv3x3_f32_kernel<64>, dim3((unsigned)(n * 4)), dim3(256), lds, (hipStream_t)stream, P);
+        hipLaunchKernelGGL((conv3x3_f32_kernel<64, 2>), grid, dim3(256), lds, (hipStream_t)stream, P);
     return iago_check_launch("iago_conv3x3_f32");
 }
 
