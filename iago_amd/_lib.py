@@ -23,12 +23,12 @@ SYMBOLS = [
     "iago_legal_moves", "iago_apply_moves", "iago_encode_planes", "iago_encode_planes_indexed",
     "iago_judge",
     "iago_sample_moves", "iago_augment8", "iago_bias_relu",
-    "iago_conv3x3_split", "iago_split_nchw", "iago_merge_nchw", "iago_value_stem", "iago_value_head",
+    "iago_conv3x3_split", "iago_split_nchw", "iago_merge_nchw", "iago_value_stem", "iago_value_stem_boards", "iago_value_head",
     "iago_conv3x3_f32", "iago_stem_f32", "iago_policy_head",
     "iago_rollout_build_table", "iago_rollout",
     "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_mcts_pending",
     "iago_leaf_values",
-    "iago_mcts_backup", "iago_mcts_best_move", "iago_mcts_advance_root",
+    "iago_mcts_backup", "iago_mcts_mix_backup", "iago_mcts_best_move", "iago_mcts_advance_root",
 ]
 
 
@@ -89,11 +89,22 @@ def lib():
     L.iago_legal_moves.argtypes = [vp, vp, vp, i64, vp]
     L.iago_apply_moves.argtypes = [vp, vp, vp, i64, vp]
     L.iago_encode_planes.argtypes = [vp, vp, vp, i64, vp]
+    L.iago_encode_planes_indexed.argtypes = [vp, vp, vp, vp, i64, vp]
     L.iago_judge.argtypes = [vp, vp, vp, i64, vp]
     L.iago_sample_moves.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
                                     i64, vp]
     L.iago_augment8.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
     L.iago_bias_relu.argtypes = [vp, vp, i64, C.c_int32, vp]
+    i32 = C.c_int32
+    L.iago_conv3x3_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
+    L.iago_split_nchw.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.iago_merge_nchw.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.iago_value_stem.argtypes = [vp, vp, vp, vp, vp, i64, vp]
+    L.iago_value_stem_boards.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
+    L.iago_value_head.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.iago_conv3x3_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp]
+    L.iago_stem_f32.argtypes = [vp, vp, vp, vp, i64, vp]
+    L.iago_policy_head.argtypes = [vp, vp, vp, vp, i64, vp]
     L.iago_rollout_build_table.argtypes = [vp, vp, vp]
     L.iago_rollout.argtypes = [C.POINTER(RolloutArgs), vp]
     tp = C.POINTER(MctsTree)
@@ -103,6 +114,8 @@ def lib():
     L.iago_mcts_expand.argtypes = [tp, vp, i64, vp, vp, vp, vp]
     L.iago_leaf_values.argtypes = [vp, vp, C.c_float, vp, i64, vp]
     L.iago_mcts_backup.argtypes = [tp, vp, vp, vp, vp]
+    L.iago_mcts_mix_backup.argtypes = [tp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
+    L.iago_mcts_pending.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp]
     L.iago_mcts_best_move.argtypes = [tp, vp, vp, vp, vp]
     L.iago_mcts_advance_root.argtypes = [tp, vp, vp, vp]
     for name in SYMBOLS[3:]:

@@ -385,7 +385,10 @@ __global__ __launch_bounds__(256) void merge_nchw_kernel(const __half *hi, const
 // ---- Value stem: block1 = 3x3 convolution 2 -> 64 + bias + ReLU (network.py:66-70),
 // float32 planes in, split channel blocks out.  K = 18: plain float32 FMAs.  One thread
 // per (board, channel block, half block, cell): 8 output channels of a cell.
-__global__ __launch_bounds__(256) void value_stem_kernel(const float *planes, const float *w, const float *bias,
+// planes: float32 [n][2][8][8], or NULL with the boards themselves in own / opp (plane 0 =
+// opponent of the side to move, plane 1 = side to move, game.py:168-174)
+__global__ __launch_bounds__(256) void value_stem_kernel(const float *planes, const uint64_t *own,
+                                                         const uint64_t *opp, const float *w, const float *bias,
                                                          uint4 *y_hi, uint4 *y_lo, int64_t n)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -395,6 +398,7 @@ __global__ __launch_bounds__(256) void value_stem_kernel(const float *planes, co
     const int64_t b = t >> 9;
     const int y = cell >> 3, x = cell & 7;
     const float *pl = planes + b * 128;
+    const uint64_t bits0 = planes ? 0ull : opp[b], bits1 = planes ? 0ull : own[b];
     float in[18];
 #pragma unroll
     for (int c = 0; c < 2; c++)
@@ -404,7 +408,13 @@ __global__ __launch_bounds__(256) void value_stem_kernel(const float *planes, co
             for (int kx = 0; kx < 3; kx++) {
                 const int yy = y + ky - 1, xx = x + kx - 1;
                 const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
-                in[c * 9 + ky * 3 + kx] = ok ? pl[c * 64 + yy * 8 + xx] : 0.0f;
+                const int a = (yy * 8 + xx) & 63;
+                float v;
+                if (planes)
+                    v = ok ? pl[c * 64 + a] : 0.0f;
+                else
+                    v = (ok && (((c ? bits1 : bits0) >> a) & 1ull)) ? 1.0f : 0.0f;
+                in[c * 9 + ky * 3 + kx] = v;
             }
     const int co0 = __builtin_amdgcn_readfirstlane(grp) * 8;
     __half h8[8], l8[8];
@@ -748,8 +758,24 @@ int iago_value_stem(const float *planes, const float *w1, const float *b1, void 
     if (!planes || !w1 || !b1 || !y_hi || !y_lo)
         return iago_fail(IAGO_ERR_INVALID, "iago_value_stem: null pointer");
     hipLaunchKernelGGL(value_stem_kernel, dim3((unsigned)((n * 512 + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, planes, w1, b1, (uint4 *)y_hi, (uint4 *)y_lo, n);
+                       (hipStream_t)stream, planes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, w1, b1,
+                       (uint4 *)y_hi, (uint4 *)y_lo, n);
     return iago_check_launch("iago_value_stem");
+}
+
+int iago_value_stem_boards(const uint64_t *own, const uint64_t *opp, const float *w1, const float *b1, void *y_hi,
+                           void *y_lo, int64_t n, void *stream)
+{
+    if (n < 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_stem_boards: negative n");
+    if (n == 0)
+        return IAGO_OK;
+    if (!own || !opp || !w1 || !b1 || !y_hi || !y_lo)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_stem_boards: null pointer");
+    hipLaunchKernelGGL(value_stem_kernel, dim3((unsigned)((n * 512 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float *)nullptr, own, opp, w1, b1, (uint4 *)y_hi,
+                       (uint4 *)y_lo, n);
+    return iago_check_launch("iago_value_stem_boards");
 }
 
 int iago_value_head(const void *x_hi, const void *x_lo, const float *w9, const float *b9, const float *w10,

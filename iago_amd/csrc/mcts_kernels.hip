@@ -233,6 +233,38 @@ __global__ __launch_bounds__(BLOCK) void backup_kernel(Tree T, const uint8_t *__
     }
 }
 
+// leaf mix (leaf_values_kernel) + backup (backup_kernel) in one launch; every game's mixed
+// value is also stored to `leaf_value`, thread 0 bumps the optional playout counter.
+__global__ __launch_bounds__(BLOCK) void mix_backup_kernel(Tree T, const uint8_t *__restrict__ active,
+                                                           const int32_t *__restrict__ cur_node,
+                                                           const float *__restrict__ v,
+                                                           const int8_t *__restrict__ z, float lmbda,
+                                                           float *__restrict__ leaf_value,
+                                                           uint32_t *__restrict__ counter)
+{
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g == 0 && counter)
+        *counter += 1u;
+    if (g >= T.n_games)
+        return;
+    // (1-lmbda)*v + lmbda*z exactly as leaf_values_kernel (MCTS.py:123-125)
+    const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * v[g] : 0.0f;
+    const float b = (lmbda > 0.0f) ? (float)((double)lmbda * (double)z[g]) : 0.0f;
+    const float lv = a + b;
+    leaf_value[g] = lv;
+    if (!active[g])
+        return;
+    const int64_t base = g * (int64_t)T.capacity;
+    int node = cur_node[g];
+    for (int depth = 0; node >= 0 && depth <= MAX_DEPTH; depth++) {
+        const int n = T.n_visits[base + node] + 1; // MCTS.py:61
+        const float q = T.q[base + node];
+        T.n_visits[base + node] = n;
+        T.q[base + node] = q + (lv - q) / (float)n; // MCTS.py:63
+        node = T.parent[base + node];
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void best_move_kernel(Tree T, const uint8_t *__restrict__ active,
                                                           int8_t *__restrict__ move,
                                                           int32_t *__restrict__ visits)
@@ -427,6 +459,21 @@ int iago_mcts_backup(const iago_mcts_tree *tree, const uint8_t *active, const in
     hipLaunchKernelGGL(backup_kernel, dim3(grid_for(tree->n_games)), dim3(BLOCK), 0,
                        (hipStream_t)stream, *tree, active, cur_node, leaf_value);
     return iago_check_launch("iago_mcts_backup");
+}
+
+int iago_mcts_mix_backup(const iago_mcts_tree *tree, const uint8_t *active, const int32_t *cur_node,
+                         const float *v, const int8_t *z, float lmbda, float *leaf_value,
+                         uint32_t *counter, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_mix_backup: bad tree"))
+        return IAGO_ERR_INVALID;
+    if (!active || !cur_node || !leaf_value || (lmbda < 1.0f && !v) || (lmbda > 0.0f && !z))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_mix_backup: null pointer");
+    if (tree->n_games == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(mix_backup_kernel, dim3(grid_for(tree->n_games)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, *tree, active, cur_node, v, z, lmbda, leaf_value, counter);
+    return iago_check_launch("iago_mcts_mix_backup");
 }
 
 int iago_mcts_best_move(const iago_mcts_tree *tree, const uint8_t *active, int8_t *move,

@@ -201,24 +201,30 @@ class BatchedMCTS(object):
                                  _p(self.legal), _p(probs), _stream()), "iago_mcts_expand")
         self._select(own, opp, pending, False)  # MCTS.py:121: recurse into the same node
 
-    def _evaluate_and_backup(self, active, stream_id=0, stream_id_dev=None):
+    def _evaluate_and_backup(self, active, stream_id=0, stream_id_dev=None, counter=None):
         """Leaf evaluation (MCTS.py:123-127) and Node.update_recursive."""
         L = _lib.lib()
         if self.lmbda < 1.0:
-            ops.encode_planes(self.cur_own, self.cur_opp, out=self.planes)
+            v = None
+            fb = getattr(self.value_fn, "forward_boards", None)
             with torch.no_grad():
-                self.v = self.value_fn(self.planes).to(torch.float32).contiguous()
+                if fb is not None:
+                    v = fb(self.cur_own, self.cur_opp)  # plane encoding fused into the first layer
+                if v is None:
+                    ops.encode_planes(self.cur_own, self.cur_opp, out=self.planes)
+                    v = self.value_fn(self.planes)
+            self.v = v.to(torch.float32).contiguous()
         if self.lmbda > 0.0:
             ops.rollout(self.cur_own, self.cur_opp, self.rollout_weights, seed=self.seed,
                         id_base=self.game_id_base, stream_id=stream_id,
                         stream_id_dev=stream_id_dev, out=self._rollout_out)
             if self.rollout_hook is not None:
                 self.rollout_hook(self)
-        check(L.iago_leaf_values(_p(self.v) if self.lmbda < 1.0 else None,
-                                 _p(self.z) if self.lmbda > 0.0 else None, self.lmbda,
-                                 _p(self.leaf_value), self.n_games, _stream()), "iago_leaf_values")
-        check(L.iago_mcts_backup(self.tree.ref(), _p(active), _p(self.cur_node),
-                                 _p(self.leaf_value), _stream()), "iago_mcts_backup")
+        check(L.iago_mcts_mix_backup(self.tree.ref(), _p(active), _p(self.cur_node),
+                                     _p(self.v) if self.lmbda < 1.0 else None,
+                                     _p(self.z) if self.lmbda > 0.0 else None, self.lmbda,
+                                     _p(self.leaf_value), _p(counter) if counter is not None else None,
+                                     _stream()), "iago_mcts_mix_backup")
 
     def simulate(self, own, opp, active, n_active=None):
         """One MCTS.playout for every active game (eager launches)."""
@@ -245,8 +251,8 @@ class BatchedMCTS(object):
             torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._evaluate_and_backup(self._g_active, stream_id=0, stream_id_dev=self._sim_dev)
-            self._sim_dev.add_(1)
+            self._evaluate_and_backup(self._g_active, stream_id=0, stream_id_dev=self._sim_dev,
+                                      counter=self._sim_dev)
             self._select(self._g_own, self._g_opp, self._g_active, True)
 
     def _search_graph(self, own, opp, active, n_sims, n_active):

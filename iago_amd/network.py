@@ -220,15 +220,29 @@ class Value(nn.Module, _NpzMixin):
                 and x.dtype == torch.float32 and x.shape[0] >= self.SPLIT_MIN_BATCH
                 and not torch.is_autocast_enabled())
 
+    def _split_trunk_head(self, a):
+        from . import ops
+        for k in range(2, 9):
+            w_hi, w_lo = self._split_weights(k)
+            a = ops.conv3x3_split(a, w_hi, w_lo, getattr(self, "block%d" % k).conv.bias)
+        return ops.value_head(a, self.block9.conv.weight, self.block9.conv.bias,
+                              self.fc10.weight, self.fc11.weight)
+
+    def forward_boards(self, own, opp):
+        """forward(make_state_var(...)) for int64 bitboards (own = side to move) without the
+        planes tensor, when the split-f16 path applies; None otherwise."""
+        if not (self.split_f16 and own.is_cuda and not self.training and not torch.is_grad_enabled()
+                and own.numel() >= self.SPLIT_MIN_BATCH and not torch.is_autocast_enabled()):
+            return None
+        from . import ops
+        return self._split_trunk_head(ops.value_stem_boards(own, opp, self.block1.conv.weight,
+                                                            self.block1.conv.bias))
+
     def forward(self, x):
         if self._use_split(x):
             from . import ops
             a = ops.value_stem(x.contiguous(), self.block1.conv.weight, self.block1.conv.bias)
-            for k in range(2, 9):
-                w_hi, w_lo = self._split_weights(k)
-                a = ops.conv3x3_split(a, w_hi, w_lo, getattr(self, "block%d" % k).conv.bias)
-            return ops.value_head(a, self.block9.conv.weight, self.block9.conv.bias,
-                                  self.fc10.weight, self.fc11.weight)
+            return self._split_trunk_head(a)
         elif (self.split_f16 and x.is_cuda and not self.training and not torch.is_grad_enabled()
               and x.dtype == torch.float32 and x.shape[0] > 0 and not torch.is_autocast_enabled()):
             # small batches (single-game serving): float32 matrix-unit kernels

@@ -182,6 +182,18 @@ def value_stem(planes, w1, b1):
     return SplitActs(hi, lo, 64)
 
 
+def value_stem_boards(own, opp, w1, b1):
+    """value_stem on the boards themselves (own = side to move): plane encoding fused in."""
+    n = own.numel()
+    hi = torch.empty((n, 4, 64, 16), dtype=torch.float16, device=own.device)
+    lo = torch.empty_like(hi)
+    check(_lib.lib().iago_value_stem_boards(_dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp"),
+                                            _dev(w1, torch.float32, "w1"), _dev(b1, torch.float32, "b1"),
+                                            _dev(hi, torch.float16, "y_hi"), _dev(lo, torch.float16, "y_lo"),
+                                            n, _stream()), "iago_value_stem_boards")
+    return SplitActs(hi, lo, 64)
+
+
 def value_head(a, w9, b9, w10, w11):
     """Value.block9 + fc10 + fc11 with train=False (network.py:78-96) on SplitActs with
     128 channels -> (n,) float32."""

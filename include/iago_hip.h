@@ -226,6 +226,9 @@ IAGO_API int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *
  */
 IAGO_API int iago_value_stem(const float *planes, const float *w1, const float *b1, void *y_hi, void *y_lo,
                              int64_t n, void *stream);
+/* iago_value_stem straight from the boards (own = side to move): iago_encode_planes fused in. */
+IAGO_API int iago_value_stem_boards(const uint64_t *own, const uint64_t *opp, const float *w1, const float *b1,
+                                    void *y_hi, void *y_lo, int64_t n, void *stream);
 IAGO_API int iago_value_head(const void *x_hi, const void *x_lo, const float *w9, const float *b9,
                              const float *w10, const float *w11, float *out, int64_t n, void *stream);
 /*
@@ -347,6 +350,16 @@ IAGO_API int iago_leaf_values(const float *v, const int8_t *z, float lmbda, floa
  */
 IAGO_API int iago_mcts_backup(const iago_mcts_tree *tree, const uint8_t *active,
                               const int32_t *cur_node, const float *leaf_value, void *stream);
+
+/*
+ * iago_leaf_values + iago_mcts_backup in one launch (MCTS.py:123-127): leaf_value[g] =
+ * (1-lmbda)*v[g] + lmbda*z[g] for every game, backed up along the path of the active
+ * ones.  counter: optional device word incremented by one (the playout number that
+ * iago_rollout_args.stream_id_dev reads when the playouts replay from a hipGraph).
+ */
+IAGO_API int iago_mcts_mix_backup(const iago_mcts_tree *tree, const uint8_t *active,
+                                  const int32_t *cur_node, const float *v, const int8_t *z, float lmbda,
+                                  float *leaf_value, uint32_t *counter, void *stream);
 
 /*
  * MCTS.get_move's final choice (MCTS.py:147): the most visited child of the

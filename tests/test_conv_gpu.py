@@ -190,3 +190,17 @@ def test_value_small_batch_uses_f32_kernels():
         m.float()
         got = m.cuda()(x.cuda()).cpu()
     assert (got - ref64).abs().max().item() < 1e-5 * max(1.0, float(ref64.abs().max()))
+
+
+def test_value_forward_boards_equals_forward_on_planes():
+    from iago_amd import network, ops
+    from tests.gpu_util import random_positions
+    torch.manual_seed(12)
+    m = network.Value().eval().cuda()
+    own, opp = random_positions(300, seed=5)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    with torch.no_grad():
+        a = m.forward_boards(o, p)
+        b = m(ops.encode_planes(o, p))
+        assert m.forward_boards(o[:5], p[:5]) is None      # small batches: the caller encodes planes
+    assert a is not None and torch.equal(a, b)
