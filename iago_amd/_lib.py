@@ -23,7 +23,7 @@ SYMBOLS = [
     "iago_legal_moves", "iago_apply_moves", "iago_encode_planes", "iago_encode_planes_indexed",
     "iago_judge",
     "iago_sample_moves", "iago_augment8", "iago_bias_relu",
-    "iago_conv3x3_split", "iago_split_nchw", "iago_merge_nchw", "iago_value_stem", "iago_value_stem_boards", "iago_value_head",
+    "iago_conv3x3_split", "iago_conv3x3_split_trunk", "iago_split_nchw", "iago_merge_nchw", "iago_value_stem", "iago_value_stem_boards", "iago_value_head",
     "iago_conv3x3_f32", "iago_stem_f32", "iago_policy_head",
     "iago_rollout_build_table", "iago_rollout",
     "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_mcts_pending",
@@ -45,6 +45,15 @@ class RolloutArgs(C.Structure):
         ("z", C.c_void_p), ("final_own", C.c_void_p), ("final_opp", C.c_void_p),
         ("n_turns", C.c_void_p), ("trace", C.c_void_p), ("log_form", C.c_int),
         ("throughput_hint", C.c_int),
+    ]
+
+
+class ConvSplitLayer(C.Structure):
+    """Mirror of iago_conv_split_layer (include/iago_hip.h)."""
+    _fields_ = [
+        ("x_hi", C.c_void_p), ("x_lo", C.c_void_p), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p),
+        ("bias", C.c_void_p), ("y_hi", C.c_void_p), ("y_lo", C.c_void_p),
+        ("cin", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -97,6 +106,7 @@ def lib():
     L.iago_bias_relu.argtypes = [vp, vp, i64, C.c_int32, vp]
     i32 = C.c_int32
     L.iago_conv3x3_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
+    L.iago_conv3x3_split_trunk.argtypes = [C.POINTER(ConvSplitLayer), i32, i64, vp]
     L.iago_split_nchw.argtypes = [vp, vp, vp, i64, i32, vp]
     L.iago_merge_nchw.argtypes = [vp, vp, vp, i64, i32, vp]
     L.iago_value_stem.argtypes = [vp, vp, vp, vp, vp, i64, vp]

@@ -150,9 +150,12 @@ __device__ __forceinline__ void mfma_step(const Frags &F, float16v (&acc_main)[N
             acc_cross[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_lo[i], F.b_hi[j], acc_cross[i][j], 0, 0, 0);
 }
 
-__global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
+extern __shared__ __align__(16) char conv_lds[]; // the dynamic LDS of the two kernels below
+
+// One layer for the 4 boards of this workgroup (the whole kernel when launched per layer).
+__device__ __forceinline__ void conv_layer(const ConvParams &P)
 {
-    extern __shared__ __align__(16) char lds[];
+    char *const lds = conv_lds;
     char *const xbuf = lds;
     char *const wbuf = lds + 2 * X_BUF;
 
@@ -334,6 +337,40 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
             const int64_t dst = b * 1024 + (e & 1023);
             P.y_hi[dst] = *(const uint4 *)(t_hi + off);
             P.y_lo[dst] = *(const uint4 *)(t_lo + off);
+        }
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
+{
+    conv_layer(P);
+}
+
+// Up to 8 consecutive layers in one launch.  A workgroup owns all 128 channels of its 4
+// boards, so layer k + 1 of a workgroup depends on nothing but its own output of layer k:
+// the activations take the usual round trip through global memory (L2), but without
+// kernel boundaries in between -- no launch gaps, and the output stores of a layer overlap
+// the first loads of the next.  Every layer writes its own buffer (an address is written
+// once, by this workgroup, before it is read once: no stale L1 lines).  The layer loop is
+// unrolled at compile time: indexing the by-value parameter array with a run-time layer
+// number sends it (and every pointer in it) through scratch memory.
+constexpr int MAX_TRUNK = 8;
+struct TrunkParams {
+    ConvParams layer[MAX_TRUNK];
+    int32_t n_layers;
+};
+
+__global__ __launch_bounds__(THREADS) void conv3x3_split_trunk_kernel(TrunkParams T)
+{
+#pragma unroll
+    for (int L = 0; L < MAX_TRUNK; L++) {
+        if (L < T.n_layers) {
+            conv_layer(T.layer[L]);
+            // the next layer of THIS workgroup reads what it just stored: workgroup scope
+            // (an agent-scope fence would write the whole L2 back, ~50 us per layer)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
     }
 }
@@ -746,6 +783,47 @@ int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, con
     const unsigned grid = (unsigned)((n + TB - 1) / TB);
     hipLaunchKernelGGL(conv3x3_split_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, P);
     return iago_check_launch("iago_conv3x3_split");
+}
+
+int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32_t n_layers, int64_t n, void *stream)
+{
+    if (n < 0 || n_layers < 1 || n_layers > MAX_TRUNK || !layers)
+        return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split_trunk: 1..8 layers expected");
+    if (n == 0)
+        return IAGO_OK;
+    TrunkParams T;
+    T.n_layers = n_layers;
+    for (int L = 0; L < n_layers; L++) {
+        const iago_conv_split_layer &a = layers[L];
+        if (a.cin <= 0 || (a.cin % 32) != 0 || !a.x_hi || !a.x_lo || !a.w_hi || !a.w_lo || !a.bias || !a.y_hi ||
+            !a.y_lo)
+            return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split_trunk: bad layer (cin a multiple of 32, no nulls)");
+        if (L > 0 && (a.x_hi != layers[L - 1].y_hi || a.x_lo != layers[L - 1].y_lo || a.cin != COUT))
+            return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split_trunk: layer k must read the output of layer k-1");
+        for (int M = 0; M < L; M++)
+            if (a.y_hi == layers[M].y_hi || a.y_lo == layers[M].y_lo || a.y_hi == layers[M].x_hi)
+                return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split_trunk: every layer needs its own output buffer");
+        ConvParams &P = T.layer[L];
+        P.x_hi = (const uint4 *)a.x_hi;
+        P.x_lo = (const uint4 *)a.x_lo;
+        P.w_hi = (const uint4 *)a.w_hi;
+        P.w_lo = (const uint4 *)a.w_lo;
+        P.bias = a.bias;
+        P.y_hi = (uint4 *)a.y_hi;
+        P.y_lo = (uint4 *)a.y_lo;
+        P.n = n;
+        P.n_chunks = a.cin / 16;
+    }
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void *)conv3x3_split_trunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess)
+            return iago_fail(IAGO_ERR_HIP, "iago_conv3x3_split_trunk: cannot reserve 159 KB of LDS");
+        configured = true;
+    }
+    const unsigned grid = (unsigned)((n + TB - 1) / TB);
+    hipLaunchKernelGGL(conv3x3_split_trunk_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, T);
+    return iago_check_launch("iago_conv3x3_split_trunk");
 }
 
 int iago_value_stem(const float *planes, const float *w1, const float *b1, void *y_hi, void *y_lo, int64_t n,

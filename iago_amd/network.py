@@ -222,9 +222,8 @@ class Value(nn.Module, _NpzMixin):
 
     def _split_trunk_head(self, a):
         from . import ops
-        for k in range(2, 9):
-            w_hi, w_lo = self._split_weights(k)
-            a = ops.conv3x3_split(a, w_hi, w_lo, getattr(self, "block%d" % k).conv.bias)
+        layers = [self._split_weights(k) + (getattr(self, "block%d" % k).conv.bias,) for k in range(2, 9)]
+        a = ops.conv3x3_split_trunk(a, layers)   # blocks 2..8 in one launch
         return ops.value_head(a, self.block9.conv.weight, self.block9.conv.bias,
                               self.fc10.weight, self.fc11.weight)
 

@@ -168,6 +168,31 @@ def merge_nchw(a):
     return y
 
 
+def conv3x3_split_trunk(a, layers):
+    """Consecutive conv3x3_split layers in one launch.  layers: list of (w_hi, w_lo, bias);
+    the first reads SplitActs `a`, each next one its predecessor's output."""
+    n = a.n
+    descs = (_lib.ConvSplitLayer * len(layers))()
+    keep = []
+    cur, cin = a, a.channels
+    for k, (w_hi, w_lo, bias) in enumerate(layers):
+        if w_hi.shape != (cin // 16, 3, 3, 128, 16):
+            raise ValueError("layer %d: weight blocks %s do not match %d input channels"
+                             % (k, tuple(w_hi.shape), cin))
+        hi = torch.empty((n, 8, 64, 16), dtype=torch.float16, device=a.hi.device)
+        lo = torch.empty_like(hi)
+        d = descs[k]
+        d.x_hi, d.x_lo = cur.hi.data_ptr(), cur.lo.data_ptr()
+        d.w_hi, d.w_lo = _dev(w_hi, torch.float16, "w_hi").value, _dev(w_lo, torch.float16, "w_lo").value
+        d.bias = _dev(bias, torch.float32, "bias").value
+        d.y_hi, d.y_lo = hi.data_ptr(), lo.data_ptr()
+        d.cin = cin
+        cur, cin = SplitActs(hi, lo, 128), 128
+        keep.append(cur)
+    check(_lib.lib().iago_conv3x3_split_trunk(descs, len(layers), n, _stream()), "iago_conv3x3_split_trunk")
+    return cur
+
+
 def value_stem(planes, w1, b1):
     """relu(conv3x3(planes, w1) + b1), 2 -> 64 channels (Value.block1, network.py:68-70):
     float32 planes (n, 2, 8, 8) -> SplitActs with 64 channels."""

@@ -249,6 +249,23 @@ IAGO_API int iago_stem_f32(const float *planes, const float *w1, const float *b1
                            void *stream);
 IAGO_API int iago_policy_head(const float *x, const float *w9, const float *b10, float *probs, int64_t n,
                               void *stream);
+/*
+ * Up to 8 consecutive iago_conv3x3_split layers in ONE launch (blocks 2..8 of the Value
+ * net): a workgroup owns all 128 channels of its 4 boards, so it runs the layers back to
+ * back on its own intermediate activations.  Layer k reads the y buffers of layer k-1;
+ * every layer writes buffers of its own.  cout = 128 throughout, cin of layer 0 a
+ * multiple of 32.
+ */
+typedef struct iago_conv_split_layer {
+    const void *x_hi, *x_lo; /* input activations  [n][cin/16][64][16] f16 */
+    const void *w_hi, *w_lo; /* weights            [cin/16][3][3][128][16] f16 */
+    const float *bias;       /* [128] */
+    void *y_hi, *y_lo;       /* output activations [n][8][64][16] f16 */
+    int32_t cin;
+    int32_t reserved;
+} iago_conv_split_layer;
+IAGO_API int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32_t n_layers, int64_t n,
+                                      void *stream);
 IAGO_API int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels, void *stream);
 IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n, int32_t channels,
                              void *stream);

@@ -204,3 +204,23 @@ def test_value_forward_boards_equals_forward_on_planes():
         b = m(ops.encode_planes(o, p))
         assert m.forward_boards(o[:5], p[:5]) is None      # small batches: the caller encodes planes
     assert a is not None and torch.equal(a, b)
+
+
+def test_trunk_kernel_equals_layer_by_layer():
+    """iago_conv3x3_split_trunk (several layers, one launch) must reproduce the per-layer
+    launches bit for bit, for a ragged batch and a 64-channel first layer."""
+    from iago_amd import ops
+    torch.manual_seed(21)
+    n = 37
+    a0 = ops.split_nchw((torch.rand(n, 64, 8, 8) * 2).cuda())
+    layers = []
+    cin = 64
+    for k in range(4):
+        w = (torch.randn(128, cin, 3, 3) / np.sqrt(9 * cin)).cuda()
+        layers.append(ops.split_weights(w) + ((torch.randn(128) * 0.1).cuda(),))
+        cin = 128
+    ref = a0
+    for w_hi, w_lo, b in layers:
+        ref = ops.conv3x3_split(ref, w_hi, w_lo, b)
+    got = ops.conv3x3_split_trunk(a0, layers)
+    assert torch.equal(got.hi, ref.hi) and torch.equal(got.lo, ref.lo)
