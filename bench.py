@@ -10,7 +10,10 @@ kernel with the reference's shipped RolloutPolicy weights (82 floats, kept as
 golden data in tests/golden/simulate.json) -- rollout-policy-only self-play.
 One step = 4096 finished games per GPU.  Steps are independent batches: by default
 256 consecutive steps share one kernel launch (1,048,576 boards), which the library
-plays with its lane-per-board rollout kernel; `--steps-per-launch 1` issues every
+plays with its lane-per-board rollout kernel; the launches alternate on two HIP streams
+so that the next one's blocks fill the CUs the tail of the previous one leaves idle
+(`roofline.kernel_ms` is then the duration of a launch that shares the chip with
+another one, `launches_in_flight` says how many).  `--steps-per-launch 1` issues every
 step as its own launch of the 8-lanes-per-board kernel, overlapped on 32 HIP
 streams / 16 hardware queues (a single 4096-board launch is only 512 waves).
 With N > 1 every rank plays its own 4096-board shard (weak scaling, Philox streams
@@ -313,6 +316,10 @@ def main():
                          "step, overlapped on --streams HIP streams)")
     ap.add_argument("--streams", type=int, default=32,
                     help="HIP streams the independent steps are issued on")
+    ap.add_argument("--launch-streams", type=int, default=2,
+                    help="HIP streams the multi-step launches alternate on: with 2 the blocks of the "
+                         "next launch fill the CUs that the tail of the previous one leaves idle "
+                         "(1: back to back)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--large-boards", type=int, default=1 << 20,
                     help="extra occupancy datapoint: boards in one launch (0 = skip)")
@@ -369,7 +376,7 @@ def main():
     gathered = torch.empty(world * n * 18, dtype=torch.uint8, device="cuda") if world > 1 or \
         "RANK" in os.environ else None
 
-    S = max(1, args.streams) if G == 1 else 1
+    S = max(1, args.streams) if G == 1 else max(1, args.launch_streams)
     streams = [torch.cuda.Stream() for _ in range(S)]
     sptr = [ctypes.c_void_p(st.cuda_stream) for st in streams]
 
