@@ -9,11 +9,10 @@ the standard start position are played to the end by the fused HIP rollout
 kernel with the reference's shipped RolloutPolicy weights (82 floats, kept as
 golden data in tests/golden/simulate.json) -- rollout-policy-only self-play.
 One step = 4096 finished games per GPU.  Steps are independent batches: by default
-256 consecutive steps share one kernel launch (1,048,576 boards), which the library
-plays with its lane-per-board rollout kernel; the launches alternate on two HIP streams
-so that the next one's blocks fill the CUs the tail of the previous one leaves idle
-(`roofline.kernel_ms` is then the duration of a launch that shares the chip with
-another one, `launches_in_flight` says how many).  `--steps-per-launch 1` issues every
+up to 2048 consecutive steps share one kernel launch (the default 2000 steps are one
+launch of 8,192,000 boards), which the library plays with its lane-per-board rollout
+kernel: the ramp and the tail of a launch (waves of different game lengths leave CUs
+idle at its end) are paid once (256 steps per launch: -10 %).  `--steps-per-launch 1` issues every
 step as its own launch of the 8-lanes-per-board kernel, overlapped on 32 HIP
 streams / 16 hardware queues (a single 4096-board launch is only 512 waves).
 With N > 1 every rank plays its own 4096-board shard (weak scaling, Philox streams
@@ -257,7 +256,8 @@ def reinforce_leg(n_iters, world, rank, dist):
     from iago_amd.train_rl import ReinforceTrainer
     torch.manual_seed(0)
     tr = ReinforceTrainer(network.SLPolicy(), pool_dir=None, N=32, seed=rank)
-    tr.step()  # warm-up: MIOpen forward/backward kernel selection
+    for _ in range(2):
+        tr.step()  # warm-up: MIOpen forward/backward kernel selection, allocator, weight-layout caches
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -287,9 +287,14 @@ def measured_pmc():
     return {}
 
 
-def measured_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes, if any."""
-    return measured_pmc().get("hbm_bytes_per_launch")
+def measured_traffic(boards_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes, if any, scaled from
+    the profiled launch size to this run's (the traffic is per board: inputs, outputs and
+    the table staged once per block)."""
+    pmc = measured_pmc()
+    if "hbm_bytes_per_launch" not in pmc:
+        return None
+    return pmc["hbm_bytes_per_launch"] * boards_per_launch / pmc.get("boards_per_launch", boards_per_launch)
 
 
 def valu_utilisation(boards, seconds):
@@ -311,15 +316,14 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
-    ap.add_argument("--steps-per-launch", type=int, default=256,
+    ap.add_argument("--steps-per-launch", type=int, default=2048,
                     help="consecutive steps played by one kernel launch (1 = one launch per "
                          "step, overlapped on --streams HIP streams)")
     ap.add_argument("--streams", type=int, default=32,
                     help="HIP streams the independent steps are issued on")
-    ap.add_argument("--launch-streams", type=int, default=2,
-                    help="HIP streams the multi-step launches alternate on: with 2 the blocks of the "
-                         "next launch fill the CUs that the tail of the previous one leaves idle "
-                         "(1: back to back)")
+    ap.add_argument("--launch-streams", type=int, default=1,
+                    help="HIP streams the multi-step launches alternate on (1: back to back, the "
+                         "kernel duration is then a launch that has the chip to itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--large-boards", type=int, default=1 << 20,
                     help="extra occupancy datapoint: boards in one launch (0 = skip)")
@@ -520,7 +524,7 @@ def main():
             "board_steps_per_sec": board_steps / dt,
             "board_steps_per_game": board_steps / games,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(launch_steps * B),
                          "kernel": "rollout_lpb_kernel" if G * B >= 32768 else "rollout_kernel",
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
