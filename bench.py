@@ -17,8 +17,9 @@ step as its own launch of the 8-lanes-per-board kernel, overlapped on 32 HIP
 streams / 16 hardware queues (a single 4096-board launch is only 512 waves).
 With N > 1 every rank plays its own 4096-board shard (weak scaling, Philox streams
 keyed by a rank-major global game id) and the finished (final boards, z, turns)
-tuples of the whole round are all-gathered over RCCL inside the timed region, as
-one collective on the round's tuple buffer.
+tuples of the whole round are all-gathered over RCCL inside the timed region: the
+run is then two launches, and the tuples of the first travel as one collective on a
+side stream beside the second.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the rollout kernel against the
 HBM roof with SURVEY.md section 8(d)'s algorithmic bytes (33 B per board-step);
@@ -324,6 +325,9 @@ def main():
     ap.add_argument("--launch-streams", type=int, default=1,
                     help="HIP streams the multi-step launches alternate on (1: back to back, the "
                          "kernel duration is then a launch that has the chip to itself)")
+    ap.add_argument("--one-launch", action="store_true",
+                    help="N > 1: keep all steps in one launch (the tuple all-gather then follows it "
+                         "instead of overlapping the later launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--large-boards", type=int, default=1 << 20,
                     help="extra occupancy datapoint: boards in one launch (0 = skip)")
@@ -367,18 +371,29 @@ def main():
     # wave-instructions per board but 8x more boards in flight to fill the chip.
     # G = 1 issues every step as its own launch, overlapped on S HIP streams.
     G = max(1, min(args.steps_per_launch, K))
+    if dist is not None and G >= K and K >= 512 and not args.one_launch:
+        # N > 1: two launches, so that the all-gather of the first one's tuples (a side
+        # stream) runs beside the second instead of after the only one (a launch of half the
+        # boards costs ~3 % more per board; four launches cost more than they hide)
+        G = (K + 1) // 2
     own = torch.full((G * B,), START_OWN, dtype=torch.int64, device="cuda")
     opp = torch.full((G * B,), START_OPP, dtype=torch.int64, device="cuda")
-    # the round's finished tuples, resident in HBM: K steps x B games, as views of ONE
-    # byte buffer so that the all-gather needs no packing pass and no host sync
+    # the round's finished tuples, resident in HBM: K steps x B games; the tuples of one
+    # launch are ONE contiguous block [final own | final opp | z | turns] of the round
+    # buffer, so that its all-gather needs no packing pass and no host sync
     n = K * B
     roundbuf = torch.empty(n * 18, dtype=torch.uint8, device="cuda")
-    fo = roundbuf[0:8 * n].view(torch.int64)
-    fp = roundbuf[8 * n:16 * n].view(torch.int64)
-    z = roundbuf[16 * n:17 * n].view(torch.int8)
-    nt = roundbuf[17 * n:18 * n]
-    gathered = torch.empty(world * n * 18, dtype=torch.uint8, device="cuda") if world > 1 or \
-        "RANK" in os.environ else None
+
+    def block(k0, g):
+        """Views (final_own, final_opp, z, n_turns, bytes) of the launch playing steps k0..k0+g-1."""
+        m = g * B
+        blk = roundbuf[k0 * B * 18:(k0 + g) * B * 18]
+        return (blk[0:8 * m].view(torch.int64), blk[8 * m:16 * m].view(torch.int64),
+                blk[16 * m:17 * m].view(torch.int8), blk[17 * m:18 * m], blk)
+
+    use_gather = world > 1 or "RANK" in os.environ
+    gathered = [torch.empty(world * min(G, K - k) * B * 18, dtype=torch.uint8, device="cuda")
+                for k in range(0, K, G)] if use_gather else None
 
     S = max(1, args.streams) if G == 1 else max(1, args.launch_streams)
     streams = [torch.cuda.Stream() for _ in range(S)]
@@ -389,8 +404,7 @@ def main():
         Global game id = (rank * 2^20 + step) * B + board (rank-major, so that the ids
         of consecutive steps of a rank are contiguous)."""
         r = ops.RolloutResult()
-        lo, hi = k0 * B, (k0 + g) * B
-        r.z, r.final_own, r.final_opp, r.n_turns = z[lo:hi], fo[lo:hi], fp[lo:hi], nt[lo:hi]
+        r.final_own, r.final_opp, r.z, r.n_turns, _ = block(k0, g)
         return ops.rollout_prepare(own[:g * B], opp[:g * B], weights, seed=2024,
                                    id_base=((rank * (1 << 20) + id_step) * B) & 0xFFFFFFFF, out=r)
 
@@ -417,6 +431,8 @@ def main():
     span0.record(main)
     for st in streams:
         st.wait_stream(main)
+    comm = torch.cuda.Stream() if dist is not None else None
+    done = [torch.cuda.Event() for _ in range(n_launches)] if dist is not None else None
     for i, p in enumerate(timed):
         j = i % S
         e = evs.get(i)
@@ -425,12 +441,21 @@ def main():
         rc |= p.launch(sptr[j])
         if e is not None:
             e[1].record(streams[j])
+        if dist is not None:
+            done[i].record(streams[j])
     for st in streams:
         main.wait_stream(st)
     span1.record(main)
     if dist is not None:
-        # every rank contributes the same K x B tuples: one collective, no host sync
-        dist.all_gather_into_tensor(gathered, roundbuf)
+        # the tuples of every launch: one collective each on the side stream, ordered
+        # behind its launch by an event, beside the launches that follow; no host sync
+        # (enqueued after all launches so that the host never stands between two launches)
+        with torch.cuda.stream(comm):
+            for i in range(n_launches):
+                comm.wait_event(done[i])
+                dist.all_gather_into_tensor(gathered[i], block(i * G, min(G, K - i * G))[4])
+    if comm is not None:
+        main.wait_stream(comm)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -443,13 +468,14 @@ def main():
     span_ms = span0.elapsed_time(span1)  # GPU time of the K launches together
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    steps_total = nt.to(torch.int64).sum().reshape(1)
+    steps_total = sum(block(k, min(G, K - k))[3].to(torch.int64).sum() for k in range(0, K, G)).reshape(1)
     launch_steps = G  # steps per (full) launch
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(steps_total)
-        mine = gathered[rank * n * 18:(rank + 1) * n * 18]
-        assert torch.equal(mine, roundbuf)
+        for i, k in enumerate(range(0, K, G)):
+            mine = block(k, min(G, K - k))[4]
+            assert torch.equal(gathered[i][rank * mine.numel():(rank + 1) * mine.numel()], mine)
     dt = float(tmax.item())
     board_steps = int(steps_total.item())
 
