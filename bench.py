@@ -568,7 +568,7 @@ def main():
             line["reinforce"] = train
         if b1 is not None:
             line["mcts_single_game"] = b1
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N = 1 figure
             line["cpu_baseline"] = cpu_baseline(w, b)
             if mcts is not None:
                 mcts["cpu_baseline"] = mcts_cpu_baseline()
