@@ -105,12 +105,12 @@ def lib():
     L.iago_augment8.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
     L.iago_bias_relu.argtypes = [vp, vp, i64, C.c_int32, vp]
     i32 = C.c_int32
-    L.iago_conv3x3_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
-    L.iago_conv3x3_split_trunk.argtypes = [C.POINTER(ConvSplitLayer), i32, i64, vp]
-    L.iago_split_nchw.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.iago_conv3x3_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
+    L.iago_conv3x3_split_trunk.argtypes = [C.POINTER(ConvSplitLayer), i32, i64, vp, vp]
+    L.iago_split_nchw.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.iago_merge_nchw.argtypes = [vp, vp, vp, i64, i32, vp]
-    L.iago_value_stem.argtypes = [vp, vp, vp, vp, vp, i64, vp]
-    L.iago_value_stem_boards.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
+    L.iago_value_stem.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
+    L.iago_value_stem_boards.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, vp]
     L.iago_value_head.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.iago_conv3x3_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp]
     L.iago_stem_f32.argtypes = [vp, vp, vp, vp, i64, vp]

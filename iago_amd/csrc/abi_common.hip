@@ -23,9 +23,27 @@ int iago_check_launch(const char *where)
     return IAGO_ERR_HIP;
 }
 
+int iago_reserve_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done, const char *who)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return iago_fail(IAGO_ERR_HIP, who);
+    }
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit)
+        return IAGO_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return iago_fail(IAGO_ERR_HIP, who);
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return IAGO_OK;
+}
+
 extern "C" {
 
-int iago_abi_version(void) { return 1; }
+int iago_abi_version(void) { return 2; }
 
 const char *iago_last_error(void) { return g_err; }
 

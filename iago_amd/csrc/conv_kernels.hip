@@ -83,6 +83,7 @@ struct ConvParams {
     uint4 *y_lo;
     int64_t n;
     int32_t n_chunks; // cin / 16
+    uint32_t *overflow; // optional: set to 1 when an output left [0, 65000] or is NaN
 };
 
 __device__ __forceinline__ half8 lds_half8(const char *p)
@@ -304,6 +305,7 @@ __device__ __forceinline__ void conv_layer(const ConvParams &P)
     if (tid < COUT)
         bias_lds[tid] = my_bias;
     __syncthreads();
+    bool saturated = false;
 #pragma unroll
     for (int i = 0; i < NI; i++)
 #pragma unroll
@@ -316,6 +318,7 @@ __device__ __forceinline__ void conv_layer(const ConvParams &P)
                 for (int t = 0; t < 4; t++) {
                     float v = acc_main[i][j][4 * q + t] + acc_cross[i][j][4 * q + t] * (1.0f / 2048.0f) +
                               bias_lds[co + t];
+                    saturated |= !(v <= 65000.0f); // beyond the f16 range, or NaN (fmaxf would hide it)
                     v = fminf(fmaxf(v, 0.0f), 65000.0f);
                     const __half vh = __float2half_rn(v);
                     hi4[t] = vh;
@@ -325,6 +328,9 @@ __device__ __forceinline__ void conv_layer(const ConvParams &P)
                 *(uint2 *)(t_hi + off) = *(const uint2 *)hi4;
                 *(uint2 *)(t_lo + off) = *(const uint2 *)lo4;
             }
+    // (boards past the end of a ragged batch recompute the last real board: no false alarm)
+    if (P.overflow && saturated)
+        *P.overflow = 1u;
     __syncthreads();
     // output pieces: per hi/lo TB * 8 blocks * 64 cells * 2 = 4096
 #pragma unroll 4
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_split_trunk_kernel(TrunkParam
 
 // float32 NCHW planes -> split channel blocks
 __global__ __launch_bounds__(256) void split_nchw_kernel(const float *x, __half *hi, __half *lo, int64_t n,
-                                                         int channels)
+                                                         int channels, uint32_t *overflow)
 {
     // one thread per (board, block, cell, 8 channels): reads 8 floats (stride 64), writes 16 B + 16 B
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -391,13 +397,18 @@ __global__ __launch_bounds__(256) void split_nchw_kernel(const float *x, __half 
     const int cb = (int)(bb - b * nb);
     const float *src = x + (b * channels + cb * 16 + hp * 8) * 64 + cell;
     __half h8[8], l8[8];
+    bool saturated = false;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const float v = fminf(fmaxf(src[k * 64], -65000.0f), 65000.0f);
+        const float raw = src[k * 64];
+        saturated |= !(fabsf(raw) <= 65000.0f);
+        const float v = fminf(fmaxf(raw, -65000.0f), 65000.0f);
         const __half vh = __float2half_rn(v);
         h8[k] = vh;
         l8[k] = __float2half_rn((v - __half2float(vh)) * 2048.0f);
     }
+    if (overflow && saturated)
+        *overflow = 1u;
     ((uint4 *)hi)[t] = *(const uint4 *)h8;
     ((uint4 *)lo)[t] = *(const uint4 *)l8;
 }
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(256) void merge_nchw_kernel(const __half *hi, const
 // opponent of the side to move, plane 1 = side to move, game.py:168-174)
 __global__ __launch_bounds__(256) void value_stem_kernel(const float *planes, const uint64_t *own,
                                                          const uint64_t *opp, const float *w, const float *bias,
-                                                         uint4 *y_hi, uint4 *y_lo, int64_t n)
+                                                         uint4 *y_hi, uint4 *y_lo, int64_t n, uint32_t *overflow)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n * 512)
@@ -455,6 +466,7 @@ __global__ __launch_bounds__(256) void value_stem_kernel(const float *planes, co
             }
     const int co0 = __builtin_amdgcn_readfirstlane(grp) * 8;
     __half h8[8], l8[8];
+    bool saturated = false;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const float *wk = w + (co0 + k) * 18; // [co][ci][ky][kx]
@@ -462,11 +474,14 @@ __global__ __launch_bounds__(256) void value_stem_kernel(const float *planes, co
 #pragma unroll
         for (int j = 0; j < 18; j++)
             acc = fmaf(wk[j], in[j], acc);
+        saturated |= !(acc <= 65000.0f);
         const float v = fminf(fmaxf(acc, 0.0f), 65000.0f);
         const __half vh = __float2half_rn(v);
         h8[k] = vh;
         l8[k] = __float2half_rn((v - __half2float(vh)) * 2048.0f);
     }
+    if (overflow && saturated)
+        *overflow = 1u;
     const int64_t dst = ((b * 4 + (grp >> 1)) * 64 + cell) * 2 + (grp & 1);
     y_hi[dst] = *(const uint4 *)h8;
     y_lo[dst] = *(const uint4 *)l8;
@@ -755,7 +770,8 @@ __global__ __launch_bounds__(64) void policy_head_kernel(const float *x, const f
 extern "C" {
 
 int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, const float *bias,
-                       void *y_hi, void *y_lo, int64_t n, int32_t cin, int32_t cout, void *stream)
+                       void *y_hi, void *y_lo, int64_t n, int32_t cin, int32_t cout, uint32_t *overflow,
+                       void *stream)
 {
     if (n < 0 || cout != COUT || cin <= 0 || (cin % 32) != 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split: cout must be 128 and cin a multiple of 32");
@@ -763,13 +779,10 @@ int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, con
         return IAGO_OK;
     if (!x_hi || !x_lo || !w_hi || !w_lo || !bias || !y_hi || !y_lo)
         return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split: null pointer");
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void *)conv3x3_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess)
-            return iago_fail(IAGO_ERR_HIP, "iago_conv3x3_split: cannot reserve 159 KB of LDS");
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};
+    if (iago_reserve_lds((const void *)conv3x3_split_kernel, LDS_BYTES, configured,
+                         "iago_conv3x3_split: cannot reserve 159 KB of LDS"))
+        return IAGO_ERR_HIP;
     ConvParams P;
     P.x_hi = (const uint4 *)x_hi;
     P.x_lo = (const uint4 *)x_lo;
@@ -780,12 +793,14 @@ int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, con
     P.y_lo = (uint4 *)y_lo;
     P.n = n;
     P.n_chunks = cin / 16;
+    P.overflow = overflow;
     const unsigned grid = (unsigned)((n + TB - 1) / TB);
     hipLaunchKernelGGL(conv3x3_split_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, P);
     return iago_check_launch("iago_conv3x3_split");
 }
 
-int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32_t n_layers, int64_t n, void *stream)
+int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32_t n_layers, int64_t n,
+                             uint32_t *overflow, void *stream)
 {
     if (n < 0 || n_layers < 1 || n_layers > MAX_TRUNK || !layers)
         return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split_trunk: 1..8 layers expected");
@@ -813,21 +828,19 @@ int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32_t n_laye
         P.y_lo = (uint4 *)a.y_lo;
         P.n = n;
         P.n_chunks = a.cin / 16;
+        P.overflow = overflow;
     }
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void *)conv3x3_split_trunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess)
-            return iago_fail(IAGO_ERR_HIP, "iago_conv3x3_split_trunk: cannot reserve 159 KB of LDS");
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};
+    if (iago_reserve_lds((const void *)conv3x3_split_trunk_kernel, LDS_BYTES, configured,
+                         "iago_conv3x3_split_trunk: cannot reserve 159 KB of LDS"))
+        return IAGO_ERR_HIP;
     const unsigned grid = (unsigned)((n + TB - 1) / TB);
     hipLaunchKernelGGL(conv3x3_split_trunk_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, T);
     return iago_check_launch("iago_conv3x3_split_trunk");
 }
 
 int iago_value_stem(const float *planes, const float *w1, const float *b1, void *y_hi, void *y_lo, int64_t n,
-                    void *stream)
+                    uint32_t *overflow, void *stream)
 {
     if (n < 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_value_stem: negative n");
@@ -837,12 +850,12 @@ int iago_value_stem(const float *planes, const float *w1, const float *b1, void 
         return iago_fail(IAGO_ERR_INVALID, "iago_value_stem: null pointer");
     hipLaunchKernelGGL(value_stem_kernel, dim3((unsigned)((n * 512 + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, planes, (const uint64_t *)nullptr, (const uint64_t *)nullptr, w1, b1,
-                       (uint4 *)y_hi, (uint4 *)y_lo, n);
+                       (uint4 *)y_hi, (uint4 *)y_lo, n, overflow);
     return iago_check_launch("iago_value_stem");
 }
 
 int iago_value_stem_boards(const uint64_t *own, const uint64_t *opp, const float *w1, const float *b1, void *y_hi,
-                           void *y_lo, int64_t n, void *stream)
+                           void *y_lo, int64_t n, uint32_t *overflow, void *stream)
 {
     if (n < 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_value_stem_boards: negative n");
@@ -852,7 +865,7 @@ int iago_value_stem_boards(const uint64_t *own, const uint64_t *opp, const float
         return iago_fail(IAGO_ERR_INVALID, "iago_value_stem_boards: null pointer");
     hipLaunchKernelGGL(value_stem_kernel, dim3((unsigned)((n * 512 + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float *)nullptr, own, opp, w1, b1, (uint4 *)y_hi,
-                       (uint4 *)y_lo, n);
+                       (uint4 *)y_lo, n, overflow);
     return iago_check_launch("iago_value_stem_boards");
 }
 
@@ -889,15 +902,12 @@ int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y
     P.cin = cin;
     const size_t lds = (size_t)(cin * F32_XPLANE + 4 * 2 * (cin / 4) * F32_CO) * sizeof(float);
     const int lds128 = (int)((128 * F32_XPLANE + 4 * 2 * 32 * F32_CO) * sizeof(float));
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void *)conv3x3_f32_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds128) != hipSuccess ||
-            hipFuncSetAttribute((const void *)conv3x3_f32_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds128) != hipSuccess)
-            return iago_fail(IAGO_ERR_HIP, "iago_conv3x3_f32: cannot reserve LDS");
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured2{0}, configured1{0};
+    if (iago_reserve_lds((const void *)conv3x3_f32_kernel<128, 2>, lds128, configured2,
+                         "iago_conv3x3_f32: cannot reserve LDS") ||
+        iago_reserve_lds((const void *)conv3x3_f32_kernel<128, 1>, lds128, configured1,
+                         "iago_conv3x3_f32: cannot reserve LDS"))
+        return IAGO_ERR_HIP;
     // up to 32 boards: eight workgroups per board (half a board each) fill the CUs
     const bool half = n <= 32;
     const dim3 grid((unsigned)(n * (half ? 8 : 4)));
@@ -937,7 +947,8 @@ int iago_policy_head(const float *x, const float *w9, const float *b10, float *p
     return iago_check_launch("iago_policy_head");
 }
 
-int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels, void *stream)
+int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels, uint32_t *overflow,
+                    void *stream)
 {
     if (n < 0 || channels <= 0 || (channels % 16) != 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_split_nchw: channels must be a multiple of 16");
@@ -947,7 +958,7 @@ int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t chann
         return iago_fail(IAGO_ERR_INVALID, "iago_split_nchw: null pointer");
     const int64_t total = n * (channels / 16) * 128;
     hipLaunchKernelGGL(split_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, (__half *)hi, (__half *)lo, n, channels);
+                       (hipStream_t)stream, x, (__half *)hi, (__half *)lo, n, channels, overflow);
     return iago_check_launch("iago_split_nchw");
 }
 

@@ -112,13 +112,20 @@ __global__ __launch_bounds__(BLOCK) void sample_moves_kernel(
     double last = 0.0; // cdf[-1] of cumsum(p / s)
     for (int k = 0; k < 64; k++)
         last += (((lg >> k) & 1ull) ? (double)pr[k] : 0.0) / s;
+    // all-zero, NaN or infinite legal probabilities: p / s holds NaNs and numpy.random.choice
+    // raises "probabilities contain NaN" (src/rl_self_play.py:122).  Every comparison below
+    // would be false (idx 0, a possibly illegal cell): report 64 instead, the host raises.
+    if (!(s > 0.0) || !(s <= 1.7976931348623157e308) || !(last > 0.0)) {
+        action[b] = 64;
+        return;
+    }
     double acc = 0.0;
     int idx = 0;
     for (int k = 0; k < 64; k++) {
         acc += (((lg >> k) & 1ull) ? (double)pr[k] : 0.0) / s;
         idx += (acc / last <= u) ? 1 : 0; // searchsorted(cdf, u, side='right')
     }
-    action[b] = (int8_t)idx; // 64 would mean NaN probabilities: the reference raises there
+    action[b] = (int8_t)idx;
 }
 
 

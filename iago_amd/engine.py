@@ -284,6 +284,9 @@ class BatchedMCTS(object):
         if int(self.tree.overflow.sum().item()) != 0:
             raise _lib.IagoError("MCTS node pool exhausted (or a search path deeper than 512): "
                                  "raise `capacity` (%d nodes per game)" % self.tree.capacity)
+        sat = getattr(self.value_fn, "check_saturation", None)
+        if sat is not None:
+            sat()  # the split-f16 Value kernels clamp at 65000: never silently
 
     def enable_stats(self):
         self.stats = torch.zeros((self.n_games, 2), dtype=torch.int32, device=self.cur_own.device)

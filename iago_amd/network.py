@@ -215,6 +215,27 @@ class Value(nn.Module, _NpzMixin):
             cache[k] = hit
         return hit[1], hit[2]
 
+    def _overflow_flag(self, device):
+        """Device word the split-f16 kernels raise when an activation leaves the f16 range
+        (|a| > 65000) or is NaN: the forward is then saturated, not the reference's."""
+        f = self.__dict__.get("_ovf")
+        if f is None or f.device != device:
+            f = torch.zeros(1, dtype=torch.int32, device=device)
+            self.__dict__["_ovf"] = f
+        return f
+
+    def check_saturation(self):
+        """Raise if any split-f16 forward since the last check saturated (one host sync; the
+        search engine calls it once per search).  The float32 path (`split_f16 = False`) has
+        the reference's unbounded range."""
+        f = self.__dict__.get("_ovf")
+        if f is not None and int(f.item()) != 0:
+            f.zero_()
+            from ._lib import IagoError
+            raise IagoError("Value net: an activation left the split-f16 range (|a| > 65000) or is "
+                            "NaN; the results of this search are saturated.  Set "
+                            "`value.split_f16 = False` to evaluate in float32")
+
     def _use_split(self, x):
         return (self.split_f16 and x.is_cuda and not self.training and not torch.is_grad_enabled()
                 and x.dtype == torch.float32 and x.shape[0] >= self.SPLIT_MIN_BATCH
@@ -223,7 +244,7 @@ class Value(nn.Module, _NpzMixin):
     def _split_trunk_head(self, a):
         from . import ops
         layers = [self._split_weights(k) + (getattr(self, "block%d" % k).conv.bias,) for k in range(2, 9)]
-        a = ops.conv3x3_split_trunk(a, layers)   # blocks 2..8 in one launch
+        a = ops.conv3x3_split_trunk(a, layers, overflow=self._overflow_flag(a.hi.device))  # blocks 2..8
         return ops.value_head(a, self.block9.conv.weight, self.block9.conv.bias,
                               self.fc10.weight, self.fc11.weight)
 
@@ -235,18 +256,21 @@ class Value(nn.Module, _NpzMixin):
             return None
         from . import ops
         return self._split_trunk_head(ops.value_stem_boards(own, opp, self.block1.conv.weight,
-                                                            self.block1.conv.bias))
+                                                            self.block1.conv.bias,
+                                                            overflow=self._overflow_flag(own.device)))
 
     def forward(self, x):
         if self._use_split(x):
             from . import ops
-            a = ops.value_stem(x.contiguous(), self.block1.conv.weight, self.block1.conv.bias)
+            a = ops.value_stem(x.contiguous(), self.block1.conv.weight, self.block1.conv.bias,
+                               overflow=self._overflow_flag(x.device))
             return self._split_trunk_head(a)
         elif (self.split_f16 and x.is_cuda and not self.training and not torch.is_grad_enabled()
               and x.dtype == torch.float32 and x.shape[0] > 0 and not torch.is_autocast_enabled()):
             # small batches (single-game serving): float32 matrix-unit kernels
             from . import ops
-            return ops.value_head(ops.split_nchw(_f32_trunk(self, x)), self.block9.conv.weight,
+            return ops.value_head(ops.split_nchw(_f32_trunk(self, x), overflow=self._overflow_flag(x.device)),
+                                  self.block9.conv.weight,
                                   self.block9.conv.bias, self.fc10.weight, self.fc11.weight)
         else:
             h = x

@@ -147,7 +147,12 @@ def split_weights(weight):
     return hi.contiguous(), lo.contiguous()
 
 
-def split_nchw(x):
+def _flag(overflow):
+    """Optional int32 CUDA word the split-f16 kernels raise on saturation (iago_hip.h)."""
+    return _dev(overflow, torch.int32, "overflow") if overflow is not None else None
+
+
+def split_nchw(x, overflow=None):
     """(n, C, 8, 8) float32 -> SplitActs."""
     n, c = x.shape[0], x.shape[1]
     if x.dim() != 4 or x.shape[2] != 8 or x.shape[3] != 8 or c % 16:
@@ -155,7 +160,8 @@ def split_nchw(x):
     hi = torch.empty((n, c // 16, 64, 16), dtype=torch.float16, device=x.device)
     lo = torch.empty_like(hi)
     check(_lib.lib().iago_split_nchw(_dev(x, torch.float32, "x"), _dev(hi, torch.float16, "hi"),
-                                     _dev(lo, torch.float16, "lo"), n, c, _stream()), "iago_split_nchw")
+                                     _dev(lo, torch.float16, "lo"), n, c, _flag(overflow), _stream()),
+          "iago_split_nchw")
     return SplitActs(hi, lo, c)
 
 
@@ -168,7 +174,7 @@ def merge_nchw(a):
     return y
 
 
-def conv3x3_split_trunk(a, layers):
+def conv3x3_split_trunk(a, layers, overflow=None):
     """Consecutive conv3x3_split layers in one launch.  layers: list of (w_hi, w_lo, bias);
     the first reads SplitActs `a`, each next one its predecessor's output."""
     n = a.n
@@ -189,11 +195,12 @@ def conv3x3_split_trunk(a, layers):
         d.cin = cin
         cur, cin = SplitActs(hi, lo, 128), 128
         keep.append(cur)
-    check(_lib.lib().iago_conv3x3_split_trunk(descs, len(layers), n, _stream()), "iago_conv3x3_split_trunk")
+    check(_lib.lib().iago_conv3x3_split_trunk(descs, len(layers), n, _flag(overflow), _stream()),
+          "iago_conv3x3_split_trunk")
     return cur
 
 
-def value_stem(planes, w1, b1):
+def value_stem(planes, w1, b1, overflow=None):
     """relu(conv3x3(planes, w1) + b1), 2 -> 64 channels (Value.block1, network.py:68-70):
     float32 planes (n, 2, 8, 8) -> SplitActs with 64 channels."""
     n = planes.shape[0]
@@ -203,11 +210,12 @@ def value_stem(planes, w1, b1):
     lo = torch.empty_like(hi)
     check(_lib.lib().iago_value_stem(_dev(planes, torch.float32, "planes"), _dev(w1, torch.float32, "w1"),
                                      _dev(b1, torch.float32, "b1"), _dev(hi, torch.float16, "y_hi"),
-                                     _dev(lo, torch.float16, "y_lo"), n, _stream()), "iago_value_stem")
+                                     _dev(lo, torch.float16, "y_lo"), n, _flag(overflow), _stream()),
+          "iago_value_stem")
     return SplitActs(hi, lo, 64)
 
 
-def value_stem_boards(own, opp, w1, b1):
+def value_stem_boards(own, opp, w1, b1, overflow=None):
     """value_stem on the boards themselves (own = side to move): plane encoding fused in."""
     n = own.numel()
     hi = torch.empty((n, 4, 64, 16), dtype=torch.float16, device=own.device)
@@ -215,7 +223,7 @@ def value_stem_boards(own, opp, w1, b1):
     check(_lib.lib().iago_value_stem_boards(_dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp"),
                                             _dev(w1, torch.float32, "w1"), _dev(b1, torch.float32, "b1"),
                                             _dev(hi, torch.float16, "y_hi"), _dev(lo, torch.float16, "y_lo"),
-                                            n, _stream()), "iago_value_stem_boards")
+                                            n, _flag(overflow), _stream()), "iago_value_stem_boards")
     return SplitActs(hi, lo, 64)
 
 
@@ -233,7 +241,7 @@ def value_head(a, w9, b9, w10, w11):
     return out
 
 
-def conv3x3_split(a, w_hi, w_lo, bias):
+def conv3x3_split(a, w_hi, w_lo, bias, overflow=None):
     """relu(conv3x3(a, w) + bias) on SplitActs: Block.__call__ (network.py:9-13) on
     the MFMA units in split-f16 arithmetic.  w_hi, w_lo from split_weights."""
     cin = a.channels
@@ -245,7 +253,7 @@ def conv3x3_split(a, w_hi, w_lo, bias):
                                         _dev(w_hi, torch.float16, "w_hi"), _dev(w_lo, torch.float16, "w_lo"),
                                         _dev(bias, torch.float32, "bias"),
                                         _dev(hi, torch.float16, "y_hi"), _dev(lo, torch.float16, "y_lo"),
-                                        a.n, cin, 128, _stream()), "iago_conv3x3_split")
+                                        a.n, cin, 128, _flag(overflow), _stream()), "iago_conv3x3_split")
     return SplitActs(hi, lo, 128)
 
 

@@ -14,8 +14,13 @@ from . import boards, ops
 
 class GameEnv(object):
 
-    def __init__(self, model1, model2):
+    def __init__(self, model1, model2, choice=None, fallback_choice=None):
+        """choice(n, p=...) replaces numpy.random.choice (rl_env.py:166) and
+        fallback_choice(seq) python's random.choice (rl_env.py:48): tests inject
+        recorded draws, exactly like game.Game's injected I/O."""
         self.model1, self.model2 = model1, model2
+        self.choice = choice if choice is not None else (lambda n, p=None: np.random.choice(n, p=p))
+        self.fallback_choice = fallback_choice if fallback_choice is not None else random.choice
         self.reset()
 
     def _obs(self):
@@ -62,11 +67,13 @@ class GameEnv(object):
             x = self._obs()
             model = self.model2
         model = getattr(model, "predictor", model)
-        with torch.no_grad():
-            out = model(x).reshape(64).to(torch.float64).cpu().numpy()
-        out = out - np.min(out)
         while True:
-            idx = np.random.choice(64, p=out / np.sum(out))
+            # the reference re-evaluates the net on every retry (rl_env.py:170-171) and
+            # shifts / normalises in the net's float32 (rl_env.py:165-166)
+            with torch.no_grad():
+                out = torch.as_tensor(model(x)).reshape(64).to(torch.float32).cpu().numpy().copy()
+            out -= np.min(out)
+            idx = int(self.choice(64, p=out / np.sum(out)))
             position = [idx // 8 + 1, idx % 8 + 1]
             if position in positions:
                 return position
@@ -77,7 +84,7 @@ class GameEnv(object):
         if len(positions) > 0:
             position = [action // 8 + 1, action % 8 + 1]
             if position not in positions:
-                position = random.choice(positions)  # rl_env.py:46-48
+                position = self.fallback_choice(positions)  # rl_env.py:46-48
             self.place_stone(position, 1)
             self.stone_num += 1
             self.pass_flg = False

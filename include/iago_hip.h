@@ -210,10 +210,18 @@ IAGO_API int iago_bias_relu(float *x, const float *bias, int64_t n, int32_t chan
  * Weights: two f16 arrays [cin/16][3][3][cout][16] (kernel row, kernel column, output
  * channel, input channel within the block) split the same way; bias float32 [cout].
  * cout must be 128, cin a multiple of 32.  All pointers 16-byte aligned.
+ *
+ * Range: an f16 "hi" part holds |a| <= 65504, so activations are clamped to [0, 65000]
+ * (inputs of iago_split_nchw to [-65000, 65000]) -- the float32 reference has no such
+ * bound.  `overflow` (every function below that writes split channel blocks; optional, NULL
+ * = no report) is a device word the kernel sets to 1 when a value was outside that range
+ * or NaN BEFORE the clamp, i.e. when the results of this call are saturated and no longer
+ * the reference's.  The caller zeroes it, reads it at its next synchronisation point and
+ * falls back to the float32 kernels (iago_conv3x3_f32 / MIOpen) or raises.
  */
 IAGO_API int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
                                 const float *bias, void *y_hi, void *y_lo, int64_t n, int32_t cin,
-                                int32_t cout, void *stream);
+                                int32_t cout, uint32_t *overflow, void *stream);
 /*
  * The ends of the Value net around the split-f16 convolutions, in float32 arithmetic:
  * iago_value_stem: block1 = conv3x3 2 -> 64 + bias + ReLU (network.py:68-70) from the
@@ -225,10 +233,10 @@ IAGO_API int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *
  *   w10 [128][64], w11 [1][128].
  */
 IAGO_API int iago_value_stem(const float *planes, const float *w1, const float *b1, void *y_hi, void *y_lo,
-                             int64_t n, void *stream);
+                             int64_t n, uint32_t *overflow, void *stream);
 /* iago_value_stem straight from the boards (own = side to move): iago_encode_planes fused in. */
 IAGO_API int iago_value_stem_boards(const uint64_t *own, const uint64_t *opp, const float *w1, const float *b1,
-                                    void *y_hi, void *y_lo, int64_t n, void *stream);
+                                    void *y_hi, void *y_lo, int64_t n, uint32_t *overflow, void *stream);
 IAGO_API int iago_value_head(const void *x_hi, const void *x_lo, const float *w9, const float *b9,
                              const float *w10, const float *w11, float *out, int64_t n, void *stream);
 /*
@@ -265,8 +273,9 @@ typedef struct iago_conv_split_layer {
     int32_t reserved;
 } iago_conv_split_layer;
 IAGO_API int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32_t n_layers, int64_t n,
-                                      void *stream);
-IAGO_API int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels, void *stream);
+                                      uint32_t *overflow, void *stream);
+IAGO_API int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels,
+                             uint32_t *overflow, void *stream);
 IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n, int32_t channels,
                              void *stream);
 

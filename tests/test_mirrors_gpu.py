@@ -195,3 +195,49 @@ def test_game_env_mirror():
         assert steps < 70
     assert env() == orc.judge(env.state, 1)
     assert done and (env.stone_num >= 64 or env.pass_flg)
+
+
+def test_game_env_replays_golden_episodes():
+    """a-14: the 6 recorded reference GameEnv episodes (rl_env.py:26-74,152-172; stand-in
+    opponent, the uniforms numpy drew) replayed through the GPU mirror: board, done,
+    stone_num, pass_flg and the observation after every step, and the final z.  The rules
+    (valid_pos, place_stone, the obs planes) run through the HIP kernels; the opponent net is
+    the fixture's stand-in, evaluated by the same float32 routine that produced the fixture,
+    so that every recorded uniform lands on the recorded cell."""
+    from iago_amd import rl_env
+    for c in load_json("env.json"):
+        w2, b2 = c["w2"], c["b2"]
+
+        def opp(x, w2=w2, b2=b2):
+            xs = x.cpu().numpy().astype(np.float32).reshape(2, 8, 8)
+            state = (xs[0] + 2 * xs[1]).astype(np.float32)
+            out = orc.rollout_policy(xs, w2, b2)[0].copy()
+            for a in orc.legal_actions(state, 2):
+                out[a] += np.float32(0.25)
+            return torch.from_numpy(out)
+
+        it = iter(c["uniforms"])
+
+        def choice(n, p=None):
+            return orc.choice_cdf(np.asarray(p, np.float64), next(it))
+
+        def no_fallback(seq):
+            raise AssertionError("the fixtures hold legal agent actions only")
+
+        env = rl_env.GameEnv(None, opp, choice=choice, fallback_choice=no_fallback)
+        obs = env.reset()
+        assert np.array_equal(obs.cpu().numpy(), orc.env_obs(orc.initial_state()))
+        for s in c["steps"]:
+            obs, r, done, info = env.step(s["action"])
+            assert boards_bits(env.state) == (s["p1"], s["p2"])
+            assert (done, r, env.stone_num, env.pass_flg) == (s["done"], s["reward"], s["stone_num"],
+                                                              s["pass_flg"])
+            assert info is None and s["obs_ok"]
+            assert np.array_equal(obs.cpu().numpy(), orc.env_obs(env.state))
+        assert next(it, None) is None  # every recorded draw was consumed
+        assert env() == c["z"]
+
+
+def boards_bits(state):
+    from iago_amd import boards
+    return boards.state_to_bits(state)

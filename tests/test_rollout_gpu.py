@@ -228,6 +228,29 @@ def test_sample_moves_bit_exact(ops):
             assert got2[i] == want
 
 
+def test_sample_moves_flags_nan_and_zero_mass(ops):
+    """numpy.random.choice raises on NaN probabilities (p / 0 or a NaN net output,
+    src/rl_self_play.py:118-122); iago_sample_moves reports 64 there and play_batch raises."""
+    own = ops.bits_to_tensor(np.full(4, 0x0000000810000000, np.uint64))
+    opp = ops.bits_to_tensor(np.full(4, 0x0000001008000000, np.uint64))
+    legal = ops.legal_moves(own, opp)               # {19, 26, 37, 44}
+    probs = np.full((4, 64), 1.0 / 64, np.float32)
+    probs[1, [19, 26, 37, 44]] = 0.0                # zero mass on the legal cells
+    probs[2, 26] = np.nan                           # NaN on a legal cell
+    probs[3, 0] = np.nan                            # NaN on an illegal cell: masked out, fine
+    u = torch.full((4,), 0.3, dtype=torch.float64, device="cuda")
+    got = ops.sample_moves(torch.from_numpy(probs).cuda(), legal, uniforms=u).cpu().numpy()
+    assert got[0] in (19, 26, 37, 44) and got[3] in (19, 26, 37, 44)
+    assert got[1] == 64 and got[2] == 64
+    from iago_amd import rl_self_play
+
+    def nan_model(x):
+        return torch.full((x.shape[0], 64), float("nan"), device=x.device)
+
+    with pytest.raises(ValueError):
+        rl_self_play.play_batch(nan_model, nan_model, 3)
+
+
 def test_product_form_with_large_common_offset(ops):
     """Softmax is shift-invariant: biases offset by +500 (product form, factors
     shifted by their own maxima) replay against the oracle like any other net."""
