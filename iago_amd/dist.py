@@ -79,3 +79,33 @@ def gather_tuples(fields, group=None):
         flat = torch.cat(parts).view(t.dtype)
         out[k] = flat.view((sum(counts),) + tuple(t.shape[1:]))
     return out
+
+
+def broadcast_tensors(tensors, src=0, group=None):
+    """In place: every rank's `tensors` (same shapes / dtypes everywhere) become rank
+    `src`'s, with ONE collective over a flat byte buffer (a model is a few MB)."""
+    tensors = list(tensors)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or not tensors:
+        return
+    flat = torch.cat([t.detach().contiguous().view(-1).view(torch.uint8) for t in tensors])
+    dist.broadcast(flat, src, group=group)
+    off = 0
+    with torch.no_grad():
+        for t in tensors:
+            nb = t.numel() * t.element_size()
+            t.copy_(flat[off:off + nb].view(t.dtype).view(t.shape))
+            off += nb
+
+
+def broadcast_object(obj, src=0, group=None):
+    """rank `src`'s python object on every rank (seeds, small configuration)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src, group=group)
+    return box[0]
+
+
+def barrier(group=None):
+    if dist.is_initialized():
+        dist.barrier(group=group)

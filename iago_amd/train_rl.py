@@ -10,9 +10,13 @@ with the WeightDecay(5e-4) hook (src/train_rl.py:24-26); Chainer is not in the
 reference tree (unpinned, readme.md:13), so `ChainerAdam` restates its published
 update rule -- PARITY UNPINNED, see DESIGN.md.
 
-Multi-GPU (BASELINE configs[4]): the games of a set shard over the ranks, the
-recorded (state, action, z) tuples are all-gathered (iago_amd.dist) and every
-rank applies the identical update -- no gradient all-reduce.
+Multi-GPU (BASELINE configs[4]): the games of a set shard over the ranks and the
+recorded (state, action, z) tuples are all-gathered (iago_amd.dist); every rank
+then computes the update from the same batch and rank 0's parameters are
+broadcast (one 3.8 MB collective per set), so the replicas cannot drift even
+where a backward kernel is not bit-reproducible across GPUs.  Opponent and
+handicap draws come from ONE seed (rank 0's), checkpoints are written atomically
+by rank 0 and followed by a barrier before anyone lists the pool again.
 """
 import glob
 import math
@@ -71,7 +75,7 @@ class ChainerAdam(object):
         return out
 
     def save_npz(self, path):
-        np.savez(path, **self.state_dict_npz())
+        _atomic_savez(path, self.state_dict_npz())
 
     def load_npz(self, path):
         src = np.load(path)
@@ -83,6 +87,16 @@ class ChainerAdam(object):
             m.copy_(torch.from_numpy(src[k + "/m"]))
             v.copy_(torch.from_numpy(src[k + "/v"]))
         return self
+
+
+def _atomic_savez(path, arrays):
+    """np.savez to a temporary name in the same directory + rename: a reader never sees
+    a partially written checkpoint."""
+    final = path if path.endswith(".npz") else path + ".npz"
+    tmp = "%s.part%d" % (final, os.getpid())  # not *.npz: invisible to the pool listing
+    with open(tmp, "wb") as f:
+        np.savez(f, **arrays)
+    os.replace(tmp, final)
 
 
 def reinforce_loss(model, own, opp, actions, rewards, pad_to=None):
@@ -114,11 +128,22 @@ class ReinforceTrainer(object):
     def __init__(self, model1, pool_dir=None, N=32, seed=0, alpha=1e-3, device="cuda"):
         self.model1 = model1.to(device)
         self.opt = ChainerAdam(self.model1, alpha=alpha)
+        # one seed for every rank: the opponent / handicap draws and the Philox key of the
+        # games (keyed by GLOBAL game id) must not depend on the rank
+        seed = idist.broadcast_object(seed)
         self.N, self.seed, self.device = N, seed, device
         self.pool_dir = pool_dir
         self.rs = np.random.RandomState(seed)
         self.models, self.cnt, self.set_index = 1, 0, 0
         self.log = []
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """Every rank takes rank 0's parameters and Adam moments."""
+        ts = [p.data for p in self.model1.parameters()]
+        for n, _ in self.model1.named_parameters():
+            ts.extend(self.opt.state[n])
+        idist.broadcast_tensors(ts)
 
     def pick_opponent(self):
         """np.random.choice(glob('../models/RL/*.npz')) (src/train_rl.py:33-37)."""
@@ -160,15 +185,19 @@ class ReinforceTrainer(object):
                               pad_to=512)
         loss.backward()
         self.opt.update()
+        idist.broadcast_tensors([p.data for p in self.model1.parameters()])  # replicas stay identical
         rate = result / (2 * self.N)
         saved = False
         if rate > 0.5:                                             # src/train_rl.py:71-72
             self.cnt += 1
         if self.cnt > 4 * math.sqrt(self.models) and rate > 0.6:  # src/train_rl.py:73-79
             if self.pool_dir and idist.rank() == 0:
-                self.model1.save_npz(os.path.join(self.pool_dir, "model%d.npz" % self.models))
+                _atomic_savez(os.path.join(self.pool_dir, "model%d.npz" % self.models),
+                              self.model1.npz_dict())
                 os.makedirs(os.path.join(self.pool_dir, "optimizers"), exist_ok=True)
                 self.opt.save_npz(os.path.join(self.pool_dir, "optimizers", "%d.npz" % self.models))
+            if self.pool_dir:
+                idist.barrier()  # nobody lists the pool before the new checkpoint is complete
             self.models += 1
             self.cnt = 0
             saved = True

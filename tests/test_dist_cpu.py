@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from iago_amd.dist import gather_tuples, shard_range
+from iago_amd.dist import broadcast_object, broadcast_tensors, gather_tuples, shard_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -44,6 +44,12 @@ def _worker(rank, world, port, q):
         # an empty shard on one rank must work too
         e = gather_tuples(dict(x=torch.arange(3 if rank == 0 else 0, dtype=torch.float32)))
         q.put((rank, e["x"].tolist()))
+        # replicas of a model take rank 0's parameters with one collective (train_rl.py)
+        a = torch.full((3, 2), float(rank + 1))
+        b = torch.full((5,), rank + 7, dtype=torch.int64)
+        broadcast_tensors([a, b])
+        assert torch.equal(a, torch.full((3, 2), 1.0)) and torch.equal(b, torch.full((5,), 7))
+        assert broadcast_object(100 + rank) == 100
     finally:
         dist.destroy_process_group()
 

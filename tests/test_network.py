@@ -12,7 +12,7 @@ from oracle import nets_np
 from oracle import oracle as orc
 
 TOL = 1e-5
-REF_MODELS = "/root/reference/models"
+REF_MODELS = "/root/reference/models"  # rollout_model.npz only; sl / value live in tests/golden
 
 
 def sample_planes(n, seed):
@@ -103,8 +103,9 @@ def test_shipped_checkpoints_known_answers():
     restatement) + the float64 oracle on the same weights."""
     s = orc.initial_state()
     x = np.concatenate([orc.make_state_var(s, 1), orc.make_state_var(s, 2)]).astype(np.float32)
-    sl = network.SLPolicy().load_npz(os.path.join(REF_MODELS, "sl_model.npz")).eval()
-    va = network.Value().load_npz(os.path.join(REF_MODELS, "value_model.npz")).eval()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sl = network.SLPolicy().load_npz(os.path.join(gold, "sl_model.npz")).eval()
+    va = network.Value().load_npz(os.path.join(gold, "value_model.npz")).eval()
     ro = network.RolloutPolicy().load_npz(os.path.join(REF_MODELS, "rollout_model.npz")).eval()
     with torch.no_grad():
         p = sl(torch.from_numpy(x)).numpy()
