@@ -8,26 +8,29 @@ Workload (BASELINE.json configs[1]): per GPU, 4096 parallel Othello boards from
 the standard start position are played to the end by the fused HIP rollout
 kernel with the reference's shipped RolloutPolicy weights (82 floats, kept as
 golden data in tests/golden/simulate.json) -- rollout-policy-only self-play.
-One step = 4096 finished games per GPU.  Steps are independent batches: by default
-up to 2048 consecutive steps share one kernel launch (the default 2000 steps are one
-launch of 8,192,000 boards), which the library plays with its lane-per-board rollout
-kernel: the ramp and the tail of a launch (waves of different game lengths leave CUs
-idle at its end) are paid once (256 steps per launch: -10 %).  `--steps-per-launch 1` issues every
-step as its own launch of the 8-lanes-per-board kernel, overlapped on 32 HIP
-streams / 16 hardware queues (a single 4096-board launch is only 512 waves).
-With N > 1 every rank plays its own 4096-board shard (weak scaling, Philox streams
-keyed by a rank-major global game id) and the finished (final boards, z, turns)
-tuples of the whole round are all-gathered over RCCL inside the timed region: the
-run is then two launches, and the tuples of the first travel as one collective on a
-side stream beside the second.
+One step = ONE launch of 4096 boards = 4096 finished games per GPU; the launches
+of a run are serialized on one stream, so 4096 boards are in flight at any time,
+as the config says.  A round is K = --steps steps; the timed region repeats the
+round R times so that it lasts >= 150 ms whatever K is (R is printed as
+`repeats`; ms_per_step = region / (K R)), which makes `value` independent of
+--steps.  With N > 1 every rank plays its own boards (weak scaling, Philox
+streams keyed by a global game id (launch * N + rank) * 4096 + board) and the
+finished (final boards, z, turns) tuples of every round are all-gathered over
+RCCL inside the timed region, on a side stream beside the next round.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the rollout kernel against the
-HBM roof with SURVEY.md section 8(d)'s algorithmic bytes (33 B per board-step);
-`cpu_baseline` times the CPU oracle (oracle/, a C port of the reference's
-Python loops) on the host cores over a bounded sample of the same workload.
-Extra objects: `large_batch` (the same kernel at 1M boards in one launch),
-`mcts` (BASELINE configs[2]: PV-MCTS 100 sims/move, 1024 games, played to the
-end: leaf-evals/s and games/s, with its own 1-core CPU baseline).
+HBM roof with SURVEY.md section 8(d)'s algorithmic bytes (33 B per board-step):
+bytes of one launch / the launch's duration, measured with HIP event pairs on the
+launch stream around a sample of the timed launches (single tenant: equals the
+rocprofv3 average of tools/profile_rollout.sh, committed under profiles/).
+`cpu_baseline` times the CPU oracle (oracle/, a C port of the reference's Python
+loops) on the host cores over a bounded sample of the same workload, with the
+Python-loop restatement on one core beside it.
+Extra objects, none of them `value`: `overlapped` (the same 4096-board launches
+on 32 HIP streams), `large_batch` (one launch of 1M boards, lane-per-board
+kernel), `mcts` (BASELINE configs[2]: PV-MCTS 100 sims/move, 1024 games, played
+to the end: leaf-evals/s and games/s, with its own 1-core CPU baseline),
+`reinforce`, `mcts_single_game`.
 """
 import argparse
 import ctypes
@@ -155,7 +158,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
            "value_conv": ("f32 (MIOpen)" if value_f32 else
                           "split-f16 MFMA: f16 hi/lo operands, 3 MFMAs per product sum, f32 accumulation; "
                           "Value forward within 1e-6 of the f32 one (tests/test_conv_gpu.py)"),
-           "policy_conv": "f32 (MIOpen)",
+           "policy_conv": "f32: hand-written conv3x3_f32 / policy_head kernels (batches <= 192: the "
+                          "expansions of a playout); MIOpen above",
            "roofline": _mcts_roofline(leaf, pol, dt, world, value_f32),
            "config": "BASELINE configs[2]: PV-MCTS %d sims/move, %d games per GPU, SLPolicy+Value "
                      "random init fp32, lmbda=0.5 c_puct=1 n_thr=15" % (n_sims, n_games),
@@ -277,38 +281,289 @@ def reinforce_leg(n_iters, world, rank, dist):
 
 
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2  # wave64 VALU instructions/ns: 1024 SIMD-32s, 2 cycles each
+TARGET_REGION_S = 0.15               # the timed region is at least this long whatever --steps is
 
 
-def measured_pmc():
-    """Per-launch figures from the committed rocprofv3 --pmc passes (profiles/), if any."""
+def measured_pmc(boards_per_launch):
+    """Per-launch figures of the rollout kernel from the committed rocprofv3 passes
+    (profiles/rollout_traffic.json, keyed by the launch size they were taken at)."""
     path = os.path.join(ROOT, "profiles", "rollout_traffic.json")
-    if os.path.exists(path):
-        with open(path) as f:
-            return json.load(f)
-    return {}
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f).get("by_boards_per_launch", {}).get(str(boards_per_launch), {})
 
 
-def measured_traffic(boards_per_launch):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes, if any, scaled from
-    the profiled launch size to this run's (the traffic is per board: inputs, outputs and
-    the table staged once per block)."""
-    pmc = measured_pmc()
-    if "hbm_bytes_per_launch" not in pmc:
-        return None
-    return pmc["hbm_bytes_per_launch"] * boards_per_launch / pmc.get("boards_per_launch", boards_per_launch)
-
-
-def valu_utilisation(boards, seconds):
-    """What really bounds the kernel: wave-level VALU instructions (PMC count per
-    board from profiles/, the instruction stream does not depend on the batch) over
-    the chip's issue peak.  None without a committed PMC profile."""
-    pmc = measured_pmc()
+def valu_utilisation(boards_per_launch, launches, seconds):
+    """What really bounds the rollout kernels: wave-level VALU instructions (PMC count of a
+    launch of this size, from profiles/) over the chip's issue peak."""
+    pmc = measured_pmc(boards_per_launch)
     if "valu_insts_per_launch" not in pmc:
         return None
-    per_board = pmc["valu_insts_per_launch"] / pmc["boards_per_launch"]
-    achieved = per_board * boards / seconds / 1e9
-    return {"valu_insts_per_board": per_board, "achieved_ginst_per_s": achieved,
-            "peak_ginst_per_s": VALU_PEAK_GINST, "frac": achieved / VALU_PEAK_GINST}
+    achieved = pmc["valu_insts_per_launch"] * launches / seconds / 1e9
+    return {"valu_insts_per_board": pmc["valu_insts_per_launch"] / boards_per_launch,
+            "achieved_ginst_per_s": achieved, "peak_ginst_per_s": VALU_PEAK_GINST,
+            "frac": achieved / VALU_PEAK_GINST, "profile": pmc.get("profile")}
+
+
+def python_loop_baseline(w, b, budget_s=4.0):
+    """The reference's execution model on ONE core: interpreted Python loops over an (8,8)
+    numpy board (oracle/py_loops.py restates rl_env.py:88-138 / mcts_self_play.py:25-134)
+    with a B = 1 torch-CPU RolloutPolicy call per move."""
+    from iago_amd import network
+    from oracle import py_loops
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        ro = network.RolloutPolicy().eval()
+        with torch.no_grad():
+            ro.conv1.weight.copy_(torch.from_numpy(w.reshape(1, 2, 3, 3)))
+            ro.bias2.b.copy_(torch.from_numpy(b))
+
+        def policy(x):
+            with torch.no_grad():
+                return ro(torch.from_numpy(x)).numpy()
+
+        s0 = np.zeros((8, 8), np.float32)
+        s0[4, 3] = s0[3, 4] = 1
+        s0[3, 3] = s0[4, 4] = 2
+        rs = np.random.RandomState(0)
+        games = steps = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            steps += py_loops.simulate(s0, 1, policy, rs)[1]
+            games += 1
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthreads)
+    return {"value": games / dt, "unit": "games/s", "cores": 1, "kind": "port",
+            "sample": "%d rollout-policy games, oracle/py_loops.py (Python loops over a numpy board, "
+                      "torch-CPU B=1 policy calls), %.1f s" % (games, dt),
+            "board_steps_per_game": steps / max(games, 1)}
+
+
+class RolloutRounds(object):
+    """BASELINE configs[1] on one rank: K steps per round, one step = ONE launch of B = 4096
+    boards from the start position played to the end (rollout_kernel, 8 lanes per board).
+    Results land in a round buffer resident in HBM: per step one contiguous block
+    [final own | final opp | z | turns] (18 B per game); two round buffers alternate so that
+    the all-gather of round r (N > 1, side stream) runs beside round r + 1."""
+
+    def __init__(self, B, K, world, rank, weights, ops):
+        self.B, self.K, self.world, self.rank, self.ops = B, K, world, rank, ops
+        self.own = torch.full((B,), START_OWN, dtype=torch.int64, device="cuda")
+        self.opp = torch.full((B,), START_OPP, dtype=torch.int64, device="cuda")
+        self.bufs = [torch.zeros(K * B * 18, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        self.launches = [[self._prepare(buf, k, weights) for k in range(K)] for buf in range(2)]
+
+    def views(self, buf, k):
+        B = self.B
+        blk = self.bufs[buf][k * B * 18:(k + 1) * B * 18]
+        return (blk[0:8 * B].view(torch.int64), blk[8 * B:16 * B].view(torch.int64),
+                blk[16 * B:17 * B].view(torch.int8), blk[17 * B:18 * B])
+
+    def _prepare(self, buf, k, weights):
+        r = self.ops.RolloutResult()
+        r.final_own, r.final_opp, r.z, r.n_turns = self.views(buf, k)
+        return self.ops.rollout_prepare(self.own, self.opp, weights, seed=2024, id_base=0, out=r)
+
+    def id_base(self, launch_index):
+        """Global game id of board 0 of a launch: (launch * world + rank) * B -- unique over
+        ranks and launches (the Philox counter word is 32 bits wide: checked by the caller)."""
+        return (launch_index * self.world + self.rank) * self.B
+
+    def launch(self, buf, k, launch_index, stream_ptr, stream_id=0):
+        p = self.launches[buf][k]
+        p.args.id_base = self.id_base(launch_index) & 0xFFFFFFFF
+        p.args.stream_id = stream_id
+        return p.launch(stream_ptr)
+
+    def board_steps(self, buf):
+        return sum(int(self.views(buf, k)[3].to(torch.int64).sum().item()) for k in range(self.K))
+
+
+def rollout_leg(args, world, rank, dist):
+    """The headline leg; returns the dict of measurements rank 0 prints."""
+    from iago_amd import _lib, ops
+    B, K, W = args.boards, args.steps, args.warmup
+    w, b = shipped_rollout_weights()
+    weights = ops.RolloutWeights(w, b)
+    rr = RolloutRounds(B, K, world, rank, weights, ops)
+    main = torch.cuda.current_stream()
+    mptr = ctypes.c_void_p(main.cuda_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    rc = 0
+    for i in range(W):                      # untimed warm-up steps (their own Philox stream)
+        rc |= rr.launch(i & 1, i % K, i, mptr, stream_id=1)
+    torch.cuda.synchronize()
+    # calibration: the duration of a step decides how many rounds make a >= 150 ms region
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ncal = 32
+    c0.record(main)
+    for i in range(ncal):
+        rc |= rr.launch(0, i % K, i, mptr, stream_id=1)
+    c1.record(main)
+    torch.cuda.synchronize()
+    t_step = torch.tensor([c0.elapsed_time(c1) * 1e-3 / ncal], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t_step, op=dist.ReduceOp.MAX)
+    R = args.repeats if args.repeats > 0 else max(1, int(np.ceil(TARGET_REGION_S / (K * float(t_step.item())))))
+    n_launches = R * K
+    if (n_launches * world + world) * B >= 1 << 32:
+        raise SystemExit("game ids exceed the 32-bit Philox counter word: lower --steps / --repeats")
+
+    use_gather = dist is not None
+    nbytes = K * B * 18
+    gathered = [torch.empty(world * nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)] \
+        if use_gather else None
+    comm = torch.cuda.Stream() if use_gather else None
+    played = [torch.cuda.Event() for _ in range(R)] if use_gather else None
+    shipped = [torch.cuda.Event() for _ in range(R)] if use_gather else None
+    # kernel duration: event pairs around a sample of the launches, on the launch stream
+    every = max(1, n_launches // 64)
+    evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for i in range(0, n_launches, every)}
+    span0, span1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    span0.record(main)
+    for r in range(R):
+        buf = r & 1
+        if use_gather and r >= 2:
+            main.wait_event(shipped[r - 2])   # this buffer's previous round has left
+        for k in range(K):
+            i = r * K + k
+            e = evs.get(i)
+            if e is not None:
+                e[0].record(main)
+            rc |= rr.launch(buf, k, i, mptr)
+            if e is not None:
+                e[1].record(main)
+        if use_gather:
+            # the round's tuples: ONE collective on the side stream, ordered behind the
+            # round by an event, beside the next round's launches; no host sync
+            played[r].record(main)
+            with torch.cuda.stream(comm):
+                comm.wait_event(played[r])
+                dist.all_gather_into_tensor(gathered[buf], rr.bufs[buf])
+                shipped[r].record(comm)
+    span1.record(main)
+    if use_gather:
+        main.wait_stream(comm)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        raise SystemExit("iago_rollout failed: %s" % _lib.lib().iago_last_error())
+
+    # Launch duration.  The launches are back to back on one stream, so the period
+    # span / launches bounds the kernel's duration from above (kernel + dispatch gap); an
+    # event pair around ONE launch adds the cost of the two event packets to it (~3 us).
+    # The roofline uses the smaller of the two -- rocprofv3's average (profiles/) is the
+    # kernel alone and must not exceed it.
+    pair_ms = sum(e[0].elapsed_time(e[1]) for e in evs.values()) / len(evs)
+    span_ms = span0.elapsed_time(span1)
+    kernel_ms = min(pair_ms, span_ms / n_launches)
+    last = (R - 1) & 1
+    steps_round = torch.tensor([rr.board_steps(last)], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if use_gather:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(steps_round)
+        g = gathered[last]
+        assert torch.equal(g[rank * nbytes:(rank + 1) * nbytes], rr.bufs[last])
+        for other in range(world):            # every rank played games of its own
+            if other != rank:
+                assert not torch.equal(g[other * nbytes:(other + 1) * nbytes], rr.bufs[last]), \
+                    "ranks %d and %d played identical games" % (rank, other)
+    dt = float(tmax.item())
+    steps_per_game = float(steps_round.item()) / (world * K * B)
+    games = world * R * K * B
+    alg = BYTES_PER_BOARD_STEP * steps_per_game * B          # algorithmic bytes of ONE launch
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    pmc = measured_pmc(B)
+    out = {
+        "value": games / dt, "ms_per_step": dt / (R * K) * 1e3, "repeats": R,
+        "timed_region_s": dt, "board_steps_per_game": steps_per_game,
+        "board_steps_per_sec": steps_per_game * games / dt,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
+                     "kernel": "rollout_kernel<true> (8 lanes per board)", "kernel_ms": kernel_ms,
+                     "kernel_ms_event_pairs": pair_ms, "kernel_ms_period": span_ms / n_launches,
+                     "kernel_ms_samples": len(evs), "boards_per_launch": B,
+                     "algorithmic_bytes_per_launch": alg,
+                     "rocprof_kernel_avg_ms": pmc.get("rocprof_kernel_avg_ms"),
+                     "profile": pmc.get("profile"),
+                     "valu": valu_utilisation(B, 1, kernel_ms * 1e-3),
+                     "note": "the HBM roof is nominal for this path: a board (16 B) lives in VGPRs "
+                             "for the whole game, measured traffic is far below the algorithmic "
+                             "bytes; the real bound of one 4096-board launch is VALU issue latency "
+                             "of 512 waves on 1024 SIMDs (DESIGN.md section 5)"},
+    }
+
+    # ---- extra datapoints (rank 0, not the headline): the same steps overlapped on HIP
+    # streams, and one launch large enough to fill the chip
+    if rank == 0 and not args.rollout_only and not args.mcts_only:
+        S = max(1, args.streams)
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        sptr = [ctypes.c_void_p(st.cuda_stream) for st in streams]
+        no = max(256, min(2048, K))
+        for rep in range(2):                 # first pass warms the streams up
+            torch.cuda.synchronize()
+            o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            o0.record(main)
+            for st in streams:
+                st.wait_stream(main)
+            for i in range(no):
+                rc |= rr.launch(0, i % K, i, sptr[i % S], stream_id=2)
+            for st in streams:
+                main.wait_stream(st)
+            o1.record(main)
+            torch.cuda.synchronize()
+        oms = o0.elapsed_time(o1)
+        out["overlapped"] = {"games_per_sec": no * B / (oms * 1e-3), "launches": no, "hip_streams": S,
+                             "boards_per_launch": B, "ms_per_step": oms / no,
+                             "hbm_frac": alg * no / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "the same 4096-board launches issued on %d HIP streams "
+                                     "(independent steps overlap on the chip); not `value`" % S}
+        if args.large_boards > 0:
+            LB = args.large_boards
+            lown = torch.full((LB,), START_OWN, dtype=torch.int64, device="cuda")
+            lopp = torch.full((LB,), START_OPP, dtype=torch.int64, device="cuda")
+            lout = ops.RolloutResult()
+            lout.z = torch.empty(LB, dtype=torch.int8, device="cuda")
+            lout.n_turns = torch.empty(LB, dtype=torch.uint8, device="cuda")
+            for k in range(3):
+                ops.rollout(lown, lopp, weights, seed=1, id_base=0, stream_id=k, out=lout)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            LK = 10
+            for k in range(LK):
+                ops.rollout(lown, lopp, weights, seed=2, id_base=0, stream_id=k, out=lout)
+            e1.record()
+            torch.cuda.synchronize()
+            lms = e0.elapsed_time(e1) / LK
+            lsteps = int(lout.n_turns.to(torch.int64).sum().item())
+            lp = measured_pmc(LB)
+            out["large_batch"] = {"boards_in_flight": LB, "kernel": "rollout_lpb_kernel (lane per board)",
+                                  "kernel_ms": lms, "games_per_sec": LB / (lms * 1e-3),
+                                  "board_steps_per_sec": lsteps / (lms * 1e-3),
+                                  "hbm_frac": BYTES_PER_BOARD_STEP * lsteps / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": lp.get("hbm_bytes_per_launch"),
+                                  "valu": valu_utilisation(LB, 1, lms * 1e-3),
+                                  "note": "one launch of %d boards: a different configuration from "
+                                          "BASELINE configs[1] (4096 boards in flight); not `value`" % LB}
+            del lown, lopp, lout
+    return out, (w, b)
 
 
 def main():
@@ -317,17 +572,15 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
-    ap.add_argument("--steps-per-launch", type=int, default=2048,
-                    help="consecutive steps played by one kernel launch (1 = one launch per "
-                         "step, overlapped on --streams HIP streams)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="rounds of --steps steps in the timed region (0 = as many as make it >= 150 ms)")
     ap.add_argument("--streams", type=int, default=32,
-                    help="HIP streams the independent steps are issued on")
-    ap.add_argument("--launch-streams", type=int, default=1,
-                    help="HIP streams the multi-step launches alternate on (1: back to back, the "
-                         "kernel duration is then a launch that has the chip to itself)")
-    ap.add_argument("--one-launch", action="store_true",
-                    help="N > 1: keep all steps in one launch (the tuple all-gather then follows it "
-                         "instead of overlapping the later launches)")
+                    help="HIP streams of the `overlapped` datapoint")
+    ap.add_argument("--rollout-only", action="store_true",
+                    help="only the headline leg (what tools/profile_rollout.sh profiles)")
+    ap.add_argument("--mcts-only", action="store_true",
+                    help="skip the extra datapoints of the rollout leg and the single-game leg (what "
+                         "tools/profile_mcts.sh profiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--large-boards", type=int, default=1 << 20,
                     help="extra occupancy datapoint: boards in one launch (0 = skip)")
@@ -339,12 +592,14 @@ def main():
                     help="PV-MCTS leg: -1 = play the games to the end (default), N > 0 = a bounded "
                          "sample of the first N turns, 0 = skip the leg")
     ap.add_argument("--mcts-eager", action="store_true",
-                    help="PV-MCTS leg: plain launches instead of the hipGraph tail (rocprofv3 does not "
+                    help="PV-MCTS leg: plain launches instead of hipGraph replay (rocprofv3 does not "
                          "attribute kernels launched from a graph)")
     ap.add_argument("--mcts-value-f32", action="store_true",
                     help="PV-MCTS leg: MIOpen float32 convolutions for the Value net instead of the "
                          "split-f16 MFMA kernels")
     args = ap.parse_args()
+    if args.rollout_only:
+        args.mcts_turns, args.train_iters, args.no_cpu_baseline = 0, 0, True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -361,220 +616,59 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    from iago_amd import _lib, ops
-
     B, K, W = args.boards, args.steps, args.warmup
-    w, b = shipped_rollout_weights()
-    weights = ops.RolloutWeights(w, b)
-    # G consecutive steps share one launch (G x B boards): with >= 32768 boards the
-    # library plays them with the lane-per-board kernel, which needs ~40 % fewer
-    # wave-instructions per board but 8x more boards in flight to fill the chip.
-    # G = 1 issues every step as its own launch, overlapped on S HIP streams.
-    G = max(1, min(args.steps_per_launch, K))
-    if dist is not None and G >= K and K >= 512 and not args.one_launch:
-        # N > 1: two launches, so that the all-gather of the first one's tuples (a side
-        # stream) runs beside the second instead of after the only one (a launch of half the
-        # boards costs ~3 % more per board; four launches cost more than they hide)
-        G = (K + 1) // 2
-    own = torch.full((G * B,), START_OWN, dtype=torch.int64, device="cuda")
-    opp = torch.full((G * B,), START_OPP, dtype=torch.int64, device="cuda")
-    # the round's finished tuples, resident in HBM: K steps x B games; the tuples of one
-    # launch are ONE contiguous block [final own | final opp | z | turns] of the round
-    # buffer, so that its all-gather needs no packing pass and no host sync
-    n = K * B
-    roundbuf = torch.empty(n * 18, dtype=torch.uint8, device="cuda")
-
-    def block(k0, g):
-        """Views (final_own, final_opp, z, n_turns, bytes) of the launch playing steps k0..k0+g-1."""
-        m = g * B
-        blk = roundbuf[k0 * B * 18:(k0 + g) * B * 18]
-        return (blk[0:8 * m].view(torch.int64), blk[8 * m:16 * m].view(torch.int64),
-                blk[16 * m:17 * m].view(torch.int8), blk[17 * m:18 * m], blk)
-
-    use_gather = world > 1 or "RANK" in os.environ
-    gathered = [torch.empty(world * min(G, K - k) * B * 18, dtype=torch.uint8, device="cuda")
-                for k in range(0, K, G)] if use_gather else None
-
-    S = max(1, args.streams) if G == 1 else max(1, args.launch_streams)
-    streams = [torch.cuda.Stream() for _ in range(S)]
-    sptr = [ctypes.c_void_p(st.cuda_stream) for st in streams]
-
-    def prepare(k0, g, id_step):
-        """One launch playing steps k0 .. k0+g-1 into their slots of the round buffer.
-        Global game id = (rank * 2^20 + step) * B + board (rank-major, so that the ids
-        of consecutive steps of a rank are contiguous)."""
-        r = ops.RolloutResult()
-        r.final_own, r.final_opp, r.z, r.n_turns, _ = block(k0, g)
-        return ops.rollout_prepare(own[:g * B], opp[:g * B], weights, seed=2024,
-                                   id_base=((rank * (1 << 20) + id_step) * B) & 0xFFFFFFFF, out=r)
-
-    warm = [prepare(0, min(G, K), 500_000 + k) for k in range(0, W, G)]
-    timed = [prepare(k, min(G, K - k), k) for k in range(0, K, G)]
-    n_launches = len(timed)
-    SAMPLE = 32 if G == 1 else 1  # launches bracketed by an event pair on their stream
-    evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for i in range(0, n_launches, SAMPLE)}
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    rc = 0
-    for i, p in enumerate(warm):
-        rc |= p.launch(sptr[i % S])
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    main = torch.cuda.current_stream()
-    span0, span1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    span0.record(main)
-    for st in streams:
-        st.wait_stream(main)
-    comm = torch.cuda.Stream() if dist is not None else None
-    done = [torch.cuda.Event() for _ in range(n_launches)] if dist is not None else None
-    for i, p in enumerate(timed):
-        j = i % S
-        e = evs.get(i)
-        if e is not None:
-            e[0].record(streams[j])
-        rc |= p.launch(sptr[j])
-        if e is not None:
-            e[1].record(streams[j])
-        if dist is not None:
-            done[i].record(streams[j])
-    for st in streams:
-        main.wait_stream(st)
-    span1.record(main)
-    if dist is not None:
-        # the tuples of every launch: one collective each on the side stream, ordered
-        # behind its launch by an event, beside the launches that follow; no host sync
-        # (enqueued after all launches so that the host never stands between two launches)
-        with torch.cuda.stream(comm):
-            for i in range(n_launches):
-                comm.wait_event(done[i])
-                dist.all_gather_into_tensor(gathered[i], block(i * G, min(G, K - i * G))[4])
-    if comm is not None:
-        main.wait_stream(comm)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if rc != 0:
-        raise SystemExit("iago_rollout failed: %s" % _lib.lib().iago_last_error())
-    # average duration of ONE launch (start -> end on its own stream)
-    full = [i for i in evs if timed[i].args.n == G * B] or list(evs)
-    kernel_ms = sum(evs[i][0].elapsed_time(evs[i][1]) for i in full) / len(full)
-    span_ms = span0.elapsed_time(span1)  # GPU time of the K launches together
-
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    steps_total = sum(block(k, min(G, K - k))[3].to(torch.int64).sum() for k in range(0, K, G)).reshape(1)
-    launch_steps = G  # steps per (full) launch
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(steps_total)
-        for i, k in enumerate(range(0, K, G)):
-            mine = block(k, min(G, K - k))[4]
-            assert torch.equal(gathered[i][rank * mine.numel():(rank + 1) * mine.numel()], mine)
-    dt = float(tmax.item())
-    board_steps = int(steps_total.item())
-
-    # the same kernel with the chip full (not the headline config): occupancy evidence
-    large = None
-    if args.large_boards > 0 and rank == 0:
-        LB = args.large_boards
-        lown = torch.full((LB,), START_OWN, dtype=torch.int64, device="cuda")
-        lopp = torch.full((LB,), START_OPP, dtype=torch.int64, device="cuda")
-        lout = ops.RolloutResult()
-        lout.z = torch.empty(LB, dtype=torch.int8, device="cuda")
-        lout.n_turns = torch.empty(LB, dtype=torch.uint8, device="cuda")
-        for k in range(3):
-            ops.rollout(lown, lopp, weights, seed=1, id_base=0, stream_id=k, out=lout)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        LK = 10
-        for k in range(LK):
-            ops.rollout(lown, lopp, weights, seed=2, id_base=0, stream_id=k, out=lout)
-        e1.record()
-        torch.cuda.synchronize()
-        lms = e0.elapsed_time(e1) / LK
-        lsteps = int(lout.n_turns.to(torch.int64).sum().item())
-        large = {"boards": LB, "kernel_ms": lms, "games_per_sec": LB / (lms * 1e-3),
-                 "board_steps_per_sec": lsteps / (lms * 1e-3),
-                 "hbm_frac": BYTES_PER_BOARD_STEP * lsteps / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "valu": valu_utilisation(LB, lms * 1e-3)}
-        del lown, lopp, lout
+    head, (w, b) = rollout_leg(args, world, rank, dist)
 
     mcts = None
     if args.mcts_turns != 0:
         mcts = mcts_leg(args.mcts_games, args.mcts_sims, max(args.mcts_turns, 0),
                         args.mcts_turns < 0, world, rank, dist, value_f32=args.mcts_value_f32,
                         use_graph=not args.mcts_eager)
-
-    if mcts is not None and not args.mcts_value_f32 and args.mcts_turns < 0:
+    if mcts is not None and not args.mcts_value_f32 and args.mcts_turns < 0 and not args.mcts_only:
         # the same leg with MIOpen float32 convolutions for the Value net, on a bounded
         # sample (first 4 turns), for comparison with the split-f16 kernels
         ref = mcts_leg(args.mcts_games, args.mcts_sims, 4, False, world, rank, dist, value_f32=True)
         mcts["value_f32_sample"] = {k: ref[k] for k in ("leaf_evals_per_sec", "leaf_evals", "seconds",
                                                         "turns_played", "value_conv")}
-
     train = reinforce_leg(args.train_iters, world, rank, dist) if args.train_iters > 0 else None
-    b1 = mcts_b1_leg() if (mcts is not None and rank == 0) else None
+    b1 = mcts_b1_leg() if (mcts is not None and rank == 0 and not args.mcts_only) else None
 
     if rank == 0:
-        games = world * K * B
-        alg_bytes_per_launch = BYTES_PER_BOARD_STEP * board_steps / (world * K) * launch_steps
-        # Roofline of the dominant kernel.  One launch moves `alg_bytes_per_launch`
-        # (algorithmic) in `kernel_ms`: an event pair brackets the launch's slot on its
-        # stream = execution + queueing behind the other streams' launches (rocprofv3's
-        # average, execution only, is ~25-30 % shorter under this overlap and equal with
-        # --streams 1; the committed figure is `rocprof_kernel_avg_ms`).
-        # `launches_in_flight` slots overlap, so the chip moves
-        # achieved = bytes per launch / launch duration x launches in flight
-        #          = bytes of the K launches / GPU span of the timed region,
-        # which is also value x bytes per game.
-        per_launch = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        achieved = alg_bytes_per_launch * (K / launch_steps) / (span_ms * 1e-3) / 1e9
         line = {
-            "metric": "self-play games/sec", "value": games / dt, "unit": "games/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "metric": "self-play games/sec", "value": head["value"], "unit": "games/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 bitboards + f32 policy", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d parallel Othello boards per GPU, "
-                                   "rollout-policy-only playouts from the start position, "
-                                   "shipped RolloutPolicy weights" % B,
-                       "boards_per_gpu": B, "games_per_step": world * B,
-                       "tuple_allgather": "rccl" if dist is not None else "none",
-                       "steps_per_launch": G, "hip_streams": S},
-            "board_steps_per_sec": board_steps / dt,
-            "board_steps_per_game": board_steps / games,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(launch_steps * B),
-                         "kernel": "rollout_lpb_kernel" if G * B >= 32768 else "rollout_kernel",
-                         "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "launches_in_flight": kernel_ms * (K / launch_steps) / span_ms,
-                         "boards_per_launch": launch_steps * B,
-                         "per_launch_achieved": per_launch,
-                         "rocprof_kernel_avg_ms": measured_pmc().get("rocprof_kernel_avg_ms"),
-                         "valu": valu_utilisation(K * B, span_ms * 1e-3)},
+            "config": {"workload": "BASELINE configs[1]: %d parallel Othello boards per GPU in ONE launch "
+                                   "per step, launches serialized on one stream, rollout-policy-only "
+                                   "playouts from the start position to the end, shipped "
+                                   "RolloutPolicy weights" % B,
+                       "boards_per_gpu": B, "boards_per_launch": B, "games_per_step": world * B,
+                       "launches_in_flight": 1,
+                       "tuple_allgather": "rccl, one per round of %d steps, side stream" % K
+                                          if dist is not None else "none"},
+            "repeats": head["repeats"], "timed_region_s": head["timed_region_s"],
+            "board_steps_per_sec": head["board_steps_per_sec"],
+            "board_steps_per_game": head["board_steps_per_game"],
+            "roofline": head["roofline"],
         }
-        if large is not None:
-            line["large_batch"] = large
+        for key in ("overlapped", "large_batch"):
+            if key in head:
+                line[key] = head[key]
         if mcts is not None:
             line["mcts"] = mcts
         if train is not None:
             line["reinforce"] = train
         if b1 is not None:
             line["mcts_single_game"] = b1
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N = 1 figure
+        if not args.no_cpu_baseline and world == 1:  # the CPU baselines are N = 1 figures
             line["cpu_baseline"] = cpu_baseline(w, b)
+            line["cpu_baseline"]["python_loops_one_core"] = python_loop_baseline(w, b)
             if mcts is not None:
                 mcts["cpu_baseline"] = mcts_cpu_baseline()
         print(json.dumps(line), flush=True)
-    barrier()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

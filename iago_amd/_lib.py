@@ -98,7 +98,7 @@ def lib():
     L.iago_legal_moves.argtypes = [vp, vp, vp, i64, vp]
     L.iago_apply_moves.argtypes = [vp, vp, vp, i64, vp]
     L.iago_encode_planes.argtypes = [vp, vp, vp, i64, vp]
-    L.iago_encode_planes_indexed.argtypes = [vp, vp, vp, vp, i64, vp]
+    L.iago_encode_planes_indexed.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.iago_judge.argtypes = [vp, vp, vp, i64, vp]
     L.iago_sample_moves.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
                                     i64, vp]
@@ -112,20 +112,20 @@ def lib():
     L.iago_value_stem.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
     L.iago_value_stem_boards.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, vp]
     L.iago_value_head.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp]
-    L.iago_conv3x3_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp]
-    L.iago_stem_f32.argtypes = [vp, vp, vp, vp, i64, vp]
-    L.iago_policy_head.argtypes = [vp, vp, vp, vp, i64, vp]
+    L.iago_conv3x3_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp]
+    L.iago_stem_f32.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+    L.iago_policy_head.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.iago_rollout_build_table.argtypes = [vp, vp, vp]
     L.iago_rollout.argtypes = [C.POINTER(RolloutArgs), vp]
     tp = C.POINTER(MctsTree)
     L.iago_mcts_reset.argtypes = [tp, vp, vp]
     L.iago_mcts_select.argtypes = [tp, vp, vp, vp, C.c_float, C.c_int32, C.c_int, vp, vp, vp, vp,
                                    vp, vp, vp]
-    L.iago_mcts_expand.argtypes = [tp, vp, i64, vp, vp, vp, vp]
+    L.iago_mcts_expand.argtypes = [tp, vp, i64, vp, vp, vp, vp, vp]
     L.iago_leaf_values.argtypes = [vp, vp, C.c_float, vp, i64, vp]
     L.iago_mcts_backup.argtypes = [tp, vp, vp, vp, vp]
     L.iago_mcts_mix_backup.argtypes = [tp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
-    L.iago_mcts_pending.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp]
+    L.iago_mcts_pending.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp]
     L.iago_mcts_best_move.argtypes = [tp, vp, vp, vp, vp]
     L.iago_mcts_advance_root.argtypes = [tp, vp, vp, vp]
     for name in SYMBOLS[3:]:

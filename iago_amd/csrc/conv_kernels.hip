@@ -590,6 +590,8 @@ struct ConvF32Params {
     const float *bias; // [128]
     float *y;          // [n][128][64]
     int32_t cin;
+    int64_t n;            // boards (upper bound when n_dev is given)
+    const int32_t *n_dev; // optional device word: only the first min(n, *n_dev) boards
 };
 
 // NJ = 2: a workgroup covers all 64 cells of its board (two 32-cell MFMA tiles per wave);
@@ -604,10 +606,20 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
     float *const xs = (float *)lds;                       // [CIN][100]
     float *const ws = xs + CIN * F32_XPLANE;              // [4 waves][2][SLAB]
     const int tid = threadIdx.x, q = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const unsigned wg = NJ == 2 ? blockIdx.x : blockIdx.x >> 1;
-    const int j0 = NJ == 2 ? 0 : (int)(blockIdx.x & 1); // first 32-cell tile of this workgroup
+    // Work items = (board, channel group[, board half]); a workgroup walks them with the
+    // grid's stride.  With a host-side count the grid has one workgroup per item; with a
+    // device-side count (n_dev: a hipGraph replays the launch without the host knowing how
+    // many leaves expand) the grid is fixed and every workgroup leaves the loop as soon as
+    // its next item is past the count.
+    int64_t n_eff = P.n;
+    if (P.n_dev)
+        n_eff = min(n_eff, (int64_t)*P.n_dev);
+    const int64_t n_items = n_eff * (NJ == 2 ? 4 : 8);
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int64_t wg = NJ == 2 ? item : item >> 1;
+    const int j0 = NJ == 2 ? 0 : (int)(item & 1); // first 32-cell tile of this workgroup
     const int64_t b = wg >> 2;
-    const int cg = wg & 3;
+    const int cg = (int)(wg & 3);
 
     // weights of taps 0 and 1 and the whole board on their way before anything waits
     const f32x4 *wsrc = (const f32x4 *)P.w + ((int64_t)(cg * 9) * CIN + q * CQ) * (F32_CO / 4) + lane;
@@ -711,16 +723,19 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
             const int co = 32 * cg + 8 * q + 4 * h + t;
             P.y[(b * COUT + co) * 64 + 32 * (j0 + j) + r] = fmaxf(s + P.bias[co], 0.0f);
         }
+    __syncthreads(); // the next item re-stages the LDS image the reduction just read
+    } // item loop
 }
 
 // float32 stem: conv3x3 2 -> 64 + bias + ReLU to float32 NCHW (SLPolicy.block1,
 // network.py:17-19); one thread per (board, channel, cell)
 __global__ __launch_bounds__(256) void stem_f32_kernel(const float *planes, const float *w, const float *bias,
-                                                       float *y, int64_t n)
+                                                       float *y, int64_t n, const int32_t *n_dev)
 {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n * 4096)
-        return;
+    // grid-stride over (board, channel, cell): with a device-side count the grid is capped
+    // and most of it leaves at once
+    const int64_t total = (n_dev ? min(n, (int64_t)*n_dev) : n) * 4096;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     const int cell = (int)(t & 63), co = __builtin_amdgcn_readfirstlane((int)((t >> 6) & 63));
     const int64_t b = t >> 12;
     const int yy0 = cell >> 3, xx0 = cell & 7;
@@ -738,14 +753,17 @@ __global__ __launch_bounds__(256) void stem_f32_kernel(const float *planes, cons
                 acc = fmaf(wk[c * 9 + ky * 3 + kx], ok ? pl[c * 64 + yy * 8 + xx] : 0.0f, acc);
             }
     y[t] = fmaxf(acc, 0.0f);
+    }
 }
 
 // SLPolicy head: conv9 (1x1, 128 -> 1, no bias), bias10 (64), softmax (network.py:29-47);
 // one wave per board, lane = cell
 __global__ __launch_bounds__(64) void policy_head_kernel(const float *x, const float *w9, const float *b10,
-                                                         float *probs, int64_t n)
+                                                         float *probs, int64_t n, const int32_t *n_dev)
 {
     const int64_t b = blockIdx.x;
+    if (n_dev && b >= (int64_t)*n_dev)
+        return;
     const int lane = threadIdx.x;
     const float *xb = x + b * COUT * 64 + lane;
     float s = 0.0f;
@@ -884,7 +902,7 @@ int iago_value_head(const void *x_hi, const void *x_lo, const float *w9, const f
 }
 
 int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y, int64_t n, int32_t cin,
-                     int32_t cout, void *stream)
+                     int32_t cout, const int32_t *n_dev, void *stream)
 {
     if (n < 0 || cout != COUT || (cin != 64 && cin != 128))
         return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_f32: cout must be 128 and cin 64 or 128");
@@ -900,6 +918,8 @@ int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y
     P.bias = bias;
     P.y = y;
     P.cin = cin;
+    P.n = n;
+    P.n_dev = n_dev;
     const size_t lds = (size_t)(cin * F32_XPLANE + 4 * 2 * (cin / 4) * F32_CO) * sizeof(float);
     const int lds128 = (int)((128 * F32_XPLANE + 4 * 2 * 32 * F32_CO) * sizeof(float));
     static std::atomic<uint64_t> configured2{0}, configured1{0};
@@ -908,9 +928,12 @@ int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y
         iago_reserve_lds((const void *)conv3x3_f32_kernel<128, 1>, lds128, configured1,
                          "iago_conv3x3_f32: cannot reserve LDS"))
         return IAGO_ERR_HIP;
-    // up to 32 boards: eight workgroups per board (half a board each) fill the CUs
+    // up to 32 boards: eight workgroups per board (half a board each) fill the CUs.
+    // Device-side count: a fixed grid of at most 1024 workgroups walks the items (the usual
+    // count is a few dozen boards, the rest of the grid exits at once).
     const bool half = n <= 32;
-    const dim3 grid((unsigned)(n * (half ? 8 : 4)));
+    const int64_t items = n * (half ? 8 : 4);
+    const dim3 grid((unsigned)(n_dev ? (items < 1024 ? items : 1024) : items));
     if (cin == 128 && half)
         hipLaunchKernelGGL((conv3x3_f32_kernel<128, 1>), grid, dim3(256), lds, (hipStream_t)stream, P);
     else if (cin == 128)
@@ -922,7 +945,8 @@ int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y
     return iago_check_launch("iago_conv3x3_f32");
 }
 
-int iago_stem_f32(const float *planes, const float *w1, const float *b1, float *y, int64_t n, void *stream)
+int iago_stem_f32(const float *planes, const float *w1, const float *b1, float *y, int64_t n,
+                  const int32_t *n_dev, void *stream)
 {
     if (n < 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_stem_f32: negative n");
@@ -930,12 +954,14 @@ int iago_stem_f32(const float *planes, const float *w1, const float *b1, float *
         return IAGO_OK;
     if (!planes || !w1 || !b1 || !y)
         return iago_fail(IAGO_ERR_INVALID, "iago_stem_f32: null pointer");
-    hipLaunchKernelGGL(stem_f32_kernel, dim3((unsigned)(n * 16)), dim3(256), 0, (hipStream_t)stream, planes, w1, b1,
-                       y, n);
+    const int64_t blocks = (n_dev && n * 16 > 2048) ? 2048 : n * 16;
+    hipLaunchKernelGGL(stem_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, planes, w1, b1,
+                       y, n, n_dev);
     return iago_check_launch("iago_stem_f32");
 }
 
-int iago_policy_head(const float *x, const float *w9, const float *b10, float *probs, int64_t n, void *stream)
+int iago_policy_head(const float *x, const float *w9, const float *b10, float *probs, int64_t n,
+                     const int32_t *n_dev, void *stream)
 {
     if (n < 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_policy_head: negative n");
@@ -943,7 +969,8 @@ int iago_policy_head(const float *x, const float *w9, const float *b10, float *p
         return IAGO_OK;
     if (!x || !w9 || !b10 || !probs)
         return iago_fail(IAGO_ERR_INVALID, "iago_policy_head: null pointer");
-    hipLaunchKernelGGL(policy_head_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, x, w9, b10, probs, n);
+    hipLaunchKernelGGL(policy_head_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, x, w9, b10, probs, n,
+                       n_dev);
     return iago_check_launch("iago_policy_head");
 }
 

@@ -150,12 +150,13 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(Tree T, const int32_t *__
                                                        int64_t n_expand,
                                                        const int32_t *__restrict__ cur_node,
                                                        const uint64_t *__restrict__ legal,
-                                                       const float *__restrict__ probs)
+                                                       const float *__restrict__ probs,
+                                                       const int32_t *__restrict__ n_dev)
 {
     const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int64_t i = gtid >> 3;
     const uint32_t r = threadIdx.x & 7u;
-    const bool live = i < n_expand;
+    const bool live = i < n_expand && (!n_dev || i < (int64_t)*n_dev);
     const int64_t g = live ? games[i] : 0;
     const int64_t base = g * (int64_t)T.capacity;
     const int node = live ? cur_node[g] : 0;
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(1024) void pending_kernel(const uint8_t *__restrict
                                                        const uint8_t *__restrict__ active, int n,
                                                        uint8_t *__restrict__ pending,
                                                        int64_t *__restrict__ index,
-                                                       int32_t *__restrict__ games, int32_t *__restrict__ count)
+                                                       int32_t *__restrict__ games, int32_t *__restrict__ count,
+                                                       int64_t *__restrict__ total)
 {
     __shared__ int wave_sum[16];
     __shared__ int base;
@@ -368,8 +370,11 @@ __global__ __launch_bounds__(1024) void pending_kernel(const uint8_t *__restrict
         }
         __syncthreads();
     }
-    if (tid == 0)
+    if (tid == 0) {
         *count = base;
+        if (total)
+            *total += base;
+    }
 }
 
 } // namespace
@@ -410,7 +415,7 @@ int iago_mcts_select(const iago_mcts_tree *tree, const uint64_t *root_own, const
 
 int iago_mcts_expand(const iago_mcts_tree *tree, const int32_t *games, int64_t n_expand,
                      const int32_t *cur_node, const uint64_t *legal, const float *probs,
-                     void *stream)
+                     const int32_t *n_dev, void *stream)
 {
     if (check_tree(tree, "iago_mcts_expand: bad tree"))
         return IAGO_ERR_INVALID;
@@ -419,19 +424,19 @@ int iago_mcts_expand(const iago_mcts_tree *tree, const int32_t *games, int64_t n
     if (n_expand == 0)
         return IAGO_OK;
     hipLaunchKernelGGL(expand_kernel, dim3(grid_for(n_expand * 8)), dim3(BLOCK), 0,
-                       (hipStream_t)stream, *tree, games, n_expand, cur_node, legal, probs);
+                       (hipStream_t)stream, *tree, games, n_expand, cur_node, legal, probs, n_dev);
     return iago_check_launch("iago_mcts_expand");
 }
 
 int iago_mcts_pending(const uint8_t *needs_expand, const uint8_t *active, int64_t n, uint8_t *pending,
-                      int64_t *index, int32_t *games, int32_t *count, void *stream)
+                      int64_t *index, int32_t *games, int32_t *count, int64_t *total, void *stream)
 {
     if (n < 0 || (n > 0 && (!needs_expand || !active || !pending || !index || !games || !count)))
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_pending: null pointer or negative n");
     if (n > (1 << 24))
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_pending: more than 2^24 games");
     hipLaunchKernelGGL(pending_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, needs_expand, active,
-                       (int)n, pending, index, games, count);
+                       (int)n, pending, index, games, count, total);
     return iago_check_launch("iago_mcts_pending");
 }
 

@@ -51,11 +51,12 @@ __global__ __launch_bounds__(BLOCK) void encode_planes_kernel(const uint64_t *__
                                                               const uint64_t *__restrict__ opp,
                                                               const int64_t *__restrict__ index,
                                                               float4 *__restrict__ planes,
-                                                              int64_t n)
+                                                              int64_t n,
+                                                              const int32_t *__restrict__ n_dev)
 {
     const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int64_t row = gtid >> 5;
-    if (row >= n)
+    if (row >= n || (n_dev && row >= (int64_t)*n_dev))
         return;
     const int64_t b = index ? index[row] : row;
     const uint32_t k = (uint32_t)gtid & 31u;
@@ -229,12 +230,13 @@ int iago_encode_planes(const uint64_t *own, const uint64_t *opp, float *planes, 
     if (n == 0)
         return IAGO_OK;
     hipLaunchKernelGGL(encode_planes_kernel, dim3(grid_for(n * 32)), dim3(BLOCK), 0,
-                       (hipStream_t)stream, own, opp, (const int64_t *)nullptr, (float4 *)planes, n);
+                       (hipStream_t)stream, own, opp, (const int64_t *)nullptr, (float4 *)planes, n,
+                       (const int32_t *)nullptr);
     return iago_check_launch("iago_encode_planes");
 }
 
 int iago_encode_planes_indexed(const uint64_t *own, const uint64_t *opp, const int64_t *index, float *planes,
-                               int64_t n, void *stream)
+                               int64_t n, const int32_t *n_dev, void *stream)
 {
     if (n < 0 || (n > 0 && (!own || !opp || !index || !planes)))
         return iago_fail(IAGO_ERR_INVALID, "iago_encode_planes_indexed: null pointer or negative n");
@@ -243,7 +245,7 @@ int iago_encode_planes_indexed(const uint64_t *own, const uint64_t *opp, const i
     if (n == 0)
         return IAGO_OK;
     hipLaunchKernelGGL(encode_planes_kernel, dim3(grid_for(n * 32)), dim3(BLOCK), 0,
-                       (hipStream_t)stream, own, opp, index, (float4 *)planes, n);
+                       (hipStream_t)stream, own, opp, index, (float4 *)planes, n, n_dev);
     return iago_check_launch("iago_encode_planes_indexed");
 }
 

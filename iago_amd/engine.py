@@ -106,10 +106,24 @@ class BatchedMCTS(object):
     planes = (L,2,8,8) float32 CUDA tensor (GameFunctions.make_state_var
     layout).  rollout_weights: ops.RolloutWeights (None = uniform random
     rollouts).  rollout_hook(engine) runs after every rollout launch (tests record `engine.z`).
+
+    Two ways through a playout (MCTS.py:105-133), same trees:
+      * sync-free (default when policy_fn has `forward_counted(planes, n_dev)`, as
+        network.SLPolicy does): the number of leaves that expand stays on the device
+        (iago_mcts_pending -> n_dev of the policy kernels and of iago_mcts_expand), so a
+        playout is a fixed sequence of launches with no host synchronisation --
+        select, pending, planes, policy net, expand, continue-select, value net, rollout,
+        leaf mix + backup.  use_graph=True captures that sequence once and replays it
+        with ONE launch per playout.
+      * host-counted (arbitrary callables, e.g. the stand-in nets of the parity tests):
+        one host sync per playout tells how many leaves expand; the policy callable sees
+        exactly those rows.  sync_free=True forces the first way for any callable (it
+        is then evaluated on all n_games rows, those past the count being ignored).
     """
 
     def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
-                 n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False):
+                 n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False,
+                 sync_free=None):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         self.n_games = n_games
@@ -126,6 +140,7 @@ class BatchedMCTS(object):
         self._pend_idx = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._pend_games = torch.zeros(n_games, dtype=torch.int32, **kw)
         self._pend_count = torch.zeros(1, dtype=torch.int32, **kw)
+        self._pend_total = torch.zeros(1, dtype=torch.int64, **kw)  # policy evaluations, on the device
         self.legal = torch.zeros(n_games, dtype=torch.int64, **kw)
         self.leaf_value = torch.zeros(n_games, dtype=torch.float32, **kw)
         self.planes = torch.zeros((n_games, 2, 8, 8), dtype=torch.float32, **kw)
@@ -135,17 +150,35 @@ class BatchedMCTS(object):
         self.visits = torch.zeros((n_games, 64), dtype=torch.int32, **kw)
         self._policy_in = torch.zeros((max(n_games, 16), 2, 8, 8), dtype=torch.float32, **kw)
         self.stats = None             # optional (n_games, 2) int32: levels, children scored
-        self.use_graph, self._graph = bool(use_graph), None
+        if sync_free is None:
+            sync_free = getattr(policy_fn, "forward_counted", None) is not None
+        self.sync_free = bool(sync_free)
+        if use_graph and not self.sync_free:
+            raise ValueError("use_graph needs the sync-free playout (a policy with forward_counted)")
+        self.use_graph, self._graph, self._graph_key = bool(use_graph), None, None
         self._g_own = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._g_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._g_active = torch.zeros(n_games, dtype=torch.uint8, **kw)
         self._sim_dev = torch.zeros(1, dtype=torch.int32, **kw)  # Philox stream id on the device
         self.sim_counter = 0          # Philox stream id: one per simulation
         self.n_leaf_evals = 0
-        self.n_policy_evals = 0
+        self._n_policy_host = 0
         self.rollout_hook = None
         self._rollout_out = ops.RolloutResult()
         self._rollout_out.z = self.z
+
+    # policy evaluations so far: counted on the host (host-counted playouts) and on the
+    # device (sync-free playouts; reading it is a host sync)
+    @property
+    def n_policy_evals(self):
+        return self._n_policy_host + int(self._pend_total.item())
+
+    @n_policy_evals.setter
+    def n_policy_evals(self, value):
+        if value != 0:
+            raise ValueError("n_policy_evals can only be reset to 0")
+        self._n_policy_host = 0
+        self._pend_total.zero_()
 
     def _bucket(self, n):
         """Smallest power-of-two batch >= n (min 16), capped at the pool size."""
@@ -157,14 +190,16 @@ class BatchedMCTS(object):
     def warmup(self):
         """Run the nets once per batch shape the search will use."""
         with torch.no_grad():
-            b = 16
-            while True:
-                nb = min(b, self._policy_in.shape[0])
-                if self.policy_fn is not None:
+            if self.policy_fn is not None and self.sync_free:
+                self._policy_counted(self._policy_in[:self.n_games], self._pend_count)
+            elif self.policy_fn is not None:
+                b = 16
+                while True:
+                    nb = min(b, self._policy_in.shape[0])
                     self.policy_fn(self._policy_in[:nb])
-                if nb == self._policy_in.shape[0]:
-                    break
-                b *= 2
+                    if nb == self._policy_in.shape[0]:
+                        break
+                    b *= 2
             if self.value_fn is not None and self.lmbda < 1.0:
                 self.value_fn(self.planes)
         torch.cuda.synchronize()
@@ -178,13 +213,18 @@ class BatchedMCTS(object):
                                  _p(self.legal), _p(self.stats) if self.stats is not None else None,
                                  _stream()), "iago_mcts_select")
 
+    def _find_pending(self, active):
+        check(_lib.lib().iago_mcts_pending(_p(self.needs_expand), _p(active), self.n_games,
+                                           _p(self._pending), _p(self._pend_idx), _p(self._pend_games),
+                                           _p(self._pend_count),
+                                           _p(self._pend_total) if self.sync_free else None,
+                                           _stream()), "iago_mcts_pending")
+
     def _expand_pending(self, own, opp, active):
         """Expansion branch of MCTS.playout (MCTS.py:109-121) for the games whose
-        cursor sits on a leaf with n_visits >= n_thr.  One host sync."""
+        cursor sits on a leaf with n_visits >= n_thr, host-counted: one host sync."""
         L = _lib.lib()
-        check(L.iago_mcts_pending(_p(self.needs_expand), _p(active), self.n_games, _p(self._pending),
-                                  _p(self._pend_idx), _p(self._pend_games), _p(self._pend_count),
-                                  _stream()), "iago_mcts_pending")
+        self._find_pending(active)
         n_exp = int(self._pend_count.item())  # the one host sync of a playout
         if n_exp == 0:
             return
@@ -196,10 +236,33 @@ class BatchedMCTS(object):
         ops.encode_planes_indexed(self.cur_own, self.cur_opp, idx, sub_planes)
         with torch.no_grad():
             probs = self.policy_fn(sub_planes).to(torch.float32).contiguous()
-        self.n_policy_evals += n_exp
+        self._n_policy_host += n_exp
         check(L.iago_mcts_expand(self.tree.ref(), _p(games), games.numel(), _p(self.cur_node),
-                                 _p(self.legal), _p(probs), _stream()), "iago_mcts_expand")
+                                 _p(self.legal), _p(probs), None, _stream()), "iago_mcts_expand")
         self._select(own, opp, pending, False)  # MCTS.py:121: recurse into the same node
+
+    def _policy_counted(self, planes, n_dev):
+        """(len(planes), 64) float32 probabilities, valid in the first *n_dev rows."""
+        fc = getattr(self.policy_fn, "forward_counted", None)
+        with torch.no_grad():
+            if fc is not None:
+                return fc(planes, n_dev)
+            return self.policy_fn(planes).to(torch.float32).contiguous()
+
+    def _expand_pending_counted(self, own, opp, active):
+        """The same branch with the count left on the device: every launch is enqueued
+        unconditionally and sized for n_games; items past *count exit at once."""
+        L = _lib.lib()
+        self._find_pending(active)
+        n = self.n_games
+        planes = self._policy_in[:n]
+        ops.encode_planes_indexed(self.cur_own, self.cur_opp, self._pend_idx, planes,
+                                  n_dev=self._pend_count)
+        probs = self._policy_counted(planes, self._pend_count)
+        check(L.iago_mcts_expand(self.tree.ref(), _p(self._pend_games), n, _p(self.cur_node),
+                                 _p(self.legal), _p(probs), _p(self._pend_count), _stream()),
+              "iago_mcts_expand")
+        self._select(own, opp, self._pending, False)  # MCTS.py:121: recurse into the same node
 
     def _evaluate_and_backup(self, active, stream_id=0, stream_id_dev=None, counter=None):
         """Leaf evaluation (MCTS.py:123-127) and Node.update_recursive."""
@@ -229,46 +292,74 @@ class BatchedMCTS(object):
     def simulate(self, own, opp, active, n_active=None):
         """One MCTS.playout for every active game (eager launches)."""
         self._select(own, opp, active, True)
-        self._expand_pending(own, opp, active)
+        if self.sync_free:
+            self._expand_pending_counted(own, opp, active)
+        else:
+            self._expand_pending(own, opp, active)
         self._evaluate_and_backup(active, stream_id=self.sim_counter)
         self.sim_counter = (self.sim_counter + 1) & 0xFFFFFFFF
         if n_active is not None:
             self.n_leaf_evals += n_active
 
-    # -- hipGraph mode: the fixed tail of a playout (planes, value net, rollout, leaf
-    # mix, backup) and the NEXT playout's descent are captured once and replayed with
-    # a single launch; only the expansion test stays on the host.  Pays off for small
-    # batches, where a playout is ~25 short launches (single-game serving mode).
+    # -- hipGraph mode: the whole sync-free playout is captured once and replayed with a
+    # single launch per playout; the rollout's Philox stream id is a device word the graph
+    # itself increments.
+    def _graph_state(self):
+        """What the captured graph baked in: device pointers and versions of every weight
+        (and of the layouts cached from them), the rollout table, the scalar arguments."""
+        key = [self.lmbda, self.c_puct, self.n_thr,
+               self.stats.data_ptr() if self.stats is not None else 0,
+               self.rollout_weights.table.data_ptr() if self.rollout_weights is not None else 0]
+        for fn in (self.policy_fn, self.value_fn):
+            params = getattr(fn, "parameters", None)
+            if params is not None:
+                key.extend((q.data_ptr(), q._version) for q in params())
+                key.append(bool(getattr(fn, "training", False)))
+                key.append(bool(getattr(fn, "split_f16", False)))
+            else:
+                key.append(id(fn))
+        return tuple(key)
+
     def _capture(self):
         if self.rollout_hook is not None:
             raise ValueError("rollout_hook is not available in graph mode")
+        # one eager evaluation of both nets first: lazy one-time setup (kernel attributes,
+        # MIOpen's choice for this shape, weight layouts cached per weight version) must not
+        # happen under capture.  Neither touches the trees.
         if self.lmbda < 1.0:
-            # one eager evaluation first: lazy one-time setup (kernel attributes, MIOpen's
-            # choice for this shape, cached weight layouts) must not happen under capture
             ops.encode_planes(self.cur_own, self.cur_opp, out=self.planes)
             with torch.no_grad():
-                self.value_fn(self.planes)
-            torch.cuda.synchronize()
+                fb = getattr(self.value_fn, "forward_boards", None)
+                if fb is None or fb(self.cur_own, self.cur_opp) is None:
+                    self.value_fn(self.planes)
+        if self.policy_fn is not None:
+            self._pend_count.zero_()
+            self._policy_counted(self._policy_in[:self.n_games], self._pend_count)
+        torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
+            self._select(self._g_own, self._g_opp, self._g_active, True)
+            self._expand_pending_counted(self._g_own, self._g_opp, self._g_active)
             self._evaluate_and_backup(self._g_active, stream_id=0, stream_id_dev=self._sim_dev,
                                       counter=self._sim_dev)
-            self._select(self._g_own, self._g_opp, self._g_active, True)
 
     def _search_graph(self, own, opp, active, n_sims, n_active):
+        key = self._graph_state()
+        if self._graph is None or key != self._graph_key:
+            # first use, or the weights / rollout table changed since the capture (training
+            # between searches, load_npz): the old graph holds pointers to freed layouts
+            self._graph = None
+            self._capture()
+            self._graph_key = key
         self._g_own.copy_(own)
         self._g_opp.copy_(opp)
         self._g_active.copy_(active)
         self._sim_dev.fill_(self.sim_counter - (1 << 32) if self.sim_counter >= (1 << 31)
                             else self.sim_counter)
-        self._select(self._g_own, self._g_opp, self._g_active, True)
         for _ in range(n_sims):
-            self._expand_pending(self._g_own, self._g_opp, self._g_active)
-            if self._graph is None:
-                self._capture()
             self._graph.replay()
-            self.sim_counter = (self.sim_counter + 1) & 0xFFFFFFFF
-            self.n_leaf_evals += n_active
+        self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
+        self.n_leaf_evals += n_active * n_sims
 
     def search(self, own, opp, active, n_sims):
         """n_sims playouts from the current roots; (own, opp) = root positions

@@ -138,6 +138,18 @@ class SLPolicy(nn.Module, _NpzMixin):
             return ops.policy_head(h, self.conv9.weight.reshape(128), self.bias10.b)
         return F.softmax(self.logits(x), dim=1)
 
+    def forward_counted(self, x, n_dev):
+        """forward(x[:k]) with k = min(len(x), *n_dev) known only on the device (int32 CUDA
+        word): the float32 matrix-unit kernels on a fixed grid, rows past k untouched.  What
+        the search engine calls on the leaves a playout expands (MCTS.py:109-121), so that
+        a whole playout is one hipGraph replay.  Inference only."""
+        if not (x.is_cuda and x.dtype == torch.float32 and not self.training):
+            raise ValueError("forward_counted: float32 CUDA planes, eval mode")
+        from . import ops
+        with torch.no_grad():
+            h = _f32_trunk(self, x, n_dev)
+            return ops.policy_head(h, self.conv9.weight.reshape(128), self.bias10.b, n_dev)
+
 
 def _f32_weights(module, k):
     """Cached [4][9][cin][32] layout of block k's weight (ops.f32_weights)."""
@@ -152,12 +164,12 @@ def _f32_weights(module, k):
     return hit[1]
 
 
-def _f32_trunk(module, x):
+def _f32_trunk(module, x, n_dev=None):
     """blocks 1..8 of SLPolicy / Value in float32 on the matrix units (small batches)."""
     from . import ops
-    h = ops.stem_f32(x.contiguous(), module.block1.conv.weight, module.block1.conv.bias)
+    h = ops.stem_f32(x.contiguous(), module.block1.conv.weight, module.block1.conv.bias, n_dev)
     for k in range(2, 9):
-        h = ops.conv3x3_f32(h, _f32_weights(module, k), getattr(module, "block%d" % k).conv.bias)
+        h = ops.conv3x3_f32(h, _f32_weights(module, k), getattr(module, "block%d" % k).conv.bias, n_dev)
     return h
 
 

@@ -73,14 +73,21 @@ def encode_planes(own, opp, out=None):
     return out
 
 
-def encode_planes_indexed(own, opp, index, out):
-    """Planes of boards index[0..k) (int64 tensor) into out[:k] (game.py:168-174)."""
+def _count(n_dev):
+    """Optional int32 CUDA word holding a device-side item count (iago_hip.h, `n_dev`)."""
+    return _dev(n_dev, torch.int32, "n_dev") if n_dev is not None else None
+
+
+def encode_planes_indexed(own, opp, index, out, n_dev=None):
+    """Planes of boards index[0..k) (int64 tensor) into out[:k] (game.py:168-174); with
+    n_dev only the first min(k, *n_dev) rows."""
     k = index.numel()
     if out.numel() < k * 128:
         raise ValueError("planes buffer is too small")
     check(_lib.lib().iago_encode_planes_indexed(_dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp"),
                                                 _dev(index, torch.int64, "index"),
-                                                _dev(out, torch.float32, "planes"), k, _stream()),
+                                                _dev(out, torch.float32, "planes"), k, _count(n_dev),
+                                                _stream()),
           "iago_encode_planes_indexed")
     return out
 
@@ -268,7 +275,7 @@ def f32_weights(weight):
     return w.permute(2, 0, 1, 3).contiguous()
 
 
-def conv3x3_f32(x, w4, bias):
+def conv3x3_f32(x, w4, bias, n_dev=None):
     """relu(conv3x3(x, w) + bias) in float32 on the matrix units; x (n, cin, 8, 8)."""
     n, cin = x.shape[0], x.shape[1]
     if tuple(w4.shape) != (4, 9, cin, 32):
@@ -276,22 +283,22 @@ def conv3x3_f32(x, w4, bias):
     y = torch.empty((n, 128, 8, 8), dtype=torch.float32, device=x.device)
     check(_lib.lib().iago_conv3x3_f32(_dev(x, torch.float32, "x"), _dev(w4, torch.float32, "w"),
                                       _dev(bias, torch.float32, "bias"), _dev(y, torch.float32, "y"),
-                                      n, cin, 128, _stream()), "iago_conv3x3_f32")
+                                      n, cin, 128, _count(n_dev), _stream()), "iago_conv3x3_f32")
     return y
 
 
-def stem_f32(planes, w1, b1):
+def stem_f32(planes, w1, b1, n_dev=None):
     n = planes.shape[0]
     if tuple(planes.shape[1:]) != (2, 8, 8) or tuple(w1.shape) != (64, 2, 3, 3):
         raise ValueError("stem_f32: planes (n,2,8,8) and w1 (64,2,3,3) expected")
     y = torch.empty((n, 64, 8, 8), dtype=torch.float32, device=planes.device)
     check(_lib.lib().iago_stem_f32(_dev(planes, torch.float32, "planes"), _dev(w1, torch.float32, "w1"),
                                    _dev(b1, torch.float32, "b1"), _dev(y, torch.float32, "y"), n,
-                                   _stream()), "iago_stem_f32")
+                                   _count(n_dev), _stream()), "iago_stem_f32")
     return y
 
 
-def policy_head(x, w9, b10):
+def policy_head(x, w9, b10, n_dev=None):
     """softmax(conv1x1(x, w9) + b10) (network.py:29-47): x (n, 128, 8, 8) -> (n, 64)."""
     n = x.shape[0]
     if tuple(x.shape[1:]) != (128, 8, 8) or w9.numel() != 128 or b10.numel() != 64:
@@ -299,7 +306,7 @@ def policy_head(x, w9, b10):
     probs = torch.empty((n, 64), dtype=torch.float32, device=x.device)
     check(_lib.lib().iago_policy_head(_dev(x, torch.float32, "x"), _dev(w9.reshape(128), torch.float32, "w9"),
                                       _dev(b10, torch.float32, "b10"), _dev(probs, torch.float32, "probs"),
-                                      n, _stream()), "iago_policy_head")
+                                      n, _count(n_dev), _stream()), "iago_policy_head")
     return probs
 
 

@@ -91,9 +91,16 @@ IAGO_API int iago_apply_moves(uint64_t *own, uint64_t *opp, const int8_t *action
 IAGO_API int iago_encode_planes(const uint64_t *own, const uint64_t *opp, float *planes, int64_t n,
                        void *stream);
 /* The same for a gather list: row b of `planes` encodes board index[b] (int64; each in
- * [0, number of boards)): the planes of the few games a playout expands (MCTS.py:109-113). */
+ * [0, number of boards)): the planes of the few games a playout expands (MCTS.py:109-113).
+ *
+ * Device-side counts.  Several entry points of the expansion path take `n_dev`, an optional
+ * device word (NULL = absent): the call then processes the first min(n, *n_dev) items, n
+ * being the capacity of the buffers (it sizes the grid).  The number of leaves a playout
+ * expands is only known on the device (iago_mcts_pending writes it); with n_dev the whole
+ * playout -- select, policy net, expand, value net, rollout, backup -- is a fixed sequence
+ * of launches with no host synchronisation, i.e. one hipGraph replay. */
 IAGO_API int iago_encode_planes_indexed(const uint64_t *own, const uint64_t *opp, const int64_t *index,
-                                        float *planes, int64_t n, void *stream);
+                                        float *planes, int64_t n, const int32_t *n_dev, void *stream);
 
 /*
  * z[b] = sign(popcount(own) - popcount(opp)) as int8.  Replaces
@@ -250,13 +257,15 @@ IAGO_API int iago_value_head(const void *x_hi, const void *x_lo, const float *w9
  *   y [n][64][8][8]; w1 [64][2][3][3].
  * iago_policy_head: conv9 (1x1, 128 -> 1, no bias) + bias10 + softmax (network.py:29-47):
  *   x [n][128][8][8] -> probs [n][64]; w9 [128], b10 [64].
+ * n_dev: optional device-side board count (see iago_encode_planes_indexed); iago_conv3x3_f32
+ *   then runs a fixed grid whose workgroups walk the (board, channel group) items.
  */
 IAGO_API int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y, int64_t n,
-                              int32_t cin, int32_t cout, void *stream);
+                              int32_t cin, int32_t cout, const int32_t *n_dev, void *stream);
 IAGO_API int iago_stem_f32(const float *planes, const float *w1, const float *b1, float *y, int64_t n,
-                           void *stream);
+                           const int32_t *n_dev, void *stream);
 IAGO_API int iago_policy_head(const float *x, const float *w9, const float *b10, float *probs, int64_t n,
-                              void *stream);
+                              const int32_t *n_dev, void *stream);
 /*
  * Up to 8 consecutive iago_conv3x3_split layers in ONE launch (blocks 2..8 of the Value
  * net): a workgroup owns all 128 channels of its 4 boards, so it runs the layers back to
@@ -346,21 +355,24 @@ IAGO_API int iago_mcts_select(const iago_mcts_tree *tree, const uint64_t *root_o
  * MCTS.py:96-98).  probs: float32 [n_expand][64], row i belongs to games[i]
  * (rows of single-move / pass leaves are ignored and may be garbage).
  * A game whose pool is full gets overflow[g] = 1 and is left unexpanded.
+ * n_dev: optional device-side count (see iago_encode_planes_indexed): min(n_expand, *n_dev)
+ * leaves are expanded.
  */
 IAGO_API int iago_mcts_expand(const iago_mcts_tree *tree, const int32_t *games, int64_t n_expand,
                               const int32_t *cur_node, const uint64_t *legal, const float *probs,
-                              void *stream);
+                              const int32_t *n_dev, void *stream);
 
 /*
  * The games a playout has to expand before it can go on (MCTS.py:109: the leaf reached
  * n_thr visits): pending[g] = needs_expand[g] && active[g] (0/1), their ids in ascending
  * order as index[] (int64) and games[] (int32, what iago_mcts_expand takes), *count =
  * how many.  index / games must hold n entries.  One small launch in place of a mask,
- * a stream compaction and a type conversion.
+ * a stream compaction and a type conversion.  total (optional): a device int64 that
+ * accumulates the counts (the number of policy evaluations of a search, read once at its end).
  */
 IAGO_API int iago_mcts_pending(const uint8_t *needs_expand, const uint8_t *active, int64_t n,
                                uint8_t *pending, int64_t *index, int32_t *games, int32_t *count,
-                               void *stream);
+                               int64_t *total, void *stream);
 
 /*
  * leaf_value = (1-lmbda)*v + lmbda*z in the reference's float32 arithmetic

@@ -56,15 +56,20 @@ def positions(n, seed, golden_rules):
     return own, opp
 
 
+@pytest.mark.parametrize("sync_free", [False, True])
 @pytest.mark.parametrize("lmbda,c_puct,n_thr,n_sims", [(0.5, 1.0, 15, 100), (0.5, 1.0, 1, 40),
                                                         (0.0, 2.5, 4, 60), (0.25, 1.0, 2, 50)])
-def test_search_trees_bit_exact(eng, golden_rules, lmbda, c_puct, n_thr, n_sims):
+def test_search_trees_bit_exact(eng, golden_rules, lmbda, c_puct, n_thr, n_sims, sync_free):
+    """sync_free=False: the host counts the expanding leaves (one sync per playout);
+    True: the count stays on the device and every launch of the playout is enqueued
+    unconditionally (what the hipGraph replays).  Same trees."""
     engine, ops = eng
     G = 12
     own, opp = positions(G, 21, golden_rules)
     policy_np, value_np, policy_t, value_t = fake_nets(int(n_thr))
     m = engine.BatchedMCTS(G, policy_t, value_t, None, lmbda=lmbda, c_puct=c_puct, n_thr=n_thr,
-                           capacity=2048, seed=5)
+                           capacity=2048, seed=5, sync_free=sync_free)
+    assert m.sync_free == sync_free
     zs = []
     m.rollout_hook = lambda mm: zs.append(mm.z.cpu().numpy().copy())
     o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
@@ -75,6 +80,10 @@ def test_search_trees_bit_exact(eng, golden_rules, lmbda, c_puct, n_thr, n_sims)
     visits = m.visits.cpu().numpy()
     assert m.n_leaf_evals == n_sims * (G - 1)
     assert int(m.tree.n_nodes[5].item()) == 1 and int(m.tree.n_visits[5 * 2048].item()) == 0
+    # every expansion of the first search was counted (on the host or on the device)
+    used = torch.arange(2048, device="cuda").reshape(1, 2048) < m.tree.n_nodes.reshape(G, 1)
+    expanded = int(((m.tree.first_child.reshape(G, 2048) >= 0) & used).sum().item())
+    assert m.n_policy_evals == expanded
 
     oracles = {}
     for g in range(G):
@@ -220,9 +229,97 @@ def test_full_size_tree_invariants(eng):
         assert torch.equal(a.reshape(G, cap)[used], b.reshape(G, cap)[used]), f
 
 
+def test_counted_kernels_equal_host_counted(eng):
+    """n_dev (device-side count) variants of the expansion path's kernels: the first
+    min(n, *n_dev) rows equal the host-counted call, rows past the count stay untouched."""
+    engine, ops = eng
+    from iago_amd import network
+    torch.manual_seed(3)
+    m = network.SLPolicy().cuda().eval()
+    own, opp = random_positions(200, seed=12)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    idx = torch.randperm(200, device="cuda")[:160].to(torch.int64)
+    for cap, k in [(160, 37), (160, 0), (160, 160), (20, 7), (1, 1), (1, 0), (160, 500)]:
+        cnt = torch.tensor([k], dtype=torch.int32, device="cuda")
+        kk = min(k, cap)
+        planes = torch.full((cap, 2, 8, 8), 7.0, device="cuda")
+        ops.encode_planes_indexed(o, p, idx[:cap].contiguous(), planes, n_dev=cnt)
+        want = torch.full((cap, 2, 8, 8), 7.0, device="cuda")
+        if kk:
+            ops.encode_planes_indexed(o, p, idx[:kk].contiguous(), want[:kk])
+        assert torch.equal(planes, want)
+        with torch.no_grad():
+            got = m.forward_counted(planes, cnt)
+            if kk:
+                ref = m(want[:kk].contiguous())   # host-counted float32 kernels (<= 192 boards)
+                assert torch.equal(got[:kk], ref), (cap, k)
+
+
+def test_sync_free_equals_host_counted_with_real_nets(eng):
+    """The same search with the real nets through both playout paths: identical visit
+    counts, moves and tree shapes; Q / P within the nets' tolerance (above 192 expanding
+    leaves the host-counted path evaluates the policy through MIOpen)."""
+    engine, ops = eng
+    from iago_amd import network
+    g = __import__("tests.conftest", fromlist=["load_json"]).load_json("simulate.json")
+    torch.manual_seed(2)
+    policy, value = network.SLPolicy().cuda().eval(), network.Value().cuda().eval()
+    w = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    G = 256
+    own, opp = random_positions(G, seed=5)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    act = torch.ones(G, dtype=torch.uint8, device="cuda")
+    out = []
+    for sync_free in (False, True):
+        m = engine.BatchedMCTS(G, policy, value, w, n_thr=4, capacity=512, seed=9, sync_free=sync_free)
+        m.search(o, p, act, 30)
+        out.append((m.tree.n_visits.cpu(), m.tree.action.cpu(), m.tree.n_nodes.cpu(), m.tree.q.cpu(),
+                    m.tree.p.cpu(), m.best_move(act)[0].cpu().clone(), m.n_policy_evals))
+    a, b = out
+    assert torch.equal(a[2], b[2]) and a[6] == b[6] and a[6] > G
+    used = torch.arange(512).reshape(1, 512) < a[2].reshape(G, 1)
+    for k in (0, 1):
+        assert torch.equal(a[k].reshape(G, 512)[used], b[k].reshape(G, 512)[used]), k
+    for k in (3, 4):
+        assert torch.allclose(a[k].reshape(G, 512)[used], b[k].reshape(G, 512)[used], rtol=0, atol=1e-5)
+    assert torch.equal(a[5], b[5])
+
+
+def test_graph_is_recaptured_when_weights_change(eng):
+    """The captured graph holds device pointers of weight layouts cached per weight version;
+    after an in-place update of the Value weights (training between searches, load_npz) the
+    next search must re-capture instead of replaying stale pointers."""
+    engine, ops = eng
+    from iago_amd import network
+    torch.manual_seed(4)
+    policy, value = network.SLPolicy().cuda().eval(), network.Value().cuda().eval()
+    G = 256
+    own, opp = random_positions(G, seed=6)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    act = torch.ones(G, dtype=torch.uint8, device="cuda")
+    m = engine.BatchedMCTS(G, policy, value, None, n_thr=3, capacity=512, seed=2, use_graph=True)
+    m.search(o, p, act, 10)
+    first = m._graph
+    with torch.no_grad():
+        for q in value.parameters():
+            q.mul_(1.5)               # new versions -> new cached split-f16 layouts
+    m.tree.reset()
+    m.sim_counter = 0
+    m.search(o, p, act, 10)
+    assert m._graph is not first
+    fresh = engine.BatchedMCTS(G, policy, value, None, n_thr=3, capacity=512, seed=2, use_graph=True)
+    fresh.search(o, p, act, 10)
+    used = torch.arange(512, device="cuda").reshape(1, 512) < fresh.tree.n_nodes.reshape(G, 1)
+    assert torch.equal(m.tree.n_nodes, fresh.tree.n_nodes)
+    for f in ("n_visits", "q", "p"):
+        assert torch.equal(getattr(m.tree, f).reshape(G, 512)[used],
+                           getattr(fresh.tree, f).reshape(G, 512)[used]), f
+
+
 def test_graph_mode_equals_eager(eng):
-    """hipGraph replay of the playout tail (planes, value net, rollout, leaf mix,
-    backup, next descent) builds the same trees as eager launches."""
+    """hipGraph replay of the whole sync-free playout (select, pending, planes, policy net,
+    expand, continue-select, value net, rollout, leaf mix, backup: one launch per playout)
+    builds the same trees as eager launches."""
     engine, ops = eng
     from iago_amd import network
     g = __import__("tests.conftest", fromlist=["load_json"]).load_json("simulate.json")
@@ -271,9 +368,11 @@ def test_pending_compaction():
         games = torch.full((n,), -1, dtype=torch.int32, device="cuda")
         cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         p = lambda t: C.c_void_p(t.data_ptr())
-        _lib.check(_lib.lib().iago_mcts_pending(p(need), p(act), n, p(pend), p(idx), p(games), p(cnt), None))
+        tot = torch.full((1,), 5, dtype=torch.int64, device="cuda")
+        _lib.check(_lib.lib().iago_mcts_pending(p(need), p(act), n, p(pend), p(idx), p(games), p(cnt),
+                                                p(tot), None))
         want = torch.nonzero(need & act).reshape(-1)
         k = int(cnt.item())
-        assert k == want.numel()
+        assert k == want.numel() and int(tot.item()) == 5 + k
         assert torch.equal(idx[:k], want) and torch.equal(games[:k].long(), want)
         assert torch.equal(pend, need & act)

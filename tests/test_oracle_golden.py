@@ -24,6 +24,31 @@ def test_rules_trace(golden_rules):
         assert orc.state_to_bits(s) == (int(q1), int(q2))
 
 
+def test_python_loop_restatement_on_the_golden_trace(golden_rules):
+    """oracle/py_loops.py (the CPU baseline in the reference's execution model) against
+    the reference's recorded rule outputs: every 3rd trace record + every edge-board move."""
+    from oracle import py_loops
+    tr = golden_rules["trace"]
+    for p1, p2, color, legal, action, q1, q2 in tr[::3]:
+        s = st(p1, p2)
+        acts = py_loops.legal_actions(s, int(color))
+        assert orc.actions_to_mask(acts) == int(legal) and acts == sorted(acts)
+        if int(action) != 0xFF:
+            py_loops.place_stone(s, int(action), int(color))
+            assert orc.state_to_bits(s) == (int(q1), int(q2))
+    boards, place = golden_rules["edge_boards"], golden_rules["edge_place"]
+    for bi, color, action, q1, q2 in place:
+        if int(action) == 0xFF:
+            continue
+        s = st(*boards[int(bi)])
+        py_loops.place_stone(s, int(action), int(color))  # illegal targets included
+        assert orc.state_to_bits(s) == (int(q1), int(q2)), (bi, color, action)
+    # a whole playout agrees with the C oracle's rules move for move
+    rs = np.random.RandomState(0)
+    z, steps = py_loops.simulate(orc.initial_state(), 1, lambda x: np.full(64, 1.0 / 64), rs)
+    assert z in (-1, 0, 1) and 58 <= steps <= 128
+
+
 def test_rules_games_judge(golden_rules):
     tr, games = golden_rules["trace"], golden_rules["games"]
     for z, turns, first, hc in games:

@@ -26,7 +26,7 @@ for it in range(120):
         sp=ops.encode_planes(m.cur_own[idx],m.cur_opp[idx]); t=tick('gather+encode',t)
         with torch.no_grad(): probs=m.policy_fn(sp).contiguous()
         t=tick('policy(n=%s)'%('var'),t)
-        _lib.check(_lib.lib().iago_mcts_expand(m.tree.ref(),C.c_void_p(games.data_ptr()),games.numel(),C.c_void_p(m.cur_node.data_ptr()),C.c_void_p(m.legal.data_ptr()),C.c_void_p(probs.data_ptr()),None)); t=tick('expand',t)
+        _lib.check(_lib.lib().iago_mcts_expand(m.tree.ref(),C.c_void_p(games.data_ptr()),games.numel(),C.c_void_p(m.cur_node.data_ptr()),C.c_void_p(m.legal.data_ptr()),C.c_void_p(probs.data_ptr()),None,None)); t=tick('expand',t)
         sub=torch.zeros_like(act); sub[idx]=1
         m._select(own,opp,sub,False); t=tick('select2',t)
     ops.encode_planes(m.cur_own,m.cur_opp,out=m.planes); t=tick('encode',t)

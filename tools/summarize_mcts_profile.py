@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-kernel means of the PMC passes of tools/profile_mcts.sh (one JSON object on stdout):
+for every kernel of the PV-MCTS playout the launches seen, the mean of every counter, the
+rocprofv3 average duration, and HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB
+(MI355X_MICROARCH.md: gfx950 reports half the bytes of 16 B/lane reads)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src = sys.argv[1]
+KERNELS = ["conv3x3_split_trunk_kernel", "select_kernel", "mix_backup_kernel", "expand_kernel",
+           "pending_kernel", "value_stem_kernel", "value_head_kernel", "conv3x3_f32_kernel",
+           "stem_f32_kernel", "policy_head_kernel", "rollout_kernel", "encode_planes_kernel",
+           "best_move_kernel", "advance_root_kernel"]
+out = collections.OrderedDict((k, collections.OrderedDict()) for k in KERNELS)
+for path in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+    for r in list(csv.reader(open(path)))[1:]:
+        for k in KERNELS:
+            if k in r[0]:
+                out[k]["calls"] = out[k].get("calls", 0) + int(r[1])
+                out[k]["total_ns"] = out[k].get("total_ns", 0) + int(float(r[2]))
+for k in KERNELS:
+    if "calls" in out[k]:
+        out[k]["avg_us"] = out[k]["total_ns"] / out[k]["calls"] / 1e3
+for path in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        for k in KERNELS:
+            if k in r["Kernel_Name"]:
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in agg.items():
+        for c, v in cs.items():
+            out[k][c] = sum(v) / len(v)
+            out[k].setdefault("pmc_launches", len(v))
+for k in KERNELS:
+    if "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
+        out[k]["hbm_bytes_per_launch"] = (2.0 * out[k]["FETCH_SIZE"] + out[k]["WRITE_SIZE"]) * 1024.0
+        if "avg_us" in out[k]:
+            out[k]["hbm_gb_per_s"] = out[k]["hbm_bytes_per_launch"] / out[k]["avg_us"] / 1e3
+cmd = os.path.join(src, "command.txt")
+print(json.dumps({"command": open(cmd).read().strip() if os.path.exists(cmd) else None,
+                  "kernels": {k: v for k, v in out.items() if v}}, indent=1))

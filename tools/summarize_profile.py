@@ -3,7 +3,11 @@
 under profiles/: the rocprofv3 kernel-stats CSV, a PMC summary (mean per launch
 of the named kernel) and the HBM traffic figure bench.py reports.
 
-    python tools/summarize_profile.py gpurun_out/prof_r01a r01a [kernel-substring]
+    python tools/summarize_profile.py gpurun_out/prof_r02a r02a [kernel-substring]
+
+The directory's `command.txt` (written by tools/profile_rollout.sh) is recorded as the source
+of the numbers; profiles/rollout_traffic.json is keyed by the launch size (boards per launch)
+the counters were taken at, so that bench.py never pairs a figure with another launch size.
 """
 import collections
 import csv
@@ -45,8 +49,12 @@ for path in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collecti
         pmc[k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
     if meta:
         pmc["_dispatch"] = meta
-summary = {"kernel": kern, "source": "rocprofv3 --pmc (separate passes), bench.py --steps 100 "
-           "--warmup 10 --no-cpu-baseline", "counters": pmc}
+cmd_path = os.path.join(src, "command.txt")
+command = open(cmd_path).read().strip() if os.path.exists(cmd_path) else "unknown"
+summary = {"kernel": kern, "source": "rocprofv3 --kernel-trace --stats, then one --pmc pass per counter "
+           "group, of: " + command, "counters": pmc}
+if rocprof_avg_ns is not None:
+    summary["rocprof_kernel_avg_ms"] = rocprof_avg_ns / 1e6
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     fetch_kb, write_kb = pmc["FETCH_SIZE"]["mean"], pmc["WRITE_SIZE"]["mean"]
     # MI355X_MICROARCH.md, HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
@@ -66,10 +74,18 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         extra.update({"valu_insts_per_launch": pmc["SQ_INSTS_VALU"]["mean"],
                       "boards_per_launch": int(pmc["_dispatch"]["Grid_Size"]) // lanes_per_board,
                       "kernel": kern})
-    with open(os.path.join(out, "rollout_traffic.json"), "w") as f:
-        json.dump(dict({"hbm_bytes_per_launch": hbm, "fetch_size_kib": fetch_kb,
-                        "write_size_kib": write_kb, "profile": tag,
-                        "note": summary["traffic_note"]}, **extra), f, indent=1)
+    if "boards_per_launch" in extra:
+        tpath = os.path.join(out, "rollout_traffic.json")
+        table = {}
+        if os.path.exists(tpath):
+            table = json.load(open(tpath))
+            if "by_boards_per_launch" not in table:
+                table = {}
+        table.setdefault("by_boards_per_launch", {})[str(extra["boards_per_launch"])] = dict(
+            {"hbm_bytes_per_launch": hbm, "fetch_size_kib": fetch_kb, "write_size_kib": write_kb,
+             "profile": tag, "command": command, "note": summary["traffic_note"]}, **extra)
+        with open(tpath, "w") as f:
+            json.dump(table, f, indent=1)
 with open(os.path.join(out, "%s_pmc_summary.json" % tag), "w") as f:
     json.dump(summary, f, indent=1)
 print(json.dumps(summary, indent=1)[:3000])
