@@ -138,6 +138,18 @@ class ReinforceTrainer(object):
         self.log = []
         self.sync_replicas()
 
+    @classmethod
+    def from_checkpoint(cls, pool_dir, k, models=None, **kw):
+        """Resume as the reference's main() does (src/train_rl.py:22-30): the learner is
+        pool_dir/model<k>.npz, the optimizer state pool_dir/optimizers/<k>.npz (Adam's t and
+        moments), `models` the number of the next snapshot (--models; default k + 1), cnt = 0."""
+        model = network.SLPolicy().load_npz(os.path.join(pool_dir, "model%d.npz" % k))
+        tr = cls(model, pool_dir=pool_dir, **kw)
+        tr.opt.load_npz(os.path.join(pool_dir, "optimizers", "%d.npz" % k))
+        tr.models = k + 1 if models is None else models
+        tr.sync_replicas()
+        return tr
+
     def sync_replicas(self):
         """Every rank takes rank 0's parameters and Adam moments."""
         ts = [p.data for p in self.model1.parameters()]

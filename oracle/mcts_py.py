@@ -237,3 +237,54 @@ def selfplay_game(mcts, n_sims, handicap=None):
                 mcts.update_with_move(-1)
                 moves.append(-1)
     return moves, orc.judge(state, 1), state
+
+
+def value_self_play(policy0, policy1, stop_num, draws):
+    """value_self_play.SelfPlay(stop_num)() -- value_self_play.py:32-59,133-161.
+    policy(planes) -> 64 float32 numbers (whatever the net returns: the reference applies
+    its own softmax on top, value_self_play.py:143,169-171); draws: iterator of the uniforms
+    consumed, in order, by numpy.random.choice (inverse CDF) and random.choice
+    (seq[floor(u * len)]).  Returns (own_bits, opp_bits of the recorded position with own =
+    the side to move there, result from that side's view, final state)."""
+    it = iter(draws)
+    state = orc.initial_state()
+    stone_num, pass_flg = 4, False
+
+    def turn(color, policy):  # value_self_play.py:150-161
+        nonlocal stone_num, pass_flg
+        acts = orc.legal_actions(state, color)
+        if len(acts) > 0:
+            out = np.asarray(policy(orc.make_state_var(state, color)), np.float32).reshape(64)
+            ex = np.exp(out)
+            p = ex / np.sum(ex)                                   # softmax(), :169-171
+            a = orc.choice_cdf(p.astype(np.float64), next(it))    # np.random.choice(64, p=...)
+            if a not in acts:                                     # :145-148
+                u = next(it)
+                a = acts[min(int(u * len(acts)), len(acts) - 1)]
+            orc.place_stone(state, a, color)
+            pass_flg = False
+            stone_num += 1
+        else:
+            if pass_flg:
+                stone_num = 64
+            pass_flg = True
+
+    cl = 1
+    while stone_num < stop_num:                                   # :34-36
+        turn(cl, policy0)
+        cl = 3 - cl
+    color = cl
+    p1, p2 = orc.state_to_bits(state)
+    own, opp = (p1, p2) if color == 1 else (p2, p1)               # :38-43: the mover becomes "2"
+    acts = orc.legal_actions(state, cl)
+    if len(acts) == 0:                                            # :46-48
+        return own, opp, -1, state
+    u = next(it)
+    orc.place_stone(state, acts[min(int(u * len(acts)), len(acts) - 1)], cl)  # :49-50
+    pass_flg = False
+    stone_num += 1
+    cl = 3 - cl
+    while stone_num < 64:                                         # :55-57
+        turn(cl, policy1)
+        cl = 3 - cl
+    return own, opp, orc.judge(state, color), state

@@ -58,7 +58,8 @@ def positions(n, seed, golden_rules):
 
 @pytest.mark.parametrize("sync_free", [False, True])
 @pytest.mark.parametrize("lmbda,c_puct,n_thr,n_sims", [(0.5, 1.0, 15, 100), (0.5, 1.0, 1, 40),
-                                                        (0.0, 2.5, 4, 60), (0.25, 1.0, 2, 50)])
+                                                        (0.0, 2.5, 4, 60), (0.25, 1.0, 2, 50),
+                                                        (0.5, 1.0, 15, 400)])  # BASELINE configs[3]
 def test_search_trees_bit_exact(eng, golden_rules, lmbda, c_puct, n_thr, n_sims, sync_free):
     """sync_free=False: the host counts the expanding leaves (one sync per playout);
     True: the count stays on the device and every launch of the playout is enqueued

@@ -241,3 +241,60 @@ def test_game_env_replays_golden_episodes():
 def boards_bits(state):
     from iago_amd import boards
     return boards.state_to_bits(state)
+
+
+class _Scaled(torch.nn.Module):
+    def __init__(self, base, k):
+        super().__init__()
+        self.base, self.k = base, float(k)
+
+    def forward(self, x):
+        return self.base(x) * self.k
+
+
+def test_value_self_play_replays_reference_runs():
+    """f-4: the 14 recorded runs of the reference's value_self_play.SelfPlay (stand-in
+    nets, the uniforms numpy / random drew; tests/golden/make_value_golden.py) through the
+    GPU mirror: same recorded position, same result, same final board, every draw consumed.
+    Covers stop_num = 4 (random move at ply 0), 64 (the SL policy plays the whole game, the
+    recorded side is stuck: result -1), both stand-in output conventions."""
+    from iago_amd import value_self_play
+    for c in load_json("value_data.json"):
+        m0 = _Scaled(_Rollout(c["w0"], c["b0"]), c["scale"])
+        m1 = _Scaled(_Rollout(c["w1"], c["b1"]), c["scale"])
+        sp = value_self_play.SelfPlay(c["stop_num"], m0, m1, draws=[u for _, u in c["draws"]])
+        state, result = sp()
+        assert boards_bits(state) == (c["opp"], c["own"]), c["stop_num"]   # the mover's stones are 2s
+        assert result == c["result"]
+        assert boards_bits(sp.state) == (c["final_p1"], c["final_p2"])
+
+
+def test_value_self_play_batch_properties():
+    """The lockstep batch (Philox draws): every recorded position has exactly stop_num
+    stones unless phase one ended by a double pass, is reachable, results are in {-1,0,1},
+    stuck games carry -1, the result equals the judge of the final board from the recorded
+    side, and the batch is deterministic in (seed, game id)."""
+    from iago_amd import network, ops, value_self_play
+    torch.manual_seed(0)
+    sl, rl = network.SLPolicy().cuda().eval(), network.RolloutPolicy().cuda().eval()
+    r = value_self_play.generate(sl, rl, 512, seed=4)
+    own, opp = ops.tensor_to_bits(r["own"]), ops.tensor_to_bits(r["opp"])
+    stones = np.array([bin(int(a | b)).count("1") for a, b in zip(own, opp)])
+    stop = r["stop_num"].cpu().numpy()
+    assert np.all(own & opp == 0) and np.all(stones <= 64)
+    assert np.mean(stones == stop) > 0.97 and np.all((stones == stop) | (stones < stop))
+    z = r["z"].cpu().numpy()
+    assert set(np.unique(z)) <= {-1, 0, 1} and len(set(np.unique(z))) == 3
+    assert np.all(z[r["dropped"].cpu().numpy()] == -1)
+    f1, f2 = ops.tensor_to_bits(r["final_p1"]), ops.tensor_to_bits(r["final_p2"])
+    col = r["color"].cpu().numpy()
+    for g in range(0, 512, 7):
+        if r["dropped"][g]:
+            continue
+        n1, n2 = bin(int(f1[g])).count("1"), bin(int(f2[g])).count("1")
+        d = (n1 - n2) if col[g] == 1 else (n2 - n1)
+        assert z[g] == (d > 0) - (d < 0)
+    r2 = value_self_play.generate(sl, rl, 512, seed=4)
+    assert torch.equal(r["own"], r2["own"]) and torch.equal(r["z"], r2["z"])
+    a, b, zz = value_self_play.generate_dataset(sl, rl, 96, batch=64, seed=1)
+    assert a.shape == b.shape == zz.shape == (96,)

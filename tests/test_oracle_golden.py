@@ -131,6 +131,21 @@ def test_rl_game(golden_json):
         assert orc.state_to_bits(final) == (c["q1"], c["q2"])
 
 
+def test_value_self_play(golden_json):
+    """oracle.mcts_py.value_self_play against the recorded runs of the reference's
+    value_self_play.SelfPlay (tests/golden/make_value_golden.py): recorded position,
+    result, final board, and every recorded draw consumed."""
+    for c in golden_json("value_data.json"):
+        k = np.float32(c["scale"])
+        f0, f1 = _rollout_fn(c["w0"], c["b0"]), _rollout_fn(c["w1"], c["b1"])
+        it = iter([u for _, u in c["draws"]])
+        own, opp, result, final = mcts_py.value_self_play(lambda x: f0(x) * k, lambda x: f1(x) * k,
+                                                          c["stop_num"], it)
+        assert (own, opp, result) == (c["own"], c["opp"], c["result"]), c["stop_num"]
+        assert orc.state_to_bits(final) == (c["final_p1"], c["final_p2"])
+        assert next(it, None) is None
+
+
 def test_env(golden_json):
     for c in golden_json("env.json"):
         base = _rollout_fn(c["w2"], c["b2"])
