@@ -348,8 +348,9 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
 
 } // namespace
 
-// defined in rollout_lpb_kernel.hip
+// defined in rollout_lpb_kernel.hip / rollout_row_kernel.hip
 void iago_launch_rollout_lpb(const iago_rollout_args *a, void *stream);
+void iago_launch_rollout_row(const iago_rollout_args *a, void *stream);
 
 extern "C" {
 
@@ -445,9 +446,8 @@ int iago_rollout(const iago_rollout_args *a, void *stream)
         return iago_fail(IAGO_ERR_INVALID, "iago_rollout: own/opp/z/table must not be null");
     if ((uintptr_t)a->table & 15u)
         return iago_fail(IAGO_ERR_INVALID, "iago_rollout: table must be 16-byte aligned");
-    if ((a->log_form != 0 && a->log_form != 1) ||
-        (a->throughput_hint != 0 && a->throughput_hint != 1))
-        return iago_fail(IAGO_ERR_INVALID, "iago_rollout: log_form / throughput_hint must be 0 or 1");
+    if ((a->log_form != 0 && a->log_form != 1) || a->throughput_hint < 0 || a->throughput_hint > 2)
+        return iago_fail(IAGO_ERR_INVALID, "iago_rollout: log_form must be 0 or 1, throughput_hint 0, 1 or 2");
     RolloutParams P;
     P.own = a->own;
     P.opp = a->opp;
@@ -474,10 +474,16 @@ int iago_rollout(const iago_rollout_args *a, void *stream)
     const int block = (threads >= 256) ? 256 : 64;
     const int64_t n_groups = (threads + block - 1) / block;
     const unsigned grid = (unsigned)(n_groups < 0x7fffffffll ? n_groups : 0x7fffffffll);
-    // Lane-per-board kernel (rollout_lpb_kernel.hip) when throughput matters more than
-    // this launch's latency; it implements the product form only.
-    if (!a->log_form && (a->throughput_hint || a->n >= 32768)) {
+    // Three kernels, one contract.  Product form (the usual case): the lane-per-board kernel
+    // (rollout_lpb_kernel.hip) when throughput matters more than this launch's latency,
+    // otherwise the 16-lanes-per-board kernel (rollout_row_kernel.hip).  The
+    // 8-lanes-per-board kernel below serves the log form and throughput_hint == 2.
+    if (!a->log_form && (a->throughput_hint == 1 || (a->throughput_hint == 0 && a->n >= 32768))) {
         iago_launch_rollout_lpb(a, stream);
+        return iago_check_launch("iago_rollout");
+    }
+    if (!a->log_form && a->throughput_hint == 0) {
+        iago_launch_rollout_row(a, stream);
         return iago_check_launch("iago_rollout");
     }
     if (a->log_form)

@@ -401,7 +401,7 @@ def rollout_prepare(own, opp, weights=None, seed=0, id_base=0, stream_id=0, unif
     a.n = n
     a.table = _dev(weights.table, torch.float32, "table")
     a.log_form = weights.log_form
-    a.throughput_hint = 1 if throughput_hint else 0
+    a.throughput_hint = int(throughput_hint)  # False / 0: automatic, True / 1: lane per board, 2: 8 lanes per board
     if uniforms is not None:
         if tuple(uniforms.shape) != (IAGO_MAX_TURNS, n):
             raise ValueError("uniforms must have shape (%d, n)" % IAGO_MAX_TURNS)

@@ -173,10 +173,13 @@ typedef struct iago_rollout_args {
     uint8_t *n_turns;        /* optional [n]: turns played (passes included) */
     uint8_t *trace;          /* optional [IAGO_MAX_TURNS][n]: action per turn, 0xFF = pass */
     int log_form;            /* 0: blob is in PRODUCT form, 1: LOG form (see above) */
-    int throughput_hint;     /* 1: the caller keeps the chip full with other launches
-                                (overlapping streams): use the lane-per-board kernel, which
-                                trades this launch's latency for ~half the work per board;
-                                also chosen automatically for n >= 32768 */
+    int throughput_hint;     /* kernel choice (all three play the same games up to float32
+                                rounding at CDF boundaries).  0: automatic -- n >= 32768: the
+                                lane-per-board kernel (least work per board, needs ~10^5
+                                boards in flight); below: half a wave per board (lowest latency
+                                of one launch; product form).  1: lane per board (the caller
+                                keeps the chip full with other launches).  2: 8 lanes per
+                                board (the round-1 kernel; also serves the log form) */
 } iago_rollout_args;
 
 /*

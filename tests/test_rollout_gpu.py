@@ -40,12 +40,18 @@ def trace_list(trace, b, nt):
     return [(-1 if a == 0xFF else int(a)) for a in trace[:nt, b]]
 
 
-@pytest.mark.parametrize("n,seed,id_base", [(1, 1, 0), (8, 2, 5), (300, 3, 1000), (2048, 4, 0)])
-def test_uniform_policy_bit_exact(ops, n, seed, id_base):
+# iago_rollout_args.throughput_hint: 0 = automatic (half a wave per board at these sizes),
+# 2 = the 8-lanes-per-board kernel; the lane-per-board kernel (1) has its own section below
+KERNELS = [0, 2]
+
+
+@pytest.mark.parametrize("hint", KERNELS)
+@pytest.mark.parametrize("n,seed,id_base", [(1, 1, 0), (3, 7, 9), (8, 2, 5), (300, 3, 1000), (2048, 4, 0)])
+def test_uniform_policy_bit_exact(ops, n, seed, id_base, hint):
     own, opp = random_positions(n, seed=seed)
     own[: n // 3] = 0x0000000810000000  # standard start, colour 1 to move
     opp[: n // 3] = 0x0000001008000000
-    z, fo, fp, nt, tr = run(ops, own, opp, None, seed=seed, id_base=id_base)
+    z, fo, fp, nt, tr = run(ops, own, opp, None, seed=seed, id_base=id_base, throughput_hint=hint)
     for b in range(n):
         oz, final, otr = orc.random_playout(state_of(own[b], opp[b]), 1, seed=seed,
                                             game_id=id_base + b)
@@ -100,8 +106,9 @@ def replay_check(own, opp, z, fo, fp, nt, tr, w, bvec, uniform_of, masked_logit_
     return sampled, exact
 
 
+@pytest.mark.parametrize("hint", KERNELS)
 @pytest.mark.parametrize("which", ["random", "shipped"])
-def test_policy_rollout_replay(ops, which):
+def test_policy_rollout_replay(ops, which, hint):
     g = load_json("simulate.json")
     w, bvec = (g["w"], g["b"]) if which == "random" else (g["shipped_w"], g["shipped_b"])
     weights = ops.RolloutWeights(w, bvec)
@@ -109,14 +116,15 @@ def test_policy_rollout_replay(ops, which):
     own, opp = random_positions(n, seed=5)
     own[:200] = 0x0000000810000000
     opp[:200] = 0x0000001008000000
-    out = run(ops, own, opp, weights, seed=seed, id_base=id_base, stream_id=stream)
+    out = run(ops, own, opp, weights, seed=seed, id_base=id_base, stream_id=stream, throughput_hint=hint)
     sampled, exact = replay_check(own, opp, *out, w, bvec,
                                   lambda b, t: orc.uniform(seed, id_base + b, t, stream))
     assert sampled > 10000
     assert exact >= sampled - 3, (sampled, exact)
 
 
-def test_golden_simulate_with_recorded_uniforms(ops):
+@pytest.mark.parametrize("hint", KERNELS)
+def test_golden_simulate_with_recorded_uniforms(ops, hint):
     """The real reference Simulate runs (tests/golden/simulate.json), driven by
     the uniforms numpy drew: same actions, same final board, same z."""
     g = load_json("simulate.json")
@@ -130,7 +138,8 @@ def test_golden_simulate_with_recorded_uniforms(ops):
         us = np.zeros((MAXT, n), np.float32)
         for i, c in enumerate(cases):
             us[:len(c["uniforms"]), i] = c["uniforms"]
-        z, fo, fp, nt, tr = run(ops, own, opp, weights, uniforms=torch.from_numpy(us).cuda())
+        z, fo, fp, nt, tr = run(ops, own, opp, weights, uniforms=torch.from_numpy(us).cuda(),
+                                throughput_hint=hint)
         for i, c in enumerate(cases):
             assert trace_list(tr, i, nt[i]) == c["trace"], i
             assert z[i] == c["z"]
@@ -138,12 +147,13 @@ def test_golden_simulate_with_recorded_uniforms(ops):
             assert (int(fo[i]), int(fp[i])) == (q_own, q_opp)
 
 
-def test_edge_positions(ops, golden_rules):
+@pytest.mark.parametrize("hint", KERNELS)
+def test_edge_positions(ops, golden_rules, hint):
     """Full board, dead position, forced passes, empty board: termination logic."""
     boards = golden_rules["edge_boards"]
     own = np.concatenate([boards[:, 0], boards[:, 1]])
     opp = np.concatenate([boards[:, 1], boards[:, 0]])
-    z, fo, fp, nt, tr = run(ops, own, opp, None, seed=9)
+    z, fo, fp, nt, tr = run(ops, own, opp, None, seed=9, throughput_hint=hint)
     for b in range(len(own)):
         oz, final, otr = orc.random_playout(state_of(own[b], opp[b]), 1, seed=9, game_id=b)
         assert trace_list(tr, b, nt[b]) == otr
@@ -251,7 +261,8 @@ def test_sample_moves_flags_nan_and_zero_mass(ops):
         rl_self_play.play_batch(nan_model, nan_model, 3)
 
 
-def test_product_form_with_large_common_offset(ops):
+@pytest.mark.parametrize("hint", KERNELS)
+def test_product_form_with_large_common_offset(ops, hint):
     """Softmax is shift-invariant: biases offset by +500 (product form, factors
     shifted by their own maxima) replay against the oracle like any other net."""
     rs = np.random.RandomState(8)
@@ -260,7 +271,7 @@ def test_product_form_with_large_common_offset(ops):
     weights = ops.RolloutWeights(w, bvec)
     assert weights.log_form == 0
     own, opp = random_positions(150, seed=17)
-    out = run(ops, own, opp, weights, seed=2, id_base=40)
+    out = run(ops, own, opp, weights, seed=2, id_base=40, throughput_hint=hint)
     sampled, exact = replay_check(own, opp, *out, w, bvec, lambda b, t: orc.uniform(2, 40 + b, t, 0))
     assert sampled > 2000 and exact >= sampled - 2
 
@@ -339,9 +350,12 @@ def test_lpb_agrees_with_8lane_kernel_statistically(ops):
     n = 4096
     own = torch.full((n,), 0x0000000810000000, dtype=torch.int64, device="cuda")
     opp = torch.full((n,), 0x0000001008000000, dtype=torch.int64, device="cuda")
-    a = ops.rollout(own, opp, weights, seed=5, want_final=True)
+    a = ops.rollout(own, opp, weights, seed=5, want_final=True, throughput_hint=2)
     b = ops.rollout(own, opp, weights, seed=5, want_final=True, throughput_hint=True)
+    c = ops.rollout(own, opp, weights, seed=5, want_final=True)  # half a wave per board
     torch.cuda.synchronize()
-    same = (a.final_own == b.final_own) & (a.final_opp == b.final_opp)
-    assert float(same.float().mean()) > 0.995
+    for x, y in ((a, b), (a, c), (b, c)):
+        same = (x.final_own == y.final_own) & (x.final_opp == y.final_opp)
+        assert float(same.float().mean()) > 0.995
     assert torch.equal(ops.judge(b.final_own, b.final_opp), b.z)
+    assert torch.equal(ops.judge(c.final_own, c.final_opp), c.z)
