@@ -598,7 +598,7 @@ struct ConvF32Params {
 // NJ = 1: half a board (rows 0-3 or 4-7), eight workgroups per board -- for batches so
 // small that four per board leave CUs idle.
 template <int CIN, int NJ>
-__global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
+__device__ __forceinline__ void conv3x3_f32_items(const ConvF32Params &P, int64_t n_eff)
 {
     constexpr int CQ = CIN / 4;              // input channels per wave
     constexpr int SLAB = CQ * F32_CO;        // floats of one (tap, wave) weight slab
@@ -611,9 +611,6 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
     // device-side count (n_dev: a hipGraph replays the launch without the host knowing how
     // many leaves expand) the grid is fixed and every workgroup leaves the loop as soon as
     // its next item is past the count.
-    int64_t n_eff = P.n;
-    if (P.n_dev)
-        n_eff = min(n_eff, (int64_t)*P.n_dev);
     const int64_t n_items = n_eff * (NJ == 2 ? 4 : 8);
     for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int64_t wg = NJ == 2 ? item : item >> 1;
@@ -727,19 +724,45 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
     } // item loop
 }
 
+template <int CIN, int NJ>
+__global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvF32Params P)
+{
+    conv3x3_f32_items<CIN, NJ>(P, P.n);
+}
+
+// Device-side count: the split (half boards up to 32 boards, whole boards above) is chosen in
+// the kernel, where the count is known.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_f32_counted_kernel(ConvF32Params P)
+{
+    const int64_t n_eff = min(P.n, (int64_t)*P.n_dev);
+    if (n_eff <= 32)
+        conv3x3_f32_items<CIN, 1>(P, n_eff);
+    else
+        conv3x3_f32_items<CIN, 2>(P, n_eff);
+}
+
 // float32 stem: conv3x3 2 -> 64 + bias + ReLU to float32 NCHW (SLPolicy.block1,
 // network.py:17-19); one thread per (board, channel, cell)
-__global__ __launch_bounds__(256) void stem_f32_kernel(const float *planes, const float *w, const float *bias,
-                                                       float *y, int64_t n, const int32_t *n_dev)
+__global__ __launch_bounds__(256) void stem_f32_kernel(const float *planes, const uint64_t *own,
+                                                       const uint64_t *opp, const int64_t *index, const float *w,
+                                                       const float *bias, float *y, int64_t n, const int32_t *n_dev)
 {
     // grid-stride over (board, channel, cell): with a device-side count the grid is capped
-    // and most of it leaves at once
+    // and most of it leaves at once.  planes == NULL: the boards themselves (row b = board
+    // index[b]; plane 0 = opponent of the side to move, plane 1 = side to move)
     const int64_t total = (n_dev ? min(n, (int64_t)*n_dev) : n) * 4096;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     const int cell = (int)(t & 63), co = __builtin_amdgcn_readfirstlane((int)((t >> 6) & 63));
     const int64_t b = t >> 12;
     const int yy0 = cell >> 3, xx0 = cell & 7;
     const float *pl = planes + b * 128;
+    uint64_t bits[2] = {0ull, 0ull};
+    if (!planes) {
+        const int64_t src = index ? index[b] : b;
+        bits[0] = opp[src];
+        bits[1] = own[src];
+    }
     const float *wk = w + co * 18;
     float acc = bias[co];
 #pragma unroll
@@ -750,7 +773,13 @@ __global__ __launch_bounds__(256) void stem_f32_kernel(const float *planes, cons
             for (int kx = 0; kx < 3; kx++) {
                 const int yy = yy0 + ky - 1, xx = xx0 + kx - 1;
                 const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
-                acc = fmaf(wk[c * 9 + ky * 3 + kx], ok ? pl[c * 64 + yy * 8 + xx] : 0.0f, acc);
+                const int a = (yy * 8 + xx) & 63;
+                float v;
+                if (planes)
+                    v = ok ? pl[c * 64 + a] : 0.0f;
+                else
+                    v = (ok && ((bits[c] >> a) & 1ull)) ? 1.0f : 0.0f;
+                acc = fmaf(wk[c * 9 + ky * 3 + kx], v, acc);
             }
     y[t] = fmaxf(acc, 0.0f);
     }
@@ -922,10 +951,12 @@ int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y
     P.n_dev = n_dev;
     const size_t lds = (size_t)(cin * F32_XPLANE + 4 * 2 * (cin / 4) * F32_CO) * sizeof(float);
     const int lds128 = (int)((128 * F32_XPLANE + 4 * 2 * 32 * F32_CO) * sizeof(float));
-    static std::atomic<uint64_t> configured2{0}, configured1{0};
+    static std::atomic<uint64_t> configured2{0}, configured1{0}, configuredc{0};
     if (iago_reserve_lds((const void *)conv3x3_f32_kernel<128, 2>, lds128, configured2,
                          "iago_conv3x3_f32: cannot reserve LDS") ||
         iago_reserve_lds((const void *)conv3x3_f32_kernel<128, 1>, lds128, configured1,
+                         "iago_conv3x3_f32: cannot reserve LDS") ||
+        iago_reserve_lds((const void *)conv3x3_f32_counted_kernel<128>, lds128, configuredc,
                          "iago_conv3x3_f32: cannot reserve LDS"))
         return IAGO_ERR_HIP;
     // up to 32 boards: eight workgroups per board (half a board each) fill the CUs.
@@ -933,7 +964,17 @@ int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y
     // count is a few dozen boards, the rest of the grid exits at once).
     const bool half = n <= 32;
     const int64_t items = n * (half ? 8 : 4);
-    const dim3 grid((unsigned)(n_dev ? (items < 1024 ? items : 1024) : items));
+    if (n_dev) {
+        // grid for the worst case of either split: 8 items per board up to 32 boards
+        const int64_t cap = n <= 32 ? n * 8 : (n * 4 < 256 ? 256 : n * 4);
+        const dim3 cgrid((unsigned)(cap < 1024 ? cap : 1024));
+        if (cin == 128)
+            hipLaunchKernelGGL((conv3x3_f32_counted_kernel<128>), cgrid, dim3(256), lds, (hipStream_t)stream, P);
+        else
+            hipLaunchKernelGGL((conv3x3_f32_counted_kernel<64>), cgrid, dim3(256), lds, (hipStream_t)stream, P);
+        return iago_check_launch("iago_conv3x3_f32");
+    }
+    const dim3 grid((unsigned)items);
     if (cin == 128 && half)
         hipLaunchKernelGGL((conv3x3_f32_kernel<128, 1>), grid, dim3(256), lds, (hipStream_t)stream, P);
     else if (cin == 128)
@@ -955,9 +996,25 @@ int iago_stem_f32(const float *planes, const float *w1, const float *b1, float *
     if (!planes || !w1 || !b1 || !y)
         return iago_fail(IAGO_ERR_INVALID, "iago_stem_f32: null pointer");
     const int64_t blocks = (n_dev && n * 16 > 2048) ? 2048 : n * 16;
-    hipLaunchKernelGGL(stem_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, planes, w1, b1,
-                       y, n, n_dev);
+    hipLaunchKernelGGL(stem_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, planes,
+                       (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const int64_t *)nullptr, w1, b1, y, n,
+                       n_dev);
     return iago_check_launch("iago_stem_f32");
+}
+
+int iago_stem_f32_boards(const uint64_t *own, const uint64_t *opp, const int64_t *index, const float *w1,
+                         const float *b1, float *y, int64_t n, const int32_t *n_dev, void *stream)
+{
+    if (n < 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_stem_f32_boards: negative n");
+    if (n == 0)
+        return IAGO_OK;
+    if (!own || !opp || !w1 || !b1 || !y)
+        return iago_fail(IAGO_ERR_INVALID, "iago_stem_f32_boards: null pointer");
+    const int64_t blocks = (n_dev && n * 16 > 2048) ? 2048 : n * 16;
+    hipLaunchKernelGGL(stem_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)nullptr, own, opp, index, w1, b1, y, n, n_dev);
+    return iago_check_launch("iago_stem_f32_boards");
 }
 
 int iago_policy_head(const float *x, const float *w9, const float *b10, float *probs, int64_t n,

@@ -255,10 +255,14 @@ class BatchedMCTS(object):
         L = _lib.lib()
         self._find_pending(active)
         n = self.n_games
-        planes = self._policy_in[:n]
-        ops.encode_planes_indexed(self.cur_own, self.cur_opp, self._pend_idx, planes,
-                                  n_dev=self._pend_count)
-        probs = self._policy_counted(planes, self._pend_count)
+        fb = getattr(self.policy_fn, "forward_counted_boards", None)
+        if fb is not None:  # plane encoding fused into the net's first layer
+            probs = fb(self.cur_own, self.cur_opp, self._pend_idx, n, self._pend_count)
+        else:
+            planes = self._policy_in[:n]
+            ops.encode_planes_indexed(self.cur_own, self.cur_opp, self._pend_idx, planes,
+                                      n_dev=self._pend_count)
+            probs = self._policy_counted(planes, self._pend_count)
         check(L.iago_mcts_expand(self.tree.ref(), _p(self._pend_games), n, _p(self.cur_node),
                                  _p(self.legal), _p(probs), _p(self._pend_count), _stream()),
               "iago_mcts_expand")

@@ -150,6 +150,16 @@ class SLPolicy(nn.Module, _NpzMixin):
             h = _f32_trunk(self, x, n_dev)
             return ops.policy_head(h, self.conv9.weight.reshape(128), self.bias10.b, n_dev)
 
+    def forward_counted_boards(self, own, opp, index, n, n_dev):
+        """forward_counted on make_state_var of boards index[0..n) (own = side to move) without
+        materialising the planes."""
+        if self.training or not own.is_cuda:
+            raise ValueError("forward_counted_boards: CUDA boards, eval mode")
+        from . import ops
+        with torch.no_grad():
+            h = _f32_trunk(self, None, n_dev, boards=(own, opp, index, n))
+            return ops.policy_head(h, self.conv9.weight.reshape(128), self.bias10.b, n_dev)
+
 
 def _f32_weights(module, k):
     """Cached [4][9][cin][32] layout of block k's weight (ops.f32_weights)."""
@@ -164,10 +174,15 @@ def _f32_weights(module, k):
     return hit[1]
 
 
-def _f32_trunk(module, x, n_dev=None):
-    """blocks 1..8 of SLPolicy / Value in float32 on the matrix units (small batches)."""
+def _f32_trunk(module, x, n_dev=None, boards=None):
+    """blocks 1..8 of SLPolicy / Value in float32 on the matrix units (small batches).
+    boards = (own, opp, index, n): block1 straight from the bitboards instead of planes x."""
     from . import ops
-    h = ops.stem_f32(x.contiguous(), module.block1.conv.weight, module.block1.conv.bias, n_dev)
+    if boards is not None:
+        own, opp, index, n = boards
+        h = ops.stem_f32_boards(own, opp, index, module.block1.conv.weight, module.block1.conv.bias, n, n_dev)
+    else:
+        h = ops.stem_f32(x.contiguous(), module.block1.conv.weight, module.block1.conv.bias, n_dev)
     for k in range(2, 9):
         h = ops.conv3x3_f32(h, _f32_weights(module, k), getattr(module, "block%d" % k).conv.bias, n_dev)
     return h

@@ -298,6 +298,22 @@ def stem_f32(planes, w1, b1, n_dev=None):
     return y
 
 
+def stem_f32_boards(own, opp, index, w1, b1, n, n_dev=None):
+    """stem_f32 of boards index[0..n) (int64 tensor or None = the first n boards) without the
+    planes tensor; own = side to move."""
+    if tuple(w1.shape) != (64, 2, 3, 3):
+        raise ValueError("stem_f32_boards: w1 (64,2,3,3) expected")
+    if index is not None and index.numel() < n:
+        raise ValueError("index is shorter than n")
+    y = torch.empty((n, 64, 8, 8), dtype=torch.float32, device=own.device)
+    check(_lib.lib().iago_stem_f32_boards(_dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp"),
+                                          _dev(index, torch.int64, "index") if index is not None else None,
+                                          _dev(w1, torch.float32, "w1"), _dev(b1, torch.float32, "b1"),
+                                          _dev(y, torch.float32, "y"), n, _count(n_dev), _stream()),
+          "iago_stem_f32_boards")
+    return y
+
+
 def policy_head(x, w9, b10, n_dev=None):
     """softmax(conv1x1(x, w9) + b10) (network.py:29-47): x (n, 128, 8, 8) -> (n, 64)."""
     n = x.shape[0]

@@ -267,6 +267,12 @@ IAGO_API int iago_conv3x3_f32(const float *x, const float *w, const float *bias,
                               int32_t cin, int32_t cout, const int32_t *n_dev, void *stream);
 IAGO_API int iago_stem_f32(const float *planes, const float *w1, const float *b1, float *y, int64_t n,
                            const int32_t *n_dev, void *stream);
+/* iago_stem_f32 straight from the boards: row b of y is block1 of board index[b] (int64
+ * gather list, NULL = identity; own = side to move) -- iago_encode_planes_indexed fused in:
+ * what a playout runs on the leaves it expands. */
+IAGO_API int iago_stem_f32_boards(const uint64_t *own, const uint64_t *opp, const int64_t *index,
+                                  const float *w1, const float *b1, float *y, int64_t n,
+                                  const int32_t *n_dev, void *stream);
 IAGO_API int iago_policy_head(const float *x, const float *w9, const float *b10, float *probs, int64_t n,
                               const int32_t *n_dev, void *stream);
 /*

@@ -251,9 +251,11 @@ def test_counted_kernels_equal_host_counted(eng):
         assert torch.equal(planes, want)
         with torch.no_grad():
             got = m.forward_counted(planes, cnt)
+            got_b = m.forward_counted_boards(o, p, idx[:cap].contiguous(), cap, cnt)  # planes fused in
             if kk:
                 ref = m(want[:kk].contiguous())   # host-counted float32 kernels (<= 192 boards)
                 assert torch.equal(got[:kk], ref), (cap, k)
+                assert torch.equal(got_b[:kk], ref), (cap, k)
 
 
 def test_sync_free_equals_host_counted_with_real_nets(eng):
