@@ -6,7 +6,7 @@
 
 Workload (BASELINE.json configs[1]): per GPU, 4096 parallel Othello boards from
 the standard start position are played to the end by the fused HIP rollout
-kernel with the reference's shipped RolloutPolicy weights (82 floats, kept as
+kernel (16 lanes per board) with the reference's shipped RolloutPolicy weights (82 floats, kept as
 golden data in tests/golden/simulate.json) -- rollout-policy-only self-play.
 One step = ONE launch of 4096 boards = 4096 finished games per GPU; the launches
 of a run are serialized on one stream, so 4096 boards are in flight at any time,
@@ -343,11 +343,11 @@ def python_loop_baseline(w, b, budget_s=4.0):
 
 
 class RolloutRounds(object):
-    """BASELINE configs[1] on one rank: K steps per round, one step = ONE launch of B = 4096
-    boards from the start position played to the end (rollout_kernel, 8 lanes per board).
-    Results land in a round buffer resident in HBM: per step one contiguous block
-    [final own | final opp | z | turns] (18 B per game); two round buffers alternate so that
-    the all-gather of round r (N > 1, side stream) runs beside round r + 1."""
+    """BASELINE configs[1] on one rank: one step = ONE launch of B = 4096 boards from the
+    start position played to the end.  Results land in an exchange buffer of K steps resident
+    in HBM: per step one contiguous block [final own | final opp | z | turns] (18 B per game);
+    two buffers alternate so that the all-gather of one (N > 1, side stream) runs beside the
+    launches that fill the other."""
 
     def __init__(self, B, K, world, rank, weights, ops):
         self.B, self.K, self.world, self.rank, self.ops = B, K, world, rank, ops
@@ -388,7 +388,6 @@ def rollout_leg(args, world, rank, dist):
     B, K, W = args.boards, args.steps, args.warmup
     w, b = shipped_rollout_weights()
     weights = ops.RolloutWeights(w, b)
-    rr = RolloutRounds(B, K, world, rank, weights, ops)
     main = torch.cuda.current_stream()
     mptr = ctypes.c_void_p(main.cuda_stream)
 
@@ -397,15 +396,16 @@ def rollout_leg(args, world, rank, dist):
             dist.barrier()
 
     rc = 0
+    cal = RolloutRounds(B, min(K, 32), world, rank, weights, ops)
     for i in range(W):                      # untimed warm-up steps (their own Philox stream)
-        rc |= rr.launch(i & 1, i % K, i, mptr, stream_id=1)
+        rc |= cal.launch(i & 1, i % cal.K, i, mptr, stream_id=1)
     torch.cuda.synchronize()
     # calibration: the duration of a step decides how many rounds make a >= 150 ms region
     c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ncal = 32
     c0.record(main)
     for i in range(ncal):
-        rc |= rr.launch(0, i % K, i, mptr, stream_id=1)
+        rc |= cal.launch(0, i % cal.K, i, mptr, stream_id=1)
     c1.record(main)
     torch.cuda.synchronize()
     t_step = torch.tensor([c0.elapsed_time(c1) * 1e-3 / ncal], dtype=torch.float64, device="cuda")
@@ -416,13 +416,20 @@ def rollout_leg(args, world, rank, dist):
     if (n_launches * world + world) * B >= 1 << 32:
         raise SystemExit("game ids exceed the 32-bit Philox counter word: lower --steps / --repeats")
 
+    # N > 1: the finished tuples are all-gathered in exchanges of S steps = whole rounds worth
+    # ~24 MB per rank (one RCCL collective per exchange on a side stream, beside the launches
+    # that fill the other buffer); the last exchange may be partial
     use_gather = dist is not None
-    nbytes = K * B * 18
-    gathered = [torch.empty(world * nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)] \
+    G = max(1, min(R, int(round(24e6 / (K * B * 18))))) if use_gather else 1
+    S = G * K
+    rr = RolloutRounds(B, S, world, rank, weights, ops)
+    del cal
+    n_exch = (n_launches + S - 1) // S
+    gathered = [torch.empty(world * S * B * 18, dtype=torch.uint8, device="cuda") for _ in range(2)] \
         if use_gather else None
     comm = torch.cuda.Stream() if use_gather else None
-    played = [torch.cuda.Event() for _ in range(R)] if use_gather else None
-    shipped = [torch.cuda.Event() for _ in range(R)] if use_gather else None
+    played = [torch.cuda.Event() for _ in range(n_exch)] if use_gather else None
+    shipped = [torch.cuda.Event() for _ in range(n_exch)] if use_gather else None
     # kernel duration: event pairs around a sample of the launches, on the launch stream
     every = max(1, n_launches // 64)
     evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -434,26 +441,26 @@ def rollout_leg(args, world, rank, dist):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     span0.record(main)
-    for r in range(R):
-        buf = r & 1
-        if use_gather and r >= 2:
-            main.wait_event(shipped[r - 2])   # this buffer's previous round has left
-        for k in range(K):
-            i = r * K + k
-            e = evs.get(i)
-            if e is not None:
-                e[0].record(main)
-            rc |= rr.launch(buf, k, i, mptr)
-            if e is not None:
-                e[1].record(main)
-        if use_gather:
-            # the round's tuples: ONE collective on the side stream, ordered behind the
-            # round by an event, beside the next round's launches; no host sync
-            played[r].record(main)
+    for i in range(n_launches):
+        x, slot = divmod(i, S)
+        buf = x & 1
+        if use_gather and slot == 0 and x >= 2:
+            main.wait_event(shipped[x - 2])   # this buffer's previous exchange has left
+        e = evs.get(i)
+        if e is not None:
+            e[0].record(main)
+        rc |= rr.launch(buf, slot, i, mptr)
+        if e is not None:
+            e[1].record(main)
+        if use_gather and (slot == S - 1 or i == n_launches - 1):
+            # ONE collective on the side stream, ordered behind the exchange's last launch
+            # by an event, beside the launches that follow; no host sync
+            nfill = (slot + 1) * B * 18
+            played[x].record(main)
             with torch.cuda.stream(comm):
-                comm.wait_event(played[r])
-                dist.all_gather_into_tensor(gathered[buf], rr.bufs[buf])
-                shipped[r].record(comm)
+                comm.wait_event(played[x])
+                dist.all_gather_into_tensor(gathered[buf][:world * nfill], rr.bufs[buf][:nfill])
+                shipped[x].record(comm)
     span1.record(main)
     if use_gather:
         main.wait_stream(comm)
@@ -472,31 +479,36 @@ def rollout_leg(args, world, rank, dist):
     pair_ms = sum(e[0].elapsed_time(e[1]) for e in evs.values()) / len(evs)
     span_ms = span0.elapsed_time(span1)
     kernel_ms = min(pair_ms, span_ms / n_launches)
-    last = (R - 1) & 1
-    steps_round = torch.tensor([rr.board_steps(last)], dtype=torch.float64, device="cuda")
+    x_last, slot_last = divmod(n_launches - 1, S)
+    last, nlast = x_last & 1, slot_last + 1          # the buffer / steps of the last exchange
+    steps_last = sum(int(rr.views(last, k)[3].to(torch.int64).sum().item()) for k in range(nlast))
+    steps_round = torch.tensor([steps_last], dtype=torch.float64, device="cuda")
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if use_gather:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(steps_round)
+        nb = nlast * B * 18
         g = gathered[last]
-        assert torch.equal(g[rank * nbytes:(rank + 1) * nbytes], rr.bufs[last])
+        assert torch.equal(g[rank * nb:(rank + 1) * nb], rr.bufs[last][:nb])
         for other in range(world):            # every rank played games of its own
             if other != rank:
-                assert not torch.equal(g[other * nbytes:(other + 1) * nbytes], rr.bufs[last]), \
+                assert not torch.equal(g[other * nb:(other + 1) * nb], rr.bufs[last][:nb]), \
                     "ranks %d and %d played identical games" % (rank, other)
     dt = float(tmax.item())
-    steps_per_game = float(steps_round.item()) / (world * K * B)
+    steps_per_game = float(steps_round.item()) / (world * nlast * B)
     games = world * R * K * B
     alg = BYTES_PER_BOARD_STEP * steps_per_game * B          # algorithmic bytes of ONE launch
     achieved = alg / (kernel_ms * 1e-3) / 1e9
     pmc = measured_pmc(B)
     out = {
+        "exchange": "rccl all-gather of the finished tuples on a side stream, one per %d steps "
+                    "(%.1f MB per rank)" % (S, S * B * 18 / 1e6),
         "value": games / dt, "ms_per_step": dt / (R * K) * 1e3, "repeats": R,
         "timed_region_s": dt, "board_steps_per_game": steps_per_game,
         "board_steps_per_sec": steps_per_game * games / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
-                     "kernel": "rollout_kernel<true> (8 lanes per board)", "kernel_ms": kernel_ms,
+                     "kernel": "rollout_row_kernel<false> (16 lanes per board)", "kernel_ms": kernel_ms,
                      "kernel_ms_event_pairs": pair_ms, "kernel_ms_period": span_ms / n_launches,
                      "kernel_ms_samples": len(evs), "boards_per_launch": B,
                      "algorithmic_bytes_per_launch": alg,
@@ -505,15 +517,16 @@ def rollout_leg(args, world, rank, dist):
                      "valu": valu_utilisation(B, 1, kernel_ms * 1e-3),
                      "note": "the HBM roof is nominal for this path: a board (16 B) lives in VGPRs "
                              "for the whole game, measured traffic is far below the algorithmic "
-                             "bytes; the real bound of one 4096-board launch is VALU issue latency "
-                             "of 512 waves on 1024 SIMDs (DESIGN.md section 5)"},
+                             "bytes; the real bound of one 4096-board launch (1024 waves = one per "
+                             "SIMD) is the length of a wave's instruction stream: a lone wave issues "
+                             "one instruction per 4 cycles (DESIGN.md section 5)"},
     }
 
     # ---- extra datapoints (rank 0, not the headline): the same steps overlapped on HIP
     # streams, and one launch large enough to fill the chip
     if rank == 0 and not args.rollout_only and not args.mcts_only:
-        S = max(1, args.streams)
-        streams = [torch.cuda.Stream() for _ in range(S)]
+        NS = max(1, args.streams)
+        streams = [torch.cuda.Stream() for _ in range(NS)]
         sptr = [ctypes.c_void_p(st.cuda_stream) for st in streams]
         no = max(256, min(2048, K))
         for rep in range(2):                 # first pass warms the streams up
@@ -523,17 +536,17 @@ def rollout_leg(args, world, rank, dist):
             for st in streams:
                 st.wait_stream(main)
             for i in range(no):
-                rc |= rr.launch(0, i % K, i, sptr[i % S], stream_id=2)
+                rc |= rr.launch(0, i % rr.K, i, sptr[i % NS], stream_id=2)
             for st in streams:
                 main.wait_stream(st)
             o1.record(main)
             torch.cuda.synchronize()
         oms = o0.elapsed_time(o1)
-        out["overlapped"] = {"games_per_sec": no * B / (oms * 1e-3), "launches": no, "hip_streams": S,
+        out["overlapped"] = {"games_per_sec": no * B / (oms * 1e-3), "launches": no, "hip_streams": NS,
                              "boards_per_launch": B, "ms_per_step": oms / no,
                              "hbm_frac": alg * no / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "note": "the same 4096-board launches issued on %d HIP streams "
-                                     "(independent steps overlap on the chip); not `value`" % S}
+                                     "(independent steps overlap on the chip); not `value`" % NS}
         if args.large_boards > 0:
             LB = args.large_boards
             lown = torch.full((LB,), START_OWN, dtype=torch.int64, device="cuda")
@@ -645,8 +658,7 @@ def main():
                                    "RolloutPolicy weights" % B,
                        "boards_per_gpu": B, "boards_per_launch": B, "games_per_step": world * B,
                        "launches_in_flight": 1,
-                       "tuple_allgather": "rccl, one per round of %d steps, side stream" % K
-                                          if dist is not None else "none"},
+                       "tuple_allgather": head["exchange"] if dist is not None else "none"},
             "repeats": head["repeats"], "timed_region_s": head["timed_region_s"],
             "board_steps_per_sec": head["board_steps_per_sec"],
             "board_steps_per_game": head["board_steps_per_game"],
