@@ -34,6 +34,7 @@
 #include "abi_common.hpp"
 
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -814,6 +815,10 @@ __global__ __launch_bounds__(64) void policy_head_kernel(const float *x, const f
 
 } // namespace
 
+// conv_trunk_kernel.hip: the layers in one launch with the activations resident in LDS
+int iago_launch_trunk_resident(const iago_conv_split_layer *layers, int32_t n_layers, int64_t n, uint32_t *overflow,
+                               void *stream);
+
 extern "C" {
 
 int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, const float *bias,
@@ -877,6 +882,8 @@ int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32_t n_laye
         P.n_chunks = a.cin / 16;
         P.overflow = overflow;
     }
+    if (!getenv("IAGO_TRUNK_STAGED"))
+        return iago_launch_trunk_resident(layers, n_layers, n, overflow, stream);
     static std::atomic<uint64_t> configured{0};
     if (iago_reserve_lds((const void *)conv3x3_split_trunk_kernel, LDS_BYTES, configured,
                          "iago_conv3x3_split_trunk: cannot reserve 159 KB of LDS"))

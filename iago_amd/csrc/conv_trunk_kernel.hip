@@ -1,0 +1,261 @@
+// conv_trunk_kernel.hip -- blocks 2..8 of the Value net (network.py:66-96) in ONE launch with
+// the activations RESIDENT IN LDS between the layers.
+//
+// conv_kernels.hip's per-layer kernel (and the round-1 trunk built from it) stages both
+// operands through LDS: 89 KB of padded activation planes + 74 KB of weight rows, double
+// buffered, one barrier per stage -- and between two layers a workgroup stores its 128 KB of
+// activations to global memory, fences, and fetches them back (~10 us of the 46 us a layer
+// took, with nothing to overlap it: 159 KB of LDS = one workgroup per CU).  Measured with
+// rocprofv3 (profiles/r02a_mcts_pmc_summary.json): MFMA pipes 56 % busy.
+//
+// Here the LDS holds nothing but the activations of the workgroup's 4 boards, all 128
+// channels, hi and lo parts: T[board][65 cell rows][528 B] = 137 KB (row 64 of a board is
+// zero: the target of every out-of-board tap).  The weights never touch LDS: in the layout
+// [cin/16][ky][kx][cout][16] the MFMA A-operand of a lane (output channel r, 8 input
+// channels) is 16 contiguous bytes and a wave's 32 channels are 1 KB, so every wave streams
+// its OWN quarter of the output channels straight from L2 into registers, three k-steps
+// ahead -- no two waves of a workgroup load the same bytes.  A wave (one per SIMD, the whole
+// register file) owns 32 output channels x all 256 cells of the 4 boards: 8 tiles of
+// v_mfma_f32_32x32x16_f16, 2 x 128 accumulator registers.  The B operands are read from T
+// through 36 per-lane tap addresses (a tap that leaves the board points at the zero row),
+// advanced by 32 B per 16-channel chunk.  The K loop has no barrier; a layer ends with
+// barrier - epilogue (bias, ReLU, re-split, written back into T in place) - barrier.
+// Same products in the same order as the per-layer kernel: bit-identical results
+// (tests/test_conv_gpu.py: test_trunk_kernel_equals_layer_by_layer).
+#include "abi_common.hpp"
+
+#include <hip/hip_fp16.h>
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TB = 4;              // boards per workgroup
+constexpr int RS = 528;            // bytes of a cell row: 128 ch hi | 128 ch lo | 16 B (bank skew)
+constexpr int BS = 65 * RS;        // bytes of a board: 64 cells + the zero row
+constexpr int T_BYTES = TB * BS;   // 137,280
+constexpr int LDS_ALLOC = T_BYTES + 1024; // the operand prefetch of the last k-step reads up to 48 B past T
+constexpr int MAX_LAYERS = 8;
+
+struct TrunkRParams {
+    const uint4 *x_hi, *x_lo;   // input of layer 0  [n][cin0/16][64][16] f16
+    uint4 *y_hi, *y_lo;         // output of the last layer [n][8][64][16] f16
+    const uint4 *w_hi[MAX_LAYERS], *w_lo[MAX_LAYERS]; // [cin/16][3][3][128][16] f16
+    const float *bias[MAX_LAYERS];
+    int64_t n;
+    int32_t cin0, n_layers;
+    uint32_t *overflow;
+};
+
+// ds_read_b128 serves lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (and the same + 32)
+// in separate LDS cycles: the first group holds cells 0-15 of a 32-cell block, the second
+// cells 16-31, so that with rows 4 banks apart (RS = 16 mod 256) the 16 lanes of a cycle hit
+// 16 different 4-bank groups for every tap.
+__device__ __forceinline__ int cell_of_lane(int r)
+{
+    return r < 4 ? r : r < 12 ? 16 + (r - 4) : r < 16 ? 4 + (r - 12) : r < 20 ? 24 + (r - 16) : r < 28 ? 8 + (r - 20)
+                                                                                              : 28 + (r - 28);
+}
+
+extern __shared__ __align__(16) char trunk_lds[];
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void trunk_resident_kernel(TrunkRParams P)
+{
+    char *const T = trunk_lds;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int64_t b0 = (int64_t)blockIdx.x * TB;
+
+    // ---- the zero rows, then the input of the first layer
+    if (tid < TB * (RS / 16))
+        *(uint4 *)(T + (tid / (RS / 16)) * BS + 64 * RS + (tid % (RS / 16)) * 16) = make_uint4(0, 0, 0, 0);
+    {
+        const int chunks0 = P.cin0 >> 4;
+        const int pieces = TB * chunks0 * 128; // 16-byte pieces per hi / lo
+        for (int e = tid; e < pieces; e += 256) {
+            const int board = e / (chunks0 * 128), rem = e - board * chunks0 * 128;
+            const int chunk = rem >> 7, cell = (rem >> 1) & 63, hp = rem & 1;
+            // boards past the end of a ragged batch read the last board (results not stored)
+            const int64_t b = min(b0 + board, P.n - 1);
+            const int64_t src = (b * chunks0 + chunk) * 128 + (rem & 127);
+            char *dst = T + board * BS + cell * RS + chunk * 32 + hp * 16;
+            *(uint4 *)dst = P.x_hi[src];
+            *(uint4 *)(dst + 256) = P.x_lo[src];
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane addresses of the B operand: cell 32 j + cell_of_lane(r), tap (ky, kx);
+    // boards 0/1 through `lo_pair`, boards 2/3 through `hi_pair` (+ an immediate BS for the
+    // odd board); the hi / lo halves of a row are 256 B apart (immediate)
+    const int lane_cell = cell_of_lane(r);
+    uint32_t addr[2][2][9]; // [board pair][j][tap]
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int cell = 32 * j + lane_cell;
+            const int yy = (cell >> 3) + tap / 3 - 1, xx = (cell & 7) + tap % 3 - 1;
+            const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
+            const uint32_t a = (uint32_t)((ok ? yy * 8 + xx : 64) * RS + h * 16);
+            addr[0][j][tap] = a;
+            addr[1][j][tap] = a + 2u * BS;
+        }
+    // rows this lane writes in the epilogue (its cells), same pairing
+    uint32_t wrow[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        wrow[0][j] = (uint32_t)((32 * j + lane_cell) * RS);
+        wrow[1][j] = wrow[0][j] + 2u * BS;
+    }
+    bool saturated = false;
+
+    for (int L = 0; L < P.n_layers; L++) {
+        const int n_chunks = L == 0 ? (P.cin0 >> 4) : 8;
+        // this lane's A operand: output channel 32 wv + r, input channels 8 h .. 8 h + 7 of
+        // the k-step's chunk; a k-step (chunk, tap) is 128 x 32 B further
+        const u32x4 *wh = (const u32x4 *)P.w_hi[L] + (32 * wv + r) * 2 + h;
+        const u32x4 *wl = (const u32x4 *)P.w_lo[L] + (32 * wv + r) * 2 + h;
+        float16v acc_main[8], acc_cross[8];
+#pragma unroll
+        for (int j8 = 0; j8 < 8; j8++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                acc_main[j8][v] = 0.0f;
+                acc_cross[j8][v] = 0.0f;
+            }
+
+        const int n_steps = 9 * n_chunks;
+        u32x4 a_hi[3], a_lo[3]; // k-steps s, s + 1, s + 2 (ring index = tap % 3)
+        a_hi[0] = wh[0];
+        a_lo[0] = wl[0];
+        a_hi[1] = wh[256];
+        a_lo[1] = wl[256];
+        // B operands one tile ahead of the MFMAs that use them (two register sets): the LDS
+        // latency of tile t + 1 runs behind the three MFMAs of tile t
+        half8 bh[2], bl[2];
+        {
+            const char *p = T + addr[0][0][0];
+            bh[0] = *(const half8 *)p;
+            bl[0] = *(const half8 *)(p + 256);
+        }
+        for (int c = 0; c < n_chunks; c++) {
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const int s = c * 9 + tap;
+                const int s2 = min(s + 2, n_steps - 1); // the last two prefetches repeat the last k-step
+                a_hi[(tap + 2) % 3] = wh[(int64_t)s2 * 256];
+                a_lo[(tap + 2) % 3] = wl[(int64_t)s2 * 256];
+                const half8 ah = __builtin_bit_cast(half8, a_hi[tap % 3]);
+                const half8 al = __builtin_bit_cast(half8, a_lo[tap % 3]);
+#pragma unroll
+                for (int j8 = 0; j8 < 8; j8++) {
+                    // next tile of this k-step, or tile 0 of the next k-step (past the last
+                    // chunk: a harmless read 32 B further in the same rows)
+                    const int nj8 = (j8 + 1) & 7, ntap = j8 == 7 ? (tap + 1) % 9 : tap;
+                    const int nbb = nj8 >> 1, nj = nj8 & 1;
+                    const char *p = T + addr[nbb >> 1][nj][ntap] + (nbb & 1) * BS + ((j8 == 7 && tap == 8) ? 32 : 0);
+                    const int cur = (tap * 8 + j8) & 1, nxt = cur ^ 1;
+                    bh[nxt] = *(const half8 *)p;
+                    bl[nxt] = *(const half8 *)(p + 256);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc_main[j8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cur], acc_main[j8], 0, 0, 0);
+                    acc_cross[j8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[cur], acc_cross[j8], 0, 0, 0);
+                    acc_cross[j8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cur], acc_cross[j8], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // next chunk of 16 input channels: 32 B further in every row (the zero rows are
+            // 528 B of zeros: their addresses move along)
+#pragma unroll
+            for (int pr = 0; pr < 2; pr++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int tap = 0; tap < 9; tap++)
+                        addr[pr][j][tap] += 32u;
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++)
+                    addr[pr][j][tap] -= 32u * (uint32_t)n_chunks;
+
+        // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T
+        // bias of the 16 channels this lane finishes: 32 wv + 8 q + 4 h + t
+        float bia[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                bia[4 * q + t] = P.bias[L][32 * wv + 8 * q + 4 * h + t];
+        __syncthreads();
+#pragma unroll
+        for (int j8 = 0; j8 < 8; j8++) {
+            const int bb = j8 >> 1, j = j8 & 1;
+            char *row = T + wrow[bb >> 1][j] + (bb & 1) * BS + (32 * wv + 4 * h) * 2;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                __half hi4[4], lo4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    float v = acc_main[j8][4 * q + t] + acc_cross[j8][4 * q + t] * (1.0f / 2048.0f) + bia[4 * q + t];
+                    saturated |= !(v <= 65000.0f); // beyond the f16 range, or NaN (fmaxf would hide it)
+                    v = fminf(fmaxf(v, 0.0f), 65000.0f);
+                    const __half vh = __float2half_rn(v);
+                    hi4[t] = vh;
+                    lo4[t] = __float2half_rn((v - __half2float(vh)) * 2048.0f);
+                }
+                *(uint2 *)(row + 16 * q) = *(const uint2 *)hi4;
+                *(uint2 *)(row + 16 * q + 256) = *(const uint2 *)lo4;
+            }
+        }
+        __syncthreads();
+    }
+    if (P.overflow && saturated)
+        *P.overflow = 1u;
+
+    // ---- the last layer's activations: coalesced 16-byte stores, [n][8][64][16] hi and lo
+    for (int e = tid; e < TB * 1024; e += 256) {
+        const int board = e >> 10, cb = (e >> 7) & 7, cell = (e >> 1) & 63, hp = e & 1;
+        const int64_t b = b0 + board;
+        if (b < P.n) {
+            const char *src = T + board * BS + cell * RS + cb * 32 + hp * 16;
+            P.y_hi[b * 1024 + (e & 1023)] = *(const uint4 *)src;
+            P.y_lo[b * 1024 + (e & 1023)] = *(const uint4 *)(src + 256);
+        }
+    }
+}
+
+} // namespace
+
+// Called by iago_conv3x3_split_trunk (conv_kernels.hip) after it has validated the layers.
+int iago_launch_trunk_resident(const iago_conv_split_layer *layers, int32_t n_layers, int64_t n, uint32_t *overflow,
+                               void *stream)
+{
+    TrunkRParams P;
+    P.x_hi = (const uint4 *)layers[0].x_hi;
+    P.x_lo = (const uint4 *)layers[0].x_lo;
+    P.y_hi = (uint4 *)layers[n_layers - 1].y_hi;
+    P.y_lo = (uint4 *)layers[n_layers - 1].y_lo;
+    for (int L = 0; L < MAX_LAYERS; L++) {
+        const iago_conv_split_layer &a = layers[L < n_layers ? L : n_layers - 1];
+        P.w_hi[L] = (const uint4 *)a.w_hi;
+        P.w_lo[L] = (const uint4 *)a.w_lo;
+        P.bias[L] = a.bias;
+    }
+    P.n = n;
+    P.cin0 = layers[0].cin;
+    P.n_layers = n_layers;
+    P.overflow = overflow;
+    static std::atomic<uint64_t> configured{0};
+    if (iago_reserve_lds((const void *)trunk_resident_kernel, LDS_ALLOC, configured,
+                         "iago_conv3x3_split_trunk: cannot reserve 134 KB of LDS"))
+        return IAGO_ERR_HIP;
+    const unsigned grid = (unsigned)((n + TB - 1) / TB);
+    hipLaunchKernelGGL(trunk_resident_kernel, dim3(grid), dim3(256), LDS_ALLOC, (hipStream_t)stream, P);
+    return iago_check_launch("iago_conv3x3_split_trunk");
+}

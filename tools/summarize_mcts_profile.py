@@ -11,9 +11,9 @@ import os
 import sys
 
 src = sys.argv[1]
-KERNELS = ["conv3x3_split_trunk_kernel", "select_kernel", "mix_backup_kernel", "expand_kernel",
+KERNELS = ["trunk_resident_kernel", "conv3x3_split_trunk_kernel", "select_kernel", "mix_backup_kernel", "expand_kernel",
            "pending_kernel", "value_stem_kernel", "value_head_kernel", "conv3x3_f32_kernel",
-           "stem_f32_kernel", "policy_head_kernel", "rollout_kernel", "encode_planes_kernel",
+           "stem_f32_kernel", "policy_head_kernel", "rollout_row_kernel", "rollout_kernel", "encode_planes_kernel",
            "best_move_kernel", "advance_root_kernel"]
 out = collections.OrderedDict((k, collections.OrderedDict()) for k in KERNELS)
 for path in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
