@@ -9,8 +9,8 @@
 // rocprofv3 (profiles/r02a_mcts_pmc_summary.json): MFMA pipes 56 % busy.
 //
 // Here the LDS holds nothing but the activations of the workgroup's 4 boards, all 128
-// channels, hi and lo parts: T[board][65 cell rows][528 B] = 137 KB (row 64 of a board is
-// zero: the target of every out-of-board tap).  The weights never touch LDS: in the layout
+// channels, hi and lo parts: T[board][64 cell rows of 528 B + 768 zero bytes] = 135 KB (the
+// zero bytes behind a board are the target of every out-of-board tap).  The weights never touch LDS: in the layout
 // [cin/16][ky][kx][cout][16] the MFMA A-operand of a lane (output channel r, 8 input
 // channels) is 16 contiguous bytes and a wave's 32 channels are 1 KB, so every wave streams
 // its OWN quarter of the output channels straight from L2 into registers, three k-steps
@@ -31,11 +31,14 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int TB = 4;              // boards per workgroup
 constexpr int RS = 528;            // bytes of a cell row: 128 ch hi | 128 ch lo | 16 B (bank skew)
-constexpr int BS = 65 * RS;        // bytes of a board: 64 cells + the zero row
-constexpr int T_BYTES = TB * BS;   // 137,280
+constexpr int ZB = 768;            // zero bytes behind a board's 64 rows: the target of every out-of-board tap
+constexpr int BS = 64 * RS + ZB;   // bytes of a board
+constexpr int T_BYTES = TB * BS;   // 138,240
 constexpr int LDS_ALLOC = T_BYTES + 1024; // the operand prefetch of the last k-step reads up to 48 B past T
 constexpr int MAX_LAYERS = 8;
 
@@ -67,9 +70,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int64_t b0 = (int64_t)blockIdx.x * TB;
 
-    // ---- the zero rows, then the input of the first layer
-    if (tid < TB * (RS / 16))
-        *(uint4 *)(T + (tid / (RS / 16)) * BS + 64 * RS + (tid % (RS / 16)) * 16) = make_uint4(0, 0, 0, 0);
+    // ---- the zero areas, then the input of the first layer
+    if (tid < TB * (ZB / 16))
+        *(uint4 *)(T + (tid / (ZB / 16)) * BS + 64 * RS + (tid % (ZB / 16)) * 16) = make_uint4(0, 0, 0, 0);
     {
         const int chunks0 = P.cin0 >> 4;
         const int pieces = TB * chunks0 * 128; // 16-byte pieces per hi / lo
@@ -98,7 +101,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int cell = 32 * j + lane_cell;
             const int yy = (cell >> 3) + tap / 3 - 1, xx = (cell & 7) + tap % 3 - 1;
             const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
-            const uint32_t a = (uint32_t)((ok ? yy * 8 + xx : 64) * RS + h * 16);
+            // an out-of-board tap reads zeros from the slot with the bank offset its cell would
+            // have had (16 B per cell index mod 16): the 16 lanes of an LDS cycle keep 16
+            // different 4-bank groups whether or not some of them are redirected
+            const int lin = (cell + (tap / 3 - 1) * 8 + (tap % 3 - 1)) & 15;
+            const uint32_t a = (uint32_t)((ok ? (yy * 8 + xx) * RS : 64 * RS + 16 * lin) + h * 16);
             addr[0][j][tap] = a;
             addr[1][j][tap] = a + 2u * BS;
         }
@@ -110,8 +117,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         wrow[1][j] = wrow[0][j] + 2u * BS;
     }
     bool saturated = false;
+#ifdef TRUNK_EXP_STAMPS // timing experiments only (tools/exp_trunk_variants.sh): s_memtime per phase
+    unsigned long long stamps[3 * MAX_LAYERS + 1];
+#define STAMP(i) stamps[i] = __builtin_readcyclecounter()
+#else
+#define STAMP(i)
+#endif
 
     for (int L = 0; L < P.n_layers; L++) {
+        STAMP(3 * L);
         const int n_chunks = L == 0 ? (P.cin0 >> 4) : 8;
         // this lane's A operand: output channel 32 wv + r, input channels 8 h .. 8 h + 7 of
         // the k-step's chunk; a k-step (chunk, tap) is 128 x 32 B further
@@ -132,33 +146,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         a_lo[0] = wl[0];
         a_hi[1] = wh[256];
         a_lo[1] = wl[256];
-        // B operands one tile ahead of the MFMAs that use them (two register sets): the LDS
-        // latency of tile t + 1 runs behind the three MFMAs of tile t
-        half8 bh[2], bl[2];
+        // B operands TWO tiles ahead of the MFMAs that use them (three register sets): an LDS
+        // read issued now has six MFMAs (192 cycles) to arrive; one tile ahead left every
+        // group of three waiting (measured: 72 us of a 1024-board forward, tools/exp_trunk_variants.sh)
+        half8 bh[3], bl[3];
+        auto b_addr = [&](int tile72) -> const char * {
+            // tile72 = tap * 8 + j8 of the running chunk; 72, 73 = the first two tiles of the next chunk
+            const int over = tile72 >= 72 ? 32 : 0, tt = tile72 % 72, tp = tt >> 3, jj = tt & 7;
+            return T + addr[jj >> 2][jj & 1][tp] + ((jj >> 1) & 1) * BS + over;
+        };
         {
-            const char *p = T + addr[0][0][0];
-            bh[0] = *(const half8 *)p;
-            bl[0] = *(const half8 *)(p + 256);
+            const char *p0 = b_addr(0), *p1 = b_addr(1);
+            bh[0] = *(const half8 *)p0;
+            bl[0] = *(const half8 *)(p0 + 256);
+            bh[1] = *(const half8 *)p1;
+            bl[1] = *(const half8 *)(p1 + 256);
         }
         for (int c = 0; c < n_chunks; c++) {
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
                 const int s = c * 9 + tap;
                 const int s2 = min(s + 2, n_steps - 1); // the last two prefetches repeat the last k-step
+#ifndef TRUNK_EXP_NO_A // (timing experiments only: tools/exp_trunk_variants.sh)
                 a_hi[(tap + 2) % 3] = wh[(int64_t)s2 * 256];
                 a_lo[(tap + 2) % 3] = wl[(int64_t)s2 * 256];
+#endif
                 const half8 ah = __builtin_bit_cast(half8, a_hi[tap % 3]);
                 const half8 al = __builtin_bit_cast(half8, a_lo[tap % 3]);
 #pragma unroll
                 for (int j8 = 0; j8 < 8; j8++) {
-                    // next tile of this k-step, or tile 0 of the next k-step (past the last
-                    // chunk: a harmless read 32 B further in the same rows)
-                    const int nj8 = (j8 + 1) & 7, ntap = j8 == 7 ? (tap + 1) % 9 : tap;
-                    const int nbb = nj8 >> 1, nj = nj8 & 1;
-                    const char *p = T + addr[nbb >> 1][nj][ntap] + (nbb & 1) * BS + ((j8 == 7 && tap == 8) ? 32 : 0);
-                    const int cur = (tap * 8 + j8) & 1, nxt = cur ^ 1;
+                    const int tile = tap * 8 + j8, cur = tile % 3, nxt = (tile + 2) % 3;
+                    // (past the last chunk: harmless reads 32 B further in the same rows)
+                    const char *p = b_addr(tile + 2);
+#ifndef TRUNK_EXP_NO_B
                     bh[nxt] = *(const half8 *)p;
                     bl[nxt] = *(const half8 *)(p + 256);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                     acc_main[j8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cur], acc_main[j8], 0, 0, 0);
                     acc_cross[j8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[cur], acc_cross[j8], 0, 0, 0);
@@ -185,36 +208,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     addr[pr][j][tap] -= 32u * (uint32_t)n_chunks;
 
         // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T
+        STAMP(3 * L + 1);
         // bias of the 16 channels this lane finishes: 32 wv + 8 q + 4 h + t
-        float bia[16];
+        f2 bia[8];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-                bia[4 * q + t] = P.bias[L][32 * wv + 8 * q + 4 * h + t];
+        for (int q = 0; q < 4; q++) {
+            const float4 bq = *(const float4 *)(P.bias[L] + 32 * wv + 8 * q + 4 * h);
+            bia[2 * q] = (f2){bq.x, bq.y};
+            bia[2 * q + 1] = (f2){bq.z, bq.w};
+        }
         __syncthreads();
+        // One wave per SIMD pays 4 cycles per instruction: packed float32 math, v_med3 for the
+        // clamp, v_cvt_pk_f16_f32; the range check is a running maximum and a running sum (a
+        // NaN survives in the sum) instead of a compare per value.
+        float vmax = 0.0f;
+        f2 vsum = (f2){0.0f, 0.0f};
+#ifdef TRUNK_EXP_NO_EPI
+        if (acc_main[0][0] == 12345.0f)
+#endif
 #pragma unroll
         for (int j8 = 0; j8 < 8; j8++) {
             const int bb = j8 >> 1, j = j8 & 1;
             char *row = T + wrow[bb >> 1][j] + (bb & 1) * BS + (32 * wv + 4 * h) * 2;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                __half hi4[4], lo4[4];
+                h2 hi[2], lo[2];
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    float v = acc_main[j8][4 * q + t] + acc_cross[j8][4 * q + t] * (1.0f / 2048.0f) + bia[4 * q + t];
-                    saturated |= !(v <= 65000.0f); // beyond the f16 range, or NaN (fmaxf would hide it)
-                    v = fminf(fmaxf(v, 0.0f), 65000.0f);
-                    const __half vh = __float2half_rn(v);
-                    hi4[t] = vh;
-                    lo4[t] = __float2half_rn((v - __half2float(vh)) * 2048.0f);
+                for (int t2 = 0; t2 < 2; t2++) {
+                    const f2 m = (f2){acc_main[j8][4 * q + 2 * t2], acc_main[j8][4 * q + 2 * t2 + 1]};
+                    const f2 c = (f2){acc_cross[j8][4 * q + 2 * t2], acc_cross[j8][4 * q + 2 * t2 + 1]};
+                    f2 v = c * (1.0f / 2048.0f) + m + bia[2 * q + t2];
+                    vmax = fmaxf(fmaxf(vmax, v.x), v.y);
+                    vsum += v;
+                    v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 65000.0f);
+                    v.y = __builtin_amdgcn_fmed3f(v.y, 0.0f, 65000.0f);
+                    hi[t2] = __builtin_convertvector(v, h2);
+                    lo[t2] = __builtin_convertvector((v - __builtin_convertvector(hi[t2], f2)) * 2048.0f, h2);
                 }
-                *(uint2 *)(row + 16 * q) = *(const uint2 *)hi4;
-                *(uint2 *)(row + 16 * q + 256) = *(const uint2 *)lo4;
+                *(uint2 *)(row + 16 * q) = (uint2){__builtin_bit_cast(uint32_t, hi[0]), __builtin_bit_cast(uint32_t, hi[1])};
+                *(uint2 *)(row + 16 * q + 256) =
+                    (uint2){__builtin_bit_cast(uint32_t, lo[0]), __builtin_bit_cast(uint32_t, lo[1])};
             }
         }
+        // beyond the f16 range, or NaN (the clamp would hide it)
+        saturated |= !(vmax <= 65000.0f) || !(vsum.x + vsum.y == vsum.x + vsum.y);
+        STAMP(3 * L + 2);
         __syncthreads();
     }
+    STAMP(3 * P.n_layers);
     if (P.overflow && saturated)
         *P.overflow = 1u;
 
@@ -228,6 +269,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             P.y_lo[b * 1024 + (e & 1023)] = *(const uint4 *)(src + 256);
         }
     }
+#ifdef TRUNK_EXP_STAMPS
+    __syncthreads();
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+        for (int i = 0; i <= 3 * P.n_layers; i++)
+            ((unsigned long long *)P.y_hi)[(blockIdx.x ? 64 : 0) + i] = stamps[i] - stamps[0];
+#endif
 }
 
 } // namespace
@@ -247,6 +294,9 @@ int iago_launch_trunk_resident(const iago_conv_split_layer *layers, int32_t n_la
         P.w_lo[L] = (const uint4 *)a.w_lo;
         P.bias[L] = a.bias;
     }
+    for (int L = 0; L < n_layers; L++)
+        if (((uintptr_t)layers[L].bias & 15u) || ((uintptr_t)layers[L].w_hi & 15u) || ((uintptr_t)layers[L].w_lo & 15u))
+            return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_split_trunk: weights and biases must be 16-byte aligned");
     P.n = n;
     P.cin0 = layers[0].cin;
     P.n_layers = n_layers;
