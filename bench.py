@@ -173,6 +173,24 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     return out
 
 
+def trunk_kernel_profile():
+    """The Value trunk kernel alone, from the committed rocprofv3 passes of the PV-MCTS leg
+    (tools/profile_mcts.sh -> profiles/*_mcts_pmc_summary.json, newest tag): average duration
+    and executed f16 MFMA FLOP/s of one launch on 1024 boards (7 layers, 3 MFMAs per product)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mcts_pmc_summary.json")))
+    for path in reversed(paths):
+        with open(path) as f:
+            k = json.load(f).get("kernels", {}).get("trunk_resident_kernel")
+        if k and "avg_us" in k:
+            flops = 1024 * 3 * 122_683_392
+            a = flops / (k["avg_us"] * 1e-6) / 1e12
+            return {"kernel": "trunk_resident_kernel", "rocprof_avg_us": k["avg_us"], "boards": 1024,
+                    "executed_tflops": a, "frac_of_2500": a / 2500.0,
+                    "hbm_bytes_per_launch": k.get("hbm_bytes_per_launch"), "profile": os.path.basename(path)}
+    return None
+
+
 def _mcts_roofline(leaf, pol, dt, world, value_f32):
     """The convolutions bound this leg.  f32 path: float32 matrix/vector peak 157.3
     TFLOP/s.  Split-f16 path: the Value convolutions of blocks 2..8 (122.68 MFLOP per
@@ -186,7 +204,10 @@ def _mcts_roofline(leaf, pol, dt, world, value_f32):
     return {"bound": "mfma", "achieved": a, "peak": 2500.0, "unit": "TFLOP/s", "frac": a / 2500.0,
             "dtype": "f16 MFMA operands (split f32), f32 accumulate",
             "mfma_flops_per_leaf_eval": 3 * 122_683_392, "flops_per_leaf_eval": 122_994_944,
-            "flops_per_policy_eval": 122_847_232}
+            "flops_per_policy_eval": 122_847_232,
+            "note": "loop level: executed MFMA FLOPs of the Value trunk over the WHOLE leg's wall time "
+                    "(tree kernels, policy net, rollout included); the trunk kernel alone: trunk_kernel",
+            "trunk_kernel": trunk_kernel_profile()}
 
 
 def mcts_cpu_baseline(n_sims=600):

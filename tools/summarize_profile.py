@@ -63,14 +63,14 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     hbm = (2.0 * fetch_kb + write_kb) * 1024.0
     summary["hbm_bytes_per_launch"] = hbm
     summary["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KiB per launch; FETCH_SIZE doubled per "
-                               "the gfx950 correction for 16 B/lane reads (the 48 KiB table staging "
-                               "is float4 loads; board loads are 8 B/lane and uncalibrated)")
+                               "the gfx950 correction for 16 B/lane reads (the table staging is "
+                               "float4 loads; board loads are 8 B/lane and uncalibrated)")
     extra = {}
     if rocprof_avg_ns is not None:
         extra["rocprof_kernel_avg_ms"] = rocprof_avg_ns / 1e6
     if "SQ_INSTS_VALU" in pmc and "Grid_Size" in pmc.get("_dispatch", {}):
         # wave-level VALU instructions of one launch and the boards it played (8 lanes each)
-        lanes_per_board = 1 if "lpb" in kern else 8
+        lanes_per_board = 1 if "lpb" in kern else (16 if "row" in kern else 8)
         extra.update({"valu_insts_per_launch": pmc["SQ_INSTS_VALU"]["mean"],
                       "boards_per_launch": int(pmc["_dispatch"]["Grid_Size"]) // lanes_per_board,
                       "kernel": kern})
