@@ -61,6 +61,7 @@ struct HwParams {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+
 template <int TT>
 __device__ __forceinline__ uint64_t bitop64(uint64_t a, uint64_t b, uint64_t c)
 {
@@ -180,23 +181,31 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
     // m << 3, cells 4-7.  Reversed orientation = the 180-degree rotated kernel: kernel row
     // 2 - ky, the window's columns mirrored (oriented column c = true column 7 - c), the
     // other half of the true row -- whose four factors then already are in true order.
+#ifdef ROW_EXP_STAMPS // diagnostic build (tools/exp_row_stamps.py): phases of a wave's life
+    const uint64_t st0 = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ f4 t4[N_T4];
-    for (uint32_t e = threadIdx.x; e < (uint32_t)N_T4; e += HW_BLOCK) {
+    // the table's global loads go out first (3 per thread, all in flight together); lane
+    // constants, the board loads and the first Philox blocks are computed under their latency
+    f4 stg[N_T4 / HW_BLOCK];
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)(N_T4 / HW_BLOCK); i++) {
+        const uint32_t e = threadIdx.x + i * HW_BLOCK;
         const uint32_t orient = e / 384u, rem = e % 384u;
         const uint32_t ky = rem >> 7, pl = (rem >> 6) & 1u, hf = (rem >> 5) & 1u, m = rem & 31u;
         uint32_t sky = ky, shf = hf, byte = hf ? (m << 3) & 0xFFu : m;
         if (orient) {
             sky = 2u - ky;
             shf = hf ^ 1u;
-            byte = 0u;
-            for (uint32_t bb = 0; bb < 5u; bb++)
-                if ((m >> bb) & 1u)
-                    byte |= 1u << (hf ? 4u - bb : 7u - bb);
+            // the window's columns mirrored: bit bb of m -> bit 4 - bb (half 1) / 7 - bb (half 0)
+            const uint32_t r5 = __builtin_bitreverse32(m) >> 27;
+            byte = hf ? r5 : (r5 << 3);
         }
-        t4[e] = *(const f4 *)(P.blob + OFF_E + (((sky * 2u + pl) * 2u + shf) * 256u + byte) * 4u);
+        stg[i] = *(const f4 *)(P.blob + OFF_E + (((sky * 2u + pl) * 2u + shf) * 256u + byte) * 4u);
     }
-    __syncthreads();
-
+#ifdef ROW_EXP_STAMPS
+    const uint64_t st1 = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     LaneHw L;
     L.l = lane & 15u;
@@ -244,15 +253,26 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
     uint32_t pass_flg = 0u, nt = 0u;
     uint32_t done = (!live || stones >= 64u) ? 1u : 0u; // `while stone_num < 64` (mcts_self_play.py:26)
 
-    uint32_t rw[4] = {0, 0, 0, 0};
+    // lane l draws Philox counter block l: the 16 lanes of a row hold the uniforms of 64 turns
+    uint32_t rw[4] = {P.id_base + (uint32_t)b, L.l, stream_id, 0u};
+    if (!P.uniforms)
+        philox4x32_10(rw, P.key0, P.key1);
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)(N_T4 / HW_BLOCK); i++)
+        t4[threadIdx.x + i * HW_BLOCK] = stg[i];
+    __syncthreads();
+#ifdef ROW_EXP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const uint64_t st2 = __builtin_amdgcn_s_memtime();
+#endif
     for (uint32_t t4 = 0; t4 < (uint32_t)IAGO_MAX_TURNS; t4 += 4) {
         float u4[4];
-        if (P.uniforms) {
+        if (__builtin_expect(P.uniforms != nullptr, 0)) {
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 u4[i] = live ? P.uniforms[(int64_t)(t4 + i) * P.n + b] : 0.0f;
         } else {
-            if ((t4 & 63u) == 0u) { // lane l draws counter block l of the next 16 = 64 turns
+            if (__builtin_expect((t4 & 63u) == 0u && t4 != 0u, 0)) { // the next 16 counter blocks = 64 turns
                 rw[0] = P.id_base + (uint32_t)b;
                 rw[1] = (t4 >> 2) + L.l;
                 rw[2] = stream_id;
@@ -266,6 +286,7 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
                 u4[i] = (float)(w >> 8) * (1.0f / 16777216.0f);
             }
         }
+        bool any_live = true;
         auto turn = [&](const int i) {
             const uint32_t t = t4 + (uint32_t)i;
             // ---- policy factors of this lane's four cells: table reads first
@@ -285,7 +306,23 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
             // ---- legal moves of the side to move (this lane's orientation)
             const uint64_t legal = legal_hw(own, opp, L);
             const uint32_t has = min(1u, (uint32_t)legal | (uint32_t)(legal >> 32));
+            // ---- pass / termination bookkeeping (mcts_self_play.py:26-28,126-133), branch-free;
+            // here, not at the end of the turn: the vector compare behind the loop's exit test
+            // is a whole turn ahead of its branch
+            const uint32_t live_turn = done ^ 1u;
+            const uint32_t play = has & live_turn;
+            const uint32_t passing = (has ^ 1u) & live_turn;
+            stones = max(stones + play, (passing & pass_flg) << 6);
+            pass_flg = (pass_flg & done) | passing;
+            nt += live_turn;
+            if (i & 1) { // `while stone_num < 64` once per pair of turns
+                done |= stones >> 6;
+                any_live = __builtin_amdgcn_ballot_w64(done == 0u) != 0ull;
+            }
             // ---- softmax numerators, zero on illegal cells (all four are in the low word)
+            // ONE wait for the six table reads (issued a move generation ago) instead of four
+            // counted ones: every instruction of a lone wave, waits included, is an issue slot
+            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
             f4 e = L.bias * fac[0];
 #pragma unroll
             for (int j = 1; j < 6; j++)
@@ -321,53 +358,52 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
             for (int j = 0; j < 4; j++)
                 over = __builtin_amdgcn_alignbit(over, __float_as_uint(thr - cdf[j]), 31);
             const uint32_t cnt = row_sum(4u - (uint32_t)__popc(over & 0xFu));
-            uint32_t action = cnt;
+            uint32_t action = cnt & 63u;
             // Rounding can leave the count one cell off a legal one (or at 64): the next legal
-            // cell, else the last one.  Rare: one branch per wave, in TRUE orientation.
-            {
-                // branch-free test (cnt <= 64): the chosen cell's bit in this lane's orientation
-                const uint32_t lbit = (uint32_t)(legal >> ((cnt ^ L.rev63) & 63u)) & 1u;
-                const bool bad = (has & ((cnt >> 6) | (lbit ^ 1u))) != 0u;
-                if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
-                    const uint64_t lt = rev ? rev64(legal) : legal;
-                    const uint64_t rem = (cnt < 64u) ? (lt & (~0ull << cnt)) : 0ull;
-                    const uint32_t fix = rem ? (uint32_t)__builtin_ctzll(rem)
-                                             : (63u - (uint32_t)__builtin_clzll(lt | 1ull));
-                    action = bad ? fix : action;
-                }
-            }
-            action &= 63u;
+            // cell, else the last one.  Rare, and a branch on a vector compare stalls a lone wave
+            // for ~24 cycles when it follows the compare directly: the test is taken here, the
+            // flips are resolved for the unfixed cell, and the branch -- far behind its compare
+            // by then -- repeats them for a fixed one.
+            const uint32_t lbit = (uint32_t)(legal >> ((cnt ^ L.rev63) & 63u)) & 1u;
+            const bool bad = (has & ((cnt >> 6) | (lbit ^ 1u))) != 0u;
+            const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
             // ---- flips and board update in this lane's orientation (branch-free)
-            const uint32_t pos_l = action ^ L.rev63;
-            const uint64_t f = flips_hw(own, opp, pos_l, L);
-            const uint32_t live_turn = done ^ 1u;
-            const uint32_t play = has & live_turn;
-            const uint32_t passing = (has ^ 1u) & live_turn;
+            uint32_t pos_l = action ^ L.rev63;
+            uint64_t f = flips_hw(own, opp, pos_l, L);
+            if (__builtin_expect(any_bad, 0)) {
+                const uint64_t lt = rev ? rev64(legal) : legal; // TRUE orientation
+                const uint64_t rem = (cnt < 64u) ? (lt & (~0ull << cnt)) : 0ull;
+                const uint32_t fix = rem ? (uint32_t)__builtin_ctzll(rem)
+                                         : (63u - (uint32_t)__builtin_clzll(lt | 1ull));
+                action = bad ? fix : action;
+                pos_l = action ^ L.rev63;
+                f = flips_hw(own, opp, pos_l, L);
+            }
             const uint32_t pm = 0u - play;
             const uint64_t fm = f & (((uint64_t)pm << 32) | pm);
             const uint64_t bit = (uint64_t)play << pos_l;
             const uint64_t nown = own | fm | bit;
             const uint64_t nopp = opp & ~fm;
-            stones = max(stones + play, (passing & pass_flg) << 6); // mcts_self_play.py:126-133
-            pass_flg = (pass_flg & done) | passing;
             if (TRACE && live_turn && L.l == 0u)
                 P.trace[(int64_t)t * P.n + b] = play ? (uint8_t)action : (uint8_t)IAGO_TRACE_PASS;
             own = nopp; // the other side moves next (finished boards swap an even number of times)
             opp = nown;
-            nt += live_turn;
-            if (t & 1u) // `while stone_num < 64` once per pair of turns (mcts_self_play.py:26-28)
-                done |= stones >> 6;
         };
         turn(0);
         turn(1);
-        if (__builtin_amdgcn_ballot_w64(done == 0u) == 0ull)
+        if (!any_live)
             break;
         turn(2);
         turn(3);
-        if (__builtin_amdgcn_ballot_w64(done == 0u) == 0ull)
+        if (!any_live)
             break;
     }
 
+#ifdef ROW_EXP_STAMPS
+    const uint64_t st3 = __builtin_amdgcn_s_memtime();
+    own = (st1 - st0) | ((st2 - st1) << 21) | ((st3 - st2) << 42);
+    opp = st0;
+#endif
     if (live && L.l == 0u) {
         const int d = __popcll(own) - __popcll(opp);
         P.z[b] = (int8_t)((d > 0) - (d < 0));
