@@ -50,7 +50,17 @@ struct TrunkRParams {
     int64_t n;
     int32_t cin0, n_layers;
     uint32_t *overflow;
+    // FUSED (iago_value_forward_split): block1 in the prologue, block9 + fc10 + fc11 after block 8
+    const float *planes;        // [n][2][8][8] float32, or NULL: the boards themselves
+    const uint64_t *own, *opp;  // own = side to move (plane 1), opp = plane 0 (game.py:168-174)
+    const float *w1, *b1;       // block1 [64][2][3][3], [64]
+    const uint4 *w9_hi, *w9_lo; // block9 as MFMA A operand [8 chunks][32 rows = taps, 9 used][16] f16
+    const float *b9, *w10, *w11;
+    float *out;                 // [n]
 };
+
+constexpr int HEAD_LDS = (9 * 256 + 256 + 512) * 4; // tap maps, block9 output, fc10 x fc11 terms
+constexpr int LDS_ALLOC_FUSED = LDS_ALLOC + HEAD_LDS;
 
 // ds_read_b128 serves lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (and the same + 32)
 // in separate LDS cycles: the first group holds cells 0-15 of a 32-cell block, the second
@@ -64,6 +74,7 @@ __device__ __forceinline__ int cell_of_lane(int r)
 
 extern __shared__ __align__(16) char trunk_lds[];
 
+template <bool FUSED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void trunk_resident_kernel(TrunkRParams P)
 {
     char *const T = trunk_lds;
@@ -73,7 +84,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- the zero areas, then the input of the first layer
     if (tid < TB * (ZB / 16))
         *(uint4 *)(T + (tid / (ZB / 16)) * BS + 64 * RS + (tid % (ZB / 16)) * 16) = make_uint4(0, 0, 0, 0);
-    {
+    bool saturated = false;
+    if constexpr (FUSED) {
+        // block1 (3x3, 2 -> 64, bias, ReLU; network.py:66-70) straight into T: the arithmetic of
+        // value_stem_kernel (conv_kernels.hip) -- same FMA order, same split -- per (board,
+        // cell = lane, 8 output channels = 16 bytes of a row); the channel group is wave-uniform
+        const int cell = tid & 63, y = cell >> 3, x = cell & 7;
+        float in[TB][18]; // the 3x3 neighbourhoods of this lane's cell on both planes, 4 boards
+#pragma unroll
+        for (int board = 0; board < TB; board++) {
+            const int64_t b = min(b0 + board, P.n - 1);
+            const float *pl = P.planes + b * 128;
+            const uint64_t bits0 = P.planes ? 0ull : P.opp[b], bits1 = P.planes ? 0ull : P.own[b];
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const int yy = y + ky - 1, xx = x + kx - 1;
+                        const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
+                        const int a = (yy * 8 + xx) & 63;
+                        float v;
+                        if (P.planes)
+                            v = ok ? pl[c * 64 + a] : 0.0f;
+                        else
+                            v = (ok && (((c ? bits1 : bits0) >> a) & 1ull)) ? 1.0f : 0.0f;
+                        in[board][c * 9 + ky * 3 + kx] = v;
+                    }
+        }
+        // the weights of an output channel are wave-uniform (scalar loads): each is fetched
+        // once and used for the 4 boards
+#pragma unroll 1
+        for (int g2 = 0; g2 < 2; g2++) {
+            const int grp = __builtin_amdgcn_readfirstlane(g2 * 4 + wv); // channel block * 2 + half
+            const int co0 = grp * 8;
+            _Float16 h8[TB][8], l8[TB][8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float *wk = P.w1 + (co0 + k) * 18; // [co][ci][ky][kx]
+                const float bk = P.b1[co0 + k];
+                float wreg[18];
+#pragma unroll
+                for (int j = 0; j < 18; j++)
+                    wreg[j] = wk[j];
+#pragma unroll
+                for (int board = 0; board < TB; board++) {
+                    float acc = bk;
+#pragma unroll
+                    for (int j = 0; j < 18; j++)
+                        acc = fmaf(wreg[j], in[board][j], acc);
+                    saturated |= !(acc <= 65000.0f);
+                    const float v = fminf(fmaxf(acc, 0.0f), 65000.0f);
+                    const _Float16 vh = (_Float16)v;
+                    h8[board][k] = vh;
+                    l8[board][k] = (_Float16)((v - (float)vh) * 2048.0f);
+                }
+            }
+#pragma unroll
+            for (int board = 0; board < TB; board++) {
+                char *dst = T + board * BS + cell * RS + (grp >> 1) * 32 + (grp & 1) * 16;
+                *(uint4 *)dst = *(const uint4 *)h8[board];
+                *(uint4 *)(dst + 256) = *(const uint4 *)l8[board];
+            }
+        }
+    } else {
         const int chunks0 = P.cin0 >> 4;
         const int pieces = TB * chunks0 * 128; // 16-byte pieces per hi / lo
         for (int e = tid; e < pieces; e += 256) {
@@ -116,7 +191,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         wrow[0][j] = (uint32_t)((32 * j + lane_cell) * RS);
         wrow[1][j] = wrow[0][j] + 2u * BS;
     }
-    bool saturated = false;
 #ifdef TRUNK_EXP_STAMPS // timing experiments only (tools/exp_trunk_variants.sh): s_memtime per phase
     unsigned long long stamps[3 * MAX_LAYERS + 1];
 #define STAMP(i) stamps[i] = __builtin_readcyclecounter()
@@ -259,6 +333,113 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (P.overflow && saturated)
         *P.overflow = 1u;
 
+    if constexpr (FUSED) {
+        // ---- block9 (3x3, 128 -> 1, bias, ReLU) + fc10 + fc11 (network.py:78-96, train=False) on
+        // the activations still in T.  The 3x3 convolution with ONE output channel as a 1x1
+        // convolution with 9: tap map M[tap][cell'] = sum_c w9[c][tap] x[c][cell'] on the MFMA
+        // units (A = the 9 tap rows of w9, zero-padded to 32; B = the centre tap's operand of
+        // the layers above; same split arithmetic), then out[cell] = sum_tap M[tap][cell + off(tap)].
+        float *const Dm = (float *)(T + LDS_ALLOC);  // [9][4 boards * 64 cells]
+        float *const h9s = Dm + 9 * 256;             // [4][64]
+        float *const hid = h9s + 256;                // [4][128]
+        // this thread's fc10 row (tid & 127), fetched under the MFMAs below
+        float4 w10row[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+            w10row[c] = ((const float4 *)(P.w10 + (tid & 127) * 64))[c];
+        const float w11j = P.w11[tid & 127];
+        {
+            const u32x4 *w9h = (const u32x4 *)P.w9_hi + r * 2 + h;
+            const u32x4 *w9l = (const u32x4 *)P.w9_lo + r * 2 + h;
+            float16v hm[2], hc[2];
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    hm[jt][v] = 0.0f;
+                    hc[jt][v] = 0.0f;
+                }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const half8 ah = __builtin_bit_cast(half8, w9h[c * 64]);
+                const half8 al = __builtin_bit_cast(half8, w9l[c * 64]);
+#pragma unroll
+                for (int jt = 0; jt < 2; jt++) {
+                    const int jj = 2 * wv + jt; // wave-uniform: board jj >> 1, cell half jj & 1
+                    const char *p = T + addr[0][jt][4] + (uint32_t)((jj >> 2) * 2 * BS + ((jj >> 1) & 1) * BS + c * 32);
+                    const half8 bh9 = *(const half8 *)p, bl9 = *(const half8 *)(p + 256);
+                    hm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh9, hm[jt], 0, 0, 0);
+                    hc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl9, hc[jt], 0, 0, 0);
+                    hc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh9, hc[jt], 0, 0, 0);
+                }
+            }
+            // D row m = 8 (v >> 2) + 4 h + (v & 3): taps 4 h .. 4 h + 3 in v = 0..3, tap 8 in v = 4 (h = 0)
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                const int jj = 2 * wv + jt;
+                const int base = (jj >> 1) * 64 + 32 * (jj & 1) + lane_cell;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    Dm[(4 * h + t) * 256 + base] = hm[jt][t] + hc[jt][t] * (1.0f / 2048.0f);
+                if (h == 0)
+                    Dm[8 * 256 + base] = hm[jt][4] + hc[jt][4] * (1.0f / 2048.0f);
+            }
+        }
+        __syncthreads();
+        {
+            const int cell = tid & 63, y = cell >> 3, x = cell & 7;
+            float s9 = 0.0f;
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8)
+                    s9 += Dm[tap * 256 + (tid & ~63) + yy * 8 + xx];
+            }
+            h9s[tid] = fmaxf(s9 + P.b9[0], 0.0f);
+        }
+        __syncthreads();
+        {
+            // fc10 row j for two boards, then its fc11 term (no bias, no activation in between)
+            const int j = tid & 127, pb = (tid >> 7) * 2;
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const float4 wq = w10row[c];
+                const float4 x0 = *(const float4 *)(h9s + pb * 64 + 4 * c);
+                const float4 x1 = *(const float4 *)(h9s + (pb + 1) * 64 + 4 * c);
+                s0 = fmaf(wq.x, x0.x, s0);
+                s0 = fmaf(wq.y, x0.y, s0);
+                s0 = fmaf(wq.z, x0.z, s0);
+                s0 = fmaf(wq.w, x0.w, s0);
+                s1 = fmaf(wq.x, x1.x, s1);
+                s1 = fmaf(wq.y, x1.y, s1);
+                s1 = fmaf(wq.z, x1.z, s1);
+                s1 = fmaf(wq.w, x1.w, s1);
+            }
+            hid[pb * 128 + j] = s0 * w11j;
+            hid[(pb + 1) * 128 + j] = s1 * w11j;
+        }
+        __syncthreads();
+        if (tid < TB && b0 + tid < P.n) {
+            // fixed order j = 0..127 (the result does not depend on the launch shape); the 32
+            // LDS reads are issued together, the additions are one dependent chain
+            float4 hv[32];
+#pragma unroll
+            for (int j4 = 0; j4 < 32; j4++)
+                hv[j4] = *(const float4 *)(hid + tid * 128 + 4 * j4);
+            float v = 0.0f;
+#pragma unroll
+            for (int j4 = 0; j4 < 32; j4++) {
+#pragma clang fp reassociate(off)
+                v += hv[j4].x;
+                v += hv[j4].y;
+                v += hv[j4].z;
+                v += hv[j4].w;
+            }
+            P.out[b0 + tid] = v;
+        }
+        return;
+    }
     // ---- the last layer's activations: coalesced 16-byte stores, [n][8][64][16] hi and lo
     for (int e = tid; e < TB * 1024; e += 256) {
         const int board = e >> 10, cb = (e >> 7) & 7, cell = (e >> 1) & 63, hp = e & 1;
@@ -301,11 +482,66 @@ int iago_launch_trunk_resident(const iago_conv_split_layer *layers, int32_t n_la
     P.cin0 = layers[0].cin;
     P.n_layers = n_layers;
     P.overflow = overflow;
+    P.planes = nullptr;
+    P.own = P.opp = nullptr;
+    P.w1 = P.b1 = P.b9 = P.w10 = P.w11 = nullptr;
+    P.w9_hi = P.w9_lo = nullptr;
+    P.out = nullptr;
     static std::atomic<uint64_t> configured{0};
-    if (iago_reserve_lds((const void *)trunk_resident_kernel, LDS_ALLOC, configured,
+    if (iago_reserve_lds((const void *)trunk_resident_kernel<false>, LDS_ALLOC, configured,
                          "iago_conv3x3_split_trunk: cannot reserve 134 KB of LDS"))
         return IAGO_ERR_HIP;
     const unsigned grid = (unsigned)((n + TB - 1) / TB);
-    hipLaunchKernelGGL(trunk_resident_kernel, dim3(grid), dim3(256), LDS_ALLOC, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(trunk_resident_kernel<false>, dim3(grid), dim3(256), LDS_ALLOC, (hipStream_t)stream, P);
     return iago_check_launch("iago_conv3x3_split_trunk");
+}
+
+int iago_value_forward_split(const iago_value_split_args *a, void *stream)
+{
+    if (!a || a->n < 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: null args or n < 0");
+    if (a->n == 0)
+        return IAGO_OK;
+    if ((!a->planes && (!a->own || !a->opp)) || !a->w1 || !a->b1 || !a->w9_hi || !a->w9_lo || !a->b9 || !a->w10 ||
+        !a->w11 || !a->out)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: null pointer");
+    TrunkRParams P;
+    for (int L = 0; L < 7; L++) {
+        if (!a->w_hi[L] || !a->w_lo[L] || !a->bias[L] || ((uintptr_t)a->w_hi[L] & 15u) || ((uintptr_t)a->w_lo[L] & 15u) ||
+            ((uintptr_t)a->bias[L] & 15u))
+            return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: weights and biases of blocks 2..8 must be "
+                                               "non-null and 16-byte aligned");
+        P.w_hi[L] = (const uint4 *)a->w_hi[L];
+        P.w_lo[L] = (const uint4 *)a->w_lo[L];
+        P.bias[L] = a->bias[L];
+    }
+    P.w_hi[7] = P.w_hi[6];
+    P.w_lo[7] = P.w_lo[6];
+    P.bias[7] = P.bias[6];
+    if (((uintptr_t)a->w9_hi & 15u) || ((uintptr_t)a->w9_lo & 15u) || ((uintptr_t)a->w10 & 15u))
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: w9_hi, w9_lo, w10 must be 16-byte aligned");
+    P.x_hi = P.x_lo = nullptr;
+    P.y_hi = P.y_lo = nullptr;
+    P.n = a->n;
+    P.cin0 = 64;
+    P.n_layers = 7;
+    P.overflow = a->overflow;
+    P.planes = a->planes;
+    P.own = a->own;
+    P.opp = a->opp;
+    P.w1 = a->w1;
+    P.b1 = a->b1;
+    P.w9_hi = (const uint4 *)a->w9_hi;
+    P.w9_lo = (const uint4 *)a->w9_lo;
+    P.b9 = a->b9;
+    P.w10 = a->w10;
+    P.w11 = a->w11;
+    P.out = a->out;
+    static std::atomic<uint64_t> configured{0};
+    if (iago_reserve_lds((const void *)trunk_resident_kernel<true>, LDS_ALLOC_FUSED, configured,
+                         "iago_value_forward_split: cannot reserve 148 KB of LDS"))
+        return IAGO_ERR_HIP;
+    const unsigned grid = (unsigned)((a->n + TB - 1) / TB);
+    hipLaunchKernelGGL(trunk_resident_kernel<true>, dim3(grid), dim3(256), LDS_ALLOC_FUSED, (hipStream_t)stream, P);
+    return iago_check_launch("iago_value_forward_split");
 }

@@ -320,6 +320,7 @@ class BatchedMCTS(object):
                 key.extend((q.data_ptr(), q._version) for q in params())
                 key.append(bool(getattr(fn, "training", False)))
                 key.append(bool(getattr(fn, "split_f16", False)))
+                key.append(bool(getattr(fn, "fused", False)))
             else:
                 key.append(id(fn))
         return tuple(key)

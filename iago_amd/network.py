@@ -269,11 +269,35 @@ class Value(nn.Module, _NpzMixin):
                 and not torch.is_autocast_enabled())
 
     def _split_trunk_head(self, a):
+        """Blocks 2..8 + head on SplitActs: the three-launch form (the fused forward below is
+        what inference runs; this is its cross-check and the path of callers that hold
+        split activations)."""
         from . import ops
         layers = [self._split_weights(k) + (getattr(self, "block%d" % k).conv.bias,) for k in range(2, 9)]
         a = ops.conv3x3_split_trunk(a, layers, overflow=self._overflow_flag(a.hi.device))  # blocks 2..8
         return ops.value_head(a, self.block9.conv.weight, self.block9.conv.bias,
                               self.fc10.weight, self.fc11.weight)
+
+    def _head_weights(self):
+        from . import ops
+        w = self.block9.conv.weight
+        key = (w._version, w.data_ptr(), str(w.device))
+        hit = self.__dict__.get("_head_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.split_head_weights(w))
+            self.__dict__["_head_cache"] = hit
+        return hit[1]
+
+    fused = True   # one launch for the whole net (iago_value_forward_split); False: stem, trunk, head
+
+    def _forward_split(self, x, device):
+        """x: planes (n,2,8,8) or (own, opp).  The whole net in one launch."""
+        from . import ops
+        layers = [self._split_weights(k) + (getattr(self, "block%d" % k).conv.bias,) for k in range(2, 9)]
+        return ops.value_forward_split(x, self.block1.conv.weight, self.block1.conv.bias, layers,
+                                       self._head_weights(), self.block9.conv.weight, self.block9.conv.bias,
+                                       self.fc10.weight, self.fc11.weight,
+                                       overflow=self._overflow_flag(device))
 
     def forward_boards(self, own, opp):
         """forward(make_state_var(...)) for int64 bitboards (own = side to move) without the
@@ -281,13 +305,17 @@ class Value(nn.Module, _NpzMixin):
         if not (self.split_f16 and own.is_cuda and not self.training and not torch.is_grad_enabled()
                 and own.numel() >= self.SPLIT_MIN_BATCH and not torch.is_autocast_enabled()):
             return None
+        if self.fused:
+            return self._forward_split((own, opp), own.device)
         from . import ops
         return self._split_trunk_head(ops.value_stem_boards(own, opp, self.block1.conv.weight,
                                                             self.block1.conv.bias,
                                                             overflow=self._overflow_flag(own.device)))
 
     def forward(self, x):
-        if self._use_split(x):
+        if self._use_split(x) and self.fused:
+            return self._forward_split(x.contiguous(), x.device)
+        elif self._use_split(x):
             from . import ops
             a = ops.value_stem(x.contiguous(), self.block1.conv.weight, self.block1.conv.bias,
                                overflow=self._overflow_flag(x.device))

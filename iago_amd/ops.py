@@ -248,6 +248,55 @@ def value_head(a, w9, b9, w10, w11):
     return out
 
 
+def split_head_weights(w9):
+    """Value.block9's (1, 128, 3, 3) weight as the MFMA operand of iago_value_forward_split:
+    (hi, lo) f16 [8 chunks][32 rows][16], row r < 9 = kernel tap r, the other rows zero."""
+    if tuple(w9.shape) != (1, 128, 3, 3):
+        raise ValueError("split_head_weights: (1, 128, 3, 3) expected")
+    w = w9.detach().to(torch.float32).reshape(8, 16, 9).permute(0, 2, 1)   # chunk, tap, channel
+    a = torch.zeros((8, 32, 16), dtype=torch.float32, device=w9.device)
+    a[:, :9, :] = w
+    hi = a.to(torch.float16)
+    lo = ((a - hi.to(torch.float32)) * 2048.0).to(torch.float16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None):
+    """The whole Value net in one launch (iago_value_forward_split).  x: float32 planes
+    (n, 2, 8, 8) or a pair (own, opp) of int64 bitboards (own = side to move); layers: the 7
+    (w_hi, w_lo, bias) of blocks 2..8 (split_weights); head: split_head_weights(w9)."""
+    a = _lib.ValueSplitArgs()
+    if isinstance(x, tuple):
+        own, opp = x
+        n, dev = own.numel(), own.device
+        a.own, a.opp = _dev(own, torch.int64, "own").value, _dev(opp, torch.int64, "opp").value
+    else:
+        if tuple(x.shape[1:]) != (2, 8, 8):
+            raise ValueError("value_forward_split: planes (n, 2, 8, 8) expected")
+        n, dev = x.shape[0], x.device
+        a.planes = _dev(x, torch.float32, "planes").value
+    if len(layers) != 7 or tuple(w1.shape) != (64, 2, 3, 3) or tuple(w10.shape) != (128, 64) \
+            or tuple(w11.shape) != (1, 128):
+        raise ValueError("value_forward_split: unexpected shapes")
+    a.n = n
+    a.w1, a.b1 = _dev(w1, torch.float32, "w1").value, _dev(b1, torch.float32, "b1").value
+    for k, (w_hi, w_lo, bias) in enumerate(layers):
+        if w_hi.shape != ((4 if k == 0 else 8), 3, 3, 128, 16):
+            raise ValueError("value_forward_split: layer %d: weight blocks %s" % (k, tuple(w_hi.shape)))
+        a.w_hi[k] = _dev(w_hi, torch.float16, "w_hi").value
+        a.w_lo[k] = _dev(w_lo, torch.float16, "w_lo").value
+        a.bias[k] = _dev(bias, torch.float32, "bias").value
+    a.w9_hi, a.w9_lo = _dev(head[0], torch.float16, "w9_hi").value, _dev(head[1], torch.float16, "w9_lo").value
+    a.b9 = _dev(b9, torch.float32, "b9").value
+    a.w10, a.w11 = _dev(w10, torch.float32, "w10").value, _dev(w11, torch.float32, "w11").value
+    out = torch.empty((n,), dtype=torch.float32, device=dev)
+    a.out = out.data_ptr()
+    f = _flag(overflow)
+    a.overflow = f.value if f is not None else None
+    check(_lib.lib().iago_value_forward_split(C.byref(a), _stream()), "iago_value_forward_split")
+    return out
+
+
 def conv3x3_split(a, w_hi, w_lo, bias, overflow=None):
     """relu(conv3x3(a, w) + bias) on SplitActs: Block.__call__ (network.py:9-13) on
     the MFMA units in split-f16 arithmetic.  w_hi, w_lo from split_weights."""

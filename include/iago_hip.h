@@ -292,6 +292,33 @@ typedef struct iago_conv_split_layer {
 } iago_conv_split_layer;
 IAGO_API int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32_t n_layers, int64_t n,
                                       uint32_t *overflow, void *stream);
+/*
+ * The WHOLE Value net (Value.__call__(x, train=False), network.py:66-96, as MCTS.playout calls
+ * it, MCTS.py:123-124) in ONE launch: iago_value_stem(_boards) + the 7-layer
+ * iago_conv3x3_split_trunk + iago_value_head with the activations resident in LDS from block1
+ * to fc11 -- no intermediate tensor is written.  Same arithmetic as the three calls (block1 in
+ * float32, blocks 2..8 in split-f16 MFMAs, bit-identical to them; block9 as a 9-row MFMA
+ * product in the same split arithmetic, fc10 / fc11 in float32).
+ *   planes: float32 [n][2][8][8], or NULL: the boards themselves in own / opp (own = side to
+ *   move; iago_encode_planes fused in).  w_hi/w_lo/bias[k]: block 2+k as in iago_conv3x3_split
+ *   (w_hi[0] has cin = 64).  w9_hi/w9_lo: block9's weight as MFMA operand
+ *   [8 chunks of 16 input channels][32 rows][16] f16, row r < 9 = kernel tap r (ky*3+kx),
+ *   rows 9..31 zero, split like every weight (hi = f16(w), lo = f16((w - hi) * 2^11)).
+ *   b9 [1], w10 [128][64], w11 [1][128], out [n].  overflow: see iago_conv3x3_split.
+ */
+typedef struct iago_value_split_args {
+    const float *planes;
+    const uint64_t *own, *opp;
+    int64_t n;
+    const float *w1, *b1;
+    const void *w_hi[7], *w_lo[7];
+    const float *bias[7];
+    const void *w9_hi, *w9_lo;
+    const float *b9, *w10, *w11;
+    float *out;
+    uint32_t *overflow;
+} iago_value_split_args;
+IAGO_API int iago_value_forward_split(const iago_value_split_args *args, void *stream);
 IAGO_API int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels,
                              uint32_t *overflow, void *stream);
 IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n, int32_t channels,

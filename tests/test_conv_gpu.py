@@ -60,13 +60,16 @@ def test_random_data_matches_float32(cin):
     assert err < 2e-6 * float(ref.abs().max()), err
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("n", [192, 333, 1024])
-def test_value_forward_split_vs_float32(n):
-    """network.py:66-96 (train=False): the split-f16 stack against MIOpen float32 on
-    the GPU and against float64 on the CPU; tolerance = the 1e-5 parity bar."""
+def test_value_forward_split_vs_float32(n, fused):
+    """network.py:66-96 (train=False): the split-f16 stack (one fused launch, and the stem /
+    trunk / head launches) against MIOpen float32 on the GPU and against float64 on the CPU;
+    tolerance = the 1e-5 parity bar."""
     from iago_amd import network
     torch.manual_seed(5)
     m = network.Value().eval()
+    m.fused = fused
     # random init gives outputs ~1e-2: scale the weights up to O(1) activations
     with torch.no_grad():
         for p in m.parameters():
@@ -204,6 +207,36 @@ def test_value_forward_boards_equals_forward_on_planes():
         b = m(ops.encode_planes(o, p))
         assert m.forward_boards(o[:5], p[:5]) is None      # small batches: the caller encodes planes
     assert a is not None and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n", [192, 193, 255, 1024])
+def test_fused_value_forward_equals_three_launches(n):
+    """iago_value_forward_split (block1, blocks 2..8 and the head in ONE launch, activations
+    resident in LDS) against iago_value_stem(_boards) + iago_conv3x3_split_trunk +
+    iago_value_head: block1 and the trunk are the same arithmetic; the head sums block9's
+    products in another order (9-row MFMA product + 9 shifted adds instead of FMA chains), so
+    the outputs agree to float32 rounding, for ragged batches, from planes and from boards."""
+    from iago_amd import network, ops
+    from tests.gpu_util import random_positions
+    torch.manual_seed(31)
+    m = network.Value().eval().cuda()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.6)
+    own, opp = random_positions(n, seed=n)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    x = ops.encode_planes(o, p)
+    with torch.no_grad():
+        m.fused = False
+        ref = m(x)
+        ref_b = m.forward_boards(o, p)
+        m.fused = True
+        got = m(x)
+        got_b = m.forward_boards(o, p)
+    assert torch.equal(ref, ref_b) and torch.equal(got, got_b)
+    scale = max(1.0, float(ref.abs().max()))
+    assert (got - ref).abs().max().item() < 2e-6 * scale, (got - ref).abs().max().item()
+    m.check_saturation()
 
 
 def test_trunk_kernel_equals_layer_by_layer():

@@ -11,6 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 torch.manual_seed(0)
 m = network.Value().cuda().eval()
+m.fused = os.environ.get("IAGO_VALUE_UNFUSED") is None   # one launch / stem + trunk + head
 g = torch.Generator().manual_seed(1)
 own = torch.randint(0, 2 ** 62, (n,), generator=g).cuda()
 opp = torch.randint(0, 2 ** 62, (n,), generator=g).cuda() & ~own
@@ -25,5 +26,5 @@ with torch.no_grad():
     e1.record()
     torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print("Value forward, %d boards: %.1f us; trunk MFMA flops 3 x 122.68 MFLOP x n / t = %.0f TFLOP/s executed"
+print(("fused" if m.fused else "3 launches") + " Value forward, %d boards: %.1f us; trunk MFMA flops 3 x 122.68 MFLOP x n / t = %.0f TFLOP/s executed"
       % (n, ms * 1e3, 3 * 122.683392e6 * n / (ms * 1e-3) / 1e12))
