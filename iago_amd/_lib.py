@@ -29,7 +29,7 @@ SYMBOLS = [
     "iago_rollout_build_table", "iago_rollout",
     "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_mcts_pending",
     "iago_leaf_values",
-    "iago_mcts_backup", "iago_mcts_mix_backup", "iago_mcts_best_move", "iago_mcts_advance_root",
+    "iago_mcts_backup", "iago_mcts_mix_backup", "iago_mcts_best_move", "iago_mcts_advance_root", "iago_mcts_compact",
 ]
 
 
@@ -143,6 +143,7 @@ def lib():
     L.iago_mcts_pending.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp]
     L.iago_mcts_best_move.argtypes = [tp, vp, vp, vp, vp]
     L.iago_mcts_advance_root.argtypes = [tp, vp, vp, vp]
+    L.iago_mcts_compact.argtypes = [tp, tp, vp, vp, vp]
     for name in SYMBOLS[3:]:
         getattr(L, name).restype = C.c_int
     _lib = L

@@ -317,6 +317,80 @@ __global__ __launch_bounds__(BLOCK) void advance_root_kernel(Tree T, const uint8
     T.root[g] = 0;
 }
 
+// ---- pool compaction (iago_mcts_compact).  Subtree reuse (advance_root) keeps the chosen
+// child's subtree and abandons its siblings' nodes in the pool; the reference's garbage
+// collector frees them (MCTS.py:149-152 drops the last reference).  Here a game's live subtree
+// is re-laid in breadth-first order from index 0: children stay contiguous and in their order,
+// so every later select / expand / backup behaves exactly as on the uncompacted pool.
+//   plan:   one thread per game walks the subtree with `order` as its queue (order[new] = old)
+//           and writes the new parent / first_child links into the scratch pool;
+//   gather: the statistics of the live nodes into the scratch pool, in the new order;
+//   commit: scratch -> pool, n_nodes = live nodes, root = 0.
+__global__ __launch_bounds__(64) void compact_plan_kernel(Tree T, Tree S, const uint8_t *__restrict__ mask,
+                                                          int32_t *__restrict__ order)
+{
+    const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (g >= T.n_games)
+        return;
+    if (mask && !mask[g]) {
+        S.n_nodes[g] = -1; // not compacted
+        return;
+    }
+    const int64_t base = g * (int64_t)T.capacity;
+    int32_t *q = order + base;
+    q[0] = T.root[g];
+    S.parent[base] = -1;
+    int head = 0, tail = 1;
+    while (head < tail) {
+        const int o = q[head];
+        const int fc = T.first_child[base + o];
+        const int k = fc >= 0 ? (int)T.n_children[base + o] : 0;
+        S.first_child[base + head] = k ? tail : -1;
+        for (int j = 0; j < k; j++) {
+            q[tail + j] = fc + j;
+            S.parent[base + tail + j] = head;
+        }
+        tail += k;
+        head++;
+    }
+    S.n_nodes[g] = tail;
+}
+
+__global__ __launch_bounds__(BLOCK) void compact_gather_kernel(Tree T, Tree S, const int32_t *__restrict__ order)
+{
+    const int64_t g = blockIdx.x;
+    const int count = S.n_nodes[g];
+    const int64_t base = g * (int64_t)T.capacity;
+    for (int i = threadIdx.x; i < count; i += BLOCK) {
+        const int64_t o = base + order[base + i];
+        S.n_children[base + i] = T.n_children[o];
+        S.action[base + i] = T.action[o];
+        S.n_visits[base + i] = T.n_visits[o];
+        S.q[base + i] = T.q[o];
+        S.p[base + i] = T.p[o];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void compact_commit_kernel(Tree T, Tree S)
+{
+    const int64_t g = blockIdx.x;
+    const int count = S.n_nodes[g];
+    const int64_t base = g * (int64_t)T.capacity;
+    for (int i = threadIdx.x; i < count; i += BLOCK) {
+        T.parent[base + i] = S.parent[base + i];
+        T.first_child[base + i] = S.first_child[base + i];
+        T.n_children[base + i] = S.n_children[base + i];
+        T.action[base + i] = S.action[base + i];
+        T.n_visits[base + i] = S.n_visits[base + i];
+        T.q[base + i] = S.q[base + i];
+        T.p[base + i] = S.p[base + i];
+    }
+    if (threadIdx.x == 0 && count >= 0) {
+        T.n_nodes[g] = count;
+        T.root[g] = 0;
+    }
+}
+
 inline unsigned grid_for(int64_t threads) { return (unsigned)((threads + BLOCK - 1) / BLOCK); }
 
 int check_tree(const Tree *t, const char *who)
@@ -507,6 +581,25 @@ int iago_mcts_advance_root(const iago_mcts_tree *tree, const uint8_t *mask, cons
     hipLaunchKernelGGL(advance_root_kernel, dim3(grid_for(tree->n_games)), dim3(BLOCK), 0,
                        (hipStream_t)stream, *tree, mask, move);
     return iago_check_launch("iago_mcts_advance_root");
+}
+
+int iago_mcts_compact(const iago_mcts_tree *tree, const iago_mcts_tree *scratch, int32_t *order,
+                      const uint8_t *mask, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_compact: bad tree") || check_tree(scratch, "iago_mcts_compact: bad scratch tree"))
+        return IAGO_ERR_INVALID;
+    if (!order || scratch->n_games != tree->n_games || scratch->capacity != tree->capacity ||
+        scratch->parent == tree->parent || scratch->n_visits == tree->n_visits)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_compact: scratch must be a second pool of the same shape");
+    if (tree->n_games == 0)
+        return IAGO_OK;
+    const unsigned games = (unsigned)tree->n_games;
+    hipLaunchKernelGGL(compact_plan_kernel, dim3((games + 63) / 64), dim3(64), 0, (hipStream_t)stream, *tree,
+                       *scratch, mask, order);
+    hipLaunchKernelGGL(compact_gather_kernel, dim3(games), dim3(BLOCK), 0, (hipStream_t)stream, *tree, *scratch,
+                       order);
+    hipLaunchKernelGGL(compact_commit_kernel, dim3(games), dim3(BLOCK), 0, (hipStream_t)stream, *tree, *scratch);
+    return iago_check_launch("iago_mcts_compact");
 }
 
 } // extern "C"

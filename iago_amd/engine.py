@@ -31,9 +31,11 @@ def _stream():
 
 
 def suggest_capacity(n_sims, n_thr=15, moves=64, branching=12):
-    """Nodes per game that a whole self-play game needs without pool compaction:
+    """Nodes per game that a whole self-play game needs without ever compacting the pools:
     every expansion adds ~`branching` children, a search adds at most
-    n_sims / n_thr + 1 expansions, abandoned siblings are never reclaimed."""
+    n_sims / n_thr + 1 expansions.  (BatchedMCTS.search compacts a pool that is half full --
+    TreePool.compact -- so a smaller capacity only costs compaction passes, as long as one
+    search's live tree fits in half of it.)"""
     per_move = (n_sims // max(n_thr, 1) + 1) * branching
     cap = 1024
     while cap < per_move * moves:
@@ -78,6 +80,29 @@ class TreePool(object):
     def bytes(self):
         return sum(getattr(self, f).numel() * getattr(self, f).element_size()
                    for f in ("parent", "first_child", "n_children", "action", "n_visits", "q", "p"))
+
+    def compact(self, mask=None):
+        """Garbage collection (iago_mcts_compact): the live subtree of every game (mask: uint8
+        per game, None = all) re-laid from index 0; the nodes abandoned by subtree reuse are
+        freed.  A second pool and an index array are allocated on first use."""
+        if getattr(self, "_scratch", None) is None:
+            dev = self.parent.device
+            sc = TreePool.__new__(TreePool)
+            sc.n_games, sc.capacity = self.n_games, self.capacity
+            for f in ("parent", "first_child", "n_children", "action", "n_visits", "q", "p", "n_nodes",
+                      "root", "overflow"):
+                setattr(sc, f, torch.empty_like(getattr(self, f)))
+            t = MctsTree()
+            t.n_games, t.capacity = self.n_games, self.capacity
+            for f in ("parent", "first_child", "n_children", "action", "n_visits", "q", "p", "n_nodes",
+                      "root", "overflow"):
+                setattr(t, f, getattr(sc, f).data_ptr())
+            sc.c = t
+            self._scratch = sc
+            self._order = torch.empty(self.n_games * self.capacity, dtype=torch.int32, device=dev)
+        check(_lib.lib().iago_mcts_compact(self.ref(), self._scratch.ref(), _p(self._order),
+                                           _p(mask) if mask is not None else None, _stream()),
+              "iago_mcts_compact")
 
     def dump(self, g, max_depth=6):
         """Host copy of game g's tree in the format of oracle.mcts_py.dump_tree."""
@@ -156,6 +181,7 @@ class BatchedMCTS(object):
         if use_graph and not self.sync_free:
             raise ValueError("use_graph needs the sync-free playout (a policy with forward_counted)")
         self.use_graph, self._graph, self._graph_key = bool(use_graph), None, None
+        self.n_compactions = 0
         self._g_own = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._g_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._g_active = torch.zeros(n_games, dtype=torch.uint8, **kw)
@@ -369,9 +395,16 @@ class BatchedMCTS(object):
     def search(self, own, opp, active, n_sims):
         """n_sims playouts from the current roots; (own, opp) = root positions
         with own = side to move; active: uint8 mask of participating games."""
-        n_active = int(active.sum().item())
+        n_active, used = (int(v) for v in torch.stack(
+            [active.sum().to(torch.int64), self.tree.n_nodes.max().to(torch.int64)]).tolist())
         if n_active == 0:
             return
+        if used > self.tree.capacity // 2:
+            # a pool is half full: free the nodes that subtree reuse left behind (what the
+            # reference's garbage collector does after MCTS.py:149-152) before this search adds
+            # its own.  A pool that fills up all the same is reported below.
+            self.tree.compact()
+            self.n_compactions += 1
         if self.use_graph:
             self._search_graph(own, opp, active, n_sims, n_active)
         else:

@@ -453,6 +453,19 @@ IAGO_API int iago_mcts_best_move(const iago_mcts_tree *tree, const uint8_t *acti
 IAGO_API int iago_mcts_advance_root(const iago_mcts_tree *tree, const uint8_t *mask,
                                     const int8_t *move, void *stream);
 
+/*
+ * Garbage collection of the node pools.  iago_mcts_advance_root keeps the chosen child's
+ * subtree and leaves its siblings' nodes behind in the pool (the reference drops its last
+ * reference to them, MCTS.py:149-152, and Python frees them).  This call re-lays the live
+ * subtree of every game with mask[g] != 0 (NULL = all) in breadth-first order from index 0:
+ * children stay contiguous and in their order, statistics are copied unchanged, root = 0,
+ * n_nodes = the number of live nodes -- a search behaves exactly as on the uncompacted pool.
+ * scratch: a second pool of the same shape (temporary copy target), order: int32
+ * [n_games*capacity] (temporary).  Call between searches (no cursor may be in flight).
+ */
+IAGO_API int iago_mcts_compact(const iago_mcts_tree *tree, const iago_mcts_tree *scratch, int32_t *order,
+                               const uint8_t *mask, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

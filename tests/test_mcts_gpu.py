@@ -152,6 +152,61 @@ def test_leaf_values_and_unknown_move_resets_root(eng):
     assert int(m.tree.root[1].item()) != 0
 
 
+def test_pool_compaction_preserves_the_search(eng, golden_rules):
+    """iago_mcts_compact (the nodes abandoned by subtree reuse are freed, the live subtree
+    re-laid from index 0): an engine with small pools that compacts along the way must play
+    the same moves with the same visit counts and end with the same trees as one whose pools
+    never fill; the compacted pools hold exactly the reachable nodes."""
+    engine, ops = eng
+    G, n_sims, turns = 12, 60, 7
+    own, opp = positions(G, 33, golden_rules)
+    _, _, policy_t, value_t = fake_nets(2)
+
+    def make(cap):
+        return engine.BatchedMCTS(G, policy_t, value_t, None, lmbda=0.5, c_puct=1.0, n_thr=2,
+                                  capacity=cap, seed=11)
+
+    small, big = make(1024), make(16384)
+    oa, pa = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    ob, pb = oa.clone(), pa.clone()
+    for t in range(turns):
+        legal = ops.legal_moves(oa, pa)
+        active = (legal != 0).to(torch.uint8)
+        small.search(oa, pa, active, n_sims)
+        big.search(ob, pb, active, n_sims)
+        ma, va = small.best_move(active)
+        mb, vb = big.best_move(active)
+        act = active.bool()
+        assert torch.equal(ma[act], mb[act]) and torch.equal(va[act], vb[act]), t
+        mv = torch.where(act, ma, torch.full_like(ma, -1))
+        for m_, o_, p_ in ((small, oa, pa), (big, ob, pb)):
+            ops.apply_moves(o_, p_, mv)
+            m_.update_with_move(mv)
+        oa, pa, ob, pb = pa, oa, pb, ob
+    assert small.n_compactions > 0 and big.n_compactions == 0
+    assert int(small.tree.overflow.sum().item()) == 0
+    for g in range(G):
+        assert small.tree.dump(g, max_depth=64) == big.tree.dump(g, max_depth=64), g
+    # a compaction on its own: pools hold exactly the nodes reachable from the root, in
+    # breadth-first order, links consistent
+    small.tree.compact()
+    T, cap = small.tree, small.tree.capacity
+    nn = T.n_nodes.cpu().numpy()
+    par = T.parent.cpu().numpy().reshape(G, cap)
+    fc = T.first_child.cpu().numpy().reshape(G, cap)
+    nc = T.n_children.cpu().numpy().reshape(G, cap)
+    assert np.all(T.root.cpu().numpy() == 0)
+    for g in range(G):
+        nxt = 1
+        assert par[g, 0] == -1
+        for i in range(nn[g]):
+            if fc[g, i] >= 0:
+                assert fc[g, i] == nxt and np.all(par[g, nxt:nxt + nc[g, i]] == i)
+                nxt += nc[g, i]
+        assert nxt == nn[g]
+        assert small.tree.dump(g, max_depth=64) == big.tree.dump(g, max_depth=64), g
+
+
 def test_pool_overflow_is_reported(eng):
     engine, ops = eng
     from iago_amd import _lib
