@@ -42,6 +42,7 @@ namespace {
 constexpr int HW_BLOCK = 256; // 16 boards per workgroup: 4096 boards = one workgroup per CU
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_MIRROR = 0x140; // lane i <-> 15 - i inside a row of 16
+constexpr int DPP_ROW_BCAST15 = 0x15F; // row_newbcast:15: every lane reads lane 15 of its row
 constexpr int N_T4 = 2 * 3 * 2 * 2 * 32; // [orientation][kernel row][plane][row half][5 window bits]
 
 struct HwParams {
@@ -306,19 +307,6 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
             // ---- legal moves of the side to move (this lane's orientation)
             const uint64_t legal = legal_hw(own, opp, L);
             const uint32_t has = min(1u, (uint32_t)legal | (uint32_t)(legal >> 32));
-            // ---- pass / termination bookkeeping (mcts_self_play.py:26-28,126-133), branch-free;
-            // here, not at the end of the turn: the vector compare behind the loop's exit test
-            // is a whole turn ahead of its branch
-            const uint32_t live_turn = done ^ 1u;
-            const uint32_t play = has & live_turn;
-            const uint32_t passing = (has ^ 1u) & live_turn;
-            stones = max(stones + play, (passing & pass_flg) << 6);
-            pass_flg = (pass_flg & done) | passing;
-            nt += live_turn;
-            if (i & 1) { // `while stone_num < 64` once per pair of turns
-                done |= stones >> 6;
-                any_live = __builtin_amdgcn_ballot_w64(done == 0u) != 0ull;
-            }
             // ---- softmax numerators, zero on illegal cells (all four are in the low word)
             // ONE wait for the six table reads (issued a move generation ago) instead of four
             // counted ones: every instruction of a lone wave, waits included, is an issue slot
@@ -333,23 +321,49 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
             for (int j = 0; j < 4; j++)
                 ev[j] = __uint_as_float(__float_as_uint(e[j]) &
                                         (uint32_t)__builtin_amdgcn_sbfe((int)lw, L.bit[j], 1u));
-            // ---- inverse CDF in cell order: running sums in the lane, exclusive prefix of
-            // the lane totals over the row
+            // ---- inverse CDF in cell order: running sums in the lane, then ONE dependent DPP
+            // chain over the row: inclusive scan of the lane totals (4 steps); the exclusive
+            // prefix is its row_shr:1 (bit for bit the exclusive scan of the shifted totals) and
+            // the total its last lane, broadcast (row_newbcast:15) -- the last element of the
+            // CDF itself, what numpy normalises by (mcts_self_play.py:103-106), instead of a
+            // second 4-step butterfly.  A dependent DPP step costs a lone wave 5 + 8 cycles
+            // (read-after-write hazard: two wait states); the pass / termination bookkeeping
+            // (mcts_self_play.py:26-28,126-133; branch-free, independent of the sampling) is
+            // placed into those wait states, which also puts the compare behind the loop's
+            // exit test far ahead of its branch.
             float cdf[4], thr;
+            uint32_t live_turn, play;
             {
 #pragma clang fp contract(off)
                 const float c1 = ev[0] + ev[1], c2 = c1 + ev[2], c3 = c2 + ev[3];
-                float xs = dpp_or_zero<DPP_ROW_SHR1>(c3);
-                xs += dpp_or_zero<DPP_ROW_SHR1>(xs);
-                xs += dpp_or_zero<DPP_ROW_SHR2>(xs);
-                xs += dpp_or_zero<DPP_ROW_SHR4>(xs);
-                xs += dpp_or_zero<DPP_ROW_SHR8>(xs);
+                float inc = c3;
+                inc += dpp_or_zero<DPP_ROW_SHR1>(inc);
+                live_turn = done ^ 1u;
+                play = has & live_turn;
+                __builtin_amdgcn_sched_barrier(0);
+                inc += dpp_or_zero<DPP_ROW_SHR2>(inc);
+                const uint32_t passing = (has ^ 1u) & live_turn;
+                const uint32_t grown = stones + play;
+                __builtin_amdgcn_sched_barrier(0);
+                inc += dpp_or_zero<DPP_ROW_SHR4>(inc);
+                stones = max(grown, (passing & pass_flg) << 6);
+                __builtin_amdgcn_sched_barrier(0);
+                inc += dpp_or_zero<DPP_ROW_SHR8>(inc);
+                pass_flg = (pass_flg & done) | passing;
+                nt += live_turn;
+                __builtin_amdgcn_sched_barrier(0);
+                const float xs = dpp_or_zero<DPP_ROW_SHR1>(inc);
+                const float total = dpp_f32<DPP_ROW_BCAST15>(inc);
+                if (i & 1) { // `while stone_num < 64` once per pair of turns
+                    done |= stones >> 6;
+                    any_live = __builtin_amdgcn_ballot_w64(done == 0u) != 0ull;
+                }
                 cdf[0] = xs + ev[0];
                 cdf[1] = xs + c1;
                 cdf[2] = xs + c2;
                 cdf[3] = xs + c3;
                 // u * total is rounded BEFORE any comparison: the uniform policy stays bit-exact
-                thr = u4[i] * row_sum(c3);
+                thr = u4[i] * total;
             }
             // sampled cell = number of cells with CDF <= thr (numpy searchsorted 'right'):
             // sign bits of thr - cdf (set iff cdf > thr) funnelled into one word
