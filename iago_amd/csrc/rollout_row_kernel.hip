@@ -75,7 +75,7 @@ constexpr int TT_A_OR_BC = 0xF8;  // a | (b & c)
 constexpr int TT_AB_OR_C = 0xEA;  // (a & b) | c
 constexpr int TT_NOR_AND = 0x02;  // ~a & ~b & c  (a=F0, b=CC, c=AA: only minterm 001)
 constexpr int TT_A_OR_NB = 0xF3;  // a | ~b
-constexpr int TT_XOR_AND = 0x28;  // (a ^ b) & c
+constexpr int TT_A_NB_C = 0x20;   // a & ~b & c
 constexpr int TT_ABC = 0x80;      // a & b & c
 
 template <int CTRL>
@@ -123,13 +123,12 @@ __device__ __forceinline__ uint64_t reduce_dirs(uint64_t x)
 struct LaneHw {
     uint32_t l;        // lane within the row, 0..15
     uint32_t rev63;    // 63 for the lanes of the reversed orientation, else 0
-    uint32_t sh;       // shift of this lane's direction (1, 7, 8, 9), opaque to the compiler
+    uint32_t sh, sh2;  // shift of this lane's direction (1, 7, 8, 9) and twice that, opaque to the compiler
     uint64_t wrap;     // destination mask of that shift (A/H-file wrap-around)
     uint64_t base;     // ray of the direction from cell 0, without cell 0
     uint32_t ca, cx;   // column-mask recipe (othello_dev.hpp: ray_mask)
     // policy: oriented cell quad q = cells 4q .. 4q+3 of this lane's board: row q >> 1, half q & 1
-    uint32_t sh_w;     // 8 * (q >> 1): funnel shift that brings rows r-1 .. r+1 down
-    uint32_t off[3];   // 8 ky + 3 (q & 1): the 5 window bits (columns 0-4 / 3-7) of kernel row ky
+    uint32_t sh_w;     // 8 * (q >> 1) + 3 * (q & 1): funnel shift that brings the 5 window columns of rows r-1 .. r+1 to bits 8 ky + 4
     uint32_t tbase;    // byte offset of this (orientation, half)'s tables
     uint32_t bit[4];   // legality bits of the lane's cells (TRUE cell order) in its low legal word
     f4 bias;           // bias factors of those cells
@@ -146,11 +145,14 @@ __device__ __forceinline__ uint64_t ray_mask_hw(const LaneHw &L, uint32_t pl)
 // reduce_dirs.  Shifts by a VGPR amount: one v_lshlrev_b64 each.
 __device__ __forceinline__ uint64_t legal_hw(uint64_t o, uint64_t p, const LaneHw &L)
 {
+    // parallel-prefix flood through up to 6 opponent stones: 1, 2, 4, 6 (the same set as six
+    // single steps, in four dependent shift + bit-op groups instead of six)
     const uint64_t pm = p & L.wrap;
     uint64_t t = (o << L.sh) & pm;
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-        t = bitop64<TT_A_OR_BC>(t, t << L.sh, pm);
+    t = bitop64<TT_A_OR_BC>(t, t << L.sh, pm);
+    const uint64_t pm2 = pm & (pm << L.sh);
+    t = bitop64<TT_A_OR_BC>(t, t << L.sh2, pm2);
+    t = bitop64<TT_A_OR_BC>(t, t << L.sh2, pm2);
     const uint64_t em = bitop64<TT_NOR_AND>(o, p, L.wrap); // empty cells, wrap-masked
     return reduce_dirs((t << L.sh) & em);
 }
@@ -162,7 +164,7 @@ __device__ __forceinline__ uint64_t flips_hw(uint64_t o, uint64_t p, uint32_t po
     const uint64_t M = ray_mask_hw(L, pos_l);
     const uint64_t x = bitop64<TT_A_OR_NB>(p, M, 0ull);
     const uint64_t t = x + 1ull;
-    const uint64_t cand = bitop64<TT_XOR_AND>(t, x, M) & p;
+    const uint64_t cand = bitop64<TT_A_NB_C>(p, t, M); // the opponent run the carry went through
     const uint64_t of = bitop64<TT_ABC>(t, M, o);
     const uint32_t zz = (uint32_t)of | (uint32_t)(of >> 32);
     const uint32_t ok = (uint32_t)((int32_t)(0u - zz) >> 31); // all ones iff bracketed
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
     {
         uint32_t s = (k == 0u) ? 1u : (6u + k);
         asm("v_mov_b32 %0, %1" : "=v"(L.sh) : "v"(s)); // keep 64-bit shifts one instruction
+        asm("v_mov_b32 %0, %1" : "=v"(L.sh2) : "v"(2u * s));
     }
     L.wrap = (k == 1u) ? ~FILE_H : ((k == 2u) ? ~0ull : ~FILE_A);
     L.base = (k == 0u)   ? 0x00000000000000FEull
@@ -226,11 +229,10 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
     L.cx = (k == 0u || k == 3u) ? 0u : 0xFFu;
     const uint32_t q = rev ? 15u - L.l : L.l; // oriented quad of cells, 0..7
     const uint32_t pr = q >> 1, pp = q & 1u;
-    L.sh_w = 8u * pr;
-    // window word w4 = ((board << 12) >> 8 pr): column c of oriented row pr + ky - 1 at bit
-    // 8 ky + c + 4 (<< 4: 16-byte table entries); the zero bits shifted in are row -1
-    for (uint32_t ky = 0; ky < 3; ky++)
-        L.off[ky] = 8u * ky + 3u * pp;
+    L.sh_w = 8u * pr + 3u * pp;
+    // window word w4 = ((board << 12) >> (8 pr + 3 pp)): column c of oriented row pr + ky - 1
+    // at bit 8 ky + c + 4 - 3 pp, i.e. the 5 window columns (0-4 / 3-7) at bits 8 ky + 4 ..
+    // 8 ky + 8 (<< 4: 16-byte table entries); the zero bits shifted in are row -1
     L.tbase = (rev ? 384u * 16u : 0u) + pp * 32u * 16u;
     // the lane's cells in TRUE order: as-is 4q .. 4q+3; reversed orientation: true cells
     // 4 l .. 4 l + 3 are oriented bits 4q+3 .. 4q
@@ -300,13 +302,14 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++) {
                     const uint32_t idx =
-                        __builtin_amdgcn_bitop3_b32(w4 >> L.off[ky], m1f0, L.tbase, TT_AB_OR_C);
+                        __builtin_amdgcn_bitop3_b32(w4 >> (8 * ky), m1f0, L.tbase, TT_AB_OR_C);
                     fac[ky * 2 + pl] = *(const f4 *)(tb + idx + (ky * 2 + pl) * 1024);
                 }
             }
             // ---- legal moves of the side to move (this lane's orientation)
             const uint64_t legal = legal_hw(own, opp, L);
-            const uint32_t has = min(1u, (uint32_t)legal | (uint32_t)(legal >> 32));
+            uint32_t has; // 1 iff the side to move has a move
+            asm("v_min_u32 %0, 1, %1" : "=v"(has) : "v"((uint32_t)legal | (uint32_t)(legal >> 32)));
             // ---- softmax numerators, zero on illegal cells (all four are in the low word)
             // ONE wait for the six table reads (issued a move generation ago) instead of four
             // counted ones: every instruction of a lone wave, waits included, is an issue slot
@@ -365,13 +368,17 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
                 // u * total is rounded BEFORE any comparison: the uniform policy stays bit-exact
                 thr = u4[i] * total;
             }
-            // sampled cell = number of cells with CDF <= thr (numpy searchsorted 'right'):
-            // sign bits of thr - cdf (set iff cdf > thr) funnelled into one word
-            uint32_t over = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                over = __builtin_amdgcn_alignbit(over, __float_as_uint(thr - cdf[j]), 31);
-            const uint32_t cnt = row_sum(4u - (uint32_t)__popc(over & 0xFu));
+            // sampled cell = number of cells with CDF <= thr (numpy searchsorted 'right'): a
+            // compare + add-with-carry per cell (4-byte encodings: 4 cycles each for a lone wave)
+            uint32_t k4; // (one asm statement: the hazard recogniser pads every statement with an s_nop)
+            asm("v_cmp_le_f32 vcc, %1, %5\n\tv_addc_co_u32 %0, vcc, 0, 0, vcc\n\t"
+                "v_cmp_le_f32 vcc, %2, %5\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+                "v_cmp_le_f32 vcc, %3, %5\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+                "v_cmp_le_f32 vcc, %4, %5\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"
+                : "=&v"(k4)
+                : "v"(cdf[0]), "v"(cdf[1]), "v"(cdf[2]), "v"(cdf[3]), "v"(thr)
+                : "vcc");
+            const uint32_t cnt = row_sum(k4);
             uint32_t action = cnt & 63u;
             // Rounding can leave the count one cell off a legal one (or at 64): the next legal
             // cell, else the last one.  Rare, and a branch on a vector compare stalls a lone wave
