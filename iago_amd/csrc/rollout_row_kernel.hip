@@ -166,16 +166,21 @@ __device__ __forceinline__ uint64_t flips_hw(uint64_t o, uint64_t p, uint32_t po
     const uint64_t t = x + 1ull;
     const uint64_t cand = bitop64<TT_A_NB_C>(p, t, M); // the opponent run the carry went through
     const uint64_t of = bitop64<TT_ABC>(t, M, o);
+#ifdef ROW_OLD_OK
     const uint32_t zz = (uint32_t)of | (uint32_t)(of >> 32);
     const uint32_t ok = (uint32_t)((int32_t)(0u - zz) >> 31); // all ones iff bracketed
     const uint64_t okm = ((uint64_t)ok << 32) | ok;
     return reduce_dirs(cand & okm);
+#else
+    return reduce_dirs(of ? cand : 0ull); // kept iff an own stone brackets the run
+#endif
 }
 
-// TRACE: the launch records the action of every turn (parity tests); a wave alone on its SIMD
-// pays a full issue slot for every instruction, scalar ones and branches included, so the
-// production instance does not even test the pointer.
-template <bool TRACE>
+// DIAG: the instance of the parity tests (the launch records the action of every turn and / or
+// takes its uniforms from a buffer); a wave alone on its SIMD pays a full issue slot for every
+// instruction, scalar ones and branches included, so the production instance does not even
+// test those pointers.
+template <bool DIAG>
 __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
 {
     // T4[orientation][kernel row][plane][row half][5 window bits] -> factors of the 4 cells
@@ -257,9 +262,18 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
     uint32_t done = (!live || stones >= 64u) ? 1u : 0u; // `while stone_num < 64` (mcts_self_play.py:26)
 
     // lane l draws Philox counter block l: the 16 lanes of a row hold the uniforms of 64 turns
+    // (kept as the float32 uniforms themselves: converted once per 64 turns, not once per fetch)
     uint32_t rw[4] = {P.id_base + (uint32_t)b, L.l, stream_id, 0u};
-    if (!P.uniforms)
+    auto draw = [&]() {
         philox4x32_10(rw, P.key0, P.key1);
+#ifndef ROW_OLD_DRAW
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            rw[i] = __float_as_uint((float)(rw[i] >> 8) * (1.0f / 16777216.0f));
+#endif
+    };
+    if (!(DIAG && P.uniforms))
+        draw();
 #pragma unroll
     for (uint32_t i = 0; i < (uint32_t)(N_T4 / HW_BLOCK); i++)
         t4[threadIdx.x + i * HW_BLOCK] = stg[i];
@@ -268,9 +282,18 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const uint64_t st2 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef ROW_PAD4 // experiment: shift the loop's code by 4-byte steps (instruction-fetch alignment)
+#define ROW_PAD_STR(n) ROW_PAD_STR2(n)
+#define ROW_PAD_STR2(n) ".rept " #n "\n s_nop 0\n .endr"
+    asm volatile(ROW_PAD_STR(ROW_PAD4));
+#endif
     for (uint32_t t4 = 0; t4 < (uint32_t)IAGO_MAX_TURNS; t4 += 4) {
         float u4[4];
+#ifdef ROW_OLD_UNI
         if (__builtin_expect(P.uniforms != nullptr, 0)) {
+#else
+        if (DIAG && P.uniforms) {
+#endif
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 u4[i] = live ? P.uniforms[(int64_t)(t4 + i) * P.n + b] : 0.0f;
@@ -280,14 +303,16 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
                 rw[1] = (t4 >> 2) + L.l;
                 rw[2] = stream_id;
                 rw[3] = 0u;
-                philox4x32_10(rw, P.key0, P.key1);
+                draw();
             }
             const int src = (int)(((lane & 48u) + ((t4 >> 2) & 15u)) << 2);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rw[i]);
-                u4[i] = (float)(w >> 8) * (1.0f / 16777216.0f);
-            }
+            for (int i = 0; i < 4; i++)
+#ifdef ROW_OLD_DRAW
+                u4[i] = (float)((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rw[i]) >> 8) * (1.0f / 16777216.0f);
+#else
+                u4[i] = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rw[i]));
+#endif
         }
         bool any_live = true;
         auto turn = [&](const int i) {
@@ -386,17 +411,22 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
             // flips are resolved for the unfixed cell, and the branch -- far behind its compare
             // by then -- repeats them for a fixed one.
             const uint32_t lbit = (uint32_t)(legal >> ((cnt ^ L.rev63) & 63u)) & 1u;
-            const bool bad = (has & ((cnt >> 6) | (lbit ^ 1u))) != 0u;
-            const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+            const uint32_t badw = has & ((cnt >> 6) | (lbit ^ 1u));
+            const bool any_bad = __builtin_amdgcn_ballot_w64(badw != 0u) != 0ull;
             // ---- flips and board update in this lane's orientation (branch-free)
             uint32_t pos_l = action ^ L.rev63;
             uint64_t f = flips_hw(own, opp, pos_l, L);
+            // (the hot path's flips are complete here: without this the compiler sinks the tail of
+            // the reduction below the branch to share it with the cold block, un-fusing its DPPs)
+            asm("" : "+v"(f));
             if (__builtin_expect(any_bad, 0)) {
                 const uint64_t lt = rev ? rev64(legal) : legal; // TRUE orientation
                 const uint64_t rem = (cnt < 64u) ? (lt & (~0ull << cnt)) : 0ull;
                 const uint32_t fix = rem ? (uint32_t)__builtin_ctzll(rem)
                                          : (63u - (uint32_t)__builtin_clzll(lt | 1ull));
-                action = bad ? fix : action;
+                uint32_t badc = badw; // (opaque: the per-lane select belongs to this block only)
+                asm("" : "+v"(badc));
+                action = badc ? fix : action;
                 pos_l = action ^ L.rev63;
                 f = flips_hw(own, opp, pos_l, L);
             }
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
             const uint64_t bit = (uint64_t)play << pos_l;
             const uint64_t nown = own | fm | bit;
             const uint64_t nopp = opp & ~fm;
-            if (TRACE && live_turn && L.l == 0u)
+            if (DIAG && P.trace && live_turn && L.l == 0u)
                 P.trace[(int64_t)t * P.n + b] = play ? (uint8_t)action : (uint8_t)IAGO_TRACE_PASS;
             own = nopp; // the other side moves next (finished boards swap an even number of times)
             opp = nown;
@@ -458,7 +488,7 @@ void iago_launch_rollout_row(const iago_rollout_args *a, void *stream)
     P.n_turns = a->n_turns;
     P.trace = a->trace;
     const unsigned grid = (unsigned)((a->n + (HW_BLOCK / 16) - 1) / (HW_BLOCK / 16));
-    if (P.trace)
+    if (P.trace || P.uniforms)
         hipLaunchKernelGGL(rollout_row_kernel<true>, dim3(grid), dim3(HW_BLOCK), 0, (hipStream_t)stream, P);
     else
         hipLaunchKernelGGL(rollout_row_kernel<false>, dim3(grid), dim3(HW_BLOCK), 0, (hipStream_t)stream, P);
