@@ -282,11 +282,16 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const uint64_t st2 = __builtin_amdgcn_s_memtime();
 #endif
-#ifdef ROW_PAD4 // experiment: shift the loop's code by 4-byte steps (instruction-fetch alignment)
-#define ROW_PAD_STR(n) ROW_PAD_STR2(n)
-#define ROW_PAD_STR2(n) ".rept " #n "\n s_nop 0\n .endr"
-    asm volatile(ROW_PAD_STR(ROW_PAD4));
+    // A lone wave fetches its instruction stream in 32-byte windows, and an 8-byte instruction
+    // that straddles two of them costs extra: the loop's speed moves by +-1 % with its offset
+    // in that grid (tools/exp_row_variants.sh, ROW_PAD4 = 0..7: 25.99 .. 26.57 us).  The loop
+    // head is therefore pinned to the grid and shifted by the best of the 8 offsets.
+#ifndef ROW_PAD4
+#define ROW_PAD4 5
 #endif
+#define ROW_PAD_STR(n) ROW_PAD_STR2(n)
+#define ROW_PAD_STR2(n) ".p2align 5\n .rept " #n "\n s_nop 0\n .endr"
+    asm volatile(ROW_PAD_STR(ROW_PAD4));
     for (uint32_t t4 = 0; t4 < (uint32_t)IAGO_MAX_TURNS; t4 += 4) {
         float u4[4];
 #ifdef ROW_OLD_UNI
