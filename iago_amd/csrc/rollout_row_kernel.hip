@@ -264,7 +264,7 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
     // lane l draws Philox counter block l: the 16 lanes of a row hold the uniforms of 64 turns
     // (kept as the float32 uniforms themselves: converted once per 64 turns, not once per fetch)
     uint32_t rw[4] = {P.id_base + (uint32_t)b, L.l, stream_id, 0u};
-    auto draw = [&]() {
+    auto draw = [&]() __attribute__((always_inline)) {
         philox4x32_10(rw, P.key0, P.key1);
 #ifndef ROW_OLD_DRAW
 #pragma unroll
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(HW_BLOCK) void rollout_row_kernel(HwParams P)
     // in that grid (tools/exp_row_variants.sh, ROW_PAD4 = 0..7: 25.99 .. 26.57 us).  The loop
     // head is therefore pinned to the grid and shifted by the best of the 8 offsets.
 #ifndef ROW_PAD4
-#define ROW_PAD4 5
+#define ROW_PAD4 1
 #endif
 #define ROW_PAD_STR(n) ROW_PAD_STR2(n)
 #define ROW_PAD_STR2(n) ".p2align 5\n .rept " #n "\n s_nop 0\n .endr"
