@@ -61,6 +61,30 @@ def test_uniform_policy_bit_exact(ops, n, seed, id_base, hint):
         assert z[b] == oz
 
 
+# games of more than 64 turns (five or more passes; one in ~3,000 under the uniform policy):
+# found with the oracle for seed 4 -- the turns past 64 take their uniforms from a SECOND draw of
+# Philox counter blocks in the 16- and 8-lane kernels
+LONG_GAME_IDS = [3125, 6296, 9537, 13141, 22126, 24090]
+
+
+@pytest.mark.parametrize("hint", [0, 1, 2])
+def test_uniform_policy_bit_exact_beyond_64_turns(ops, hint):
+    start_own, start_opp = 0x0000000810000000, 0x0000001008000000
+    longest = 0
+    for g in LONG_GAME_IDS:
+        n, first = 5, g - 2      # the long game in the middle of a small launch
+        own = np.full(n, start_own, dtype=np.uint64)
+        opp = np.full(n, start_opp, dtype=np.uint64)
+        z, fo, fp, nt, tr = run(ops, own, opp, None, seed=4, id_base=first, throughput_hint=hint)
+        for b in range(n):
+            oz, final, otr = orc.random_playout(state_of(own[b], opp[b]), 1, seed=4, game_id=first + b)
+            assert trace_list(tr, b, nt[b]) == otr, (g, b)
+            assert (int(fo[b]), int(fp[b])) == orc.state_to_bits(final) and z[b] == oz, (g, b)
+        assert nt[2] > 64, (g, nt[2])
+        longest = max(longest, int(nt[2]))
+    assert longest >= 70
+
+
 def replay_check(own, opp, z, fo, fp, nt, tr, w, bvec, uniform_of, masked_logit_softmax=False):
     """Replay GPU traces through the oracle rules; returns (#sampled, #exact)."""
     sampled = exact = 0
