@@ -76,7 +76,7 @@ constexpr int TT_A_OR_B_OR_C = 0xFE; // a | b | c
 // v_lshlrev_b64 / v_lshrrev_b64 (the issue cost of a single 32-bit left shift on
 // gfx950), while a constant amount gets split into v_alignbit_b32 + a 32-bit shift.
 struct ShiftAmounts {
-    uint32_t s1, s7, s8, s9;
+    uint32_t s1, s7, s8, s9, s14, s16, s18;
 };
 __device__ __forceinline__ ShiftAmounts opaque_shift_amounts()
 {
@@ -85,27 +85,34 @@ __device__ __forceinline__ ShiftAmounts opaque_shift_amounts()
     asm("v_mov_b32 %0, 7" : "=v"(A.s7));
     asm("v_mov_b32 %0, 8" : "=v"(A.s8));
     asm("v_mov_b32 %0, 9" : "=v"(A.s9));
+    asm("v_mov_b32 %0, 14" : "=v"(A.s14));
+    asm("v_mov_b32 %0, 16" : "=v"(A.s16));
+    asm("v_mov_b32 %0, 18" : "=v"(A.s18));
     return A;
 }
 
+// Parallel-prefix flood through up to 6 opponent stones (1, 2, 4, 6): the same set as six single
+// steps, in four dependent shift + bit-op groups.  sh2 = 2 * sh.
 __device__ __forceinline__ uint64_t moves_up(uint64_t own, uint64_t opp, uint64_t empty, uint64_t m,
-                                             uint32_t sh)
+                                             uint32_t sh, uint32_t sh2)
 {
     const uint64_t pm = opp & m;
     uint64_t t = (own << sh) & pm;
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-        t = bitop64<TT_A_OR_BC>(t, t << sh, pm);
+    t = bitop64<TT_A_OR_BC>(t, t << sh, pm);
+    const uint64_t pm2 = pm & (pm << sh);
+    t = bitop64<TT_A_OR_BC>(t, t << sh2, pm2);
+    t = bitop64<TT_A_OR_BC>(t, t << sh2, pm2);
     return (t << sh) & (empty & m);
 }
 __device__ __forceinline__ uint64_t moves_down(uint64_t own, uint64_t opp, uint64_t empty,
-                                               uint64_t m, uint32_t sh)
+                                               uint64_t m, uint32_t sh, uint32_t sh2)
 {
     const uint64_t pm = opp & m;
     uint64_t t = (own >> sh) & pm;
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-        t = bitop64<TT_A_OR_BC>(t, t >> sh, pm);
+    t = bitop64<TT_A_OR_BC>(t, t >> sh, pm);
+    const uint64_t pm2 = pm & (pm >> sh);
+    t = bitop64<TT_A_OR_BC>(t, t >> sh2, pm2);
+    t = bitop64<TT_A_OR_BC>(t, t >> sh2, pm2);
     return (t >> sh) & (empty & m);
 }
 
@@ -129,12 +136,12 @@ __device__ __forceinline__ uint64_t legal_moves_1(uint64_t own, uint64_t opp, ui
     const uint64_t e = ~(own | opp);
     const uint64_t a = bitop64<TT_A_OR_B_OR_C>(moves_east(own, opp, e, A.s1),
                                                rev64(moves_east(ro, rp, rev64(e), A.s1)),
-                                               moves_up(own, opp, e, ~FILE_H, A.s7));
-    const uint64_t b = bitop64<TT_A_OR_B_OR_C>(moves_up(own, opp, e, ~0ull, A.s8),
-                                               moves_up(own, opp, e, ~FILE_A, A.s9),
-                                               moves_down(own, opp, e, ~FILE_A, A.s7));
-    return bitop64<TT_A_OR_B_OR_C>(a, b, moves_down(own, opp, e, ~0ull, A.s8) |
-                                             moves_down(own, opp, e, ~FILE_H, A.s9));
+                                               moves_up(own, opp, e, ~FILE_H, A.s7, A.s14));
+    const uint64_t b = bitop64<TT_A_OR_B_OR_C>(moves_up(own, opp, e, ~0ull, A.s8, A.s16),
+                                               moves_up(own, opp, e, ~FILE_A, A.s9, A.s18),
+                                               moves_down(own, opp, e, ~FILE_A, A.s7, A.s14));
+    return bitop64<TT_A_OR_B_OR_C>(a, b, moves_down(own, opp, e, ~0ull, A.s8, A.s16) |
+                                             moves_down(own, opp, e, ~FILE_H, A.s9, A.s18));
 }
 
 // Adds the flips along the ray of direction K (0: +1, 1: +7, 2: +8, 3: +9) from `pos`

@@ -24,7 +24,7 @@ def set_rollout_model(model_or_path):
 class Simulate(object):
     _counter = 0
 
-    def __init__(self, state, weights=None, seed=0):
+    def __init__(self, state, weights=None, seed=0, uniforms=None):
         self.state = copy.deepcopy(state)                      # mcts_self_play.py:13
         self.stone_num = 64 - int(np.sum(self.state == 0))     # mcts_self_play.py:15
         self.pass_flg = False
@@ -32,6 +32,10 @@ class Simulate(object):
         if self.weights is None:
             raise RuntimeError("no rollout weights: call set_rollout_model(path or RolloutPolicy)")
         self.seed = seed
+        # test hook: the draws of np.random.choice in the reference run (mcts_self_play.py:104-106),
+        # indexed by turn (the entry of a passing turn is not consumed), instead of the Philox
+        # stream -- what the parity tests replay the recorded reference games with
+        self.uniforms = uniforms
         Simulate._counter += 1
         self.rollout_id = Simulate._counter
 
@@ -39,8 +43,14 @@ class Simulate(object):
         """Play to the end with the rollout policy; +1/0/-1 from `color`'s view
         (mcts_self_play.py:25-29,113-121).  self.state ends as the final board."""
         own, opp = boards.own_opp(self.state, color)
+        us = None
+        if self.uniforms is not None:
+            from ._lib import IAGO_MAX_TURNS
+            us = torch.zeros((IAGO_MAX_TURNS, 1), dtype=torch.float32, device=own.device)
+            u = torch.as_tensor(np.asarray(self.uniforms, np.float32))
+            us[:u.numel(), 0] = u.to(own.device)
         res = ops.rollout(own, opp, self.weights, seed=self.seed, id_base=self.rollout_id,
-                          want_final=True, want_turns=True)
+                          uniforms=us, want_final=True, want_turns=True)
         a, b = ops.tensor_to_bits(res.final_own)[0], ops.tensor_to_bits(res.final_opp)[0]
         boards.bits_to_state(a if color == 1 else b, b if color == 1 else a, out=self.state)
         self.stone_num = 64
