@@ -30,6 +30,7 @@ SYMBOLS = [
     "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_mcts_pending",
     "iago_leaf_values",
     "iago_mcts_backup", "iago_mcts_mix_backup", "iago_mcts_best_move", "iago_mcts_advance_root", "iago_mcts_compact",
+    "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
 ]
 
 
@@ -55,6 +56,16 @@ class ConvSplitLayer(C.Structure):
         ("x_hi", C.c_void_p), ("x_lo", C.c_void_p), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p),
         ("bias", C.c_void_p), ("y_hi", C.c_void_p), ("y_lo", C.c_void_p),
         ("cin", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class MctsLookahead(C.Structure):
+    """Mirror of iago_mcts_lookahead (include/iago_hip.h)."""
+    _fields_ = [
+        ("trigger", C.c_int32), ("slots", C.c_int32), ("next_seq", C.c_void_p), ("cache_seq", C.c_void_p),
+        ("cache", C.c_void_p), ("q_count", C.c_void_p), ("q_capacity", C.c_int32), ("reserved", C.c_int32),
+        ("q_own", C.c_void_p), ("q_opp", C.c_void_p), ("q_game", C.c_void_p), ("q_seq", C.c_void_p),
+        ("error", C.c_void_p),
     ]
 
 
@@ -144,6 +155,10 @@ def lib():
     L.iago_mcts_best_move.argtypes = [tp, vp, vp, vp, vp]
     L.iago_mcts_advance_root.argtypes = [tp, vp, vp, vp]
     L.iago_mcts_compact.argtypes = [tp, tp, vp, vp, vp]
+    lp = C.POINTER(MctsLookahead)
+    L.iago_mcts_mix_backup_lookahead.argtypes = [tp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, lp, vp]
+    L.iago_mcts_store_priors.argtypes = [lp, vp, vp, vp]
+    L.iago_mcts_expand_cached.argtypes = [tp, vp, vp, vp, vp, lp, vp, vp]
     for name in SYMBOLS[3:]:
         getattr(L, name).restype = C.c_int
     _lib = L

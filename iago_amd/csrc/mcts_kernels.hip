@@ -317,6 +317,156 @@ __global__ __launch_bounds__(BLOCK) void advance_root_kernel(Tree T, const uint8
     T.root[g] = 0;
 }
 
+// ---- policy look-ahead (iago_mcts_mix_backup_lookahead / _store_priors / _expand_cached).
+// The reference evaluates the policy net at the visit that expands a leaf (MCTS.py:109-121), a
+// handful of games per lockstep playout: nine latency-bound launches on the critical path of
+// EVERY playout.  policy_func(state) is a pure function of the leaf's position, so it can be
+// evaluated earlier: a leaf is queued when its visit count reaches n_thr - K, the queue is
+// flushed through the net every K playouts (one larger batch), the priors wait in a per-game
+// cache, and the expansion -- at the same visit as in the reference, with the same values --
+// reads them from there.  An unexpanded leaf carries its cache tag in first_child:
+// -1 = not queued, -2 - seq = priors of sequence number seq (slot seq % slots of its game).
+struct Lookahead {
+    int32_t trigger;            // visit count at which a leaf is queued (n_thr - K)
+    int32_t slots;              // cache slots per game
+    int32_t *next_seq;          // [n_games] sequence numbers handed out so far
+    int32_t *cache_seq;         // [n_games][slots] sequence number stored in a slot, -1 = empty
+    float *cache;               // [n_games][slots][64] priors (raw softmax entries)
+    int32_t *q_count;           // entries in the queue
+    int32_t q_capacity;
+    uint64_t *q_own, *q_opp;    // the queued leaves' positions (own = side to move)
+    int32_t *q_game, *q_seq;
+    int32_t *error;             // raised when a cache slot was recycled before its leaf expanded,
+                                // a leaf reaches n_thr without priors, or the queue is full
+};
+
+__global__ __launch_bounds__(BLOCK) void mix_backup_lookahead_kernel(
+    Tree T, const uint8_t *__restrict__ active, const int32_t *__restrict__ cur_node,
+    const uint64_t *__restrict__ cur_own, const uint64_t *__restrict__ cur_opp, const float *__restrict__ v,
+    const int8_t *__restrict__ z, float lmbda, float *__restrict__ leaf_value, uint32_t *__restrict__ counter,
+    Lookahead A)
+{
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g == 0 && counter)
+        *counter += 1u;
+    if (g >= T.n_games)
+        return;
+    // (1-lmbda)*v + lmbda*z exactly as leaf_values_kernel (MCTS.py:123-125)
+    const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * v[g] : 0.0f;
+    const float b = (lmbda > 0.0f) ? (float)((double)lmbda * (double)z[g]) : 0.0f;
+    const float lv = a + b;
+    leaf_value[g] = lv;
+    if (!active[g])
+        return;
+    const int64_t base = g * (int64_t)T.capacity;
+    const int leaf = cur_node[g];
+    int node = leaf;
+    for (int depth = 0; node >= 0 && depth <= MAX_DEPTH; depth++) {
+        const int n = T.n_visits[base + node] + 1; // MCTS.py:61
+        const float q = T.q[base + node];
+        T.n_visits[base + node] = n;
+        T.q[base + node] = q + (lv - q) / (float)n; // MCTS.py:63
+        node = T.parent[base + node];
+    }
+    // the leaf of this playout crosses the trigger exactly once (it gains one visit per playout
+    // that ends on it): queue its position for the next flush
+    if (T.n_visits[base + leaf] == A.trigger && T.first_child[base + leaf] == -1) {
+        const int pos = atomicAdd(A.q_count, 1);
+        if (pos < A.q_capacity) {
+            const int seq = A.next_seq[g];
+            A.next_seq[g] = seq + 1;
+            T.first_child[base + leaf] = -2 - seq;
+            A.q_own[pos] = cur_own[g];
+            A.q_opp[pos] = cur_opp[g];
+            A.q_game[pos] = (int32_t)g;
+            A.q_seq[pos] = seq;
+        } else {
+            *A.error = 1;
+        }
+    }
+}
+
+// probs [>= *q_count][64]: the net's outputs for the queued positions, row i for queue entry i
+__global__ __launch_bounds__(BLOCK) void store_priors_kernel(Lookahead A, const float *__restrict__ probs,
+                                                             int64_t *__restrict__ total)
+{
+    const int count = min(*A.q_count, A.q_capacity);
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t == 0 && total)
+        *total += count;
+    for (int64_t e = t; e < (int64_t)count * 16; e += (int64_t)gridDim.x * BLOCK) {
+        const int i = (int)(e >> 4), piece = (int)(e & 15);
+        const int64_t g = A.q_game[i];
+        const int seq = A.q_seq[i], slot = seq % A.slots;
+        ((float4 *)(A.cache + (g * A.slots + slot) * 64))[piece] = ((const float4 *)(probs + (int64_t)i * 64))[piece];
+        if (piece == 0)
+            A.cache_seq[g * A.slots + slot] = seq;
+    }
+}
+
+// Node.expand (MCTS.py:27-37, 109-121) for every active game whose cursor sits on a leaf with
+// n_visits >= n_thr, the priors taken from the cache; expanded[g] = 1 for those games (the
+// mask of the descent that continues into the new children), 0 for the others.
+__global__ __launch_bounds__(BLOCK) void expand_cached_kernel(Tree T, const uint8_t *__restrict__ active,
+                                                              const uint8_t *__restrict__ needs_expand,
+                                                              const int32_t *__restrict__ cur_node,
+                                                              const uint64_t *__restrict__ legal, Lookahead A,
+                                                              uint8_t *__restrict__ expanded)
+{
+    const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t g = gtid >> 3;
+    const uint32_t r = threadIdx.x & 7u;
+    const bool live = g < T.n_games && active[g] != 0 && needs_expand[g] != 0;
+    if (g < T.n_games && r == 0u)
+        expanded[g] = live ? 1 : 0;
+    const int64_t base = live ? g * (int64_t)T.capacity : 0;
+    const int node = live ? cur_node[g] : 0;
+    const uint64_t lg = live ? legal[g] : 0ull;
+    const int k = lg ? __popcll(lg) : 1;
+    const int tag = live ? T.first_child[base + node] : 0;
+    uint32_t fc1 = 0; // first child + 1, 0 = no room / already expanded
+    if (live && r == 0u && tag < 0) {
+        const int at = T.n_nodes[g];
+        if (at + k <= T.capacity) {
+            T.n_nodes[g] = at + k;
+            fc1 = (uint32_t)at + 1u;
+        } else {
+            T.overflow[g] = 1;
+        }
+    }
+    fc1 = group8_add(fc1);
+    if (!live || fc1 == 0u)
+        return;
+    const int fc = (int)fc1 - 1;
+    if (lg == 0ull || k == 1) {
+        // pass child / single legal move: Node(node, 1), no net (MCTS.py:112-117)
+        if (r == 0u) {
+            const int a = lg ? (int)__builtin_ctzll(lg) : -1;
+            init_node(T, base + fc, node, a, 1.0f + 0.1f);
+        }
+    } else {
+        const int seq = -2 - tag;
+        const int slot = tag <= -2 ? seq % A.slots : 0;
+        const float *probs = A.cache + (g * A.slots + slot) * 64;
+        if (tag > -2 || A.cache_seq[g * A.slots + slot] != seq) {
+            if (r == 0u)
+                *A.error = 2; // no priors for this leaf (not queued, or its slot was recycled)
+        }
+        uint32_t row = (uint32_t)(lg >> (8u * r)) & 0xFFu;
+        int at = fc + __popcll(lg & ((1ull << (8u * r)) - 1ull));
+        while (row) {
+            const int a = (int)(8u * r) + __builtin_ctz(row);
+            row &= row - 1u;
+            init_node(T, base + at, node, a, probs[a] + 0.1f); // MCTS.py:19
+            at++;
+        }
+    }
+    if (r == 0u) {
+        T.first_child[base + node] = fc;
+        T.n_children[base + node] = (uint8_t)k;
+    }
+}
+
 // ---- pool compaction (iago_mcts_compact).  Subtree reuse (advance_root) keeps the chosen
 // child's subtree and abandons its siblings' nodes in the pool; the reference's garbage
 // collector frees them (MCTS.py:149-152 drops the last reference).  Here a game's live subtree
@@ -345,7 +495,7 @@ __global__ __launch_bounds__(64) void compact_plan_kernel(Tree T, Tree S, const 
         const int o = q[head];
         const int fc = T.first_child[base + o];
         const int k = fc >= 0 ? (int)T.n_children[base + o] : 0;
-        S.first_child[base + head] = k ? tail : -1;
+        S.first_child[base + head] = k ? tail : fc; // (fc < 0: an unexpanded leaf keeps its prior-cache tag)
         for (int j = 0; j < k; j++) {
             q[tail + j] = fc + j;
             S.parent[base + tail + j] = head;
@@ -600,6 +750,83 @@ int iago_mcts_compact(const iago_mcts_tree *tree, const iago_mcts_tree *scratch,
                        order);
     hipLaunchKernelGGL(compact_commit_kernel, dim3(games), dim3(BLOCK), 0, (hipStream_t)stream, *tree, *scratch);
     return iago_check_launch("iago_mcts_compact");
+}
+
+} // extern "C"
+
+namespace {
+int lookahead_of(const iago_mcts_lookahead *a, Lookahead &A, const char *who)
+{
+    if (!a || a->trigger < 1 || a->slots < 1 || a->q_capacity < 1 || !a->next_seq || !a->cache_seq || !a->cache ||
+        !a->q_count || !a->q_own || !a->q_opp || !a->q_game || !a->q_seq || !a->error)
+        return iago_fail(IAGO_ERR_INVALID, who);
+    if ((uintptr_t)a->cache & 15u)
+        return iago_fail(IAGO_ERR_INVALID, who);
+    A.trigger = a->trigger;
+    A.slots = a->slots;
+    A.next_seq = a->next_seq;
+    A.cache_seq = a->cache_seq;
+    A.cache = a->cache;
+    A.q_count = a->q_count;
+    A.q_capacity = a->q_capacity;
+    A.q_own = a->q_own;
+    A.q_opp = a->q_opp;
+    A.q_game = a->q_game;
+    A.q_seq = a->q_seq;
+    A.error = a->error;
+    return IAGO_OK;
+}
+} // namespace
+
+extern "C" {
+
+int iago_mcts_mix_backup_lookahead(const iago_mcts_tree *tree, const uint8_t *active, const int32_t *cur_node,
+                                   const uint64_t *cur_own, const uint64_t *cur_opp, const float *v,
+                                   const int8_t *z, float lmbda, float *leaf_value, uint32_t *counter,
+                                   const iago_mcts_lookahead *la, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_mix_backup_lookahead: bad tree"))
+        return IAGO_ERR_INVALID;
+    Lookahead A;
+    if (lookahead_of(la, A, "iago_mcts_mix_backup_lookahead: bad look-ahead state"))
+        return IAGO_ERR_INVALID;
+    if (!active || !cur_node || !cur_own || !cur_opp || !leaf_value || (lmbda < 1.0f && !v) || (lmbda > 0.0f && !z))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_mix_backup_lookahead: null pointer");
+    if (tree->n_games == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(mix_backup_lookahead_kernel, dim3(grid_for(tree->n_games)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, *tree, active, cur_node, cur_own, cur_opp, v, z, lmbda, leaf_value,
+                       counter, A);
+    return iago_check_launch("iago_mcts_mix_backup_lookahead");
+}
+
+int iago_mcts_store_priors(const iago_mcts_lookahead *la, const float *probs, int64_t *total, void *stream)
+{
+    Lookahead A;
+    if (lookahead_of(la, A, "iago_mcts_store_priors: bad look-ahead state"))
+        return IAGO_ERR_INVALID;
+    if (!probs || ((uintptr_t)probs & 15u))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_store_priors: probs must be non-null and 16-byte aligned");
+    hipLaunchKernelGGL(store_priors_kernel, dim3(64), dim3(BLOCK), 0, (hipStream_t)stream, A, probs, total);
+    return iago_check_launch("iago_mcts_store_priors");
+}
+
+int iago_mcts_expand_cached(const iago_mcts_tree *tree, const uint8_t *active, const uint8_t *needs_expand,
+                            const int32_t *cur_node, const uint64_t *legal, const iago_mcts_lookahead *la,
+                            uint8_t *expanded, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_expand_cached: bad tree"))
+        return IAGO_ERR_INVALID;
+    Lookahead A;
+    if (lookahead_of(la, A, "iago_mcts_expand_cached: bad look-ahead state"))
+        return IAGO_ERR_INVALID;
+    if (!active || !needs_expand || !cur_node || !legal || !expanded)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_expand_cached: null pointer");
+    if (tree->n_games == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(expand_cached_kernel, dim3(grid_for(tree->n_games * 8)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       *tree, active, needs_expand, cur_node, legal, A, expanded);
+    return iago_check_launch("iago_mcts_expand_cached");
 }
 
 } // extern "C"

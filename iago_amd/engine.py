@@ -76,6 +76,8 @@ class TreePool(object):
     def reset(self, mask=None):
         check(_lib.lib().iago_mcts_reset(self.ref(), _p(mask) if mask is not None else None,
                                          _stream()), "iago_mcts_reset")
+        for hook in getattr(self, "reset_hooks", ()):
+            hook(mask)
 
     def bytes(self):
         return sum(getattr(self, f).numel() * getattr(self, f).element_size()
@@ -148,7 +150,7 @@ class BatchedMCTS(object):
 
     def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
                  n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False,
-                 sync_free=None):
+                 sync_free=None, lookahead=None, lookahead_slots=None):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         self.n_games = n_games
@@ -182,6 +184,51 @@ class BatchedMCTS(object):
             raise ValueError("use_graph needs the sync-free playout (a policy with forward_counted)")
         self.use_graph, self._graph, self._graph_key = bool(use_graph), None, None
         self.n_compactions = 0
+        # Policy look-ahead (iago_mcts_lookahead in include/iago_hip.h): leaves are queued K
+        # visits before they expand and the policy net runs on the queue every K playouts, off
+        # the playouts' critical path.  Default: K = 4 whenever the sync-free playout with a
+        # board-fed policy net applies and n_thr leaves room for it; 0 = the net runs inside the
+        # playout that expands (the reference's order of evaluation).  Same trees either way.
+        can = (self.sync_free and getattr(policy_fn, "forward_counted_boards", None) is not None)
+        if lookahead is None:
+            import os
+            k = int(os.environ.get("IAGO_LOOKAHEAD", "4"))   # (tuning knob: tools/)
+            lookahead = k if (can and self.n_thr > k) else 0
+        if lookahead and not (can and self.n_thr > lookahead):
+            raise ValueError("lookahead needs the sync-free playout, a policy net with "
+                             "forward_counted_boards and n_thr > lookahead")
+        self.lookahead = int(lookahead)
+        if self.lookahead:
+            K = self.lookahead
+            slots = int(lookahead_slots) if lookahead_slots else max(256, capacity // 8)
+            Q = n_games * K
+            self._la_next_seq = torch.zeros(n_games, dtype=torch.int32, **kw)
+            self._la_cache_seq = torch.full((n_games, slots), -1, dtype=torch.int32, **kw)
+            self._la_cache = torch.zeros((n_games, slots, 64), dtype=torch.float32, **kw)
+            self._la_q_count = torch.zeros(1, dtype=torch.int32, **kw)
+            self._la_q_own = torch.zeros(Q, dtype=torch.int64, **kw)
+            self._la_q_opp = torch.zeros(Q, dtype=torch.int64, **kw)
+            self._la_q_game = torch.zeros(Q, dtype=torch.int32, **kw)
+            self._la_q_seq = torch.zeros(Q, dtype=torch.int32, **kw)
+            self._la_error = torch.zeros(1, dtype=torch.int32, **kw)
+            a = _lib.MctsLookahead()
+            a.trigger, a.slots, a.q_capacity = self.n_thr - K, slots, Q
+            a.next_seq, a.cache_seq = self._la_next_seq.data_ptr(), self._la_cache_seq.data_ptr()
+            a.cache, a.q_count = self._la_cache.data_ptr(), self._la_q_count.data_ptr()
+            a.q_own, a.q_opp = self._la_q_own.data_ptr(), self._la_q_opp.data_ptr()
+            a.q_game, a.q_seq = self._la_q_game.data_ptr(), self._la_q_seq.data_ptr()
+            a.error = self._la_error.data_ptr()
+            self._la = a
+
+            def reset_lookahead(mask):
+                if mask is None:
+                    self._la_next_seq.zero_()
+                    self._la_cache_seq.fill_(-1)
+                else:
+                    m = mask.bool()
+                    self._la_next_seq[m] = 0
+                    self._la_cache_seq[m] = -1
+            self.tree.reset_hooks = [reset_lookahead]
         self._g_own = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._g_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._g_active = torch.zeros(n_games, dtype=torch.uint8, **kw)
@@ -313,14 +360,48 @@ class BatchedMCTS(object):
                         stream_id_dev=stream_id_dev, out=self._rollout_out)
             if self.rollout_hook is not None:
                 self.rollout_hook(self)
+        if self.lookahead:
+            check(L.iago_mcts_mix_backup_lookahead(
+                self.tree.ref(), _p(active), _p(self.cur_node), _p(self.cur_own), _p(self.cur_opp),
+                _p(self.v) if self.lmbda < 1.0 else None, _p(self.z) if self.lmbda > 0.0 else None,
+                self.lmbda, _p(self.leaf_value), _p(counter) if counter is not None else None,
+                C.byref(self._la), _stream()), "iago_mcts_mix_backup_lookahead")
+            return
         check(L.iago_mcts_mix_backup(self.tree.ref(), _p(active), _p(self.cur_node),
                                      _p(self.v) if self.lmbda < 1.0 else None,
                                      _p(self.z) if self.lmbda > 0.0 else None, self.lmbda,
                                      _p(self.leaf_value), _p(counter) if counter is not None else None,
                                      _stream()), "iago_mcts_mix_backup")
 
+    def _playout_lookahead(self, own, opp, active, stream_id=0, stream_id_dev=None, counter=None):
+        """One MCTS.playout for every active game with the priors of the expanding leaves taken
+        from the look-ahead cache: select, expand, continue the descent, evaluate, back up (and
+        queue the leaves that are K visits from expanding)."""
+        L = _lib.lib()
+        self._select(own, opp, active, True)
+        check(L.iago_mcts_expand_cached(self.tree.ref(), _p(active), _p(self.needs_expand), _p(self.cur_node),
+                                        _p(self.legal), C.byref(self._la), _p(self._pending), _stream()),
+              "iago_mcts_expand_cached")
+        self._select(own, opp, self._pending, False)  # MCTS.py:121: recurse into the same node
+        self._evaluate_and_backup(active, stream_id=stream_id, stream_id_dev=stream_id_dev, counter=counter)
+
+    def _flush_lookahead(self):
+        """The policy net on the queued leaves (one batch), its outputs into the prior cache."""
+        n = self._la_q_own.numel()
+        probs = self.policy_fn.forward_counted_boards(self._la_q_own, self._la_q_opp, None, n, self._la_q_count)
+        check(_lib.lib().iago_mcts_store_priors(C.byref(self._la), _p(probs), _p(self._pend_total), _stream()),
+              "iago_mcts_store_priors")
+        self._la_q_count.zero_()
+
     def simulate(self, own, opp, active, n_active=None):
         """One MCTS.playout for every active game (eager launches)."""
+        if self.lookahead:
+            self._playout_lookahead(own, opp, active, stream_id=self.sim_counter)
+            self._flush_lookahead()  # a lone playout flushes at once: the queue is empty between calls
+            self.sim_counter = (self.sim_counter + 1) & 0xFFFFFFFF
+            if n_active is not None:
+                self.n_leaf_evals += n_active
+            return
         self._select(own, opp, active, True)
         if self.sync_free:
             self._expand_pending_counted(own, opp, active)
@@ -337,7 +418,7 @@ class BatchedMCTS(object):
     def _graph_state(self):
         """What the captured graph baked in: device pointers and versions of every weight
         (and of the layouts cached from them), the rollout table, the scalar arguments."""
-        key = [self.lmbda, self.c_puct, self.n_thr,
+        key = [self.lmbda, self.c_puct, self.n_thr, self.lookahead,
                self.stats.data_ptr() if self.stats is not None else 0,
                self.rollout_weights.table.data_ptr() if self.rollout_weights is not None else 0]
         for fn in (self.policy_fn, self.value_fn):
@@ -367,12 +448,22 @@ class BatchedMCTS(object):
             self._pend_count.zero_()
             self._policy_counted(self._policy_in[:self.n_games], self._pend_count)
         torch.cuda.synchronize()
+        if self.lookahead:
+            self._flush_lookahead()  # (queue empty: allocations and one-time setup only)
+            torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._select(self._g_own, self._g_opp, self._g_active, True)
-            self._expand_pending_counted(self._g_own, self._g_opp, self._g_active)
-            self._evaluate_and_backup(self._g_active, stream_id=0, stream_id_dev=self._sim_dev,
-                                      counter=self._sim_dev)
+            if self.lookahead:
+                # K playouts and the flush of the leaves they queued: ONE replay
+                for _ in range(self.lookahead):
+                    self._playout_lookahead(self._g_own, self._g_opp, self._g_active, stream_id=0,
+                                            stream_id_dev=self._sim_dev, counter=self._sim_dev)
+                self._flush_lookahead()
+            else:
+                self._select(self._g_own, self._g_opp, self._g_active, True)
+                self._expand_pending_counted(self._g_own, self._g_opp, self._g_active)
+                self._evaluate_and_backup(self._g_active, stream_id=0, stream_id_dev=self._sim_dev,
+                                          counter=self._sim_dev)
 
     def _search_graph(self, own, opp, active, n_sims, n_active):
         key = self._graph_state()
@@ -387,8 +478,18 @@ class BatchedMCTS(object):
         self._g_active.copy_(active)
         self._sim_dev.fill_(self.sim_counter - (1 << 32) if self.sim_counter >= (1 << 31)
                             else self.sim_counter)
-        for _ in range(n_sims):
-            self._graph.replay()
+        if self.lookahead:
+            for _ in range(n_sims // self.lookahead):
+                self._graph.replay()
+            rest = n_sims % self.lookahead
+            for _ in range(rest):  # the same launches, not captured
+                self._playout_lookahead(self._g_own, self._g_opp, self._g_active, stream_id=0,
+                                        stream_id_dev=self._sim_dev, counter=self._sim_dev)
+            if rest:
+                self._flush_lookahead()
+        else:
+            for _ in range(n_sims):
+                self._graph.replay()
         self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
         self.n_leaf_evals += n_active * n_sims
 
@@ -407,12 +508,28 @@ class BatchedMCTS(object):
             self.n_compactions += 1
         if self.use_graph:
             self._search_graph(own, opp, active, n_sims, n_active)
+        elif self.lookahead:
+            for i in range(n_sims):
+                self._playout_lookahead(own, opp, active, stream_id=self.sim_counter)
+                self.sim_counter = (self.sim_counter + 1) & 0xFFFFFFFF
+                if (i + 1) % self.lookahead == 0 or i + 1 == n_sims:
+                    self._flush_lookahead()
+            self.n_leaf_evals += n_active * n_sims
         else:
             for _ in range(n_sims):
                 self.simulate(own, opp, active, n_active)
         if int(self.tree.overflow.sum().item()) != 0:
             raise _lib.IagoError("MCTS node pool exhausted (or a search path deeper than 512): "
                                  "raise `capacity` (%d nodes per game)" % self.tree.capacity)
+        if self.lookahead:
+            err = int(self._la_error.item())
+            if err:
+                self._la_error.zero_()
+                raise _lib.IagoError("policy look-ahead: %s" % (
+                    "the queue overflowed" if err == 1 else
+                    "a leaf reached n_thr without cached priors (raise `lookahead_slots`, now %d per "
+                    "game; the look-ahead must be on from the reset of the trees and n_thr must "
+                    "not change)" % self._la.slots))
         sat = getattr(self.value_fn, "check_saturation", None)
         if sat is not None:
             sat()  # the split-f16 Value kernels clamp at 65000: never silently

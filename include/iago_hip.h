@@ -466,6 +466,50 @@ IAGO_API int iago_mcts_advance_root(const iago_mcts_tree *tree, const uint8_t *m
 IAGO_API int iago_mcts_compact(const iago_mcts_tree *tree, const iago_mcts_tree *scratch, int32_t *order,
                                const uint8_t *mask, void *stream);
 
+/*
+ * Policy look-ahead.  The reference evaluates the policy net at the visit that expands a leaf
+ * (MCTS.policy_func inside MCTS.playout, MCTS.py:93-96,109-121) -- for lockstep games a few
+ * positions per playout, nine latency-bound launches on every playout's critical path.
+ * policy_func(state) depends on nothing but the leaf's position, so the engine evaluates it
+ * EARLIER: a leaf is queued when its visit count reaches `trigger` = n_thr - K, the queue is
+ * flushed through the net every K playouts as one batch, the priors wait in a per-game cache
+ * and the expansion -- at the same visit and with the same values as in the reference --
+ * takes them from there.  Trees are bit-identical to those of iago_mcts_expand.
+ *   iago_mcts_mix_backup_lookahead: iago_mcts_mix_backup + queueing of the playout's leaf
+ *     (its position from cur_own / cur_opp) when its visit count reaches `trigger`;
+ *   iago_mcts_store_priors: rows 0 .. *q_count-1 of probs (the net's outputs for q_own / q_opp
+ *     in queue order) into the cache; *total += *q_count when given.  The caller zeroes
+ *     *q_count afterwards;
+ *   iago_mcts_expand_cached: iago_mcts_expand for every active game with needs_expand, priors
+ *     from the cache; expanded[g] = 1 for those games, else 0.
+ * An unexpanded leaf carries its cache tag in first_child (-1 not queued, -2 - seq queued).
+ * *error is raised (1: queue full, 2: a leaf reached n_thr without valid priors -- its slot
+ * was recycled (`slots` too small) or it never crossed the trigger).  All arrays caller-owned:
+ * next_seq [n_games] (zeroed with the trees), cache_seq [n_games][slots] (-1), cache
+ * [n_games][slots][64] float32, the queue arrays [q_capacity].
+ */
+typedef struct iago_mcts_lookahead {
+    int32_t trigger, slots;
+    int32_t *next_seq;
+    int32_t *cache_seq;
+    float *cache;
+    int32_t *q_count;
+    int32_t q_capacity, reserved;
+    uint64_t *q_own, *q_opp;
+    int32_t *q_game, *q_seq;
+    int32_t *error;
+} iago_mcts_lookahead;
+IAGO_API int iago_mcts_mix_backup_lookahead(const iago_mcts_tree *tree, const uint8_t *active,
+                                            const int32_t *cur_node, const uint64_t *cur_own,
+                                            const uint64_t *cur_opp, const float *v, const int8_t *z, float lmbda,
+                                            float *leaf_value, uint32_t *counter,
+                                            const iago_mcts_lookahead *la, void *stream);
+IAGO_API int iago_mcts_store_priors(const iago_mcts_lookahead *la, const float *probs, int64_t *total,
+                                    void *stream);
+IAGO_API int iago_mcts_expand_cached(const iago_mcts_tree *tree, const uint8_t *active, const uint8_t *needs_expand,
+                                     const int32_t *cur_node, const uint64_t *legal, const iago_mcts_lookahead *la,
+                                     uint8_t *expanded, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

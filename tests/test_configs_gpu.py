@@ -51,8 +51,11 @@ def test_config3_share_1024_games_400_sims():
     assert int(T.overflow.sum().item()) == 0 and np.all(nv[:, 0] == n_sims)
     live = np.arange(used)[None, :] < nn[:, None]
     expanded = live & (fc >= 0)
-    assert m.n_policy_evals == int(expanded.sum()) + 0 * G  # every expansion evaluated the policy once
-    # (single-move / pass expansions also count: the batch evaluates every expanding leaf)
+    # every expansion had the policy evaluated exactly once (single-move / pass expansions too:
+    # the batch evaluates every queued leaf); with the policy look-ahead the leaves that are
+    # queued but not yet expanded (first_child <= -2) have been evaluated as well
+    assert m.lookahead == 4
+    assert m.n_policy_evals == int(expanded.sum()) + int((live & (fc <= -2)).sum())
     for g in range(0, G, 37):
         for i in np.nonzero(expanded[g])[0]:
             kids = slice(fc[g, i], fc[g, i] + nc[g, i])

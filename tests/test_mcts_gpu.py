@@ -343,6 +343,71 @@ def test_sync_free_equals_host_counted_with_real_nets(eng):
     assert torch.equal(a[5], b[5])
 
 
+@pytest.mark.parametrize("n_thr,K,use_graph,cap", [(15, 4, False, 128), (15, 4, True, 128), (6, 4, False, 512),
+                                                   (9, 8, True, 256), (15, 1, False, 128)])
+def test_policy_lookahead_builds_the_same_trees(eng, n_thr, K, use_graph, cap):
+    """Policy look-ahead (leaves queued K visits before they expand, the policy net on the queue
+    every K playouts, priors from a cache) against the reference's order of evaluation (the net
+    inside the playout that expands): bit-identical trees -- visit counts, Q, P, child order --
+    and moves, over several moves with subtree reuse, small pools that compact on the way and
+    playout counts that are not multiples of K."""
+    engine, ops = eng
+    from iago_amd import network
+    g = __import__("tests.conftest", fromlist=["load_json"]).load_json("simulate.json")
+    torch.manual_seed(4)
+    policy, value = network.SLPolicy().cuda().eval(), network.Value().cuda().eval()
+    w = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    G = 200
+    own, opp = random_positions(G, seed=8)
+    own[:40] = 0x0000000810000000
+    opp[:40] = 0x0000001008000000
+
+    def make(lookahead):
+        return engine.BatchedMCTS(G, policy, value, w, n_thr=n_thr, capacity=cap, seed=13, sync_free=True,
+                                  lookahead=lookahead, use_graph=use_graph and lookahead > 0)
+
+    ref, la = make(0), make(K)
+    assert ref.lookahead == 0 and la.lookahead == K
+    oa, pa = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    ob, pb = oa.clone(), pa.clone()
+    for t, n_sims in enumerate([70, 50, 61, 44, 37]):
+        active = (ops.legal_moves(oa, pa) != 0).to(torch.uint8)
+        ref.search(oa, pa, active, n_sims)
+        la.search(ob, pb, active, n_sims)
+        ma, va = ref.best_move(active)
+        mb, vb = la.best_move(active)
+        act = active.bool()
+        assert torch.equal(ma[act], mb[act]) and torch.equal(va[act], vb[act]), t
+        mv = torch.where(act, ma, torch.full_like(ma, -1))
+        for m_, o_, p_ in ((ref, oa, pa), (la, ob, pb)):
+            ops.apply_moves(o_, p_, mv)
+            m_.update_with_move(mv)
+        oa, pa, ob, pb = pa, oa, pb, ob
+    assert ref.n_compactions == la.n_compactions and (n_thr != 15 or la.n_compactions > 0)
+    for gi in range(0, G, 3):
+        assert ref.tree.dump(gi, max_depth=64) == la.tree.dump(gi, max_depth=64), gi
+    # every expansion had its priors; the look-ahead evaluates a few leaves that never expand
+    assert la.n_policy_evals >= ref.n_policy_evals > G
+    # (leaves that reach n_thr - K visits and never n_thr are evaluated for nothing: 1.3 x the
+    # reference's evaluations at n_thr = 15, K = 4; more when the trigger is a small count)
+    print("policy evaluations: look-ahead %d, reference order %d" % (la.n_policy_evals, ref.n_policy_evals))
+    assert n_thr != 15 or la.n_policy_evals < 2 * ref.n_policy_evals
+
+
+def test_policy_lookahead_reports_a_recycled_cache_slot(eng):
+    engine, ops = eng
+    from iago_amd import _lib, network
+    g = __import__("tests.conftest", fromlist=["load_json"]).load_json("simulate.json")
+    torch.manual_seed(4)
+    policy, value = network.SLPolicy().cuda().eval(), network.Value().cuda().eval()
+    w = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    m = engine.BatchedMCTS(16, policy, value, w, n_thr=6, capacity=4096, seed=1, lookahead=4, lookahead_slots=1)
+    o = torch.full((16,), engine.START_OWN, dtype=torch.int64, device="cuda")
+    p = torch.full((16,), engine.START_OPP, dtype=torch.int64, device="cuda")
+    with pytest.raises(_lib.IagoError):
+        m.search(o, p, torch.ones(16, dtype=torch.uint8, device="cuda"), 400)
+
+
 def test_graph_is_recaptured_when_weights_change(eng):
     """The captured graph holds device pointers of weight layouts cached per weight version;
     after an in-place update of the Value weights (training between searches, load_npz) the
