@@ -184,6 +184,7 @@ class BatchedMCTS(object):
             raise ValueError("use_graph needs the sync-free playout (a policy with forward_counted)")
         self.use_graph, self._graph, self._graph_key = bool(use_graph), None, None
         self.n_compactions = 0
+        self._live_after_compaction = 0
         # Policy look-ahead (iago_mcts_lookahead in include/iago_hip.h): leaves are queued K
         # visits before they expand and the policy net runs on the queue every K playouts, off
         # the playouts' critical path.  Default: K = 4 whenever the sync-free playout with a
@@ -229,6 +230,8 @@ class BatchedMCTS(object):
                     self._la_next_seq[m] = 0
                     self._la_cache_seq[m] = -1
             self.tree.reset_hooks = [reset_lookahead]
+        self.tree.reset_hooks = list(getattr(self.tree, "reset_hooks", ())) + [
+            lambda mask: setattr(self, "_live_after_compaction", 0)]
         self._g_own = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._g_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._g_active = torch.zeros(n_games, dtype=torch.uint8, **kw)
@@ -500,12 +503,15 @@ class BatchedMCTS(object):
             [active.sum().to(torch.int64), self.tree.n_nodes.max().to(torch.int64)]).tolist())
         if n_active == 0:
             return
-        if used > self.tree.capacity // 2:
+        if used > self.tree.capacity // 2 and used > self._live_after_compaction * 5 // 4:
             # a pool is half full: free the nodes that subtree reuse left behind (what the
             # reference's garbage collector does after MCTS.py:149-152) before this search adds
-            # its own.  A pool that fills up all the same is reported below.
+            # its own.  A pool that fills up all the same is reported below.  (Not again until
+            # the pool has grown by a quarter over what the last pass left: a live tree that
+            # itself fills half the pool would otherwise be re-laid before every search.)
             self.tree.compact()
             self.n_compactions += 1
+            self._live_after_compaction = int(self.tree.n_nodes.max().item())
         if self.use_graph:
             self._search_graph(own, opp, active, n_sims, n_active)
         elif self.lookahead:
