@@ -143,24 +143,36 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    stats = torch.tensor([dt, m.n_leaf_evals, m.n_policy_evals], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([dt, m.n_leaf_evals, m.n_policy_evals, m.n_value_evals], dtype=torch.float64,
+                         device="cuda")
     if dist is not None:
         tm = stats[:1].clone()
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats)
         stats[0] = tm[0]
-    dt, leaf, pol = (float(x) for x in stats.tolist())
-    flops = leaf * 122_994_944 + pol * 122_847_232  # Value / SLPolicy per eval
+    dt, leaf, pol, val = (float(x) for x in stats.tolist())
+    # Value / SLPolicy FLOPs per evaluation, for the evaluations EXECUTED (with the
+    # value cache the net runs on a leaf's first visit only; the policy look-ahead also evaluates
+    # leaves that never expand)
+    flops = val * 122_994_944 + pol * 122_847_232
     out = {"leaf_evals_per_sec": leaf / dt, "leaf_evals": int(leaf), "policy_evals": int(pol),
+           "value_evals": int(val),
+           "leaf_eval_definition": "one leaf-eval = one playout (MCTS.py:105-133) ending in the leaf "
+                                   "evaluation of MCTS.py:123-127: value_func(leaf) + rollout + backup; "
+                                   "value_func is a pure function of the position, computed at a leaf's "
+                                   "first visit and taken from the node afterwards (value_evals = net "
+                                   "launches' rows), the rollout runs at every visit; trees bit-identical "
+                                   "to evaluating the net at every visit (tests/test_mcts_gpu.py)",
+           "value_cache": bool(m.value_cache), "policy_lookahead": int(m.lookahead),
            "seconds": dt, "turns_played": res.n_turns, "sims_per_move": n_sims,
            "games_per_gpu": n_games, "full_games": bool(full_games),
-           "net_tflops_fp32": flops / dt / 1e12,   # float32-equivalent FLOP/s of both nets
+           "net_tflops_fp32": flops / dt / 1e12,   # float32-equivalent FLOP/s of both nets, executed evaluations
            "value_conv": ("f32 (MIOpen)" if value_f32 else
                           "split-f16 MFMA: f16 hi/lo operands, 3 MFMAs per product sum, f32 accumulation; "
                           "Value forward within 1e-6 of the f32 one (tests/test_conv_gpu.py)"),
            "policy_conv": "f32: hand-written conv3x3_f32 / policy_head kernels (batches <= 192: the "
                           "expansions of a playout); MIOpen above",
-           "roofline": _mcts_roofline(leaf, pol, dt, world, value_f32),
+           "roofline": _mcts_roofline(val, pol, dt, world, value_f32),
            "config": "BASELINE configs[2]: PV-MCTS %d sims/move, %d games per GPU, SLPolicy+Value "
                      "random init fp32, lmbda=0.5 c_puct=1 n_thr=15" % (n_sims, n_games),
            "tree_pool_bytes_per_gpu": m.tree.bytes(), "tree_traffic_rank0": m.tree_bytes(),
@@ -191,7 +203,7 @@ def trunk_kernel_profile():
     return None
 
 
-def _mcts_roofline(leaf, pol, dt, world, value_f32):
+def _mcts_roofline(leaf, pol, dt, world, value_f32):  # leaf = value-net evaluations executed
     """The convolutions bound this leg.  f32 path: float32 matrix/vector peak 157.3
     TFLOP/s.  Split-f16 path: the Value convolutions of blocks 2..8 (122.68 MFLOP per
     evaluation) execute 3 f16 MFMAs per product sum against the dense f16 peak of
@@ -205,8 +217,9 @@ def _mcts_roofline(leaf, pol, dt, world, value_f32):
             "dtype": "f16 MFMA operands (split f32), f32 accumulate",
             "mfma_flops_per_leaf_eval": 3 * 122_683_392, "flops_per_leaf_eval": 122_994_944,
             "flops_per_policy_eval": 122_847_232,
-            "note": "loop level: executed MFMA FLOPs of the Value trunk over the WHOLE leg's wall time "
-                    "(tree kernels, policy net, rollout included); the trunk kernel alone: trunk_kernel",
+            "note": "loop level: executed MFMA FLOPs of the Value trunk (value-net evaluations actually run: "
+                    "the value cache skips re-evaluations of a leaf) over the WHOLE leg's wall time (tree "
+                    "kernels, policy net, rollout included); the trunk kernel alone: trunk_kernel",
             "trunk_kernel": trunk_kernel_profile()}
 
 

@@ -31,6 +31,7 @@ SYMBOLS = [
     "iago_leaf_values",
     "iago_mcts_backup", "iago_mcts_mix_backup", "iago_mcts_best_move", "iago_mcts_advance_root", "iago_mcts_compact",
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
+    "iago_mcts_fresh_leaves",
 ]
 
 
@@ -77,7 +78,7 @@ class ValueSplitArgs(C.Structure):
         ("w_hi", C.c_void_p * 7), ("w_lo", C.c_void_p * 7), ("bias", C.c_void_p * 7),
         ("w9_hi", C.c_void_p), ("w9_lo", C.c_void_p),
         ("b9", C.c_void_p), ("w10", C.c_void_p), ("w11", C.c_void_p),
-        ("out", C.c_void_p), ("overflow", C.c_void_p),
+        ("out", C.c_void_p), ("overflow", C.c_void_p), ("index", C.c_void_p), ("n_dev", C.c_void_p),
     ]
 
 
@@ -87,7 +88,7 @@ class MctsTree(C.Structure):
         ("n_games", C.c_int64), ("capacity", C.c_int32), ("reserved", C.c_int32),
         ("parent", C.c_void_p), ("first_child", C.c_void_p), ("n_children", C.c_void_p),
         ("action", C.c_void_p), ("n_visits", C.c_void_p), ("q", C.c_void_p), ("p", C.c_void_p),
-        ("n_nodes", C.c_void_p), ("root", C.c_void_p), ("overflow", C.c_void_p),
+        ("n_nodes", C.c_void_p), ("root", C.c_void_p), ("overflow", C.c_void_p), ("v", C.c_void_p),
     ]
 
 
@@ -159,6 +160,7 @@ def lib():
     L.iago_mcts_mix_backup_lookahead.argtypes = [tp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, lp, vp]
     L.iago_mcts_store_priors.argtypes = [lp, vp, vp, vp]
     L.iago_mcts_expand_cached.argtypes = [tp, vp, vp, vp, vp, lp, vp, vp]
+    L.iago_mcts_fresh_leaves.argtypes = [tp, vp, vp, vp, vp, vp, vp]
     for name in SYMBOLS[3:]:
         getattr(L, name).restype = C.c_int
     _lib = L

@@ -34,12 +34,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-constexpr int TB = 4;              // boards per workgroup
 constexpr int RS = 528;            // bytes of a cell row: 128 ch hi | 128 ch lo | 16 B (bank skew)
 constexpr int ZB = 768;            // zero bytes behind a board's 64 rows: the target of every out-of-board tap
 constexpr int BS = 64 * RS + ZB;   // bytes of a board
-constexpr int T_BYTES = TB * BS;   // 138,240
-constexpr int LDS_ALLOC = T_BYTES + 1024; // the operand prefetch of the last k-step reads up to 48 B past T
+// boards per workgroup TB = 4 (138,240 B of LDS) or 2 (small batches: half the latency per workgroup)
+constexpr int lds_alloc(int tb) { return tb * BS + 1024; } // the operand prefetch of the last k-step reads up to 48 B past T
 constexpr int MAX_LAYERS = 8;
 
 struct TrunkRParams {
@@ -56,11 +55,14 @@ struct TrunkRParams {
     const float *w1, *b1;       // block1 [64][2][3][3], [64]
     const uint4 *w9_hi, *w9_lo; // block9 as MFMA A operand [8 chunks][32 rows = taps, 9 used][16] f16
     const float *b9, *w10, *w11;
-    float *out;                 // [n]
+    float *out;                 // [n] (scattered by index when given)
+    const int64_t *index;       // optional gather list: row b = board index[b] of own / opp, value to out[index[b]]
+    const int32_t *n_dev;       // optional device-side row count: only the first min(n, *n_dev) rows
+    int32_t count_lo, count_hi; // this launch runs iff count_lo < rows <= count_hi (variant choice on the device)
 };
 
-constexpr int HEAD_LDS = (9 * 256 + 256 + 512) * 4; // tap maps, block9 output, fc10 x fc11 terms
-constexpr int LDS_ALLOC_FUSED = LDS_ALLOC + HEAD_LDS;
+constexpr int head_lds(int tb) { return (9 * 64 * tb + 64 * tb + 128 * tb) * 4; } // tap maps, block9 output, fc terms
+constexpr int lds_alloc_fused(int tb) { return lds_alloc(tb) + head_lds(tb); }
 
 // ds_read_b128 serves lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (and the same + 32)
 // in separate LDS cycles: the first group holds cells 0-15 of a 32-cell block, the second
@@ -74,12 +76,22 @@ __device__ __forceinline__ int cell_of_lane(int r)
 
 extern __shared__ __align__(16) char trunk_lds[];
 
-template <bool FUSED>
+template <bool FUSED, int TB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void trunk_resident_kernel(TrunkRParams P)
 {
+    constexpr int NT = 2 * TB;      // 32-cell tiles of a wave: TB boards x 2 halves
+    constexpr int NPAIR = TB / 2;   // board pairs (address sets)
     char *const T = trunk_lds;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int64_t b0 = (int64_t)blockIdx.x * TB;
+    int64_t n_rows = P.n;
+    if constexpr (FUSED) {
+        // device-side row count and variant choice: uniform over the launch, before any barrier
+        if (P.n_dev)
+            n_rows = min(P.n, (int64_t)*P.n_dev);
+        if (n_rows <= P.count_lo || n_rows > P.count_hi || b0 >= n_rows)
+            return;
+    }
 
     // ---- the zero areas, then the input of the first layer
     if (tid < TB * (ZB / 16))
@@ -93,7 +105,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float in[TB][18]; // the 3x3 neighbourhoods of this lane's cell on both planes, 4 boards
 #pragma unroll
         for (int board = 0; board < TB; board++) {
-            const int64_t b = min(b0 + board, P.n - 1);
+            const int64_t row = min(b0 + board, n_rows - 1);
+            const int64_t b = P.index ? P.index[row] : row;
             const float *pl = P.planes + b * 128;
             const uint64_t bits0 = P.planes ? 0ull : P.opp[b], bits1 = P.planes ? 0ull : P.own[b];
 #pragma unroll
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // boards 0/1 through `lo_pair`, boards 2/3 through `hi_pair` (+ an immediate BS for the
     // odd board); the hi / lo halves of a row are 256 B apart (immediate)
     const int lane_cell = cell_of_lane(r);
-    uint32_t addr[2][2][9]; // [board pair][j][tap]
+    uint32_t addr[NPAIR][2][9]; // [board pair][j][tap]
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -181,16 +194,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // different 4-bank groups whether or not some of them are redirected
             const int lin = (cell + (tap / 3 - 1) * 8 + (tap % 3 - 1)) & 15;
             const uint32_t a = (uint32_t)((ok ? (yy * 8 + xx) * RS : 64 * RS + 16 * lin) + h * 16);
-            addr[0][j][tap] = a;
-            addr[1][j][tap] = a + 2u * BS;
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; pr++)
+                addr[pr][j][tap] = a + (uint32_t)(pr * 2 * BS);
         }
     // rows this lane writes in the epilogue (its cells), same pairing
-    uint32_t wrow[2][2];
+    uint32_t wrow[NPAIR][2];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        wrow[0][j] = (uint32_t)((32 * j + lane_cell) * RS);
-        wrow[1][j] = wrow[0][j] + 2u * BS;
-    }
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; pr++)
+            wrow[pr][j] = (uint32_t)((32 * j + lane_cell) * RS + pr * 2 * BS);
 #ifdef TRUNK_EXP_STAMPS // timing experiments only (tools/exp_trunk_variants.sh): s_memtime per phase
     unsigned long long stamps[3 * MAX_LAYERS + 1];
 #define STAMP(i) stamps[i] = __builtin_readcyclecounter()
@@ -205,9 +219,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // the k-step's chunk; a k-step (chunk, tap) is 128 x 32 B further
         const u32x4 *wh = (const u32x4 *)P.w_hi[L] + (32 * wv + r) * 2 + h;
         const u32x4 *wl = (const u32x4 *)P.w_lo[L] + (32 * wv + r) * 2 + h;
-        float16v acc_main[8], acc_cross[8];
+        float16v acc_main[NT], acc_cross[NT];
 #pragma unroll
-        for (int j8 = 0; j8 < 8; j8++)
+        for (int j8 = 0; j8 < NT; j8++)
 #pragma unroll
             for (int v = 0; v < 16; v++) {
                 acc_main[j8][v] = 0.0f;
@@ -225,8 +239,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // group of three waiting (measured: 72 us of a 1024-board forward, tools/exp_trunk_variants.sh)
         half8 bh[3], bl[3];
         auto b_addr = [&](int tile72) -> const char * {
-            // tile72 = tap * 8 + j8 of the running chunk; 72, 73 = the first two tiles of the next chunk
-            const int over = tile72 >= 72 ? 32 : 0, tt = tile72 % 72, tp = tt >> 3, jj = tt & 7;
+            // tile72 = tap * NT + j8 of the running chunk; 9 NT, 9 NT + 1 = the first two tiles of the next chunk
+            const int over = tile72 >= 9 * NT ? 32 : 0, tt = tile72 % (9 * NT), tp = tt / NT, jj = tt % NT;
             return T + addr[jj >> 2][jj & 1][tp] + ((jj >> 1) & 1) * BS + over;
         };
         {
@@ -248,8 +262,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const half8 ah = __builtin_bit_cast(half8, a_hi[tap % 3]);
                 const half8 al = __builtin_bit_cast(half8, a_lo[tap % 3]);
 #pragma unroll
-                for (int j8 = 0; j8 < 8; j8++) {
-                    const int tile = tap * 8 + j8, cur = tile % 3, nxt = (tile + 2) % 3;
+                for (int j8 = 0; j8 < NT; j8++) {
+                    const int tile = tap * NT + j8, cur = tile % 3, nxt = (tile + 2) % 3;
                     // (past the last chunk: harmless reads 32 B further in the same rows)
                     const char *p = b_addr(tile + 2);
 #ifndef TRUNK_EXP_NO_B
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // next chunk of 16 input channels: 32 B further in every row (the zero rows are
             // 528 B of zeros: their addresses move along)
 #pragma unroll
-            for (int pr = 0; pr < 2; pr++)
+            for (int pr = 0; pr < NPAIR; pr++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         addr[pr][j][tap] += 32u;
         }
 #pragma unroll
-        for (int pr = 0; pr < 2; pr++)
+        for (int pr = 0; pr < NPAIR; pr++)
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -301,7 +315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (acc_main[0][0] == 12345.0f)
 #endif
 #pragma unroll
-        for (int j8 = 0; j8 < 8; j8++) {
+        for (int j8 = 0; j8 < NT; j8++) {
             const int bb = j8 >> 1, j = j8 & 1;
             char *row = T + wrow[bb >> 1][j] + (bb & 1) * BS + (32 * wv + 4 * h) * 2;
 #pragma unroll
@@ -339,16 +353,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // convolution with 9: tap map M[tap][cell'] = sum_c w9[c][tap] x[c][cell'] on the MFMA
         // units (A = the 9 tap rows of w9, zero-padded to 32; B = the centre tap's operand of
         // the layers above; same split arithmetic), then out[cell] = sum_tap M[tap][cell + off(tap)].
-        float *const Dm = (float *)(T + LDS_ALLOC);  // [9][4 boards * 64 cells]
-        float *const h9s = Dm + 9 * 256;             // [4][64]
-        float *const hid = h9s + 256;                // [4][128]
+        constexpr int NC = 64 * TB;                      // cells of the workgroup's boards
+        float *const Dm = (float *)(T + lds_alloc(TB));  // [9][TB boards * 64 cells]
+        float *const h9s = Dm + 9 * NC;                  // [TB][64]
+        float *const hid = h9s + NC;                     // [TB][128]
         // this thread's fc10 row (tid & 127), fetched under the MFMAs below
         float4 w10row[16];
 #pragma unroll
         for (int c = 0; c < 16; c++)
             w10row[c] = ((const float4 *)(P.w10 + (tid & 127) * 64))[c];
         const float w11j = P.w11[tid & 127];
-        {
+        if (wv < TB) { // wave wv takes board wv
             const u32x4 *w9h = (const u32x4 *)P.w9_hi + r * 2 + h;
             const u32x4 *w9l = (const u32x4 *)P.w9_lo + r * 2 + h;
             float16v hm[2], hc[2];
@@ -380,25 +395,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int base = (jj >> 1) * 64 + 32 * (jj & 1) + lane_cell;
 #pragma unroll
                 for (int t = 0; t < 4; t++)
-                    Dm[(4 * h + t) * 256 + base] = hm[jt][t] + hc[jt][t] * (1.0f / 2048.0f);
+                    Dm[(4 * h + t) * NC + base] = hm[jt][t] + hc[jt][t] * (1.0f / 2048.0f);
                 if (h == 0)
-                    Dm[8 * 256 + base] = hm[jt][4] + hc[jt][4] * (1.0f / 2048.0f);
+                    Dm[8 * NC + base] = hm[jt][4] + hc[jt][4] * (1.0f / 2048.0f);
             }
         }
         __syncthreads();
-        {
+        if (tid < NC) {
             const int cell = tid & 63, y = cell >> 3, x = cell & 7;
             float s9 = 0.0f;
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
                 const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
                 if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8)
-                    s9 += Dm[tap * 256 + (tid & ~63) + yy * 8 + xx];
+                    s9 += Dm[tap * NC + (tid & ~63) + yy * 8 + xx];
             }
             h9s[tid] = fmaxf(s9 + P.b9[0], 0.0f);
         }
         __syncthreads();
-        {
+        if ((tid >> 7) * 2 < TB) {
             // fc10 row j for two boards, then its fc11 term (no bias, no activation in between)
             const int j = tid & 127, pb = (tid >> 7) * 2;
             float s0 = 0.0f, s1 = 0.0f;
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             hid[(pb + 1) * 128 + j] = s1 * w11j;
         }
         __syncthreads();
-        if (tid < TB && b0 + tid < P.n) {
+        if (tid < TB && b0 + tid < n_rows) {
             // fixed order j = 0..127 (the result does not depend on the launch shape); the 32
             // LDS reads are issued together, the additions are one dependent chain
             float4 hv[32];
@@ -436,7 +451,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 v += hv[j4].z;
                 v += hv[j4].w;
             }
-            P.out[b0 + tid] = v;
+            const int64_t row = b0 + tid;
+            P.out[P.index ? P.index[row] : row] = v;
         }
         return;
     }
@@ -487,12 +503,16 @@ int iago_launch_trunk_resident(const iago_conv_split_layer *layers, int32_t n_la
     P.w1 = P.b1 = P.b9 = P.w10 = P.w11 = nullptr;
     P.w9_hi = P.w9_lo = nullptr;
     P.out = nullptr;
+    P.index = nullptr;
+    P.n_dev = nullptr;
+    P.count_lo = 0;
+    P.count_hi = 0x7fffffff;
     static std::atomic<uint64_t> configured{0};
-    if (iago_reserve_lds((const void *)trunk_resident_kernel<false>, LDS_ALLOC, configured,
+    if (iago_reserve_lds((const void *)trunk_resident_kernel<false, 4>, lds_alloc(4), configured,
                          "iago_conv3x3_split_trunk: cannot reserve 134 KB of LDS"))
         return IAGO_ERR_HIP;
-    const unsigned grid = (unsigned)((n + TB - 1) / TB);
-    hipLaunchKernelGGL(trunk_resident_kernel<false>, dim3(grid), dim3(256), LDS_ALLOC, (hipStream_t)stream, P);
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    hipLaunchKernelGGL((trunk_resident_kernel<false, 4>), dim3(grid), dim3(256), lds_alloc(4), (hipStream_t)stream, P);
     return iago_check_launch("iago_conv3x3_split_trunk");
 }
 
@@ -537,11 +557,34 @@ int iago_value_forward_split(const iago_value_split_args *a, void *stream)
     P.w10 = a->w10;
     P.w11 = a->w11;
     P.out = a->out;
-    static std::atomic<uint64_t> configured{0};
-    if (iago_reserve_lds((const void *)trunk_resident_kernel<true>, LDS_ALLOC_FUSED, configured,
-                         "iago_value_forward_split: cannot reserve 148 KB of LDS"))
+    if (a->index && a->planes)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: a gather list needs the boards, not planes");
+    P.index = a->index;
+    P.n_dev = a->n_dev;
+    static std::atomic<uint64_t> configured4{0}, configured2{0};
+    if (iago_reserve_lds((const void *)trunk_resident_kernel<true, 4>, lds_alloc_fused(4), configured4,
+                         "iago_value_forward_split: cannot reserve 148 KB of LDS") ||
+        iago_reserve_lds((const void *)trunk_resident_kernel<true, 2>, lds_alloc_fused(2), configured2,
+                         "iago_value_forward_split: cannot reserve 75 KB of LDS"))
         return IAGO_ERR_HIP;
-    const unsigned grid = (unsigned)((a->n + TB - 1) / TB);
-    hipLaunchKernelGGL(trunk_resident_kernel<true>, dim3(grid), dim3(256), LDS_ALLOC_FUSED, (hipStream_t)stream, P);
+    // Two boards per workgroup up to SMALL rows (twice the workgroups, half the latency of
+    // each: the launch is latency-bound until the chip is full), four above.  Same products
+    // in the same order per board: bit-identical values.  With a device-side count both
+    // variants are enqueued and the one whose window holds the count runs.
+    constexpr int64_t SMALL = 512;
+    const bool host_known = a->n_dev == nullptr;
+    if (!host_known || a->n <= SMALL) {
+        P.count_lo = 0;
+        P.count_hi = (int32_t)SMALL;
+        const int64_t rows = a->n < SMALL ? a->n : SMALL;
+        hipLaunchKernelGGL((trunk_resident_kernel<true, 2>), dim3((unsigned)((rows + 1) / 2)), dim3(256),
+                           lds_alloc_fused(2), (hipStream_t)stream, P);
+    }
+    if (a->n > SMALL) {
+        P.count_lo = host_known ? 0 : (int32_t)SMALL;
+        P.count_hi = 0x7fffffff;
+        hipLaunchKernelGGL((trunk_resident_kernel<true, 4>), dim3((unsigned)((a->n + 3) / 4)), dim3(256),
+                           lds_alloc_fused(4), (hipStream_t)stream, P);
+    }
     return iago_check_launch("iago_value_forward_split");
 }

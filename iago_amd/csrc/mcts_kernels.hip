@@ -38,6 +38,8 @@ __device__ __forceinline__ void init_node(const Tree &T, int64_t i, int parent, 
     T.n_visits[i] = 0;
     T.q[i] = 0.0f;
     T.p[i] = p;
+    if (T.v)
+        T.v[i] = __builtin_nanf(""); // value_func(node) not evaluated yet
 }
 
 __global__ __launch_bounds__(BLOCK) void reset_kernel(Tree T, const uint8_t *__restrict__ mask)
@@ -248,14 +250,26 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_kernel(Tree T, const uint8_t
         *counter += 1u;
     if (g >= T.n_games)
         return;
+    // value_func(leaf) (MCTS.py:97-103,124) is a pure function of the leaf's position: with a
+    // value cache (T.v) the net ran only for the leaves it has not seen (iago_mcts_fresh_leaves),
+    // whose values are in v[g] and are stored now; the others take the stored value
+    const int64_t base = g * (int64_t)T.capacity;
+    float vg = (lmbda < 1.0f) ? v[g] : 0.0f;
+    if (T.v && lmbda < 1.0f && active[g]) {
+        float *slot = T.v + base + cur_node[g];
+        const float cached = *slot;
+        if (cached != cached)
+            *slot = vg;
+        else
+            vg = cached;
+    }
     // (1-lmbda)*v + lmbda*z exactly as leaf_values_kernel (MCTS.py:123-125)
-    const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * v[g] : 0.0f;
+    const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * vg : 0.0f;
     const float b = (lmbda > 0.0f) ? (float)((double)lmbda * (double)z[g]) : 0.0f;
     const float lv = a + b;
     leaf_value[g] = lv;
     if (!active[g])
         return;
-    const int64_t base = g * (int64_t)T.capacity;
     int node = cur_node[g];
     for (int depth = 0; node >= 0 && depth <= MAX_DEPTH; depth++) {
         const int n = T.n_visits[base + node] + 1; // MCTS.py:61
@@ -351,14 +365,26 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_lookahead_kernel(
         *counter += 1u;
     if (g >= T.n_games)
         return;
+    // value_func(leaf) (MCTS.py:97-103,124) is a pure function of the leaf's position: with a
+    // value cache (T.v) the net ran only for the leaves it has not seen (iago_mcts_fresh_leaves),
+    // whose values are in v[g] and are stored now; the others take the stored value
+    const int64_t base = g * (int64_t)T.capacity;
+    float vg = (lmbda < 1.0f) ? v[g] : 0.0f;
+    if (T.v && lmbda < 1.0f && active[g]) {
+        float *slot = T.v + base + cur_node[g];
+        const float cached = *slot;
+        if (cached != cached)
+            *slot = vg;
+        else
+            vg = cached;
+    }
     // (1-lmbda)*v + lmbda*z exactly as leaf_values_kernel (MCTS.py:123-125)
-    const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * v[g] : 0.0f;
+    const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * vg : 0.0f;
     const float b = (lmbda > 0.0f) ? (float)((double)lmbda * (double)z[g]) : 0.0f;
     const float lv = a + b;
     leaf_value[g] = lv;
     if (!active[g])
         return;
-    const int64_t base = g * (int64_t)T.capacity;
     const int leaf = cur_node[g];
     int node = leaf;
     for (int depth = 0; node >= 0 && depth <= MAX_DEPTH; depth++) {
@@ -518,6 +544,8 @@ __global__ __launch_bounds__(BLOCK) void compact_gather_kernel(Tree T, Tree S, c
         S.n_visits[base + i] = T.n_visits[o];
         S.q[base + i] = T.q[o];
         S.p[base + i] = T.p[o];
+        if (T.v && S.v)
+            S.v[base + i] = T.v[o];
     }
 }
 
@@ -534,6 +562,8 @@ __global__ __launch_bounds__(BLOCK) void compact_commit_kernel(Tree T, Tree S)
         T.n_visits[base + i] = S.n_visits[base + i];
         T.q[base + i] = S.q[base + i];
         T.p[base + i] = S.p[base + i];
+        if (T.v && S.v)
+            T.v[base + i] = S.v[base + i];
     }
     if (threadIdx.x == 0 && count >= 0) {
         T.n_nodes[g] = count;
@@ -585,6 +615,52 @@ __global__ __launch_bounds__(1024) void pending_kernel(const uint8_t *__restrict
             index[k] = g;
             games[k] = g;
         }
+        __syncthreads();
+        if (tid == 0) {
+            int t = base;
+            for (int w = 0; w < 16; w++)
+                t += wave_sum[w];
+            base = t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *count = base;
+        if (total)
+            *total += base;
+    }
+}
+
+// The active games whose leaf has no cached value yet (T.v is NaN), in ascending order, and
+// their number: the rows of the value net's next launch.
+__global__ __launch_bounds__(1024) void fresh_leaves_kernel(Tree T, const uint8_t *__restrict__ active,
+                                                            const int32_t *__restrict__ cur_node,
+                                                            int64_t *__restrict__ index, int32_t *__restrict__ count,
+                                                            int64_t *__restrict__ total)
+{
+    __shared__ int wave_sum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = (int)T.n_games;
+    if (tid == 0)
+        base = 0;
+    __syncthreads();
+    for (int g0 = 0; g0 < n; g0 += 1024) {
+        const int g = g0 + tid;
+        bool p = false;
+        if (g < n && active[g] != 0) {
+            const float c = T.v[(int64_t)g * T.capacity + cur_node[g]];
+            p = c != c;
+        }
+        const unsigned long long m = __ballot(p);
+        if (lane == 0)
+            wave_sum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; w++)
+            off += wave_sum[w];
+        if (p)
+            index[off + __popcll(m & ((1ull << lane) - 1ull))] = g;
         __syncthreads();
         if (tid == 0) {
             int t = base;
@@ -827,6 +903,20 @@ int iago_mcts_expand_cached(const iago_mcts_tree *tree, const uint8_t *active, c
     hipLaunchKernelGGL(expand_cached_kernel, dim3(grid_for(tree->n_games * 8)), dim3(BLOCK), 0, (hipStream_t)stream,
                        *tree, active, needs_expand, cur_node, legal, A, expanded);
     return iago_check_launch("iago_mcts_expand_cached");
+}
+
+int iago_mcts_fresh_leaves(const iago_mcts_tree *tree, const uint8_t *active, const int32_t *cur_node,
+                           int64_t *index, int32_t *count, int64_t *total, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_fresh_leaves: bad tree"))
+        return IAGO_ERR_INVALID;
+    if (!tree->v || !active || !cur_node || !index || !count)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_fresh_leaves: null pointer (the tree needs its value cache `v`)");
+    if (tree->n_games > 0x7fffffffll)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_fresh_leaves: too many games");
+    hipLaunchKernelGGL(fresh_leaves_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *tree, active, cur_node,
+                       index, count, total);
+    return iago_check_launch("iago_mcts_fresh_leaves");
 }
 
 } // extern "C"

@@ -46,12 +46,16 @@ def suggest_capacity(n_sims, n_thr=15, moves=64, branching=12):
 class TreePool(object):
     """Device memory of the per-game search trees (iago_mcts_tree)."""
 
-    def __init__(self, n_games, capacity, device="cuda"):
+    FIELDS = ("parent", "first_child", "n_children", "action", "n_visits", "q", "p", "n_nodes", "root", "overflow")
+
+    def __init__(self, n_games, capacity, device="cuda", value_cache=False):
         if not torch.cuda.is_available():
             raise _lib.IagoError("TreePool needs a HIP device (no CPU fallback)")
         n = n_games * capacity
         kw = dict(device=device)
         self.n_games, self.capacity = n_games, capacity
+        # value_func(node) once evaluated, NaN before (iago_mcts_fresh_leaves); None = no cache
+        self.v = torch.full((n,), float("nan"), dtype=torch.float32, **kw) if value_cache else None
         self.parent = torch.empty(n, dtype=torch.int32, **kw)
         self.first_child = torch.empty(n, dtype=torch.int32, **kw)
         self.n_children = torch.empty(n, dtype=torch.uint8, **kw)
@@ -64,9 +68,9 @@ class TreePool(object):
         self.overflow = torch.zeros(n_games, dtype=torch.int32, **kw)
         t = MctsTree()
         t.n_games, t.capacity = n_games, capacity
-        for f in ("parent", "first_child", "n_children", "action", "n_visits", "q", "p", "n_nodes",
-                  "root", "overflow"):
+        for f in self.FIELDS:
             setattr(t, f, getattr(self, f).data_ptr())
+        t.v = self.v.data_ptr() if self.v is not None else None
         self.c = t
         self.reset()
 
@@ -91,14 +95,14 @@ class TreePool(object):
             dev = self.parent.device
             sc = TreePool.__new__(TreePool)
             sc.n_games, sc.capacity = self.n_games, self.capacity
-            for f in ("parent", "first_child", "n_children", "action", "n_visits", "q", "p", "n_nodes",
-                      "root", "overflow"):
+            for f in self.FIELDS:
                 setattr(sc, f, torch.empty_like(getattr(self, f)))
+            sc.v = torch.empty_like(self.v) if self.v is not None else None
             t = MctsTree()
             t.n_games, t.capacity = self.n_games, self.capacity
-            for f in ("parent", "first_child", "n_children", "action", "n_visits", "q", "p", "n_nodes",
-                      "root", "overflow"):
+            for f in self.FIELDS:
                 setattr(t, f, getattr(sc, f).data_ptr())
+            t.v = sc.v.data_ptr() if sc.v is not None else None
             sc.c = t
             self._scratch = sc
             self._order = torch.empty(self.n_games * self.capacity, dtype=torch.int32, device=dev)
@@ -150,15 +154,31 @@ class BatchedMCTS(object):
 
     def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
                  n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False,
-                 sync_free=None, lookahead=None, lookahead_slots=None):
+                 sync_free=None, lookahead=None, lookahead_slots=None, value_cache=None):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         self.n_games = n_games
         self.policy_fn, self.value_fn, self.rollout_weights = policy_fn, value_fn, rollout_weights
         self.lmbda, self.c_puct, self.n_thr = float(lmbda), float(c_puct), int(n_thr)
         self.seed, self.game_id_base = seed, game_id_base
-        self.tree = TreePool(n_games, capacity, device)
         kw = dict(device=device)
+        # Value cache (iago_mcts_fresh_leaves in include/iago_hip.h): the value net runs only on
+        # the leaves it has not evaluated yet (~15 % of the playouts' leaves); every other visit
+        # of a leaf takes the value stored in its node.  Same trees.  Default: on whenever the
+        # value net can be fed a device-side list of boards.
+        can_cache = (value_fn is not None and self.lmbda < 1.0
+                     and getattr(value_fn, "forward_boards_counted", None) is not None
+                     and getattr(value_fn, "split_f16", False))
+        if value_cache is None:
+            value_cache = can_cache
+        if value_cache and not can_cache:
+            raise ValueError("value_cache needs a value net with forward_boards_counted (split-f16 path) and lmbda < 1")
+        self.value_cache = bool(value_cache)
+        self.tree = TreePool(n_games, capacity, device, value_cache=self.value_cache)
+        self._fresh_idx = torch.zeros(n_games, dtype=torch.int64, **kw)
+        self._fresh_count = torch.zeros(1, dtype=torch.int32, **kw)
+        self._value_total = torch.zeros(1, dtype=torch.int64, **kw)  # value-net evaluations, on the device
+        self._value_key = None
         self.cur_node = torch.zeros(n_games, dtype=torch.int32, **kw)
         self.cur_own = torch.zeros(n_games, dtype=torch.int64, **kw)
         self.cur_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
@@ -248,6 +268,11 @@ class BatchedMCTS(object):
     @property
     def n_policy_evals(self):
         return self._n_policy_host + int(self._pend_total.item())
+
+    @property
+    def n_value_evals(self):
+        """Value-net evaluations so far (with the value cache: first visits of leaves only)."""
+        return int(self._value_total.item()) if self.value_cache else self.n_leaf_evals
 
     @n_policy_evals.setter
     def n_policy_evals(self, value):
@@ -347,7 +372,15 @@ class BatchedMCTS(object):
     def _evaluate_and_backup(self, active, stream_id=0, stream_id_dev=None, counter=None):
         """Leaf evaluation (MCTS.py:123-127) and Node.update_recursive."""
         L = _lib.lib()
-        if self.lmbda < 1.0:
+        if self.lmbda < 1.0 and self.value_cache:
+            # the value net on the leaves without a stored value only (device-side list + count)
+            check(L.iago_mcts_fresh_leaves(self.tree.ref(), _p(active), _p(self.cur_node), _p(self._fresh_idx),
+                                           _p(self._fresh_count), _p(self._value_total), _stream()),
+                  "iago_mcts_fresh_leaves")
+            with torch.no_grad():
+                self.value_fn.forward_boards_counted(self.cur_own, self.cur_opp, self._fresh_idx,
+                                                     self._fresh_count, self.v)
+        elif self.lmbda < 1.0:
             v = None
             fb = getattr(self.value_fn, "forward_boards", None)
             with torch.no_grad():
@@ -421,7 +454,7 @@ class BatchedMCTS(object):
     def _graph_state(self):
         """What the captured graph baked in: device pointers and versions of every weight
         (and of the layouts cached from them), the rollout table, the scalar arguments."""
-        key = [self.lmbda, self.c_puct, self.n_thr, self.lookahead,
+        key = [self.lmbda, self.c_puct, self.n_thr, self.lookahead, self.value_cache,
                self.stats.data_ptr() if self.stats is not None else 0,
                self.rollout_weights.table.data_ptr() if self.rollout_weights is not None else 0]
         for fn in (self.policy_fn, self.value_fn):
@@ -441,7 +474,12 @@ class BatchedMCTS(object):
         # one eager evaluation of both nets first: lazy one-time setup (kernel attributes,
         # MIOpen's choice for this shape, weight layouts cached per weight version) must not
         # happen under capture.  Neither touches the trees.
-        if self.lmbda < 1.0:
+        if self.lmbda < 1.0 and self.value_cache:
+            self._fresh_count.zero_()
+            with torch.no_grad():
+                self.value_fn.forward_boards_counted(self.cur_own, self.cur_opp, self._fresh_idx,
+                                                     self._fresh_count, self.v)
+        elif self.lmbda < 1.0:
             ops.encode_planes(self.cur_own, self.cur_opp, out=self.planes)
             with torch.no_grad():
                 fb = getattr(self.value_fn, "forward_boards", None)
@@ -503,6 +541,13 @@ class BatchedMCTS(object):
             [active.sum().to(torch.int64), self.tree.n_nodes.max().to(torch.int64)]).tolist())
         if n_active == 0:
             return
+        if self.value_cache:
+            # the stored values belong to the weights that computed them
+            key = tuple((q.data_ptr(), q._version) for q in self.value_fn.parameters())
+            if key != self._value_key:
+                if self._value_key is not None:
+                    self.tree.v.fill_(float("nan"))
+                self._value_key = key
         if used > self.tree.capacity // 2 and used > self._live_after_compaction * 5 // 4:
             # a pool is half full: free the nodes that subtree reuse left behind (what the
             # reference's garbage collector does after MCTS.py:149-152) before this search adds

@@ -299,6 +299,21 @@ class Value(nn.Module, _NpzMixin):
                                        self.fc10.weight, self.fc11.weight,
                                        overflow=self._overflow_flag(device))
 
+    def forward_boards_counted(self, own, opp, index, n_dev, out):
+        """The net on boards index[0 .. *n_dev) only (int64 gather list and int32 count on the
+        device: the leaves of a playout that have no cached value), values to out[index[i]];
+        one enqueue whatever the count (iago_value_forward_split picks its variant on the
+        device).  Split-f16 path for every count."""
+        if not (self.split_f16 and own.is_cuda and not self.training and not torch.is_grad_enabled()
+                and not torch.is_autocast_enabled()):
+            raise ValueError("forward_boards_counted: CUDA boards, eval mode, split_f16")
+        from . import ops
+        layers = [self._split_weights(k) + (getattr(self, "block%d" % k).conv.bias,) for k in range(2, 9)]
+        return ops.value_forward_split((own, opp), self.block1.conv.weight, self.block1.conv.bias, layers,
+                                       self._head_weights(), self.block9.conv.weight, self.block9.conv.bias,
+                                       self.fc10.weight, self.fc11.weight,
+                                       overflow=self._overflow_flag(own.device), index=index, n_dev=n_dev, out=out)
+
     def forward_boards(self, own, opp):
         """forward(make_state_var(...)) for int64 bitboards (own = side to move) without the
         planes tensor, when the split-f16 path applies; None otherwise."""

@@ -261,10 +261,13 @@ def split_head_weights(w9):
     return hi.contiguous(), lo.contiguous()
 
 
-def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None):
+def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None, index=None, n_dev=None,
+                        out=None):
     """The whole Value net in one launch (iago_value_forward_split).  x: float32 planes
     (n, 2, 8, 8) or a pair (own, opp) of int64 bitboards (own = side to move); layers: the 7
-    (w_hi, w_lo, bias) of blocks 2..8 (split_weights); head: split_head_weights(w9)."""
+    (w_hi, w_lo, bias) of blocks 2..8 (split_weights); head: split_head_weights(w9).
+    index / n_dev (boards only): evaluate boards index[0 .. min(n, *n_dev)) and write their
+    values to out[index[i]] (out: (n_boards,) float32, the other entries untouched)."""
     a = _lib.ValueSplitArgs()
     if isinstance(x, tuple):
         own, opp = x
@@ -289,8 +292,17 @@ def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None
     a.w9_hi, a.w9_lo = _dev(head[0], torch.float16, "w9_hi").value, _dev(head[1], torch.float16, "w9_lo").value
     a.b9 = _dev(b9, torch.float32, "b9").value
     a.w10, a.w11 = _dev(w10, torch.float32, "w10").value, _dev(w11, torch.float32, "w11").value
-    out = torch.empty((n,), dtype=torch.float32, device=dev)
-    a.out = out.data_ptr()
+    if index is not None:
+        if not isinstance(x, tuple) or out is None:
+            raise ValueError("value_forward_split: a gather list needs (own, opp) boards and an `out` buffer")
+        n = min(index.numel(), n)
+        a.n = n
+        a.index = _dev(index, torch.int64, "index").value
+    if n_dev is not None:
+        a.n_dev = _dev(n_dev, torch.int32, "n_dev").value
+    if out is None:
+        out = torch.empty((n,), dtype=torch.float32, device=dev)
+    a.out = _dev(out, torch.float32, "out").value
     f = _flag(overflow)
     a.overflow = f.value if f is not None else None
     check(_lib.lib().iago_value_forward_split(C.byref(a), _stream()), "iago_value_forward_split")

@@ -305,6 +305,9 @@ IAGO_API int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32
  *   [8 chunks of 16 input channels][32 rows][16] f16, row r < 9 = kernel tap r (ky*3+kx),
  *   rows 9..31 zero, split like every weight (hi = f16(w), lo = f16((w - hi) * 2^11)).
  *   b9 [1], w10 [128][64], w11 [1][128], out [n].  overflow: see iago_conv3x3_split.
+ * Up to 512 rows a workgroup takes two boards instead of four (twice the workgroups, half the
+ * latency of each; the same products in the same order per board: bit-identical values); with
+ * a device-side count both variants are enqueued and the one the count selects runs.
  */
 typedef struct iago_value_split_args {
     const float *planes;
@@ -317,6 +320,9 @@ typedef struct iago_value_split_args {
     const float *b9, *w10, *w11;
     float *out;
     uint32_t *overflow;
+    const int64_t *index;  /* optional gather list (boards only): row b evaluates board index[b] of own / opp
+                              and writes out[index[b]] -- the leaves of a playout that need the net */
+    const int32_t *n_dev;  /* optional device-side row count: only the first min(n, *n_dev) rows */
 } iago_value_split_args;
 IAGO_API int iago_value_forward_split(const iago_value_split_args *args, void *stream);
 IAGO_API int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels,
@@ -350,6 +356,8 @@ typedef struct iago_mcts_tree {
     int32_t *n_nodes;      /* [n_games] nodes allocated so far */
     int32_t *root;         /* [n_games] local id of the current root */
     int32_t *overflow;     /* [n_games] set to 1 when an expansion did not fit */
+    float *v;              /* optional [n_games*capacity]: value_func(node) once evaluated, NaN before
+                              (the value cache, see iago_mcts_fresh_leaves); NULL = no cache */
 } iago_mcts_tree;
 
 /*
@@ -509,6 +517,23 @@ IAGO_API int iago_mcts_store_priors(const iago_mcts_lookahead *la, const float *
 IAGO_API int iago_mcts_expand_cached(const iago_mcts_tree *tree, const uint8_t *active, const uint8_t *needs_expand,
                                      const int32_t *cur_node, const uint64_t *legal, const iago_mcts_lookahead *la,
                                      uint8_t *expanded, void *stream);
+
+/*
+ * Value cache.  MCTS.playout evaluates value_func(state) at every visit of a leaf
+ * (MCTS.py:97-103,123-124) -- n_thr times for a leaf that goes on to expand, with the same
+ * result every time: the net is a pure function of the position (the rollout, MCTS.py:125, is
+ * not, and runs every time).  With `v` in the tree the value of a node is computed at its first
+ * visit only: iago_mcts_fresh_leaves lists the active games whose leaf (cur_node) has no value
+ * yet (index[0 .. *count), ascending; *total += *count when given), the value net runs on
+ * those boards (iago_value_forward_split with index / n_dev: values to v_out[game]), and
+ * iago_mcts_mix_backup(_lookahead) stores the new values into the tree and takes the stored
+ * one for every other leaf.  ~85 % of a search's value evaluations go away; the trees are
+ * bit-identical (the net's output for a board does not depend on its batch).  iago_mcts_reset,
+ * expansion and iago_mcts_advance_root mark new nodes as not evaluated; after a change of the
+ * value net's weights the caller fills `v` with NaN.
+ */
+IAGO_API int iago_mcts_fresh_leaves(const iago_mcts_tree *tree, const uint8_t *active, const int32_t *cur_node,
+                                    int64_t *index, int32_t *count, int64_t *total, void *stream);
 
 #ifdef __cplusplus
 }

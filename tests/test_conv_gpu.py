@@ -239,6 +239,38 @@ def test_fused_value_forward_equals_three_launches(n):
     m.check_saturation()
 
 
+@pytest.mark.parametrize("count", [0, 1, 7, 200, 512, 513, 1000])
+def test_counted_value_forward_is_bit_identical(count):
+    """iago_value_forward_split with a device-side gather list and count (what the value cache
+    runs: two boards per workgroup up to 512 rows, four above, chosen on the device) against the
+    plain forward of all boards: the listed boards get bit-identical values, the others are not
+    written."""
+    from iago_amd import network, ops
+    from tests.gpu_util import random_positions
+    torch.manual_seed(32)
+    m = network.Value().eval().cuda()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.6)
+    n = 1024
+    own, opp = random_positions(n, seed=77)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    gen = torch.Generator().manual_seed(count)
+    pick = torch.randperm(n, generator=gen)[:count].sort().values.cuda()
+    index = torch.zeros(n, dtype=torch.int64, device="cuda")
+    index[:count] = pick
+    n_dev = torch.tensor([count], dtype=torch.int32, device="cuda")
+    with torch.no_grad():
+        full = m.forward_boards(o, p)                      # 1024 rows: four boards per workgroup
+        out = torch.full((n,), -77.0, dtype=torch.float32, device="cuda")
+        m.forward_boards_counted(o, p, index, n_dev, out)
+    assert torch.equal(out[pick], full[pick])
+    rest = torch.ones(n, dtype=torch.bool, device="cuda")
+    rest[pick] = False
+    assert bool((out[rest] == -77.0).all())
+    m.check_saturation()
+
+
 def test_trunk_kernel_equals_layer_by_layer():
     """iago_conv3x3_split_trunk (several layers, one launch) must reproduce the per-layer
     launches bit for bit, for a ragged batch and a 64-channel first layer."""

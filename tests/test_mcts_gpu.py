@@ -394,6 +394,64 @@ def test_policy_lookahead_builds_the_same_trees(eng, n_thr, K, use_graph, cap):
     assert n_thr != 15 or la.n_policy_evals < 2 * ref.n_policy_evals
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_value_cache_builds_the_same_trees(eng, use_graph):
+    """Value cache (the value net only on leaves it has not evaluated yet, every other visit takes
+    the value stored in the node) against the reference's evaluation at every visit
+    (MCTS.py:123-124): bit-identical trees -- visit counts, float32 Q, P, child order -- and
+    moves over several moves with subtree reuse and compaction; the cache saves most evaluations;
+    after an update of the value weights the stored values are dropped."""
+    engine, ops = eng
+    from iago_amd import network
+    g = __import__("tests.conftest", fromlist=["load_json"]).load_json("simulate.json")
+    torch.manual_seed(6)
+    policy, value = network.SLPolicy().cuda().eval(), network.Value().cuda().eval()
+    w = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    G, cap = 256, 96    # >= 192 games: the uncached engine runs the same split-f16 kernels on all leaves
+    own, opp = random_positions(G, seed=18)
+    own[:50] = 0x0000000810000000
+    opp[:50] = 0x0000001008000000
+
+    def make(cache):
+        return engine.BatchedMCTS(G, policy, value, w, n_thr=15, capacity=cap, seed=21, sync_free=True,
+                                  value_cache=cache, use_graph=use_graph)
+
+    ref, vc = make(False), make(True)
+    assert not ref.value_cache and vc.value_cache and ref.tree.v is None
+    oa, pa = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    ob, pb = oa.clone(), pa.clone()
+    for t, n_sims in enumerate([70, 50, 61, 44, 37]):
+        active = (ops.legal_moves(oa, pa) != 0).to(torch.uint8)
+        ref.search(oa, pa, active, n_sims)
+        vc.search(ob, pb, active, n_sims)
+        ma, va = ref.best_move(active)
+        mb, vb = vc.best_move(active)
+        act = active.bool()
+        assert torch.equal(ma[act], mb[act]) and torch.equal(va[act], vb[act]), t
+        mv = torch.where(act, ma, torch.full_like(ma, -1))
+        for m_, o_, p_ in ((ref, oa, pa), (vc, ob, pb)):
+            ops.apply_moves(o_, p_, mv)
+            m_.update_with_move(mv)
+        oa, pa, ob, pb = pa, oa, pb, ob
+    assert ref.n_compactions == vc.n_compactions > 0
+    for gi in range(0, G, 3):
+        assert ref.tree.dump(gi, max_depth=64) == vc.tree.dump(gi, max_depth=64), gi
+    assert ref.n_value_evals == ref.n_leaf_evals == vc.n_leaf_evals
+    assert vc.n_value_evals < 0.4 * vc.n_leaf_evals, (vc.n_value_evals, vc.n_leaf_evals)
+    # new weights: every stored value is recomputed (one fresh evaluation per visited leaf)
+    with torch.no_grad():
+        value.fc11.weight.mul_(1.5)
+    before = vc.n_value_evals
+    active = (ops.legal_moves(ob, pb) != 0).to(torch.uint8)
+    ref.search(oa, pa, active, 20)
+    vc.search(ob, pb, active, 20)
+    assert vc.n_value_evals - before >= int(active.sum().item())   # at least the roots were re-evaluated
+    for gi in range(0, G, 5):
+        assert ref.tree.dump(gi, max_depth=64) == vc.tree.dump(gi, max_depth=64), gi
+    with torch.no_grad():
+        value.fc11.weight.div_(1.5)
+
+
 def test_policy_lookahead_reports_a_recycled_cache_slot(eng):
     engine, ops = eng
     from iago_amd import _lib, network
