@@ -80,7 +80,7 @@ template <bool FUSED, int TB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void trunk_resident_kernel(TrunkRParams P)
 {
     constexpr int NT = 2 * TB;      // 32-cell tiles of a wave: TB boards x 2 halves
-    constexpr int NPAIR = TB / 2;   // board pairs (address sets)
+    constexpr int NPAIR = (TB + 1) / 2; // board pairs (address sets)
     char *const T = trunk_lds;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int64_t b0 = (int64_t)blockIdx.x * TB;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int c = 0; c < 16; c++) {
                 const float4 wq = w10row[c];
                 const float4 x0 = *(const float4 *)(h9s + pb * 64 + 4 * c);
-                const float4 x1 = *(const float4 *)(h9s + (pb + 1) * 64 + 4 * c);
+                const float4 x1 = *(const float4 *)(h9s + (pb + 1 < TB ? pb + 1 : pb) * 64 + 4 * c);
                 s0 = fmaf(wq.x, x0.x, s0);
                 s0 = fmaf(wq.y, x0.y, s0);
                 s0 = fmaf(wq.z, x0.z, s0);
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 s1 = fmaf(wq.w, x1.w, s1);
             }
             hid[pb * 128 + j] = s0 * w11j;
-            hid[(pb + 1) * 128 + j] = s1 * w11j;
+            if (pb + 1 < TB)
+                hid[(pb + 1) * 128 + j] = s1 * w11j;
         }
         __syncthreads();
         if (tid < TB && b0 + tid < n_rows) {
@@ -516,6 +517,18 @@ int iago_launch_trunk_resident(const iago_conv_split_layer *layers, int32_t n_la
     return iago_check_launch("iago_conv3x3_split_trunk");
 }
 
+namespace {
+// rows up to which a workgroup takes ONE board (tuning knob: IAGO_VALUE_TINY, default 256)
+int64_t iago_value_tiny_rows()
+{
+    static const int64_t v = [] {
+        const char *e = getenv("IAGO_VALUE_TINY");
+        return e ? (int64_t)atoll(e) : (int64_t)256;
+    }();
+    return v;
+}
+} // namespace
+
 int iago_value_forward_split(const iago_value_split_args *a, void *stream)
 {
     if (!a || a->n < 0)
@@ -561,29 +574,41 @@ int iago_value_forward_split(const iago_value_split_args *a, void *stream)
         return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: a gather list needs the boards, not planes");
     P.index = a->index;
     P.n_dev = a->n_dev;
-    static std::atomic<uint64_t> configured4{0}, configured2{0};
+    static std::atomic<uint64_t> configured4{0}, configured2{0}, configured1{0};
     if (iago_reserve_lds((const void *)trunk_resident_kernel<true, 4>, lds_alloc_fused(4), configured4,
                          "iago_value_forward_split: cannot reserve 148 KB of LDS") ||
         iago_reserve_lds((const void *)trunk_resident_kernel<true, 2>, lds_alloc_fused(2), configured2,
-                         "iago_value_forward_split: cannot reserve 75 KB of LDS"))
+                         "iago_value_forward_split: cannot reserve 75 KB of LDS") ||
+        iago_reserve_lds((const void *)trunk_resident_kernel<true, 1>, lds_alloc_fused(1), configured1,
+                         "iago_value_forward_split: cannot reserve 39 KB of LDS"))
         return IAGO_ERR_HIP;
-    // Two boards per workgroup up to SMALL rows (twice the workgroups, half the latency of
-    // each: the launch is latency-bound until the chip is full), four above.  Same products
-    // in the same order per board: bit-identical values.  With a device-side count both
-    // variants are enqueued and the one whose window holds the count runs.
-    constexpr int64_t SMALL = 512;
+    // Boards per workgroup by the number of rows: the launch is latency-bound until the chip is
+    // full, so fewer boards per workgroup (more workgroups, each with a shorter chain) win for
+    // small batches: one up to TINY rows, two up to SMALL, four above.  Same products in the same
+    // order per board: bit-identical values.  With a device-side count every variant whose
+    // window the bound n reaches is enqueued and the one that holds the count runs.
+    const int64_t TINY = iago_value_tiny_rows(), SMALL = 512;
     const bool host_known = a->n_dev == nullptr;
-    if (!host_known || a->n <= SMALL) {
+    const int64_t rows = a->n;
+    if (!host_known || rows <= TINY) {
         P.count_lo = 0;
+        P.count_hi = (int32_t)TINY;
+        const int64_t r = rows < TINY ? rows : TINY;
+        if (TINY > 0)
+            hipLaunchKernelGGL((trunk_resident_kernel<true, 1>), dim3((unsigned)r), dim3(256), lds_alloc_fused(1),
+                               (hipStream_t)stream, P);
+    }
+    if (rows > TINY && (!host_known || rows <= SMALL)) {
+        P.count_lo = host_known ? 0 : (int32_t)TINY;
         P.count_hi = (int32_t)SMALL;
-        const int64_t rows = a->n < SMALL ? a->n : SMALL;
-        hipLaunchKernelGGL((trunk_resident_kernel<true, 2>), dim3((unsigned)((rows + 1) / 2)), dim3(256),
+        const int64_t r = rows < SMALL ? rows : SMALL;
+        hipLaunchKernelGGL((trunk_resident_kernel<true, 2>), dim3((unsigned)((r + 1) / 2)), dim3(256),
                            lds_alloc_fused(2), (hipStream_t)stream, P);
     }
-    if (a->n > SMALL) {
+    if (rows > SMALL) {
         P.count_lo = host_known ? 0 : (int32_t)SMALL;
         P.count_hi = 0x7fffffff;
-        hipLaunchKernelGGL((trunk_resident_kernel<true, 4>), dim3((unsigned)((a->n + 3) / 4)), dim3(256),
+        hipLaunchKernelGGL((trunk_resident_kernel<true, 4>), dim3((unsigned)((rows + 3) / 4)), dim3(256),
                            lds_alloc_fused(4), (hipStream_t)stream, P);
     }
     return iago_check_launch("iago_value_forward_split");
