@@ -154,7 +154,7 @@ class BatchedMCTS(object):
 
     def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
                  n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False,
-                 sync_free=None, lookahead=None, lookahead_slots=None, value_cache=None):
+                 sync_free=None, lookahead=None, lookahead_slots=None, value_cache=None, lookahead_overlap=None):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         self.n_games = n_games
@@ -211,14 +211,25 @@ class BatchedMCTS(object):
         # board-fed policy net applies and n_thr leaves room for it; 0 = the net runs inside the
         # playout that expands (the reference's order of evaluation).  Same trees either way.
         can = (self.sync_free and getattr(policy_fn, "forward_counted_boards", None) is not None)
+        import os
         if lookahead is None:
-            import os
             k = int(os.environ.get("IAGO_LOOKAHEAD", "4"))   # (tuning knob: tools/)
-            lookahead = k if (can and self.n_thr > k) else 0
-        if lookahead and not (can and self.n_thr > lookahead):
-            raise ValueError("lookahead needs the sync-free playout, a policy net with "
-                             "forward_counted_boards and n_thr > lookahead")
+            lookahead = k if (can and self.n_thr > k + 1) else 0
+        # lookahead_overlap = j: the policy batch of a group of K playouts runs on a second stream
+        # BESIDE the first j playouts of the next group (0: at the end of its own group, on the
+        # same stream); leaves are then queued j - 1 visits earlier so that their priors are
+        # stored before any of them can expand.
+        if lookahead_overlap is None:
+            lookahead_overlap = int(os.environ.get("IAGO_LOOKAHEAD_OVERLAP", "2"))
         self.lookahead = int(lookahead)
+        j = min(int(lookahead_overlap), max(self.lookahead - 1, 0)) if self.lookahead else 0
+        while j > 0 and not self.n_thr > self.lookahead + j - 1:
+            j -= 1   # n_thr leaves no room to queue the leaves that much earlier
+        self.lookahead_overlap = j
+        margin = self.lookahead + max(self.lookahead_overlap - 1, 0)
+        if self.lookahead and not (can and self.n_thr > margin):
+            raise ValueError("lookahead needs the sync-free playout, a policy net with "
+                             "forward_counted_boards and n_thr > lookahead (+ overlap - 1)")
         if self.lookahead:
             K = self.lookahead
             slots = int(lookahead_slots) if lookahead_slots else max(256, capacity // 8)
@@ -226,20 +237,24 @@ class BatchedMCTS(object):
             self._la_next_seq = torch.zeros(n_games, dtype=torch.int32, **kw)
             self._la_cache_seq = torch.full((n_games, slots), -1, dtype=torch.int32, **kw)
             self._la_cache = torch.zeros((n_games, slots, 64), dtype=torch.float32, **kw)
-            self._la_q_count = torch.zeros(1, dtype=torch.int32, **kw)
-            self._la_q_own = torch.zeros(Q, dtype=torch.int64, **kw)
-            self._la_q_opp = torch.zeros(Q, dtype=torch.int64, **kw)
-            self._la_q_game = torch.zeros(Q, dtype=torch.int32, **kw)
-            self._la_q_seq = torch.zeros(Q, dtype=torch.int32, **kw)
             self._la_error = torch.zeros(1, dtype=torch.int32, **kw)
-            a = _lib.MctsLookahead()
-            a.trigger, a.slots, a.q_capacity = self.n_thr - K, slots, Q
-            a.next_seq, a.cache_seq = self._la_next_seq.data_ptr(), self._la_cache_seq.data_ptr()
-            a.cache, a.q_count = self._la_cache.data_ptr(), self._la_q_count.data_ptr()
-            a.q_own, a.q_opp = self._la_q_own.data_ptr(), self._la_q_opp.data_ptr()
-            a.q_game, a.q_seq = self._la_q_game.data_ptr(), self._la_q_seq.data_ptr()
-            a.error = self._la_error.data_ptr()
-            self._la = a
+            # two queues: the playouts of a group fill one while the other one's batch is in flight
+            self._la_queues, self._la = [], []
+            for _ in range(2):
+                q = dict(count=torch.zeros(1, dtype=torch.int32, **kw), own=torch.zeros(Q, dtype=torch.int64, **kw),
+                         opp=torch.zeros(Q, dtype=torch.int64, **kw), game=torch.zeros(Q, dtype=torch.int32, **kw),
+                         seq=torch.zeros(Q, dtype=torch.int32, **kw))
+                a = _lib.MctsLookahead()
+                a.trigger, a.slots, a.q_capacity = self.n_thr - margin, slots, Q
+                a.next_seq, a.cache_seq = self._la_next_seq.data_ptr(), self._la_cache_seq.data_ptr()
+                a.cache, a.q_count = self._la_cache.data_ptr(), q["count"].data_ptr()
+                a.q_own, a.q_opp = q["own"].data_ptr(), q["opp"].data_ptr()
+                a.q_game, a.q_seq = q["game"].data_ptr(), q["seq"].data_ptr()
+                a.error = self._la_error.data_ptr()
+                self._la_queues.append(q)
+                self._la.append(a)
+            self._la_cur = 0   # the queue the playouts fill
+            self._la_side = torch.cuda.Stream(device=device) if self.lookahead_overlap else None
 
             def reset_lookahead(mask):
                 if mask is None:
@@ -401,7 +416,7 @@ class BatchedMCTS(object):
                 self.tree.ref(), _p(active), _p(self.cur_node), _p(self.cur_own), _p(self.cur_opp),
                 _p(self.v) if self.lmbda < 1.0 else None, _p(self.z) if self.lmbda > 0.0 else None,
                 self.lmbda, _p(self.leaf_value), _p(counter) if counter is not None else None,
-                C.byref(self._la), _stream()), "iago_mcts_mix_backup_lookahead")
+                C.byref(self._la[self._la_cur]), _stream()), "iago_mcts_mix_backup_lookahead")
             return
         check(L.iago_mcts_mix_backup(self.tree.ref(), _p(active), _p(self.cur_node),
                                      _p(self.v) if self.lmbda < 1.0 else None,
@@ -416,24 +431,69 @@ class BatchedMCTS(object):
         L = _lib.lib()
         self._select(own, opp, active, True)
         check(L.iago_mcts_expand_cached(self.tree.ref(), _p(active), _p(self.needs_expand), _p(self.cur_node),
-                                        _p(self.legal), C.byref(self._la), _p(self._pending), _stream()),
+                                        _p(self.legal), C.byref(self._la[0]), _p(self._pending), _stream()),
               "iago_mcts_expand_cached")
         self._select(own, opp, self._pending, False)  # MCTS.py:121: recurse into the same node
         self._evaluate_and_backup(active, stream_id=stream_id, stream_id_dev=stream_id_dev, counter=counter)
 
-    def _flush_lookahead(self):
-        """The policy net on the queued leaves (one batch), its outputs into the prior cache."""
-        n = self._la_q_own.numel()
-        probs = self.policy_fn.forward_counted_boards(self._la_q_own, self._la_q_opp, None, n, self._la_q_count)
-        check(_lib.lib().iago_mcts_store_priors(C.byref(self._la), _p(probs), _p(self._pend_total), _stream()),
-              "iago_mcts_store_priors")
-        self._la_q_count.zero_()
+    def _flush_lookahead(self, which=0):
+        """The policy net on the leaves of queue `which` (one batch), its outputs into the prior
+        cache; the queue is empty afterwards."""
+        q = self._la_queues[which]
+        n = q["own"].numel()
+        probs = self.policy_fn.forward_counted_boards(q["own"], q["opp"], None, n, q["count"])
+        check(_lib.lib().iago_mcts_store_priors(C.byref(self._la[which]), _p(probs), _p(self._pend_total),
+                                                _stream()), "iago_mcts_store_priors")
+        q["count"].zero_()
+
+    def _lookahead_block(self, own, opp, active, stream_ids):
+        """Two groups of K playouts.  On entry queue 1 may hold the leaves of the previous block's
+        second group and queue 0 is empty; on exit the same.  With lookahead_overlap = j > 0 the
+        batch of the previous group runs on the side stream beside the first j playouts of a group
+        (its leaves were queued early enough for that); with 0 every group ends with its own
+        batch on the one stream.  stream_ids: None (the device word, graph capture / replay) or an
+        iterator of 2 K Philox stream ids."""
+        K, j = self.lookahead, self.lookahead_overlap
+        main = torch.cuda.current_stream()
+        for grp in (0, 1):
+            self._la_cur = grp
+            if j:
+                self._la_side.wait_stream(main)
+                with torch.cuda.stream(self._la_side):
+                    self._flush_lookahead(1 - grp)
+            for i in range(K):
+                if j and i == j:
+                    main.wait_stream(self._la_side)
+                if stream_ids is None:
+                    self._playout_lookahead(own, opp, active, stream_id=0, stream_id_dev=self._sim_dev,
+                                            counter=self._sim_dev)
+                else:
+                    self._playout_lookahead(own, opp, active, stream_id=next(stream_ids))
+            if not j:
+                self._flush_lookahead(grp)
+        self._la_cur = 0
+
+    def _lookahead_tail(self, own, opp, active, n, stream_ids):
+        """The rest of a search after its whole blocks: queue 1's batch, then n < 2 K playouts with
+        a batch after every K of them and at the end (one stream); both queues end empty."""
+        if self.lookahead_overlap:
+            self._flush_lookahead(1)
+        self._la_cur = 0
+        for i in range(n):
+            if stream_ids is None:
+                self._playout_lookahead(own, opp, active, stream_id=0, stream_id_dev=self._sim_dev,
+                                        counter=self._sim_dev)
+            else:
+                self._playout_lookahead(own, opp, active, stream_id=next(stream_ids))
+            if (i + 1) % self.lookahead == 0 or i + 1 == n:
+                self._flush_lookahead(0)
 
     def simulate(self, own, opp, active, n_active=None):
         """One MCTS.playout for every active game (eager launches)."""
         if self.lookahead:
+            self._la_cur = 0
             self._playout_lookahead(own, opp, active, stream_id=self.sim_counter)
-            self._flush_lookahead()  # a lone playout flushes at once: the queue is empty between calls
+            self._flush_lookahead(0)  # a lone playout flushes at once: the queues are empty between calls
             self.sim_counter = (self.sim_counter + 1) & 0xFFFFFFFF
             if n_active is not None:
                 self.n_leaf_evals += n_active
@@ -454,7 +514,7 @@ class BatchedMCTS(object):
     def _graph_state(self):
         """What the captured graph baked in: device pointers and versions of every weight
         (and of the layouts cached from them), the rollout table, the scalar arguments."""
-        key = [self.lmbda, self.c_puct, self.n_thr, self.lookahead, self.value_cache,
+        key = [self.lmbda, self.c_puct, self.n_thr, self.lookahead, self.lookahead_overlap, self.value_cache,
                self.stats.data_ptr() if self.stats is not None else 0,
                self.rollout_weights.table.data_ptr() if self.rollout_weights is not None else 0]
         for fn in (self.policy_fn, self.value_fn):
@@ -490,16 +550,14 @@ class BatchedMCTS(object):
             self._policy_counted(self._policy_in[:self.n_games], self._pend_count)
         torch.cuda.synchronize()
         if self.lookahead:
-            self._flush_lookahead()  # (queue empty: allocations and one-time setup only)
+            self._flush_lookahead(0)  # (queues empty: allocations and one-time setup only)
+            self._flush_lookahead(1)
             torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             if self.lookahead:
-                # K playouts and the flush of the leaves they queued: ONE replay
-                for _ in range(self.lookahead):
-                    self._playout_lookahead(self._g_own, self._g_opp, self._g_active, stream_id=0,
-                                            stream_id_dev=self._sim_dev, counter=self._sim_dev)
-                self._flush_lookahead()
+                # 2 K playouts and the policy batches of the leaves they queue: ONE replay
+                self._lookahead_block(self._g_own, self._g_opp, self._g_active, None)
             else:
                 self._select(self._g_own, self._g_opp, self._g_active, True)
                 self._expand_pending_counted(self._g_own, self._g_opp, self._g_active)
@@ -520,14 +578,11 @@ class BatchedMCTS(object):
         self._sim_dev.fill_(self.sim_counter - (1 << 32) if self.sim_counter >= (1 << 31)
                             else self.sim_counter)
         if self.lookahead:
-            for _ in range(n_sims // self.lookahead):
+            block = 2 * self.lookahead
+            for _ in range(n_sims // block):
                 self._graph.replay()
-            rest = n_sims % self.lookahead
-            for _ in range(rest):  # the same launches, not captured
-                self._playout_lookahead(self._g_own, self._g_opp, self._g_active, stream_id=0,
-                                        stream_id_dev=self._sim_dev, counter=self._sim_dev)
-            if rest:
-                self._flush_lookahead()
+            # the same launches, not captured
+            self._lookahead_tail(self._g_own, self._g_opp, self._g_active, n_sims % block, None)
         else:
             for _ in range(n_sims):
                 self._graph.replay()
@@ -560,11 +615,12 @@ class BatchedMCTS(object):
         if self.use_graph:
             self._search_graph(own, opp, active, n_sims, n_active)
         elif self.lookahead:
-            for i in range(n_sims):
-                self._playout_lookahead(own, opp, active, stream_id=self.sim_counter)
-                self.sim_counter = (self.sim_counter + 1) & 0xFFFFFFFF
-                if (i + 1) % self.lookahead == 0 or i + 1 == n_sims:
-                    self._flush_lookahead()
+            block = 2 * self.lookahead
+            ids = iter([(self.sim_counter + i) & 0xFFFFFFFF for i in range(n_sims)])
+            for _ in range(n_sims // block):
+                self._lookahead_block(own, opp, active, ids)
+            self._lookahead_tail(own, opp, active, n_sims % block, ids)
+            self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
             self.n_leaf_evals += n_active * n_sims
         else:
             for _ in range(n_sims):
@@ -580,7 +636,7 @@ class BatchedMCTS(object):
                     "the queue overflowed" if err == 1 else
                     "a leaf reached n_thr without cached priors (raise `lookahead_slots`, now %d per "
                     "game; the look-ahead must be on from the reset of the trees and n_thr must "
-                    "not change)" % self._la.slots))
+                    "not change)" % self._la[0].slots))
         sat = getattr(self.value_fn, "check_saturation", None)
         if sat is not None:
             sat()  # the split-f16 Value kernels clamp at 65000: never silently

@@ -343,14 +343,17 @@ def test_sync_free_equals_host_counted_with_real_nets(eng):
     assert torch.equal(a[5], b[5])
 
 
-@pytest.mark.parametrize("n_thr,K,use_graph,cap", [(15, 4, False, 128), (15, 4, True, 128), (6, 4, False, 512),
-                                                   (9, 8, True, 256), (15, 1, False, 128)])
-def test_policy_lookahead_builds_the_same_trees(eng, n_thr, K, use_graph, cap):
+@pytest.mark.parametrize("n_thr,K,use_graph,cap,overlap", [(15, 4, False, 128, 2), (15, 4, True, 128, 2),
+                                                           (15, 4, True, 128, 1), (15, 4, True, 128, 0),
+                                                           (6, 4, False, 512, 2), (9, 8, True, 256, 2),
+                                                           (15, 1, False, 128, 0)])
+def test_policy_lookahead_builds_the_same_trees(eng, n_thr, K, use_graph, cap, overlap):
     """Policy look-ahead (leaves queued K visits before they expand, the policy net on the queue
     every K playouts, priors from a cache) against the reference's order of evaluation (the net
     inside the playout that expands): bit-identical trees -- visit counts, Q, P, child order --
     and moves, over several moves with subtree reuse, small pools that compact on the way and
-    playout counts that are not multiples of K."""
+    playout counts that are not multiples of K; with the batch of a group at the group's end
+    (overlap 0) or on a second stream beside the first playouts of the next group."""
     engine, ops = eng
     from iago_amd import network
     g = __import__("tests.conftest", fromlist=["load_json"]).load_json("simulate.json")
@@ -364,7 +367,8 @@ def test_policy_lookahead_builds_the_same_trees(eng, n_thr, K, use_graph, cap):
 
     def make(lookahead):
         return engine.BatchedMCTS(G, policy, value, w, n_thr=n_thr, capacity=cap, seed=13, sync_free=True,
-                                  lookahead=lookahead, use_graph=use_graph and lookahead > 0)
+                                  lookahead=lookahead, lookahead_overlap=overlap,
+                                  use_graph=use_graph and lookahead > 0)
 
     ref, la = make(0), make(K)
     assert ref.lookahead == 0 and la.lookahead == K
