@@ -76,22 +76,14 @@ __device__ __forceinline__ int cell_of_lane(int r)
 
 extern __shared__ __align__(16) char trunk_lds[];
 
+// The work of one workgroup on the TB boards (rows) b0 .. b0 + TB - 1 of n_rows.
 template <bool FUSED, int TB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void trunk_resident_kernel(TrunkRParams P)
+__device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t b0, const int64_t n_rows)
 {
     constexpr int NT = 2 * TB;      // 32-cell tiles of a wave: TB boards x 2 halves
     constexpr int NPAIR = (TB + 1) / 2; // board pairs (address sets)
     char *const T = trunk_lds;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int64_t b0 = (int64_t)blockIdx.x * TB;
-    int64_t n_rows = P.n;
-    if constexpr (FUSED) {
-        // device-side row count and variant choice: uniform over the launch, before any barrier
-        if (P.n_dev)
-            n_rows = min(P.n, (int64_t)*P.n_dev);
-        if (n_rows <= P.count_lo || n_rows > P.count_hi || b0 >= n_rows)
-            return;
-    }
 
     // ---- the zero areas, then the input of the first layer
     if (tid < TB * (ZB / 16))
@@ -475,6 +467,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
+template <bool FUSED, int TB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void trunk_resident_kernel(TrunkRParams P)
+{
+    int64_t n_rows = P.n;
+    if constexpr (FUSED) {
+        // device-side row count and variant choice: uniform over the launch, before any barrier
+        if (P.n_dev)
+            n_rows = min(P.n, (int64_t)*P.n_dev);
+        if (n_rows <= P.count_lo || n_rows > P.count_hi)
+            return;
+    }
+    // a workgroup walks its rows with the grid's stride (one pass unless the grid was capped:
+    // the device-counted launch of the value cache, iago_value_forward_split)
+    for (int64_t b0 = (int64_t)blockIdx.x * TB; b0 < n_rows; b0 += (int64_t)gridDim.x * TB) {
+        trunk_item<FUSED, TB>(P, b0, n_rows);
+        __syncthreads(); // the next pass re-stages the LDS image the head just read
+    }
+}
+
 } // namespace
 
 // Called by iago_conv3x3_split_trunk (conv_kernels.hip) after it has validated the layers.
@@ -524,6 +535,16 @@ int64_t iago_value_tiny_rows()
     static const int64_t v = [] {
         const char *e = getenv("IAGO_VALUE_TINY");
         return e ? (int64_t)atoll(e) : (int64_t)256;
+    }();
+    return v;
+}
+// device-counted launches as one persistent launch of the one-board variant (IAGO_VALUE_PERSIST=0:
+// the three windowed variants)
+bool iago_value_persistent()
+{
+    static const bool v = [] {
+        const char *e = getenv("IAGO_VALUE_PERSIST");
+        return !(e && e[0] == '0');
     }();
     return v;
 }
@@ -590,6 +611,18 @@ int iago_value_forward_split(const iago_value_split_args *a, void *stream)
     const int64_t TINY = iago_value_tiny_rows(), SMALL = 512;
     const bool host_known = a->n_dev == nullptr;
     const int64_t rows = a->n;
+    if (!host_known && iago_value_persistent()) {
+        // Device-side count (the value cache: usually 15-20 % of the games have a leaf without a
+        // value): ONE launch of the one-board variant on a grid of at most one workgroup per CU,
+        // walking the rows with the grid's stride -- one pass up to 256 rows; the rare larger
+        // counts take more passes instead of two more (mostly empty) launches per playout.
+        P.count_lo = 0;
+        P.count_hi = 0x7fffffff;
+        const int64_t grid = rows < 256 ? rows : 256;
+        hipLaunchKernelGGL((trunk_resident_kernel<true, 1>), dim3((unsigned)grid), dim3(256), lds_alloc_fused(1),
+                           (hipStream_t)stream, P);
+        return iago_check_launch("iago_value_forward_split");
+    }
     if (!host_known || rows <= TINY) {
         P.count_lo = 0;
         P.count_hi = (int32_t)TINY;
