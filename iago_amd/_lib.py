@@ -31,7 +31,7 @@ SYMBOLS = [
     "iago_leaf_values",
     "iago_mcts_backup", "iago_mcts_mix_backup", "iago_mcts_best_move", "iago_mcts_advance_root", "iago_mcts_compact",
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
-    "iago_mcts_fresh_leaves",
+    "iago_mcts_fresh_leaves", "iago_mcts_descend",
 ]
 
 
@@ -66,7 +66,7 @@ class MctsLookahead(C.Structure):
         ("trigger", C.c_int32), ("slots", C.c_int32), ("next_seq", C.c_void_p), ("cache_seq", C.c_void_p),
         ("cache", C.c_void_p), ("q_count", C.c_void_p), ("q_capacity", C.c_int32), ("reserved", C.c_int32),
         ("q_own", C.c_void_p), ("q_opp", C.c_void_p), ("q_game", C.c_void_p), ("q_seq", C.c_void_p),
-        ("error", C.c_void_p),
+        ("error", C.c_void_p), ("clear_word", C.c_void_p),
     ]
 
 
@@ -161,6 +161,7 @@ def lib():
     L.iago_mcts_store_priors.argtypes = [lp, vp, vp, vp]
     L.iago_mcts_expand_cached.argtypes = [tp, vp, vp, vp, vp, lp, vp, vp]
     L.iago_mcts_fresh_leaves.argtypes = [tp, vp, vp, vp, vp, vp, vp]
+    L.iago_mcts_descend.argtypes = [tp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, vp, lp, vp, vp, vp, vp]
     for name in SYMBOLS[3:]:
         getattr(L, name).restype = C.c_int
     _lib = L

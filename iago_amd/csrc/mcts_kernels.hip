@@ -352,6 +352,7 @@ struct Lookahead {
     int32_t *q_game, *q_seq;
     int32_t *error;             // raised when a cache slot was recycled before its leaf expanded,
                                 // a leaf reaches n_thr without priors, or the queue is full
+    int32_t *clear_word;        // optional: set to 0 by the backup (the fresh-leaf count of the next descent)
 };
 
 __global__ __launch_bounds__(BLOCK) void mix_backup_lookahead_kernel(
@@ -363,6 +364,8 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_lookahead_kernel(
     const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (g == 0 && counter)
         *counter += 1u;
+    if (g == 0 && A.clear_word)
+        *A.clear_word = 0;
     if (g >= T.n_games)
         return;
     // value_func(leaf) (MCTS.py:97-103,124) is a pure function of the leaf's position: with a
@@ -490,6 +493,150 @@ __global__ __launch_bounds__(BLOCK) void expand_cached_kernel(Tree T, const uint
     if (r == 0u) {
         T.first_child[base + node] = fc;
         T.n_children[base + node] = (uint8_t)k;
+    }
+}
+
+// ---- the whole descent of a playout in ONE launch (iago_mcts_descend): select from the root
+// (MCTS.py:129-133), and where the leaf it reaches has n_visits >= n_thr (MCTS.py:109) the
+// expansion from the prior cache and the continued descent into the new children (MCTS.py:
+// 110-121), then the list of the leaves that have no cached value yet -- select_kernel,
+// expand_cached_kernel, select_kernel again and fresh_leaves_kernel with the same arithmetic.
+// A game's 8 lanes expand together; the fresh list is appended with an atomic counter (its
+// order varies from run to run: the value net's output for a board does not depend on its row).
+__global__ __launch_bounds__(BLOCK) void descend_kernel(
+    Tree T, const uint64_t *__restrict__ root_own, const uint64_t *__restrict__ root_opp,
+    const uint8_t *__restrict__ active, float c_puct, int n_thr, int32_t *__restrict__ cur_node,
+    uint64_t *__restrict__ cur_own, uint64_t *__restrict__ cur_opp, uint64_t *__restrict__ legal_out,
+    int32_t *__restrict__ stats, Lookahead A, int64_t *__restrict__ fresh_index, int32_t *__restrict__ fresh_count,
+    int64_t *__restrict__ fresh_total)
+{
+    int st_levels = 0, st_children = 0;
+    const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t g = gtid >> 3;
+    const Lane8 L = make_lane8(threadIdx.x);
+    const uint32_t r = L.l8;
+    const bool live = g < T.n_games && active[g] != 0;
+    const int64_t base = live ? g * (int64_t)T.capacity : 0;
+
+    int node = 0;
+    uint64_t own = 0, opp = 0;
+    if (live) {
+        node = T.root[g];
+        own = root_own[g];
+        opp = root_opp[g];
+    }
+    bool descending = live, may_expand = live;
+    for (int depth = 0; depth < MAX_DEPTH; depth++) {
+        int fc = descending ? T.first_child[base + node] : -1;
+        // a leaf with n_visits >= n_thr expands here and the descent goes on into its children
+        // (once per playout: the new children have no visits)
+        const bool expand = descending && may_expand && fc < 0 && T.n_visits[base + node] >= n_thr;
+        if (__builtin_amdgcn_ballot_w64(expand) != 0ull) {
+            const uint64_t lg = group8_legal(to_lane(own, L), to_lane(opp, L), L);
+            if (expand) {
+                may_expand = false;
+                const int k = lg ? __popcll(lg) : 1;
+                const int tag = fc;
+                uint32_t fc1 = 0; // first child + 1, 0 = no room
+                if (r == 0u) {
+                    const int at = T.n_nodes[g];
+                    if (at + k <= T.capacity) {
+                        T.n_nodes[g] = at + k;
+                        fc1 = (uint32_t)at + 1u;
+                    } else {
+                        T.overflow[g] = 1;
+                    }
+                }
+                fc1 = group8_add(fc1);
+                if (fc1 != 0u) {
+                    const int nf = (int)fc1 - 1;
+                    if (lg == 0ull || k == 1) {
+                        // pass child / single legal move: Node(node, 1), no net (MCTS.py:112-117)
+                        if (r == 0u)
+                            init_node(T, base + nf, node, lg ? (int)__builtin_ctzll(lg) : -1, 1.0f + 0.1f);
+                    } else {
+                        const int seq = -2 - tag;
+                        const int slot = tag <= -2 ? seq % A.slots : 0;
+                        const float *probs = A.cache + (g * A.slots + slot) * 64;
+                        if ((tag > -2 || A.cache_seq[g * A.slots + slot] != seq) && r == 0u)
+                            *A.error = 2; // no priors for this leaf (not queued, or its slot was recycled)
+                        uint32_t row = (uint32_t)(lg >> (8u * r)) & 0xFFu;
+                        int at = nf + __popcll(lg & ((1ull << (8u * r)) - 1ull));
+                        while (row) {
+                            const int a = (int)(8u * r) + __builtin_ctz(row);
+                            row &= row - 1u;
+                            init_node(T, base + at, node, a, probs[a] + 0.1f); // MCTS.py:19
+                            at++;
+                        }
+                    }
+                    if (r == 0u) {
+                        T.first_child[base + node] = nf;
+                        T.n_children[base + node] = (uint8_t)k;
+                    }
+                    fc = nf;
+                }
+            }
+            __threadfence_block(); // the new children are read by the other lanes of the group below
+        }
+        descending = descending && fc >= 0; // leaf reached (MCTS.py:107)
+        if (__builtin_amdgcn_ballot_w64(descending) == 0ull)
+            break;
+        const int k = descending ? (int)T.n_children[base + node] : 0;
+        const int pn = descending ? T.n_visits[base + node] : 0;
+        st_levels += descending ? 1 : 0;
+        st_children += k;
+        const double sq = sqrt((double)pn); // np.sqrt(parent.n_visits), MCTS.py:49
+        double best_v = -INFINITY;
+        int best_i = 0x7fffffff;
+        for (int j = (int)L.l8; j < k; j += 8) {
+            const int64_t c = base + fc + j;
+            const float cp = c_puct * T.p[c];                        // float32, MCTS.py:49
+            const double u = (double)cp * sq / (0.01 + (double)T.n_visits[c]);
+            const double v = (double)T.q[c] + u;                     // get_value, MCTS.py:75-76
+            if (v > best_v) { // strict: the first maximum wins (python max, MCTS.py:46)
+                best_v = v;
+                best_i = j;
+            }
+        }
+        argmax_step<DPP_XOR1>(best_v, best_i);
+        argmax_step<DPP_XOR2>(best_v, best_i);
+        argmax_step<DPP_HALF_MIRROR>(best_v, best_i);
+        const int child = fc + best_i;
+        const int a = descending ? (int)T.action[base + child] : -1;
+        // GameFunctions.place_stone(state, action, c); c = 3 - c  (MCTS.py:131-132)
+        const uint64_t f = group8_flips(to_lane(own, L), to_lane(opp, L), (uint32_t)a & 63u, L);
+        if (descending) {
+            uint64_t no = own, np_ = opp;
+            if (a >= 0) {
+                const uint64_t bit = 1ull << (a & 63);
+                no = own | f | bit;
+                np_ = opp & ~f & ~bit;
+            }
+            own = np_;
+            opp = no;
+            node = child;
+        }
+    }
+    const uint64_t legal = group8_legal(to_lane(own, L), to_lane(opp, L), L);
+    if (live && r == 0 && descending && T.first_child[base + node] >= 0)
+        T.overflow[g] = 1; // path longer than MAX_DEPTH: reported like a full pool
+    if (live && r == 0) {
+        cur_node[g] = node;
+        cur_own[g] = own;
+        cur_opp[g] = opp;
+        legal_out[g] = legal;
+        if (stats) {
+            stats[2 * g] += st_levels;
+            stats[2 * g + 1] += st_children;
+        }
+        if (fresh_index) {
+            const float c = T.v[base + node];
+            if (c != c) {
+                fresh_index[atomicAdd(fresh_count, 1)] = g;
+                if (fresh_total)
+                    atomicAdd((unsigned long long *)fresh_total, 1ull);
+            }
+        }
     }
 }
 
@@ -850,6 +997,7 @@ int lookahead_of(const iago_mcts_lookahead *a, Lookahead &A, const char *who)
     A.q_game = a->q_game;
     A.q_seq = a->q_seq;
     A.error = a->error;
+    A.clear_word = a->clear_word;
     return IAGO_OK;
 }
 } // namespace
@@ -917,6 +1065,31 @@ int iago_mcts_fresh_leaves(const iago_mcts_tree *tree, const uint8_t *active, co
     hipLaunchKernelGGL(fresh_leaves_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *tree, active, cur_node,
                        index, count, total);
     return iago_check_launch("iago_mcts_fresh_leaves");
+}
+
+int iago_mcts_descend(const iago_mcts_tree *tree, const uint64_t *root_own, const uint64_t *root_opp,
+                      const uint8_t *active, float c_puct, int32_t n_thr, int32_t *cur_node, uint64_t *cur_own,
+                      uint64_t *cur_opp, uint64_t *legal, int32_t *stats, const iago_mcts_lookahead *la,
+                      int64_t *fresh_index, int32_t *fresh_count, int64_t *fresh_total, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_descend: bad tree"))
+        return IAGO_ERR_INVALID;
+    Lookahead A;
+    if (lookahead_of(la, A, "iago_mcts_descend: bad look-ahead state"))
+        return IAGO_ERR_INVALID;
+    if (!root_own || !root_opp || !active || !cur_node || !cur_own || !cur_opp || !legal)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_descend: null pointer");
+    if (fresh_index && (!fresh_count || !tree->v))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_descend: the fresh-leaf list needs its count word and the "
+                                           "tree's value cache");
+    if (n_thr < 1)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_descend: n_thr must be >= 1");
+    if (tree->n_games == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(descend_kernel, dim3(grid_for(tree->n_games * 8)), dim3(BLOCK), 0, (hipStream_t)stream, *tree,
+                       root_own, root_opp, active, c_puct, n_thr, cur_node, cur_own, cur_opp, legal, stats, A,
+                       fresh_index, fresh_count, fresh_total);
+    return iago_check_launch("iago_mcts_descend");
 }
 
 } // extern "C"

@@ -251,9 +251,12 @@ class BatchedMCTS(object):
                 a.q_own, a.q_opp = q["own"].data_ptr(), q["opp"].data_ptr()
                 a.q_game, a.q_seq = q["game"].data_ptr(), q["seq"].data_ptr()
                 a.error = self._la_error.data_ptr()
+                # the backup clears the fresh-leaf count that the next descent appends to
+                a.clear_word = self._fresh_count.data_ptr() if self.value_cache else None
                 self._la_queues.append(q)
                 self._la.append(a)
             self._la_cur = 0   # the queue the playouts fill
+            self.fused_descent = os.environ.get("IAGO_FUSED_DESCENT", "1") != "0"
             self._la_side = torch.cuda.Stream(device=device) if self.lookahead_overlap else None
 
             def reset_lookahead(mask):
@@ -384,14 +387,15 @@ class BatchedMCTS(object):
               "iago_mcts_expand")
         self._select(own, opp, self._pending, False)  # MCTS.py:121: recurse into the same node
 
-    def _evaluate_and_backup(self, active, stream_id=0, stream_id_dev=None, counter=None):
+    def _evaluate_and_backup(self, active, stream_id=0, stream_id_dev=None, counter=None, fresh_listed=False):
         """Leaf evaluation (MCTS.py:123-127) and Node.update_recursive."""
         L = _lib.lib()
         if self.lmbda < 1.0 and self.value_cache:
             # the value net on the leaves without a stored value only (device-side list + count)
-            check(L.iago_mcts_fresh_leaves(self.tree.ref(), _p(active), _p(self.cur_node), _p(self._fresh_idx),
-                                           _p(self._fresh_count), _p(self._value_total), _stream()),
-                  "iago_mcts_fresh_leaves")
+            if not fresh_listed:
+                check(L.iago_mcts_fresh_leaves(self.tree.ref(), _p(active), _p(self.cur_node), _p(self._fresh_idx),
+                                               _p(self._fresh_count), _p(self._value_total), _stream()),
+                      "iago_mcts_fresh_leaves")
             with torch.no_grad():
                 self.value_fn.forward_boards_counted(self.cur_own, self.cur_opp, self._fresh_idx,
                                                      self._fresh_count, self.v)
@@ -429,6 +433,18 @@ class BatchedMCTS(object):
         from the look-ahead cache: select, expand, continue the descent, evaluate, back up (and
         queue the leaves that are K visits from expanding)."""
         L = _lib.lib()
+        if self.fused_descent:
+            # select, expand from the cache, continue, list the leaves without a value: one launch
+            check(L.iago_mcts_descend(self.tree.ref(), _p(own), _p(opp), _p(active), self.c_puct, self.n_thr,
+                                      _p(self.cur_node), _p(self.cur_own), _p(self.cur_opp), _p(self.legal),
+                                      _p(self.stats) if self.stats is not None else None, C.byref(self._la[0]),
+                                      _p(self._fresh_idx) if self.value_cache else None,
+                                      _p(self._fresh_count) if self.value_cache else None,
+                                      _p(self._value_total) if self.value_cache else None, _stream()),
+                  "iago_mcts_descend")
+            self._evaluate_and_backup(active, stream_id=stream_id, stream_id_dev=stream_id_dev, counter=counter,
+                                      fresh_listed=self.value_cache)
+            return
         self._select(own, opp, active, True)
         check(L.iago_mcts_expand_cached(self.tree.ref(), _p(active), _p(self.needs_expand), _p(self.cur_node),
                                         _p(self.legal), C.byref(self._la[0]), _p(self._pending), _stream()),
@@ -515,6 +531,7 @@ class BatchedMCTS(object):
         """What the captured graph baked in: device pointers and versions of every weight
         (and of the layouts cached from them), the rollout table, the scalar arguments."""
         key = [self.lmbda, self.c_puct, self.n_thr, self.lookahead, self.lookahead_overlap, self.value_cache,
+               getattr(self, "fused_descent", False),
                self.stats.data_ptr() if self.stats is not None else 0,
                self.rollout_weights.table.data_ptr() if self.rollout_weights is not None else 0]
         for fn in (self.policy_fn, self.value_fn):

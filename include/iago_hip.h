@@ -506,6 +506,8 @@ typedef struct iago_mcts_lookahead {
     uint64_t *q_own, *q_opp;
     int32_t *q_game, *q_seq;
     int32_t *error;
+    int32_t *clear_word;   /* optional device word iago_mcts_mix_backup_lookahead sets to 0 (the fresh-leaf
+                              count that the next iago_mcts_descend appends to) */
 } iago_mcts_lookahead;
 IAGO_API int iago_mcts_mix_backup_lookahead(const iago_mcts_tree *tree, const uint8_t *active,
                                             const int32_t *cur_node, const uint64_t *cur_own,
@@ -534,6 +536,19 @@ IAGO_API int iago_mcts_expand_cached(const iago_mcts_tree *tree, const uint8_t *
  */
 IAGO_API int iago_mcts_fresh_leaves(const iago_mcts_tree *tree, const uint8_t *active, const int32_t *cur_node,
                                     int64_t *index, int32_t *count, int64_t *total, void *stream);
+/*
+ * The whole descent of a playout in one launch: iago_mcts_select from the root, for the games
+ * whose leaf has n_visits >= n_thr iago_mcts_expand_cached and the continued iago_mcts_select
+ * into the new children (MCTS.py:105-121,129-133), and -- when fresh_index is given -- the list
+ * of iago_mcts_fresh_leaves, appended through *fresh_count (which the caller, or the previous
+ * iago_mcts_mix_backup_lookahead through `clear_word`, has set to 0); the list's order is not
+ * defined.  Same arithmetic as the separate calls: same trees.
+ */
+IAGO_API int iago_mcts_descend(const iago_mcts_tree *tree, const uint64_t *root_own, const uint64_t *root_opp,
+                               const uint8_t *active, float c_puct, int32_t n_thr, int32_t *cur_node,
+                               uint64_t *cur_own, uint64_t *cur_opp, uint64_t *legal, int32_t *stats,
+                               const iago_mcts_lookahead *la, int64_t *fresh_index, int32_t *fresh_count,
+                               int64_t *fresh_total, void *stream);
 
 #ifdef __cplusplus
 }
