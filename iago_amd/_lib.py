@@ -24,7 +24,7 @@ SYMBOLS = [
     "iago_judge",
     "iago_sample_moves", "iago_augment8", "iago_bias_relu",
     "iago_conv3x3_split", "iago_conv3x3_split_trunk", "iago_split_nchw", "iago_merge_nchw", "iago_value_stem", "iago_value_stem_boards", "iago_value_head",
-    "iago_value_forward_split",
+    "iago_value_forward_split", "iago_value_rollout",
     "iago_conv3x3_f32", "iago_stem_f32", "iago_stem_f32_boards", "iago_policy_head",
     "iago_rollout_build_table", "iago_rollout",
     "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_mcts_pending",
@@ -133,6 +133,7 @@ def lib():
     L.iago_conv3x3_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
     L.iago_conv3x3_split_trunk.argtypes = [C.POINTER(ConvSplitLayer), i32, i64, vp, vp]
     L.iago_value_forward_split.argtypes = [C.POINTER(ValueSplitArgs), vp]
+    L.iago_value_rollout.argtypes = [C.POINTER(ValueSplitArgs), C.POINTER(RolloutArgs), vp]
     L.iago_split_nchw.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.iago_merge_nchw.argtypes = [vp, vp, vp, i64, i32, vp]
     L.iago_value_stem.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]

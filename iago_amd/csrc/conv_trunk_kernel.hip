@@ -23,6 +23,7 @@
 // Same products in the same order as the per-layer kernel: bit-identical results
 // (tests/test_conv_gpu.py: test_trunk_kernel_equals_layer_by_layer).
 #include "abi_common.hpp"
+#include "rollout_row_body.hpp"
 
 #include <hip/hip_fp16.h>
 
@@ -467,8 +468,10 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t 
 #endif
 }
 
+// Workgroup `bid` of `nb` walks its rows with that stride (one pass unless the grid was capped:
+// the device-counted launch of the value cache, iago_value_forward_split).
 template <bool FUSED, int TB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void trunk_resident_kernel(TrunkRParams P)
+__device__ __forceinline__ void trunk_walk(const TrunkRParams &P, const int64_t bid, const int64_t nb)
 {
     int64_t n_rows = P.n;
     if constexpr (FUSED) {
@@ -478,12 +481,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (n_rows <= P.count_lo || n_rows > P.count_hi)
             return;
     }
-    // a workgroup walks its rows with the grid's stride (one pass unless the grid was capped:
-    // the device-counted launch of the value cache, iago_value_forward_split)
-    for (int64_t b0 = (int64_t)blockIdx.x * TB; b0 < n_rows; b0 += (int64_t)gridDim.x * TB) {
+    for (int64_t b0 = bid * TB; b0 < n_rows; b0 += nb * TB) {
         trunk_item<FUSED, TB>(P, b0, n_rows);
         __syncthreads(); // the next pass re-stages the LDS image the head just read
     }
+}
+
+template <bool FUSED, int TB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void trunk_resident_kernel(TrunkRParams P)
+{
+    trunk_walk<FUSED, TB>(P, blockIdx.x, gridDim.x);
+}
+
+// The leaf evaluation of a playout (MCTS.py:123-125) in ONE launch: workgroups 0 .. n_ro-1 play
+// the rollouts of ALL leaves (the 16-lanes-per-board kernel's body), the others run the value net
+// on the leaves that have no stored value (one board per workgroup, device-side list).  With the
+// value cache the net covers ~180 CUs and the rollouts' 64 workgroups the rest: two kernels on
+// two streams cost more in graph edges than they hide, one launch with two kinds of
+// workgroups costs nothing.  The rollout workgroups come first in the grid: they are dispatched
+// first and never wait behind a value workgroup.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void value_rollout_kernel(
+    TrunkRParams P, iago_row::HwParams R, uint32_t n_ro)
+{
+    if (blockIdx.x < n_ro) {
+        iago_row::rollout_row_body<false>(R, blockIdx.x);
+        return;
+    }
+    trunk_walk<true, 1>(P, blockIdx.x - n_ro, gridDim.x - n_ro);
 }
 
 } // namespace
@@ -550,16 +574,14 @@ bool iago_value_persistent()
 }
 } // namespace
 
-int iago_value_forward_split(const iago_value_split_args *a, void *stream)
+// validates `a` and fills the kernel parameters; `who` names the entry point in error messages
+static int value_params_of(const iago_value_split_args *a, TrunkRParams &P)
 {
     if (!a || a->n < 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: null args or n < 0");
-    if (a->n == 0)
-        return IAGO_OK;
     if ((!a->planes && (!a->own || !a->opp)) || !a->w1 || !a->b1 || !a->w9_hi || !a->w9_lo || !a->b9 || !a->w10 ||
         !a->w11 || !a->out)
         return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: null pointer");
-    TrunkRParams P;
     for (int L = 0; L < 7; L++) {
         if (!a->w_hi[L] || !a->w_lo[L] || !a->bias[L] || ((uintptr_t)a->w_hi[L] & 15u) || ((uintptr_t)a->w_lo[L] & 15u) ||
             ((uintptr_t)a->bias[L] & 15u))
@@ -595,6 +617,16 @@ int iago_value_forward_split(const iago_value_split_args *a, void *stream)
         return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: a gather list needs the boards, not planes");
     P.index = a->index;
     P.n_dev = a->n_dev;
+    return IAGO_OK;
+}
+
+int iago_value_forward_split(const iago_value_split_args *a, void *stream)
+{
+    if (a && a->n == 0)
+        return IAGO_OK;
+    TrunkRParams P;
+    if (const int rc = value_params_of(a, P))
+        return rc;
     static std::atomic<uint64_t> configured4{0}, configured2{0}, configured1{0};
     if (iago_reserve_lds((const void *)trunk_resident_kernel<true, 4>, lds_alloc_fused(4), configured4,
                          "iago_value_forward_split: cannot reserve 148 KB of LDS") ||
@@ -645,4 +677,31 @@ int iago_value_forward_split(const iago_value_split_args *a, void *stream)
                            lds_alloc_fused(4), (hipStream_t)stream, P);
     }
     return iago_check_launch("iago_value_forward_split");
+}
+
+int iago_value_rollout(const iago_value_split_args *a, const iago_rollout_args *ro, void *stream)
+{
+    if (!a || !ro)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_rollout: null args");
+    if (!a->n_dev || !a->index || a->n < 1)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_rollout: the value net takes its rows from a device-side list "
+                                           "(index, n_dev)");
+    if (ro->n < 1 || ro->n > 0x7fffffffll || !ro->own || !ro->opp || !ro->z || !ro->table || ((uintptr_t)ro->table & 15u) ||
+        ro->log_form || ro->trace || ro->uniforms || ro->throughput_hint != 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_rollout: product-form rollout without trace / uniforms expected");
+    TrunkRParams P;
+    if (const int rc = value_params_of(a, P))
+        return rc;
+    P.count_lo = 0;
+    P.count_hi = 0x7fffffff;
+    static std::atomic<uint64_t> configured{0};
+    if (iago_reserve_lds((const void *)value_rollout_kernel, lds_alloc_fused(1), configured,
+                         "iago_value_rollout: cannot reserve 45 KB of LDS"))
+        return IAGO_ERR_HIP;
+    const iago_row::HwParams R = iago_row::hw_params_of(ro);
+    const unsigned n_ro = (unsigned)((ro->n + (iago_row::HW_BLOCK / 16) - 1) / (iago_row::HW_BLOCK / 16));
+    const unsigned n_val = (unsigned)(a->n < 256 ? a->n : 256);
+    hipLaunchKernelGGL(value_rollout_kernel, dim3(n_ro + n_val), dim3(256), lds_alloc_fused(1), (hipStream_t)stream, P, R,
+                       n_ro);
+    return iago_check_launch("iago_value_rollout");
 }

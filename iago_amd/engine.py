@@ -179,6 +179,8 @@ class BatchedMCTS(object):
         self._fresh_count = torch.zeros(1, dtype=torch.int32, **kw)
         self._value_total = torch.zeros(1, dtype=torch.int64, **kw)  # value-net evaluations, on the device
         self._value_key = None
+        import os as _os
+        self.fused_leaf_eval = _os.environ.get("IAGO_FUSED_LEAF_EVAL", "1") != "0"
         self.cur_node = torch.zeros(n_games, dtype=torch.int32, **kw)
         self.cur_own = torch.zeros(n_games, dtype=torch.int64, **kw)
         self.cur_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
@@ -390,15 +392,25 @@ class BatchedMCTS(object):
     def _evaluate_and_backup(self, active, stream_id=0, stream_id_dev=None, counter=None, fresh_listed=False):
         """Leaf evaluation (MCTS.py:123-127) and Node.update_recursive."""
         L = _lib.lib()
+        rolled = False  # the rollout has run inside the value net's launch
         if self.lmbda < 1.0 and self.value_cache:
             # the value net on the leaves without a stored value only (device-side list + count)
             if not fresh_listed:
                 check(L.iago_mcts_fresh_leaves(self.tree.ref(), _p(active), _p(self.cur_node), _p(self._fresh_idx),
                                                _p(self._fresh_count), _p(self._value_total), _stream()),
                       "iago_mcts_fresh_leaves")
+            # ... and, in the same launch, the rollouts of all leaves (two kinds of workgroups)
+            both = (self.fused_leaf_eval and self.lmbda > 0.0 and self.rollout_hook is None
+                    and self.rollout_weights is not None and not self.rollout_weights.log_form)
+            ro = None
+            if both:
+                ro = ops.rollout_prepare(self.cur_own, self.cur_opp, self.rollout_weights, seed=self.seed,
+                                         id_base=self.game_id_base, stream_id=stream_id,
+                                         stream_id_dev=stream_id_dev, out=self._rollout_out)
             with torch.no_grad():
                 self.value_fn.forward_boards_counted(self.cur_own, self.cur_opp, self._fresh_idx,
-                                                     self._fresh_count, self.v)
+                                                     self._fresh_count, self.v, rollout=ro)
+            rolled = both
         elif self.lmbda < 1.0:
             v = None
             fb = getattr(self.value_fn, "forward_boards", None)
@@ -409,7 +421,7 @@ class BatchedMCTS(object):
                     ops.encode_planes(self.cur_own, self.cur_opp, out=self.planes)
                     v = self.value_fn(self.planes)
             self.v = v.to(torch.float32).contiguous()
-        if self.lmbda > 0.0:
+        if self.lmbda > 0.0 and not rolled:
             ops.rollout(self.cur_own, self.cur_opp, self.rollout_weights, seed=self.seed,
                         id_base=self.game_id_base, stream_id=stream_id,
                         stream_id_dev=stream_id_dev, out=self._rollout_out)
@@ -531,7 +543,7 @@ class BatchedMCTS(object):
         """What the captured graph baked in: device pointers and versions of every weight
         (and of the layouts cached from them), the rollout table, the scalar arguments."""
         key = [self.lmbda, self.c_puct, self.n_thr, self.lookahead, self.lookahead_overlap, self.value_cache,
-               getattr(self, "fused_descent", False),
+               getattr(self, "fused_descent", False), self.fused_leaf_eval,
                self.stats.data_ptr() if self.stats is not None else 0,
                self.rollout_weights.table.data_ptr() if self.rollout_weights is not None else 0]
         for fn in (self.policy_fn, self.value_fn):

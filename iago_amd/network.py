@@ -299,7 +299,7 @@ class Value(nn.Module, _NpzMixin):
                                        self.fc10.weight, self.fc11.weight,
                                        overflow=self._overflow_flag(device))
 
-    def forward_boards_counted(self, own, opp, index, n_dev, out):
+    def forward_boards_counted(self, own, opp, index, n_dev, out, rollout=None):
         """The net on boards index[0 .. *n_dev) only (int64 gather list and int32 count on the
         device: the leaves of a playout that have no cached value), values to out[index[i]];
         one enqueue whatever the count (iago_value_forward_split picks its variant on the
@@ -312,7 +312,8 @@ class Value(nn.Module, _NpzMixin):
         return ops.value_forward_split((own, opp), self.block1.conv.weight, self.block1.conv.bias, layers,
                                        self._head_weights(), self.block9.conv.weight, self.block9.conv.bias,
                                        self.fc10.weight, self.fc11.weight,
-                                       overflow=self._overflow_flag(own.device), index=index, n_dev=n_dev, out=out)
+                                       overflow=self._overflow_flag(own.device), index=index, n_dev=n_dev, out=out,
+                                       rollout=rollout)
 
     def forward_boards(self, own, opp):
         """forward(make_state_var(...)) for int64 bitboards (own = side to move) without the

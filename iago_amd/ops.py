@@ -262,12 +262,14 @@ def split_head_weights(w9):
 
 
 def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None, index=None, n_dev=None,
-                        out=None):
+                        out=None, rollout=None):
     """The whole Value net in one launch (iago_value_forward_split).  x: float32 planes
     (n, 2, 8, 8) or a pair (own, opp) of int64 bitboards (own = side to move); layers: the 7
     (w_hi, w_lo, bias) of blocks 2..8 (split_weights); head: split_head_weights(w9).
     index / n_dev (boards only): evaluate boards index[0 .. min(n, *n_dev)) and write their
-    values to out[index[i]] (out: (n_boards,) float32, the other entries untouched)."""
+    values to out[index[i]] (out: (n_boards,) float32, the other entries untouched).
+    rollout: a PreparedRollout (rollout_prepare) to play in the SAME launch (iago_value_rollout:
+    the leaf evaluation of a playout, value net on the listed leaves + rollout of all)."""
     a = _lib.ValueSplitArgs()
     if isinstance(x, tuple):
         own, opp = x
@@ -305,7 +307,10 @@ def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None
     a.out = _dev(out, torch.float32, "out").value
     f = _flag(overflow)
     a.overflow = f.value if f is not None else None
-    check(_lib.lib().iago_value_forward_split(C.byref(a), _stream()), "iago_value_forward_split")
+    if rollout is not None:
+        check(_lib.lib().iago_value_rollout(C.byref(a), rollout.ref, _stream()), "iago_value_rollout")
+    else:
+        check(_lib.lib().iago_value_forward_split(C.byref(a), _stream()), "iago_value_forward_split")
     return out
 
 

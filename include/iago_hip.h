@@ -325,6 +325,16 @@ typedef struct iago_value_split_args {
     const int32_t *n_dev;  /* optional device-side row count: only the first min(n, *n_dev) rows */
 } iago_value_split_args;
 IAGO_API int iago_value_forward_split(const iago_value_split_args *args, void *stream);
+
+/*
+ * The leaf evaluation of a playout (MCTS.py:123-125) in ONE launch: iago_rollout of all leaves
+ * (product form, no trace / recorded uniforms) and iago_value_forward_split on the leaves of a
+ * device-side list (args->index, args->n_dev: the leaves without a stored value,
+ * iago_mcts_fresh_leaves / iago_mcts_descend) as two kinds of workgroups of one grid.  Same
+ * results as the two calls.
+ */
+IAGO_API int iago_value_rollout(const iago_value_split_args *args, const iago_rollout_args *rollout,
+                                void *stream);
 IAGO_API int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels,
                              uint32_t *overflow, void *stream);
 IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n, int32_t channels,
