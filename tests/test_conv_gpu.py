@@ -271,6 +271,43 @@ def test_counted_value_forward_is_bit_identical(count):
     m.check_saturation()
 
 
+@pytest.mark.parametrize("count", [0, 5, 180, 700])
+def test_value_and_rollout_in_one_launch(count):
+    """iago_value_rollout (the value net on a device-side list of boards and the rollout of ALL
+    boards as two kinds of workgroups of one launch) against the two separate calls: identical
+    values for the listed boards, identical games (z, final boards, turns) for all."""
+    from iago_amd import network, ops
+    from tests.conftest import load_json
+    from tests.gpu_util import random_positions
+    torch.manual_seed(33)
+    m = network.Value().eval().cuda()
+    g = load_json("simulate.json")
+    w = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    n = 1024
+    own, opp = random_positions(n, seed=91)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    gen = torch.Generator().manual_seed(count + 1)
+    pick = torch.randperm(n, generator=gen)[:count].sort().values.cuda()
+    index = torch.zeros(n, dtype=torch.int64, device="cuda")
+    index[:count] = pick
+    n_dev = torch.tensor([count], dtype=torch.int32, device="cuda")
+    sid = torch.tensor([5], dtype=torch.int32, device="cuda")
+    with torch.no_grad():
+        want_v = torch.full((n,), -77.0, dtype=torch.float32, device="cuda")
+        m.forward_boards_counted(o, p, index, n_dev, want_v)
+        want = ops.rollout(o, p, w, seed=11, id_base=3000, stream_id=2, stream_id_dev=sid, want_final=True,
+                           want_turns=True)
+        got_v = torch.full((n,), -77.0, dtype=torch.float32, device="cuda")
+        res = ops.RolloutResult()
+        prep = ops.rollout_prepare(o, p, w, seed=11, id_base=3000, stream_id=2, stream_id_dev=sid, want_final=True,
+                                   want_turns=True, out=res)
+        m.forward_boards_counted(o, p, index, n_dev, got_v, rollout=prep)
+    torch.cuda.synchronize()
+    assert torch.equal(got_v, want_v)
+    assert torch.equal(res.z, want.z) and torch.equal(res.n_turns, want.n_turns)
+    assert torch.equal(res.final_own, want.final_own) and torch.equal(res.final_opp, want.final_opp)
+
+
 def test_trunk_kernel_equals_layer_by_layer():
     """iago_conv3x3_split_trunk (several layers, one launch) must reproduce the per-layer
     launches bit for bit, for a ragged batch and a 64-channel first layer."""
