@@ -39,10 +39,10 @@ import os
 import sys
 import time
 
-# The independent 4096-board steps overlap on the chip through HIP streams; the
-# runtime maps streams onto 4 hardware queues unless told otherwise, which caps
-# the overlap at ~3.4 launches.  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (GPU_MAX_HW_QUEUES is left at the runtime's default of 4 hardware queues.  Round 1 raised it to
+# 16 for the `overlapped` extra; with the 16-lane kernel 4 queues give MORE overlap (238 vs 219 M
+# games/s), and with 8 or more queues the PV-MCTS graph -- two streams -- replays 1.5x slower once
+# RCCL has created its own streams (tools/exp_nccl_bench_leg.py: 4.4 vs 6.6 M leaf-evals/s).)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -259,7 +259,8 @@ class BatchedMCTS(object):
                 self._la.append(a)
             self._la_cur = 0   # the queue the playouts fill
             self.fused_descent = os.environ.get("IAGO_FUSED_DESCENT", "1") != "0"
-            self._la_side = torch.cuda.Stream(device=device) if self.lookahead_overlap else None
+            prio = int(os.environ.get("IAGO_SIDE_PRIORITY", "0"))
+            self._la_side = torch.cuda.Stream(device=device, priority=prio) if self.lookahead_overlap else None
 
             def reset_lookahead(mask):
                 if mask is None:
