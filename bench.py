@@ -29,8 +29,11 @@ Python-loop restatement on one core beside it.
 Extra objects, none of them `value`: `overlapped` (the same 4096-board launches
 on 32 HIP streams), `large_batch` (one launch of 1M boards, lane-per-board
 kernel), `mcts` (BASELINE configs[2]: PV-MCTS 100 sims/move, 1024 games, played
-to the end: leaf-evals/s and games/s, with its own 1-core CPU baseline),
-`reinforce`, `mcts_single_game`.
+to the end: leaf-evals/s = playouts/s and games/s, with its own 1-core CPU
+baseline; `value_evals` / `policy_evals` = rows the nets really processed -- the
+value of a leaf is computed at its first visit only and the policy runs a few
+visits ahead of the expansion), `reinforce`,
+`mcts_single_game`.
 """
 import argparse
 import ctypes
