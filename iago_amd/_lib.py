@@ -25,7 +25,7 @@ SYMBOLS = [
     "iago_sample_moves", "iago_augment8", "iago_bias_relu",
     "iago_conv3x3_split", "iago_conv3x3_split_trunk", "iago_split_nchw", "iago_merge_nchw", "iago_value_stem", "iago_value_stem_boards", "iago_value_head",
     "iago_value_forward_split", "iago_value_rollout",
-    "iago_conv3x3_f32", "iago_stem_f32", "iago_stem_f32_boards", "iago_policy_head",
+    "iago_conv3x3_f32", "iago_stem_f32", "iago_stem_f32_boards", "iago_policy_head", "iago_policy_forward_split3",
     "iago_rollout_build_table", "iago_rollout",
     "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_mcts_pending",
     "iago_leaf_values",
@@ -57,6 +57,16 @@ class ConvSplitLayer(C.Structure):
         ("x_hi", C.c_void_p), ("x_lo", C.c_void_p), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p),
         ("bias", C.c_void_p), ("y_hi", C.c_void_p), ("y_lo", C.c_void_p),
         ("cin", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class PolicySplit3Args(C.Structure):
+    """Mirror of iago_policy_split3_args (include/iago_hip.h)."""
+    _fields_ = [
+        ("own", C.c_void_p), ("opp", C.c_void_p), ("index", C.c_void_p), ("n_dev", C.c_void_p), ("n", C.c_int64),
+        ("w1", C.c_void_p), ("b1", C.c_void_p),
+        ("w_hi", C.c_void_p * 7), ("w_mid", C.c_void_p * 7), ("w_lo", C.c_void_p * 7), ("bias", C.c_void_p * 7),
+        ("w9", C.c_void_p), ("b10", C.c_void_p), ("probs", C.c_void_p), ("overflow", C.c_void_p),
     ]
 
 
@@ -133,6 +143,7 @@ def lib():
     L.iago_conv3x3_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
     L.iago_conv3x3_split_trunk.argtypes = [C.POINTER(ConvSplitLayer), i32, i64, vp, vp]
     L.iago_value_forward_split.argtypes = [C.POINTER(ValueSplitArgs), vp]
+    L.iago_policy_forward_split3.argtypes = [C.POINTER(PolicySplit3Args), vp]
     L.iago_value_rollout.argtypes = [C.POINTER(ValueSplitArgs), C.POINTER(RolloutArgs), vp]
     L.iago_split_nchw.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.iago_merge_nchw.argtypes = [vp, vp, vp, i64, i32, vp]

@@ -14,6 +14,8 @@ rollout policy additionally lives fused inside the HIP rollout kernel
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -150,12 +152,39 @@ class SLPolicy(nn.Module, _NpzMixin):
             h = _f32_trunk(self, x, n_dev)
             return ops.policy_head(h, self.conv9.weight.reshape(128), self.bias10.b, n_dev)
 
+    # The whole net in one launch with three f16 pieces per float32 operand
+    # (csrc/conv_policy_kernel.hip) instead of the per-layer float32 kernels.
+    split3 = os.environ.get("IAGO_POLICY_SPLIT3", "1") != "0"
+
+    def _split3_layers(self):
+        from . import ops
+        ws = [getattr(self, "block%d" % k).conv for k in range(2, 9)]
+        key = tuple((c.weight._version, c.weight.data_ptr(), c.bias._version) for c in ws)
+        hit = self.__dict__.get("_split3_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, [ops.split_weights3(c.weight) + (c.bias.detach().float().contiguous(),) for c in ws])
+            self.__dict__["_split3_cache"] = hit
+        return hit[1]
+
+    def forward_boards_split3(self, own, opp, index=None, n=None, n_dev=None, overflow=None):
+        """The move distributions of boards (own = side to move; rows index[0..n) when a gather
+        list is given) through the one-launch kernel.  Inference only."""
+        if self.training or not own.is_cuda:
+            raise ValueError("forward_boards_split3: CUDA boards, eval mode")
+        from . import ops
+        with torch.no_grad():
+            return ops.policy_forward_split3(own, opp, self.block1.conv.weight, self.block1.conv.bias,
+                                             self._split3_layers(), self.conv9.weight, self.bias10.b,
+                                             n=n, index=index, n_dev=n_dev, overflow=overflow)
+
     def forward_counted_boards(self, own, opp, index, n, n_dev):
         """forward_counted on make_state_var of boards index[0..n) (own = side to move) without
         materialising the planes."""
         if self.training or not own.is_cuda:
             raise ValueError("forward_counted_boards: CUDA boards, eval mode")
         from . import ops
+        if self.split3:
+            return self.forward_boards_split3(own, opp, index, n, n_dev)
         with torch.no_grad():
             h = _f32_trunk(self, None, n_dev, boards=(own, opp, index, n))
             return ops.policy_head(h, self.conv9.weight.reshape(128), self.bias10.b, n_dev)

@@ -248,6 +248,55 @@ def value_head(a, w9, b9, w10, w11):
     return out
 
 
+def split_weights3(weight):
+    """(128, cin, 3, 3) float32 conv weight -> (w_hi, w_mid, w_lo) f16 tensors
+    [cin/16][3][3][128][16] with w == hi + mid 2^-11 + lo 2^-22 exactly
+    (iago_policy_forward_split3)."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or cin % 16 or cout != 128:
+        raise ValueError("split_weights3: need a (128, 16k, 3, 3) weight")
+    w = weight.detach().to(torch.float32).permute(2, 3, 0, 1)          # ky, kx, co, ci
+    w = w.reshape(3, 3, cout, cin // 16, 16).permute(3, 0, 1, 2, 4).contiguous()
+    hi = w.to(torch.float16)
+    r1 = (w - hi.to(torch.float32)) * 2048.0
+    mid = r1.to(torch.float16)
+    lo = ((r1 - mid.to(torch.float32)) * 2048.0).to(torch.float16)
+    return hi.contiguous(), mid.contiguous(), lo.contiguous()
+
+
+def policy_forward_split3(own, opp, w1, b1, layers, w9, b10, n=None, index=None, n_dev=None, overflow=None):
+    """The whole SLPolicy net in one launch (iago_policy_forward_split3): boards (own = side to
+    move) -> (n, 64) probabilities.  layers: the 7 (w_hi, w_mid, w_lo, bias) of blocks 2..8
+    (split_weights3); index / n_dev: optional device-side gather list and row count."""
+    a = _lib.PolicySplit3Args()
+    n = own.numel() if n is None else n
+    if index is not None:
+        n = min(n, index.numel())
+        a.index = _dev(index, torch.int64, "index").value
+    if n_dev is not None:
+        a.n_dev = _dev(n_dev, torch.int32, "n_dev").value
+    if len(layers) != 7 or tuple(w1.shape) != (64, 2, 3, 3) or w9.numel() != 128 or b10.numel() != 64:
+        raise ValueError("policy_forward_split3: unexpected shapes")
+    a.own, a.opp = _dev(own, torch.int64, "own").value, _dev(opp, torch.int64, "opp").value
+    a.n = n
+    a.w1, a.b1 = _dev(w1, torch.float32, "w1").value, _dev(b1, torch.float32, "b1").value
+    for k, (w_hi, w_mid, w_lo, bias) in enumerate(layers):
+        if w_hi.shape != ((4 if k == 0 else 8), 3, 3, 128, 16):
+            raise ValueError("policy_forward_split3: layer %d: weight blocks %s" % (k, tuple(w_hi.shape)))
+        a.w_hi[k] = _dev(w_hi, torch.float16, "w_hi").value
+        a.w_mid[k] = _dev(w_mid, torch.float16, "w_mid").value
+        a.w_lo[k] = _dev(w_lo, torch.float16, "w_lo").value
+        a.bias[k] = _dev(bias, torch.float32, "bias").value
+    a.w9 = _dev(w9.reshape(128), torch.float32, "w9").value
+    a.b10 = _dev(b10, torch.float32, "b10").value
+    probs = torch.empty((n, 64), dtype=torch.float32, device=own.device)
+    a.probs = probs.data_ptr()
+    f = _flag(overflow)
+    a.overflow = f.value if f is not None else None
+    check(_lib.lib().iago_policy_forward_split3(C.byref(a), _stream()), "iago_policy_forward_split3")
+    return probs
+
+
 def split_head_weights(w9):
     """Value.block9's (1, 128, 3, 3) weight as the MFMA operand of iago_value_forward_split:
     (hi, lo) f16 [8 chunks][32 rows][16], row r < 9 = kernel tap r, the other rows zero."""

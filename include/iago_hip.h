@@ -275,6 +275,34 @@ IAGO_API int iago_stem_f32_boards(const uint64_t *own, const uint64_t *opp, cons
                                   const int32_t *n_dev, void *stream);
 IAGO_API int iago_policy_head(const float *x, const float *w9, const float *b10, float *probs, int64_t n,
                               const int32_t *n_dev, void *stream);
+
+/*
+ * The WHOLE SLPolicy net (SLPolicy.__call__, network.py:15-47: 8 x [conv3x3 + bias + ReLU], conv
+ * 1x1 128 -> 1, per-cell bias, softmax) in ONE launch on the f16 matrix units with float32-exact
+ * products: every float32 operand as three f16 pieces (33 bits), six MFMAs per product sum into
+ * three float32 accumulators -- a float32 convolution with its own summation order at 2.7x the
+ * float32 MFMA rate (the policy's distribution must hold 1e-5 on a near one-hot net: the
+ * two-piece split of the Value net is not enough).  Activations stay in LDS from block1 to the
+ * head, one board per workgroup.  For the batches a search evaluates the policy on.
+ *   own / opp: the boards (own = side to move; iago_encode_planes fused in), row b = board
+ *   index[b] when a gather list is given; n_dev: optional device-side row count.
+ *   w_hi / w_mid / w_lo[k]: block 2+k as three f16 tensors [cin/16][3][3][128][16]
+ *   (hi = f16(w), mid = f16((w - hi) 2^11), lo = f16(((w - hi) 2^11 - mid) 2^11)); w1 [64][2][3][3],
+ *   b1 [64], bias[k] [128], w9 [128], b10 [64]; probs [n][64].  overflow: see iago_conv3x3_split.
+ */
+typedef struct iago_policy_split3_args {
+    const uint64_t *own, *opp;
+    const int64_t *index;
+    const int32_t *n_dev;
+    int64_t n;
+    const float *w1, *b1;
+    const void *w_hi[7], *w_mid[7], *w_lo[7];
+    const float *bias[7];
+    const float *w9, *b10;
+    float *probs;
+    uint32_t *overflow;
+} iago_policy_split3_args;
+IAGO_API int iago_policy_forward_split3(const iago_policy_split3_args *args, void *stream);
 /*
  * Up to 8 consecutive iago_conv3x3_split layers in ONE launch (blocks 2..8 of the Value
  * net): a workgroup owns all 128 channels of its 4 boards, so it runs the layers back to

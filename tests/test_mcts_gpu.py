@@ -306,11 +306,17 @@ def test_counted_kernels_equal_host_counted(eng):
         assert torch.equal(planes, want)
         with torch.no_grad():
             got = m.forward_counted(planes, cnt)
-            got_b = m.forward_counted_boards(o, p, idx[:cap].contiguous(), cap, cnt)  # planes fused in
+            m.split3 = False   # per-layer float32 kernels, planes fused into the stem
+            got_b = m.forward_counted_boards(o, p, idx[:cap].contiguous(), cap, cnt)
+            m.split3 = True    # the whole net in one launch (three-piece split)
+            got_s = m.forward_counted_boards(o, p, idx[:cap].contiguous(), cap, cnt)
             if kk:
                 ref = m(want[:kk].contiguous())   # host-counted float32 kernels (<= 192 boards)
                 assert torch.equal(got[:kk], ref), (cap, k)
                 assert torch.equal(got_b[:kk], ref), (cap, k)
+                ref_s = m.forward_boards_split3(o, p, idx[:kk].contiguous(), kk)   # host-counted
+                assert torch.equal(got_s[:kk], ref_s), (cap, k)
+                assert (got_s[:kk] - ref).abs().max().item() < 2e-6   # random-init net: flat distributions
 
 
 def test_sync_free_equals_host_counted_with_real_nets(eng):
