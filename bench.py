@@ -173,9 +173,12 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
            "value_conv": ("f32 (MIOpen)" if value_f32 else
                           "split-f16 MFMA: f16 hi/lo operands, 3 MFMAs per product sum, f32 accumulation; "
                           "Value forward within 1e-6 of the f32 one (tests/test_conv_gpu.py)"),
-           "policy_conv": "f32: hand-written conv3x3_f32 / policy_head kernels (batches <= 192: the "
-                          "expansions of a playout); MIOpen above",
-           "roofline": _mcts_roofline(val, pol, dt, world, value_f32),
+           "policy_conv": ("three-piece split on the f16 matrix units, the whole net in one launch "
+                           "(iago_policy_forward_split3: 6 MFMAs per product sum, float32-exact products; within "
+                           "1e-5 of the float64 outputs on the shipped net, tests/test_nets_shipped.py)"
+                           if policy.split3 else
+                           "f32: hand-written conv3x3_f32 / policy_head kernels (batches <= 192); MIOpen above"),
+           "roofline": _mcts_roofline(val, pol, dt, world, value_f32, policy.split3),
            "config": "BASELINE configs[2]: PV-MCTS %d sims/move, %d games per GPU, SLPolicy+Value "
                      "random init fp32, lmbda=0.5 c_puct=1 n_thr=15" % (n_sims, n_games),
            "tree_pool_bytes_per_gpu": m.tree.bytes(), "tree_traffic_rank0": m.tree_bytes(),
@@ -206,23 +209,26 @@ def trunk_kernel_profile():
     return None
 
 
-def _mcts_roofline(leaf, pol, dt, world, value_f32):  # leaf = value-net evaluations executed
+def _mcts_roofline(leaf, pol, dt, world, value_f32, policy_split3=False):  # leaf = value-net evaluations executed
     """The convolutions bound this leg.  f32 path: float32 matrix/vector peak 157.3
     TFLOP/s.  Split-f16 path: the Value convolutions of blocks 2..8 (122.68 MFLOP per
-    evaluation) execute 3 f16 MFMAs per product sum against the dense f16 peak of
-    2,500 TFLOP/s (MI355X_MICROARCH.md)."""
+    evaluation) execute 3 f16 MFMAs per product sum -- and the SLPolicy ones (same shape) 6 with
+    the three-piece split -- against the dense f16 peak of 2,500 TFLOP/s (MI355X_MICROARCH.md)."""
     if value_f32:
         a = (leaf * 122_994_944 + pol * 122_847_232) / dt / 1e12 / world
         return {"bound": "mfma", "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
                 "flops_per_leaf_eval": 122_994_944, "flops_per_policy_eval": 122_847_232}
-    a = leaf * 3 * 122_683_392 / dt / 1e12 / world
+    a = (leaf * 3 + (pol * 6 if policy_split3 else 0)) * 122_683_392 / dt / 1e12 / world
     return {"bound": "mfma", "achieved": a, "peak": 2500.0, "unit": "TFLOP/s", "frac": a / 2500.0,
             "dtype": "f16 MFMA operands (split f32), f32 accumulate",
-            "mfma_flops_per_leaf_eval": 3 * 122_683_392, "flops_per_leaf_eval": 122_994_944,
+            "mfma_flops_per_leaf_eval": 3 * 122_683_392,
+            "mfma_flops_per_policy_eval": (6 * 122_683_392 if policy_split3 else 0),
+            "flops_per_leaf_eval": 122_994_944,
             "flops_per_policy_eval": 122_847_232,
-            "note": "loop level: executed MFMA FLOPs of the Value trunk (value-net evaluations actually run: "
-                    "the value cache skips re-evaluations of a leaf) over the WHOLE leg's wall time (tree "
-                    "kernels, policy net, rollout included); the trunk kernel alone: trunk_kernel",
+            "note": "loop level: executed f16 MFMA FLOPs of both nets' trunks (evaluations actually run: "
+                    "the value cache skips re-evaluations of a leaf, the policy look-ahead also evaluates "
+                    "leaves that never expand) over the WHOLE leg's wall time (tree kernels and rollouts "
+                    "included); the Value trunk kernel alone: trunk_kernel",
             "trunk_kernel": trunk_kernel_profile()}
 
 

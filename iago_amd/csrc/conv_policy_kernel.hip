@@ -24,6 +24,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -347,7 +349,11 @@ int iago_policy_forward_split3(const iago_policy_split3_args *a, void *stream)
                          "iago_policy_forward_split3: cannot reserve 52 KB of LDS"))
         return IAGO_ERR_HIP;
     // one board per workgroup; at most one workgroup per CU, walking the rows with the grid's stride
-    const int64_t cap = 256;
+    static const int64_t cap = []() {
+        const char *e = getenv("IAGO_POLICY_GRID"); // tuning knob (tools/)
+        const long v = e ? atol(e) : 256;
+        return (int64_t)(v < 1 ? 1 : v > 1024 ? 1024 : v);
+    }();
     const unsigned grid = (unsigned)(a->n < cap ? a->n : cap);
     hipLaunchKernelGGL(policy_resident_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, P);
     return iago_check_launch("iago_policy_forward_split3");

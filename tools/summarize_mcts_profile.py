@@ -11,7 +11,7 @@ import os
 import sys
 
 src = sys.argv[1]
-KERNELS = ["value_rollout_kernel", "trunk_resident_kernel", "conv3x3_split_trunk_kernel", "descend_kernel", "fresh_leaves_kernel", "select_kernel",
+KERNELS = ["value_rollout_kernel", "policy_resident_kernel", "trunk_resident_kernel", "conv3x3_split_trunk_kernel", "descend_kernel", "fresh_leaves_kernel", "select_kernel",
            "mix_backup_lookahead_kernel",
            "expand_cached_kernel", "store_priors_kernel", "mix_backup_kernel", "expand_kernel",
            "pending_kernel", "value_stem_kernel", "value_head_kernel", "conv3x3_f32_counted_kernel", "conv3x3_f32_kernel",
@@ -21,7 +21,7 @@ out = collections.OrderedDict((k, collections.OrderedDict()) for k in KERNELS)
 for path in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     for r in list(csv.reader(open(path)))[1:]:
         for k in KERNELS:
-            if k in r[0]:
+            if "::" + k + "(" in r[0].replace("<", "(") or r[0].startswith(k + "("):
                 out[k]["calls"] = out[k].get("calls", 0) + int(r[1])
                 out[k]["total_ns"] = out[k].get("total_ns", 0) + int(float(r[2]))
 for k in KERNELS:
@@ -31,7 +31,7 @@ for path in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collecti
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         for k in KERNELS:
-            if k in r["Kernel_Name"]:
+            if "::" + k + "(" in r["Kernel_Name"].replace("<", "(") or r["Kernel_Name"].startswith(k + "("):
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in agg.items():
         for c, v in cs.items():
