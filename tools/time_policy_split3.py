@@ -13,7 +13,7 @@ from iago_amd import network, ops  # noqa: E402
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 gold = np.load(os.path.join(GOLDEN, "nets_shipped.npz"))
 m = network.SLPolicy().load_npz(os.path.join(GOLDEN, "sl_model.npz")).cuda().eval()
-for n in (32, 64, 128, 170, 192, 256, 512):
+for n in (1, 2, 4, 8, 16, 32, 64, 128, 170, 192, 256, 512):
     idx = np.arange(n) % 256
     own, opp = ops.bits_to_tensor(gold["own"][idx]), ops.bits_to_tensor(gold["opp"][idx])
     index = torch.arange(n, device="cuda")
