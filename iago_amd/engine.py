@@ -667,9 +667,10 @@ class BatchedMCTS(object):
                     "a leaf reached n_thr without cached priors (raise `lookahead_slots`, now %d per "
                     "game; the look-ahead must be on from the reset of the trees and n_thr must "
                     "not change)" % self._la[0].slots))
-        sat = getattr(self.value_fn, "check_saturation", None)
-        if sat is not None:
-            sat()  # the split-f16 Value kernels clamp at 65000: never silently
+        for fn in (self.value_fn, self.policy_fn):
+            sat = getattr(fn, "check_saturation", None)
+            if sat is not None:
+                sat()  # the split-f16 kernels of both nets clamp at 65000: never silently
 
     def enable_stats(self):
         self.stats = torch.zeros((self.n_games, 2), dtype=torch.int32, device=self.cur_own.device)

@@ -166,12 +166,36 @@ class SLPolicy(nn.Module, _NpzMixin):
             self.__dict__["_split3_cache"] = hit
         return hit[1]
 
+    def _overflow_flag(self, device):
+        """Device word the three-piece kernel raises when an activation leaves the f16 range
+        (|a| > 65000: the 'hi' piece cannot hold it) or is NaN."""
+        f = self.__dict__.get("_ovf")
+        if f is None or f.device != device:
+            f = torch.zeros(1, dtype=torch.int32, device=device)
+            self.__dict__["_ovf"] = f
+        return f
+
+    def check_saturation(self):
+        """Raise if any three-piece forward since the last check saturated (one host sync; the
+        search engine calls it once per search).  `split3 = False` evaluates in float32, with
+        the reference's unbounded range."""
+        f = self.__dict__.get("_ovf")
+        if f is not None and int(f.item()) != 0:
+            f.zero_()
+            from ._lib import IagoError
+            raise IagoError("SLPolicy: an activation left the f16 range of the three-piece split "
+                            "(|a| > 65000) or is NaN; the priors of this search are saturated.  Set "
+                            "`policy.split3 = False` to evaluate in float32")
+
     def forward_boards_split3(self, own, opp, index=None, n=None, n_dev=None, overflow=None):
         """The move distributions of boards (own = side to move; rows index[0..n) when a gather
-        list is given) through the one-launch kernel.  Inference only."""
+        list is given) through the one-launch kernel.  Inference only.  overflow: the device
+        word to raise on saturation (default: the module's, see check_saturation)."""
         if self.training or not own.is_cuda:
             raise ValueError("forward_boards_split3: CUDA boards, eval mode")
         from . import ops
+        if overflow is None:
+            overflow = self._overflow_flag(own.device)
         with torch.no_grad():
             return ops.policy_forward_split3(own, opp, self.block1.conv.weight, self.block1.conv.bias,
                                              self._split3_layers(), self.conv9.weight, self.bias10.b,
