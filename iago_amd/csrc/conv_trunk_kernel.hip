@@ -543,12 +543,16 @@ int iago_launch_trunk_resident(const iago_conv_split_layer *layers, int32_t n_la
     P.n_dev = nullptr;
     P.count_lo = 0;
     P.count_hi = 0x7fffffff;
+#ifndef TRUNK_EXP_TB // boards per workgroup (timing experiments build 1 / 2: tools/exp_trunk_variants.sh)
+#define TRUNK_EXP_TB 4
+#endif
+    constexpr int TB = TRUNK_EXP_TB;
     static std::atomic<uint64_t> configured{0};
-    if (iago_reserve_lds((const void *)trunk_resident_kernel<false, 4>, lds_alloc(4), configured,
+    if (iago_reserve_lds((const void *)trunk_resident_kernel<false, TB>, lds_alloc(TB), configured,
                          "iago_conv3x3_split_trunk: cannot reserve 134 KB of LDS"))
         return IAGO_ERR_HIP;
-    const unsigned grid = (unsigned)((n + 3) / 4);
-    hipLaunchKernelGGL((trunk_resident_kernel<false, 4>), dim3(grid), dim3(256), lds_alloc(4), (hipStream_t)stream, P);
+    const unsigned grid = (unsigned)((n + TB - 1) / TB);
+    hipLaunchKernelGGL((trunk_resident_kernel<false, TB>), dim3(grid), dim3(256), lds_alloc(TB), (hipStream_t)stream, P);
     return iago_check_launch("iago_conv3x3_split_trunk");
 }
 

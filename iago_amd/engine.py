@@ -205,6 +205,10 @@ class BatchedMCTS(object):
         if use_graph and not self.sync_free:
             raise ValueError("use_graph needs the sync-free playout (a policy with forward_counted)")
         self.use_graph, self._graph, self._graph_key = bool(use_graph), None, None
+        # look-ahead blocks (of 2 K playouts) per replay of the long graph (tuning knob: DESIGN.md)
+        import os as _os2
+        self.graph_blocks = max(1, int(_os2.environ.get("IAGO_GRAPH_BLOCKS", "4")))
+        self._graph_long = None
         self.n_compactions = 0
         self._live_after_compaction = 0
         # Policy look-ahead (iago_mcts_lookahead in include/iago_hip.h): leaves are queued K
@@ -583,6 +587,15 @@ class BatchedMCTS(object):
             self._flush_lookahead(0)  # (queues empty: allocations and one-time setup only)
             self._flush_lookahead(1)
             torch.cuda.synchronize()
+        self._graph_long = None
+        if self.lookahead and self.graph_blocks > 1:
+            # the same block several times over: a replay costs tens of microseconds on the
+            # device whatever it holds, so long searches replay the long graph and finish with
+            # the one-block graph
+            self._graph_long = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_long):
+                for _ in range(self.graph_blocks):
+                    self._lookahead_block(self._g_own, self._g_opp, self._g_active, None)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             if self.lookahead:
@@ -609,7 +622,12 @@ class BatchedMCTS(object):
                             else self.sim_counter)
         if self.lookahead:
             block = 2 * self.lookahead
-            for _ in range(n_sims // block):
+            n_blocks = n_sims // block
+            if self._graph_long is not None:
+                for _ in range(n_blocks // self.graph_blocks):
+                    self._graph_long.replay()
+                n_blocks %= self.graph_blocks
+            for _ in range(n_blocks):
                 self._graph.replay()
             # the same launches, not captured
             self._lookahead_tail(self._g_own, self._g_opp, self._g_active, n_sims % block, None)
