@@ -507,7 +507,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         iago_row::rollout_row_body<false>(R, blockIdx.x);
         return;
     }
-    trunk_walk<true, 1>(P, blockIdx.x - n_ro, gridDim.x - n_ro);
+    // one board per workgroup while the rows fit the value workgroups in one pass; more rows (a
+    // few playouts in a hundred): two boards per workgroup share the weight stream, which bounds
+    // the one-board walk -- one pass up to twice as many rows
+    const int64_t nb = (int64_t)gridDim.x - n_ro;
+    const int64_t n_rows = min(P.n, (int64_t)*P.n_dev);
+    if (n_rows <= nb)
+        trunk_walk<true, 1>(P, blockIdx.x - n_ro, nb);
+    else
+        trunk_walk<true, 2>(P, blockIdx.x - n_ro, nb);
 }
 
 } // namespace
@@ -699,13 +707,13 @@ int iago_value_rollout(const iago_value_split_args *a, const iago_rollout_args *
     P.count_lo = 0;
     P.count_hi = 0x7fffffff;
     static std::atomic<uint64_t> configured{0};
-    if (iago_reserve_lds((const void *)value_rollout_kernel, lds_alloc_fused(1), configured,
-                         "iago_value_rollout: cannot reserve 45 KB of LDS"))
+    if (iago_reserve_lds((const void *)value_rollout_kernel, lds_alloc_fused(2), configured,
+                         "iago_value_rollout: cannot reserve 80 KB of LDS"))
         return IAGO_ERR_HIP;
     const iago_row::HwParams R = iago_row::hw_params_of(ro);
     const unsigned n_ro = (unsigned)((ro->n + (iago_row::HW_BLOCK / 16) - 1) / (iago_row::HW_BLOCK / 16));
     const unsigned n_val = (unsigned)(a->n < 256 ? a->n : 256);
-    hipLaunchKernelGGL(value_rollout_kernel, dim3(n_ro + n_val), dim3(256), lds_alloc_fused(1), (hipStream_t)stream, P, R,
+    hipLaunchKernelGGL(value_rollout_kernel, dim3(n_ro + n_val), dim3(256), lds_alloc_fused(2), (hipStream_t)stream, P, R,
                        n_ro);
     return iago_check_launch("iago_value_rollout");
 }

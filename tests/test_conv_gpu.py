@@ -271,7 +271,7 @@ def test_counted_value_forward_is_bit_identical(count):
     m.check_saturation()
 
 
-@pytest.mark.parametrize("count", [0, 5, 180, 700])
+@pytest.mark.parametrize("count", [0, 5, 180, 256, 257, 511, 700, 1024])
 def test_value_and_rollout_in_one_launch(count):
     """iago_value_rollout (the value net on a device-side list of boards and the rollout of ALL
     boards as two kinds of workgroups of one launch) against the two separate calls: identical
