@@ -228,7 +228,10 @@ def _mcts_roofline(leaf, pol, dt, world, value_f32, policy_split3=False):  # lea
             "note": "loop level: executed f16 MFMA FLOPs of both nets' trunks (evaluations actually run: "
                     "the value cache skips re-evaluations of a leaf, the policy look-ahead also evaluates "
                     "leaves that never expand) over the WHOLE leg's wall time (tree kernels and rollouts "
-                    "included); the Value trunk kernel alone: trunk_kernel",
+                    "included); the Value trunk kernel alone: trunk_kernel.  The one-board-per-workgroup "
+                    "launches of the search (Value 3.9 MB, SLPolicy 5.8 MB of weights per board into ONE CU) "
+                    "are bound by that CU's L2 bandwidth (~70 GB/s: 56 of 69 us, 83 of 113 us), not by the "
+                    "matrix pipe (DESIGN.md section 5)",
             "trunk_kernel": trunk_kernel_profile()}
 
 
