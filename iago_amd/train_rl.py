@@ -160,12 +160,17 @@ class ReinforceTrainer(object):
     def pick_opponent(self):
         """np.random.choice(glob('../models/RL/*.npz')) (src/train_rl.py:33-37)."""
         paths = sorted(glob.glob(os.path.join(self.pool_dir, "*.npz"))) if self.pool_dir else []
-        m2 = network.SLPolicy()
+        m2 = self.__dict__.get("_opponent")
+        if m2 is None:   # one opponent module for the whole run, refilled per set
+            m2 = self._opponent = network.SLPolicy().to(self.device).eval()
         if paths:
             m2.load_npz(paths[self.rs.randint(len(paths))])
         else:
-            m2.load_npz(self.model1.npz_dict())  # self-play against the current weights
-        return m2.to(self.device).eval()
+            # self-play against the current weights: device-to-device copies
+            with torch.no_grad():
+                for q, p1 in zip(m2.parameters(), self.model1.parameters()):
+                    q.copy_(p1)
+        return m2
 
     def play_set(self, model2):
         """2N games; odd games carry the handicap stone (src/train_rl.py:41-47).
