@@ -74,9 +74,9 @@ class MctsLookahead(C.Structure):
     """Mirror of iago_mcts_lookahead (include/iago_hip.h)."""
     _fields_ = [
         ("trigger", C.c_int32), ("slots", C.c_int32), ("next_seq", C.c_void_p), ("cache_seq", C.c_void_p),
-        ("cache", C.c_void_p), ("q_count", C.c_void_p), ("q_capacity", C.c_int32), ("reserved", C.c_int32),
+        ("cache", C.c_void_p), ("q_count", C.c_void_p), ("q_capacity", C.c_int32), ("path_stride", C.c_int32),
         ("q_own", C.c_void_p), ("q_opp", C.c_void_p), ("q_game", C.c_void_p), ("q_seq", C.c_void_p),
-        ("error", C.c_void_p), ("clear_word", C.c_void_p),
+        ("error", C.c_void_p), ("clear_word", C.c_void_p), ("path", C.c_void_p), ("path_len", C.c_void_p),
     ]
 
 

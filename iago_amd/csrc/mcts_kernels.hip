@@ -65,6 +65,24 @@ __device__ __forceinline__ void argmax_step(double &v, int &idx)
     idx = take ? oi : idx;
 }
 
+// the same step carrying four payload words of the winner
+template <int CTRL>
+__device__ __forceinline__ void argmax_step_payload(double &v, int &idx, uint32_t (&pl)[4])
+{
+    const uint64_t bits = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = dpp_u32<CTRL>((uint32_t)bits), hi = dpp_u32<CTRL>((uint32_t)(bits >> 32));
+    const double ov = __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    const int oi = (int)dpp_u32<CTRL>((uint32_t)idx);
+    const bool take = (ov > v) || (ov == v && oi < idx);
+    v = take ? ov : v;
+    idx = take ? oi : idx;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t o = dpp_u32<CTRL>(pl[i]);
+        pl[i] = take ? o : pl[i];
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void select_kernel(
     Tree T, const uint64_t *__restrict__ root_own, const uint64_t *__restrict__ root_opp,
     const uint8_t *__restrict__ active, float c_puct, int n_thr, int from_root,
@@ -353,6 +371,8 @@ struct Lookahead {
     int32_t *error;             // raised when a cache slot was recycled before its leaf expanded,
                                 // a leaf reaches n_thr without priors, or the queue is full
     int32_t *clear_word;        // optional: set to 0 by the backup (the fresh-leaf count of the next descent)
+    int32_t *path, *path_len;   // optional: the nodes of a game's last descent, root first ([n_games][path_stride])
+    int32_t path_stride;
 };
 
 __global__ __launch_bounds__(BLOCK) void mix_backup_lookahead_kernel(
@@ -400,6 +420,78 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_lookahead_kernel(
     // the leaf of this playout crosses the trigger exactly once (it gains one visit per playout
     // that ends on it): queue its position for the next flush
     if (T.n_visits[base + leaf] == A.trigger && T.first_child[base + leaf] == -1) {
+        const int pos = atomicAdd(A.q_count, 1);
+        if (pos < A.q_capacity) {
+            const int seq = A.next_seq[g];
+            A.next_seq[g] = seq + 1;
+            T.first_child[base + leaf] = -2 - seq;
+            A.q_own[pos] = cur_own[g];
+            A.q_opp[pos] = cur_opp[g];
+            A.q_game[pos] = (int32_t)g;
+            A.q_seq[pos] = seq;
+        } else {
+            *A.error = 1;
+        }
+    }
+}
+
+// The same backup with the path the descent recorded (iago_mcts_descend with A.path): the 8 lanes
+// of a game update its nodes side by side -- no climb through `parent`, whose loads depend on
+// each other (one round trip per level).  Same arithmetic per node: same trees.
+__global__ __launch_bounds__(BLOCK) void mix_backup_path_kernel(
+    Tree T, const uint8_t *__restrict__ active, const int32_t *__restrict__ cur_node,
+    const uint64_t *__restrict__ cur_own, const uint64_t *__restrict__ cur_opp, const float *__restrict__ v,
+    const int8_t *__restrict__ z, float lmbda, float *__restrict__ leaf_value, uint32_t *__restrict__ counter,
+    Lookahead A)
+{
+    const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t g = gtid >> 3;
+    const uint32_t r = threadIdx.x & 7u;
+    if (gtid == 0 && counter)
+        *counter += 1u;
+    if (gtid == 0 && A.clear_word)
+        *A.clear_word = 0;
+    if (g >= T.n_games)
+        return;
+    const int64_t base = g * (int64_t)T.capacity;
+    const bool act = active[g] != 0;
+    const int leaf = cur_node[g];
+    float vg = (lmbda < 1.0f) ? v[g] : 0.0f;
+    if (T.v && lmbda < 1.0f && act) {
+        // (every lane reads the slot, lane 0 fills it: the loads of a wave come before its stores)
+        float *slot = T.v + base + leaf;
+        const float cached = *slot;
+        if (cached != cached) {
+            if (r == 0u)
+                *slot = vg;
+        } else {
+            vg = cached;
+        }
+    }
+    // (1-lmbda)*v + lmbda*z exactly as leaf_values_kernel (MCTS.py:123-125)
+    const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * vg : 0.0f;
+    const float b = (lmbda > 0.0f) ? (float)((double)lmbda * (double)z[g]) : 0.0f;
+    const float lv = a + b;
+    if (r == 0u)
+        leaf_value[g] = lv;
+    if (!act)
+        return;
+    // lane 0 decides the queueing from the leaf's count BEFORE this playout (+ 1 = after it)
+    int leaf_n = 0, leaf_tag = 0;
+    if (r == 0u) {
+        leaf_n = T.n_visits[base + leaf];
+        leaf_tag = T.first_child[base + leaf];
+    }
+    const int len = A.path_len[g];
+    const int32_t *path = A.path + g * (int64_t)A.path_stride;
+    for (int d = (int)r; d < len; d += 8) {
+        const int node = path[d];
+        const int n = T.n_visits[base + node] + 1; // MCTS.py:61
+        const float q = T.q[base + node];
+        T.n_visits[base + node] = n;
+        T.q[base + node] = q + (lv - q) / (float)n; // MCTS.py:63
+    }
+    if (r == 0u && leaf_n + 1 == A.trigger && leaf_tag == -1) {
         const int pos = atomicAdd(A.q_count, 1);
         if (pos < A.q_capacity) {
             const int seq = A.next_seq[g];
@@ -518,30 +610,49 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
     const bool live = g < T.n_games && active[g] != 0;
     const int64_t base = live ? g * (int64_t)T.capacity : 0;
 
-    int node = 0;
+    // The descent is a chain of dependent loads (a level cannot start before the previous one
+    // has chosen its child): ONE round trip per level.  A lane that scores child c also loads
+    // c's action and c's own header (first_child, n_children, n_visits -- the statistics are
+    // loaded anyway -- and the stored value); the argmax butterfly carries them along, so the
+    // winner's move and the next level's header arrive with the winner's index.
+    int node = 0, fc = -1, k = 0, nv = 0;
+    uint32_t vbits = 0; // T.v[node] (the value cache), NaN = not evaluated
     uint64_t own = 0, opp = 0;
     if (live) {
         node = T.root[g];
         own = root_own[g];
         opp = root_opp[g];
+        fc = T.first_child[base + node];
+        k = (int)T.n_children[base + node];
+        nv = T.n_visits[base + node];
+        if (T.v)
+            vbits = __float_as_uint(T.v[base + node]);
     }
+    int32_t *const path = (A.path && live) ? A.path + g * (int64_t)A.path_stride : nullptr;
+    int path_n = 0;
     bool descending = live, may_expand = live;
     for (int depth = 0; depth < MAX_DEPTH; depth++) {
-        int fc = descending ? T.first_child[base + node] : -1;
+        if (path && descending && r == 0u) {
+            if (depth < A.path_stride)
+                path[depth] = node;
+            else
+                T.overflow[g] = 1; // deeper than the path buffer: reported like a full pool
+        }
+        path_n += descending ? 1 : 0;
         // a leaf with n_visits >= n_thr expands here and the descent goes on into its children
         // (once per playout: the new children have no visits)
-        const bool expand = descending && may_expand && fc < 0 && T.n_visits[base + node] >= n_thr;
+        const bool expand = descending && may_expand && fc < 0 && nv >= n_thr;
         if (__builtin_amdgcn_ballot_w64(expand) != 0ull) {
             const uint64_t lg = group8_legal(to_lane(own, L), to_lane(opp, L), L);
             if (expand) {
                 may_expand = false;
-                const int k = lg ? __popcll(lg) : 1;
+                const int kn = lg ? __popcll(lg) : 1;
                 const int tag = fc;
                 uint32_t fc1 = 0; // first child + 1, 0 = no room
                 if (r == 0u) {
                     const int at = T.n_nodes[g];
-                    if (at + k <= T.capacity) {
-                        T.n_nodes[g] = at + k;
+                    if (at + kn <= T.capacity) {
+                        T.n_nodes[g] = at + kn;
                         fc1 = (uint32_t)at + 1u;
                     } else {
                         T.overflow[g] = 1;
@@ -550,7 +661,7 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
                 fc1 = group8_add(fc1);
                 if (fc1 != 0u) {
                     const int nf = (int)fc1 - 1;
-                    if (lg == 0ull || k == 1) {
+                    if (lg == 0ull || kn == 1) {
                         // pass child / single legal move: Node(node, 1), no net (MCTS.py:112-117)
                         if (r == 0u)
                             init_node(T, base + nf, node, lg ? (int)__builtin_ctzll(lg) : -1, 1.0f + 0.1f);
@@ -571,9 +682,10 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
                     }
                     if (r == 0u) {
                         T.first_child[base + node] = nf;
-                        T.n_children[base + node] = (uint8_t)k;
+                        T.n_children[base + node] = (uint8_t)kn;
                     }
                     fc = nf;
+                    k = kn;
                 }
             }
             __threadfence_block(); // the new children are read by the other lanes of the group below
@@ -581,28 +693,50 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
         descending = descending && fc >= 0; // leaf reached (MCTS.py:107)
         if (__builtin_amdgcn_ballot_w64(descending) == 0ull)
             break;
-        const int k = descending ? (int)T.n_children[base + node] : 0;
-        const int pn = descending ? T.n_visits[base + node] : 0;
+        const int kk = descending ? k : 0;
         st_levels += descending ? 1 : 0;
-        st_children += k;
-        const double sq = sqrt((double)pn); // np.sqrt(parent.n_visits), MCTS.py:49
+        st_children += kk;
+        const double sq = sqrt((double)nv); // np.sqrt(parent.n_visits), MCTS.py:49
         double best_v = -INFINITY;
         int best_i = 0x7fffffff;
-        for (int j = (int)L.l8; j < k; j += 8) {
-            const int64_t c = base + fc + j;
-            const float cp = c_puct * T.p[c];                        // float32, MCTS.py:49
-            const double u = (double)cp * sq / (0.01 + (double)T.n_visits[c]);
-            const double v = (double)T.q[c] + u;                     // get_value, MCTS.py:75-76
-            if (v > best_v) { // strict: the first maximum wins (python max, MCTS.py:46)
-                best_v = v;
-                best_i = j;
+        uint32_t pl[4] = {0u, 0u, 0u, 0u}; // of the best child: first_child, n_visits, action | n_children << 8, v
+        // two children per lane and pass (16 per group): their loads are all in flight together
+        for (int j0 = (int)r; j0 < kk; j0 += 16) {
+            const int j1 = j0 + 8;
+            const bool two = j1 < kk;
+            const int64_t c0 = base + fc + j0, c1 = two ? base + fc + j1 : c0;
+            const float p0 = T.p[c0], q0 = T.q[c0], p1 = T.p[c1], q1 = T.q[c1];
+            const int n0 = T.n_visits[c0], n1 = T.n_visits[c1];
+            const int f0 = T.first_child[c0], f1 = T.first_child[c1];
+            const uint32_t a0 = (uint32_t)(uint8_t)T.action[c0] | ((uint32_t)T.n_children[c0] << 8);
+            const uint32_t a1 = (uint32_t)(uint8_t)T.action[c1] | ((uint32_t)T.n_children[c1] << 8);
+            const uint32_t w0 = T.v ? __float_as_uint(T.v[c0]) : 0u, w1 = T.v ? __float_as_uint(T.v[c1]) : 0u;
+            {
+                const float cp = c_puct * p0;                          // float32, MCTS.py:49
+                const double u = (double)cp * sq / (0.01 + (double)n0);
+                const double v = (double)q0 + u;                       // get_value, MCTS.py:75-76
+                if (v > best_v) { // strict: the first maximum wins (python max, MCTS.py:46)
+                    best_v = v;
+                    best_i = j0;
+                    pl[0] = (uint32_t)f0, pl[1] = (uint32_t)n0, pl[2] = a0, pl[3] = w0;
+                }
+            }
+            if (two) {
+                const float cp = c_puct * p1;
+                const double u = (double)cp * sq / (0.01 + (double)n1);
+                const double v = (double)q1 + u;
+                if (v > best_v) {
+                    best_v = v;
+                    best_i = j1;
+                    pl[0] = (uint32_t)f1, pl[1] = (uint32_t)n1, pl[2] = a1, pl[3] = w1;
+                }
             }
         }
-        argmax_step<DPP_XOR1>(best_v, best_i);
-        argmax_step<DPP_XOR2>(best_v, best_i);
-        argmax_step<DPP_HALF_MIRROR>(best_v, best_i);
+        argmax_step_payload<DPP_XOR1>(best_v, best_i, pl);
+        argmax_step_payload<DPP_XOR2>(best_v, best_i, pl);
+        argmax_step_payload<DPP_HALF_MIRROR>(best_v, best_i, pl);
         const int child = fc + best_i;
-        const int a = descending ? (int)T.action[base + child] : -1;
+        const int a = descending ? (int)(int8_t)(pl[2] & 0xFFu) : -1;
         // GameFunctions.place_stone(state, action, c); c = 3 - c  (MCTS.py:131-132)
         const uint64_t f = group8_flips(to_lane(own, L), to_lane(opp, L), (uint32_t)a & 63u, L);
         if (descending) {
@@ -615,22 +749,28 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
             own = np_;
             opp = no;
             node = child;
+            fc = (int)pl[0];
+            nv = (int)pl[1];
+            k = (int)(pl[2] >> 8);
+            vbits = pl[3];
         }
     }
     const uint64_t legal = group8_legal(to_lane(own, L), to_lane(opp, L), L);
-    if (live && r == 0 && descending && T.first_child[base + node] >= 0)
+    if (live && r == 0 && descending && fc >= 0)
         T.overflow[g] = 1; // path longer than MAX_DEPTH: reported like a full pool
     if (live && r == 0) {
         cur_node[g] = node;
         cur_own[g] = own;
         cur_opp[g] = opp;
         legal_out[g] = legal;
+        if (A.path)
+            A.path_len[g] = path_n < A.path_stride ? path_n : A.path_stride;
         if (stats) {
             stats[2 * g] += st_levels;
             stats[2 * g + 1] += st_children;
         }
         if (fresh_index) {
-            const float c = T.v[base + node];
+            const float c = __uint_as_float(vbits);
             if (c != c) {
                 fresh_index[atomicAdd(fresh_count, 1)] = g;
                 if (fresh_total)
@@ -998,6 +1138,11 @@ int lookahead_of(const iago_mcts_lookahead *a, Lookahead &A, const char *who)
     A.q_seq = a->q_seq;
     A.error = a->error;
     A.clear_word = a->clear_word;
+    A.path = a->path_stride > 0 ? a->path : nullptr;
+    A.path_len = a->path_len;
+    A.path_stride = a->path_stride;
+    if (A.path && (!A.path_len || a->path_stride < 8))
+        return iago_fail(IAGO_ERR_INVALID, who);
     return IAGO_OK;
 }
 } // namespace
@@ -1018,9 +1163,14 @@ int iago_mcts_mix_backup_lookahead(const iago_mcts_tree *tree, const uint8_t *ac
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_mix_backup_lookahead: null pointer");
     if (tree->n_games == 0)
         return IAGO_OK;
-    hipLaunchKernelGGL(mix_backup_lookahead_kernel, dim3(grid_for(tree->n_games)), dim3(BLOCK), 0,
-                       (hipStream_t)stream, *tree, active, cur_node, cur_own, cur_opp, v, z, lmbda, leaf_value,
-                       counter, A);
+    if (A.path) // the descent recorded the path: 8 lanes per game update its nodes side by side
+        hipLaunchKernelGGL(mix_backup_path_kernel, dim3(grid_for(tree->n_games * 8)), dim3(BLOCK), 0,
+                           (hipStream_t)stream, *tree, active, cur_node, cur_own, cur_opp, v, z, lmbda, leaf_value,
+                           counter, A);
+    else
+        hipLaunchKernelGGL(mix_backup_lookahead_kernel, dim3(grid_for(tree->n_games)), dim3(BLOCK), 0,
+                           (hipStream_t)stream, *tree, active, cur_node, cur_own, cur_opp, v, z, lmbda, leaf_value,
+                           counter, A);
     return iago_check_launch("iago_mcts_mix_backup_lookahead");
 }
 

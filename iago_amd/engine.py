@@ -244,6 +244,13 @@ class BatchedMCTS(object):
             self._la_cache_seq = torch.full((n_games, slots), -1, dtype=torch.int32, **kw)
             self._la_cache = torch.zeros((n_games, slots, 64), dtype=torch.float32, **kw)
             self._la_error = torch.zeros(1, dtype=torch.int32, **kw)
+            # the nodes of a game's last descent (the one-launch descent records them, the backup
+            # updates them side by side): a path has at most one node per remaining ply
+            self.PATH_STRIDE = 128
+            self.fused_descent = os.environ.get("IAGO_FUSED_DESCENT", "1") != "0"
+            use_path = self.fused_descent and os.environ.get("IAGO_BACKUP_PATH", "1") != "0"
+            self._la_path = torch.zeros((n_games, self.PATH_STRIDE), dtype=torch.int32, **kw) if use_path else None
+            self._la_path_len = torch.zeros(n_games, dtype=torch.int32, **kw) if use_path else None
             # two queues: the playouts of a group fill one while the other one's batch is in flight
             self._la_queues, self._la = [], []
             for _ in range(2):
@@ -259,10 +266,12 @@ class BatchedMCTS(object):
                 a.error = self._la_error.data_ptr()
                 # the backup clears the fresh-leaf count that the next descent appends to
                 a.clear_word = self._fresh_count.data_ptr() if self.value_cache else None
+                if self._la_path is not None:
+                    a.path, a.path_len = self._la_path.data_ptr(), self._la_path_len.data_ptr()
+                    a.path_stride = self.PATH_STRIDE
                 self._la_queues.append(q)
                 self._la.append(a)
             self._la_cur = 0   # the queue the playouts fill
-            self.fused_descent = os.environ.get("IAGO_FUSED_DESCENT", "1") != "0"
             prio = int(os.environ.get("IAGO_SIDE_PRIORITY", "0"))
             self._la_side = torch.cuda.Stream(device=device, priority=prio) if self.lookahead_overlap else None
 

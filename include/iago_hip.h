@@ -540,12 +540,19 @@ typedef struct iago_mcts_lookahead {
     int32_t *cache_seq;
     float *cache;
     int32_t *q_count;
-    int32_t q_capacity, reserved;
+    int32_t q_capacity;
+    int32_t path_stride;   /* entries per game of `path` (>= 8), 0 = no path */
     uint64_t *q_own, *q_opp;
     int32_t *q_game, *q_seq;
     int32_t *error;
     int32_t *clear_word;   /* optional device word iago_mcts_mix_backup_lookahead sets to 0 (the fresh-leaf
                               count that the next iago_mcts_descend appends to) */
+    int32_t *path;         /* optional [n_games][path_stride]: iago_mcts_descend records the nodes it visits, root
+                              first (Node.update_recursive's ancestors, MCTS.py:66-72, in reverse), and their
+                              number in path_len [n_games]; iago_mcts_mix_backup_lookahead then updates them side
+                              by side instead of climbing through `parent`.  A descent deeper than path_stride
+                              sets the game's `overflow` */
+    int32_t *path_len;
 } iago_mcts_lookahead;
 IAGO_API int iago_mcts_mix_backup_lookahead(const iago_mcts_tree *tree, const uint8_t *active,
                                             const int32_t *cur_node, const uint64_t *cur_own,
