@@ -245,8 +245,10 @@ class BatchedMCTS(object):
             self._la_cache = torch.zeros((n_games, slots, 64), dtype=torch.float32, **kw)
             self._la_error = torch.zeros(1, dtype=torch.int32, **kw)
             # the nodes of a game's last descent (the one-launch descent records them, the backup
-            # updates them side by side): a path has at most one node per remaining ply
-            self.PATH_STRIDE = 128
+            # updates them side by side).  A path can be much longer than the plies left: at a
+            # finished position every expansion adds one more pass child (MCTS.py:112-114), so the
+            # buffer covers the descent's own bound of 512 levels
+            self.PATH_STRIDE = 520
             self.fused_descent = os.environ.get("IAGO_FUSED_DESCENT", "1") != "0"
             use_path = self.fused_descent and os.environ.get("IAGO_BACKUP_PATH", "1") != "0"
             self._la_path = torch.zeros((n_games, self.PATH_STRIDE), dtype=torch.int32, **kw) if use_path else None

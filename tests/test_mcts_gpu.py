@@ -404,6 +404,40 @@ def test_policy_lookahead_builds_the_same_trees(eng, n_thr, K, use_graph, cap, o
     assert n_thr != 15 or la.n_policy_evals < 2 * ref.n_policy_evals
 
 
+def test_pass_chains_deeper_than_the_plies_left(eng):
+    """At a finished position (neither side can move) every expansion adds one more pass child
+    (MCTS.py:112-114), so a search path grows far beyond the plies left -- here past 200 nodes.
+    The one-launch descent records the path and the backup walks the record: same trees as the
+    reference's order with the climb through `parent`."""
+    engine, ops = eng
+    from iago_amd import network
+    g = __import__("tests.conftest", fromlist=["load_json"]).load_json("simulate.json")
+    torch.manual_seed(9)
+    policy, value = network.SLPolicy().cuda().eval(), network.Value().cuda().eval()
+    w = ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+    G = 16
+    own = np.full(G, 1, np.uint64)                      # one stone each, far apart: no move for either side
+    opp = np.full(G, 1 << 63, np.uint64)
+    own[8:], opp[8:] = 0x0000000810000000, 0x0000001008000000   # and ordinary games beside them
+
+    def make(lookahead):
+        return engine.BatchedMCTS(G, policy, value, w, n_thr=3, capacity=4096, seed=2, sync_free=True,
+                                  lookahead=lookahead, lookahead_overlap=0, use_graph=False)
+
+    ref, la = make(0), make(1)
+    assert la._la_path is not None and la.PATH_STRIDE >= 512
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    act = torch.ones(G, dtype=torch.uint8, device="cuda")
+    ref.search(o, p, act, 700)
+    la.search(o.clone(), p.clone(), act, 700)
+    depth = int(la._la_path_len[:8].max().item())
+    assert depth > 200, depth
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 5000))
+    for gi in range(G):
+        assert ref.tree.dump(gi, max_depth=1000) == la.tree.dump(gi, max_depth=1000), gi
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_value_cache_builds_the_same_trees(eng, use_graph):
     """Value cache (the value net only on leaves it has not evaluated yet, every other visit takes
