@@ -130,7 +130,10 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     eng = engine.SelfPlayEngine(m, max_turns=(128 if full_games else n_turns))
     m.enable_stats()
     m.warmup()                 # MIOpen kernel selection for every batch bucket
-    engine.SelfPlayEngine(m, max_turns=4).play(16, record=False)  # allocator, code objects
+    warm = engine.SelfPlayEngine(m, max_turns=4).play(16, record=True)  # allocator, code objects
+    if dist is not None and full_games:
+        from iago_amd.dist import gather_tuples
+        gather_tuples(warm.tuples())   # (RCCL sets up a collective of a new size class on its first use)
     m.n_leaf_evals = m.n_policy_evals = 0
     m.stats.zero_()
     torch.cuda.synchronize()
@@ -139,8 +142,11 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     t0 = time.perf_counter()
     res = eng.play(n_sims, record=True)
     gathered = None
+    t_play = None
     if dist is not None and full_games:
         from iago_amd.dist import gather_tuples
+        torch.cuda.synchronize()
+        t_play = time.perf_counter() - t0
         gathered = gather_tuples(res.tuples())
     torch.cuda.synchronize()
     if dist is not None:
@@ -188,6 +194,7 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
         out["games_per_sec"] = world * n_games / dt
         if gathered is not None:
             out["gathered_tuples"] = int(gathered["z"].numel())
+            out["play_seconds_rank0"] = t_play   # the rest of `seconds`: packing + all-gather of the tuples + barrier
     return out
 
 
