@@ -67,6 +67,7 @@ class PolicySplit3Args(C.Structure):
         ("w1", C.c_void_p), ("b1", C.c_void_p),
         ("w_hi", C.c_void_p * 7), ("w_mid", C.c_void_p * 7), ("w_lo", C.c_void_p * 7), ("bias", C.c_void_p * 7),
         ("w9", C.c_void_p), ("b10", C.c_void_p), ("probs", C.c_void_p), ("overflow", C.c_void_p),
+        ("parts", C.c_int32), ("reserved", C.c_int32), ("scratch", C.c_void_p),
     ]
 
 

@@ -52,6 +52,11 @@ struct PolicyParams {
     const float *w9, *b10;      // conv9 [128] (1x1, no bias), bias10 [64]
     float *probs;               // [n][64]
     uint32_t *overflow;
+    // a launch may run only the layers [layer_lo, layer_hi) of blocks 2..8 (0..7): block1 comes
+    // with layer_lo == 0, the head with layer_hi == 7, a board's LDS image (64 rows of RS bytes)
+    // travels between the launches through `scratch` [n][64 * RS]
+    int layer_lo, layer_hi;
+    uint4 *scratch;
 };
 
 // (conv_trunk_kernel.hip) ds_read_b128 serves lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}
@@ -85,7 +90,11 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
     if (tid < ZB / 16)
         *(uint4 *)(T + 64 * RS + tid * 16) = make_uint4(0, 0, 0, 0);
     bool saturated = false;
-    {
+    if (P.layer_lo > 0) {
+        const uint4 *src = P.scratch + row_id * (64 * RS / 16);
+        for (int e = tid; e < 64 * RS / 16; e += 256)
+            *(uint4 *)(T + e * 16) = src[e];
+    } else {
         const int cell = tid & 63, y = cell >> 3, x = cell & 7;
         const uint64_t bits0 = P.opp[b], bits1 = P.own[b];
         float in[18];
@@ -151,7 +160,7 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
     for (int j = 0; j < 2; j++)
         wrow[j] = (uint32_t)((32 * j + lane_cell) * RS);
 
-    for (int L = 0; L < 7; L++) {
+    for (int L = P.layer_lo; L < P.layer_hi; L++) {
         const int n_chunks = L == 0 ? 4 : 8;
         // this lane's A operand: output channel 32 wv + r, input channels 8 h .. 8 h + 7 of the
         // k-step's chunk; a k-step (chunk, tap) is 128 x 32 B further
@@ -267,6 +276,12 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
     }
     if (P.overflow && saturated)
         *P.overflow = 1u;
+    if (P.layer_hi < 7) { // the next launch goes on from this image
+        uint4 *dst = P.scratch + row_id * (64 * RS / 16);
+        for (int e = tid; e < 64 * RS / 16; e += 256)
+            dst[e] = *(const uint4 *)(T + e * 16);
+        return;
+    }
 
     // ---- head (network.py:29-47): conv9 (1x1, 128 -> 1, no bias), + bias10 per cell, softmax over
     // the 64 cells.  One wave: lane = cell, float32 on the exact values hi + mid 2^-11 + lo 2^-22.
@@ -355,6 +370,18 @@ int iago_policy_forward_split3(const iago_policy_split3_args *a, void *stream)
         return (int64_t)(v < 1 ? 1 : v > 1024 ? 1024 : v);
     }();
     const unsigned grid = (unsigned)(a->n < cap ? a->n : cap);
-    hipLaunchKernelGGL(policy_resident_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, P);
+    // parts > 1: the 7 convolution blocks as that many launches of 7 / parts blocks each (short
+    // launches leave the CUs to the other stream's kernels sooner), the boards' LDS images
+    // travelling through `scratch`
+    const int parts = a->parts < 1 ? 1 : (a->parts > 7 ? 7 : a->parts);
+    if (parts > 1 && (!a->scratch || ((uintptr_t)a->scratch & 15u)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_policy_forward_split3: parts > 1 needs a 16-byte aligned scratch "
+                                           "buffer of n x 50,176 bytes");
+    P.scratch = (uint4 *)a->scratch;
+    for (int p = 0; p < parts; p++) {
+        P.layer_lo = 7 * p / parts;
+        P.layer_hi = 7 * (p + 1) / parts;
+        hipLaunchKernelGGL(policy_resident_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, P);
+    }
     return iago_check_launch("iago_policy_forward_split3");
 }

@@ -569,6 +569,7 @@ class BatchedMCTS(object):
                 key.append(bool(getattr(fn, "training", False)))
                 key.append(bool(getattr(fn, "split_f16", False)))
                 key.append(bool(getattr(fn, "fused", False)))
+                key.append((getattr(fn, "split3", None), getattr(fn, "split3_parts", None)))
             else:
                 key.append(id(fn))
         return tuple(key)

@@ -155,6 +155,9 @@ class SLPolicy(nn.Module, _NpzMixin):
     # The whole net in one launch with three f16 pieces per float32 operand
     # (csrc/conv_policy_kernel.hip) instead of the per-layer float32 kernels.
     split3 = os.environ.get("IAGO_POLICY_SPLIT3", "1") != "0"
+    # launches per forward: two half-nets leave the CUs to the playouts' kernels sooner than one
+    # launch that holds them for the whole net (tuning knob: DESIGN.md)
+    split3_parts = int(os.environ.get("IAGO_POLICY_PARTS", "2"))
 
     def _split3_layers(self):
         from . import ops
@@ -199,7 +202,8 @@ class SLPolicy(nn.Module, _NpzMixin):
         with torch.no_grad():
             return ops.policy_forward_split3(own, opp, self.block1.conv.weight, self.block1.conv.bias,
                                              self._split3_layers(), self.conv9.weight, self.bias10.b,
-                                             n=n, index=index, n_dev=n_dev, overflow=overflow)
+                                             n=n, index=index, n_dev=n_dev, overflow=overflow,
+                                             parts=self.split3_parts)
 
     def forward_counted_boards(self, own, opp, index, n, n_dev):
         """forward_counted on make_state_var of boards index[0..n) (own = side to move) without

@@ -264,7 +264,11 @@ def split_weights3(weight):
     return hi.contiguous(), mid.contiguous(), lo.contiguous()
 
 
-def policy_forward_split3(own, opp, w1, b1, layers, w9, b10, n=None, index=None, n_dev=None, overflow=None):
+_POLICY_SCRATCH = {}
+
+
+def policy_forward_split3(own, opp, w1, b1, layers, w9, b10, n=None, index=None, n_dev=None, overflow=None,
+                          parts=1):
     """The whole SLPolicy net in one launch (iago_policy_forward_split3): boards (own = side to
     move) -> (n, 64) probabilities.  layers: the 7 (w_hi, w_mid, w_lo, bias) of blocks 2..8
     (split_weights3); index / n_dev: optional device-side gather list and row count."""
@@ -291,6 +295,14 @@ def policy_forward_split3(own, opp, w1, b1, layers, w9, b10, n=None, index=None,
     a.b10 = _dev(b10, torch.float32, "b10").value
     probs = torch.empty((n, 64), dtype=torch.float32, device=own.device)
     a.probs = probs.data_ptr()
+    if parts > 1:
+        # one buffer per (device, stream, capacity): the launches of a call, and the calls of a
+        # stream, run in order; calls on different streams must not share it
+        key = (str(own.device), _stream().value, n)
+        scratch = _POLICY_SCRATCH.get(key)
+        if scratch is None:
+            scratch = _POLICY_SCRATCH[key] = torch.empty((n, 50176), dtype=torch.uint8, device=own.device)
+        a.parts, a.scratch = parts, scratch.data_ptr()
     f = _flag(overflow)
     a.overflow = f.value if f is not None else None
     check(_lib.lib().iago_policy_forward_split3(C.byref(a), _stream()), "iago_policy_forward_split3")

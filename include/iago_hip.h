@@ -301,6 +301,9 @@ typedef struct iago_policy_split3_args {
     const float *w9, *b10;
     float *probs;
     uint32_t *overflow;
+    int32_t parts;          /* 0 / 1: one launch; 2..7: the 7 blocks as that many launches of 7 / parts blocks */
+    int32_t reserved;
+    void *scratch;          /* parts > 1: [n][50,176] bytes, a board's activations between the launches */
 } iago_policy_split3_args;
 IAGO_API int iago_policy_forward_split3(const iago_policy_split3_args *args, void *stream);
 /*
