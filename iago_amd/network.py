@@ -199,11 +199,29 @@ class SLPolicy(nn.Module, _NpzMixin):
         from . import ops
         if overflow is None:
             overflow = self._overflow_flag(own.device)
+        rows = own.numel() if n is None else n
+        scratch = self._split3_scratch(own.device, rows) if self.split3_parts > 1 else None
         with torch.no_grad():
             return ops.policy_forward_split3(own, opp, self.block1.conv.weight, self.block1.conv.bias,
                                              self._split3_layers(), self.conv9.weight, self.bias10.b,
                                              n=n, index=index, n_dev=n_dev, overflow=overflow,
-                                             parts=self.split3_parts)
+                                             parts=self.split3_parts, scratch=scratch)
+
+    def _split3_scratch(self, device, rows):
+        """The buffer a multi-launch forward parks the boards' activations in: one per stream
+        (calls on different streams must not share it), kept for the module's lifetime -- a
+        captured hipGraph of the search engine holds its address."""
+        from . import ops
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        pool = self.__dict__.setdefault("_split3_scratch_pool", {})
+        buf = pool.get(key)
+        if buf is None or buf.shape[0] < rows:
+            # (a larger request replaces the buffer; the old one stays referenced so that graphs
+            # captured with it keep valid memory)
+            if buf is not None:
+                pool.setdefault("retired", []).append(buf)
+            buf = pool[key] = torch.empty((rows, ops.POLICY_SCRATCH_ROW_BYTES), dtype=torch.uint8, device=device)
+        return buf
 
     def forward_counted_boards(self, own, opp, index, n, n_dev):
         """forward_counted on make_state_var of boards index[0..n) (own = side to move) without

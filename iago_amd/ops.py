@@ -264,11 +264,11 @@ def split_weights3(weight):
     return hi.contiguous(), mid.contiguous(), lo.contiguous()
 
 
-_POLICY_SCRATCH = {}
+POLICY_SCRATCH_ROW_BYTES = 50176   # a board's LDS image in iago_policy_forward_split3 (64 rows of 784 B)
 
 
 def policy_forward_split3(own, opp, w1, b1, layers, w9, b10, n=None, index=None, n_dev=None, overflow=None,
-                          parts=1):
+                          parts=1, scratch=None):
     """The whole SLPolicy net in one launch (iago_policy_forward_split3): boards (own = side to
     move) -> (n, 64) probabilities.  layers: the 7 (w_hi, w_mid, w_lo, bias) of blocks 2..8
     (split_weights3); index / n_dev: optional device-side gather list and row count."""
@@ -296,13 +296,12 @@ def policy_forward_split3(own, opp, w1, b1, layers, w9, b10, n=None, index=None,
     probs = torch.empty((n, 64), dtype=torch.float32, device=own.device)
     a.probs = probs.data_ptr()
     if parts > 1:
-        # one buffer per (device, stream, capacity): the launches of a call, and the calls of a
-        # stream, run in order; calls on different streams must not share it
-        key = (str(own.device), _stream().value, n)
-        scratch = _POLICY_SCRATCH.get(key)
-        if scratch is None:
-            scratch = _POLICY_SCRATCH[key] = torch.empty((n, 50176), dtype=torch.uint8, device=own.device)
-        a.parts, a.scratch = parts, scratch.data_ptr()
+        # parts launches; scratch: uint8 [>= n][POLICY_SCRATCH_ROW_BYTES], not shared with a call on
+        # another stream (the launches of a call, and the calls of a stream, run in order)
+        if scratch is None or scratch.numel() < n * POLICY_SCRATCH_ROW_BYTES:
+            raise ValueError("policy_forward_split3: parts > 1 needs a scratch buffer of n x %d bytes"
+                             % POLICY_SCRATCH_ROW_BYTES)
+        a.parts, a.scratch = parts, _dev(scratch, torch.uint8, "scratch").value
     f = _flag(overflow)
     a.overflow = f.value if f is not None else None
     check(_lib.lib().iago_policy_forward_split3(C.byref(a), _stream()), "iago_policy_forward_split3")
