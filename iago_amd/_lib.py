@@ -104,6 +104,7 @@ class MctsTree(C.Structure):
 
 
 _lib = None
+ABI_VERSION = 5   # iago_abi_version() of the include/iago_hip.h these bindings mirror
 
 
 def lib():
@@ -129,6 +130,10 @@ def lib():
     L = C.CDLL(SO_PATH)
     vp, i64 = C.c_void_p, C.c_int64
     L.iago_abi_version.restype = C.c_int
+    if L.iago_abi_version() != ABI_VERSION:
+        # the ctypes structures below mirror ONE version of include/iago_hip.h
+        raise IagoError("%s has ABI version %d, these bindings are for %d: rebuild it "
+                        "(`python -m iago_amd.build`)" % (SO_PATH, L.iago_abi_version(), ABI_VERSION))
     L.iago_last_error.restype = C.c_char_p
     L.iago_device_count.restype = C.c_int
     L.iago_legal_moves.argtypes = [vp, vp, vp, i64, vp]
