@@ -649,11 +649,18 @@ class BatchedMCTS(object):
         self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
         self.n_leaf_evals += n_active * n_sims
 
-    def search(self, own, opp, active, n_sims):
+    def search_counts(self, active):
+        """Device tensor int64[2]: games in `active`, nodes of the fullest pool -- what search()
+        reads back before it starts (a caller that batches its readbacks passes them in)."""
+        return torch.stack([active.sum().to(torch.int64), self.tree.n_nodes.max().to(torch.int64)])
+
+    def search(self, own, opp, active, n_sims, counts=None, check=True):
         """n_sims playouts from the current roots; (own, opp) = root positions
-        with own = side to move; active: uint8 mask of participating games."""
-        n_active, used = (int(v) for v in torch.stack(
-            [active.sum().to(torch.int64), self.tree.n_nodes.max().to(torch.int64)]).tolist())
+        with own = side to move; active: uint8 mask of participating games.
+        counts: (games in `active`, nodes of the fullest pool) when the caller has read
+        search_counts() back already; check=False: the error flags are not read back here (one
+        host sync each) -- the caller reads error_flags() and calls raise_errors()."""
+        n_active, used = (int(v) for v in (self.search_counts(active).tolist() if counts is None else counts))
         if n_active == 0:
             return
         if self.value_cache:
@@ -685,22 +692,37 @@ class BatchedMCTS(object):
         else:
             for _ in range(n_sims):
                 self.simulate(own, opp, active, n_active)
-        if int(self.tree.overflow.sum().item()) != 0:
+        if check:
+            self.raise_errors(self.error_flags().tolist())
+
+    def error_flags(self):
+        """Device tensor int64[4]: pools that overflowed, the look-ahead's error word, the
+        saturation flags of the value and the policy net (0 where a net has none)."""
+        dev = self.cur_own.device
+        zero = torch.zeros((), dtype=torch.int64, device=dev)
+        parts = [self.tree.overflow.sum().to(torch.int64),
+                 self._la_error[0].to(torch.int64) if self.lookahead else zero]
+        for fn in (self.value_fn, self.policy_fn):
+            f = getattr(fn, "__dict__", {}).get("_ovf") if hasattr(fn, "check_saturation") else None
+            parts.append(f.reshape(-1)[0].to(torch.int64) if f is not None and f.device == dev else zero)
+        return torch.stack(parts)
+
+    def raise_errors(self, flags):
+        """The errors of a search from the host copy of error_flags()."""
+        overflow, err, sat_v, sat_p = (int(x) for x in flags)
+        if overflow != 0:
             raise _lib.IagoError("MCTS node pool exhausted (or a search path deeper than 512): "
                                  "raise `capacity` (%d nodes per game)" % self.tree.capacity)
-        if self.lookahead:
-            err = int(self._la_error.item())
-            if err:
-                self._la_error.zero_()
-                raise _lib.IagoError("policy look-ahead: %s" % (
-                    "the queue overflowed" if err == 1 else
-                    "a leaf reached n_thr without cached priors (raise `lookahead_slots`, now %d per "
-                    "game; the look-ahead must be on from the reset of the trees and n_thr must "
-                    "not change)" % self._la[0].slots))
-        for fn in (self.value_fn, self.policy_fn):
-            sat = getattr(fn, "check_saturation", None)
-            if sat is not None:
-                sat()  # the split-f16 kernels of both nets clamp at 65000: never silently
+        if err:
+            self._la_error.zero_()
+            raise _lib.IagoError("policy look-ahead: %s" % (
+                "the queue overflowed" if err == 1 else
+                "a leaf reached n_thr without cached priors (raise `lookahead_slots`, now %d per "
+                "game; the look-ahead must be on from the reset of the trees and n_thr must "
+                "not change)" % self._la[0].slots))
+        for fn, flag in ((self.value_fn, sat_v), (self.policy_fn, sat_p)):
+            if flag:
+                fn.check_saturation()  # raises (and clears the flag): the split-f16 kernels clamp at 65000
 
     def enable_stats(self):
         self.stats = torch.zeros((self.n_games, 2), dtype=torch.int32, device=self.cur_own.device)
@@ -779,18 +801,18 @@ class SelfPlayEngine(object):
             res.valid = torch.zeros((T, B), dtype=torch.uint8, device=dev)
             res.move = torch.full((T, B), -1, dtype=torch.int8, device=dev)
         res.mover = []
+        def next_active():
+            return ((ops.legal_moves(own, opp) != 0) & ~done).to(torch.uint8)
+
         t = 0
+        active = next_active()
+        counts = m.search_counts(active).tolist()
         while t < T:
-            legal = ops.legal_moves(own, opp)
-            has = legal != 0
-            active = (has & ~done).to(torch.uint8)
-            m.search(own, opp, active, n_sims)
+            # ONE readback per move (below): the flags of this move's search, the check of its
+            # moves, the end-of-game test and the counts the next search starts from
+            m.search(own, opp, active, n_sims, counts=counts, check=False)
             move, visits = m.best_move(active)
             mv = torch.where(active.bool(), move, torch.full_like(move, -1))
-            if bool((mv == -2).any().item()):
-                # what max() over an empty children dict raises in MCTS.get_move (MCTS.py:147)
-                raise ValueError("a searched root has no children: n_sims is below the "
-                                 "expansion threshold n_thr")
             if record:
                 res.own[t], res.opp[t], res.valid[t], res.move[t] = own, opp, active, mv
                 res.pi[t] = visits * active.reshape(B, 1).to(torch.int32)
@@ -806,8 +828,17 @@ class SelfPlayEngine(object):
             t += 1
             if t % 2 == 0:  # `while game.stone_num < 64` once per pair of turns (game.py:253-255)
                 done = done | (stone_num >= 64)
-                if bool(done.all().item()):
-                    break
+            active = next_active()
+            back = torch.cat([m.error_flags(), (mv == -2).any().to(torch.int64).reshape(1),
+                              done.all().to(torch.int64).reshape(1), m.search_counts(active)]).tolist()
+            m.raise_errors(back[:4])
+            if back[4]:
+                # what max() over an empty children dict raises in MCTS.get_move (MCTS.py:147)
+                raise ValueError("a searched root has no children: n_sims is below the "
+                                 "expansion threshold n_thr")
+            if t % 2 == 0 and back[5]:
+                break
+            counts = back[6:8]
         # colour 1's stones are `own` after an even number of turns
         p1, p2 = (own, opp) if t % 2 == 0 else (opp, own)
         res.z = ops.judge(p1, p2)

@@ -90,6 +90,11 @@ for L, x in zip(lab, t):
         seg["policy batch"].append(x - last[P0])
     last[L] = x
 print("turns %d, stamps %d" % (res.n_turns, n))
+g = np.asarray(seg["backup end -> next descent start"])
+big = g[g > 60.0]
+print("gaps backup -> next descent above 60 us (between the searches of two moves, replay boundaries): "
+      "%d, mean %.1f us, total %.1f ms of %.1f ms" % (len(big), big.mean() if len(big) else 0.0, big.sum() / 1e3,
+                                                        (t.max() - t.min()) / 1e3))
 for k, v in seg.items():
     v = np.asarray(v)
     v = v[v < 5000]   # (drop the gaps between moves: host work)
