@@ -20,7 +20,7 @@ TRACE_PASS = 0xFF
 # against the header and the built library)
 SYMBOLS = [
     "iago_abi_version", "iago_last_error", "iago_device_count",
-    "iago_legal_moves", "iago_apply_moves", "iago_encode_planes", "iago_encode_planes_indexed",
+    "iago_legal_moves", "iago_apply_moves", "iago_play_turn", "iago_encode_planes", "iago_encode_planes_indexed",
     "iago_judge",
     "iago_sample_moves", "iago_augment8", "iago_bias_relu",
     "iago_conv3x3_split", "iago_conv3x3_split_trunk", "iago_split_nchw", "iago_merge_nchw", "iago_value_stem", "iago_value_stem_boards", "iago_value_head",
@@ -138,6 +138,7 @@ def lib():
     L.iago_device_count.restype = C.c_int
     L.iago_legal_moves.argtypes = [vp, vp, vp, i64, vp]
     L.iago_apply_moves.argtypes = [vp, vp, vp, i64, vp]
+    L.iago_play_turn.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, i64, vp]
     L.iago_encode_planes.argtypes = [vp, vp, vp, i64, vp]
     L.iago_encode_planes_indexed.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.iago_judge.argtypes = [vp, vp, vp, i64, vp]

@@ -44,6 +44,53 @@ __global__ __launch_bounds__(BLOCK) void apply_moves_kernel(uint64_t *__restrict
     }
 }
 
+// iago_play_turn: the move, the turn bookkeeping, the swap of sides and the next mover's legal
+// moves in one pass (8 lanes per game; lane 0 keeps the books).
+__global__ __launch_bounds__(BLOCK) void play_turn_kernel(uint64_t *__restrict__ own, uint64_t *__restrict__ opp,
+                                                          const int8_t *__restrict__ action,
+                                                          const uint8_t *__restrict__ active_in,
+                                                          int32_t *__restrict__ stone_num, uint8_t *__restrict__ pass_flg,
+                                                          uint8_t *__restrict__ done, int close_pair,
+                                                          uint64_t *__restrict__ legal, uint8_t *__restrict__ active_out,
+                                                          int64_t n)
+{
+    const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t b = gtid >> 3;
+    const Lane8 L = make_lane8(threadIdx.x);
+    const bool live = b < n;
+    uint64_t o = live ? own[b] : 0ull, p = live ? opp[b] : 0ull;
+    const bool placed = live && active_in[b] != 0; // the mover had a legal move (and is not done)
+    const int a = placed ? (int)action[b] : -1;
+    const uint32_t pos = (uint32_t)a & 63u;
+    const uint64_t f = group8_flips(to_lane(o, L), to_lane(p, L), pos, L);
+    if (a >= 0) {
+        const uint64_t bit = 1ull << pos;
+        o = o | f | bit;
+        p = p & ~f & ~bit;
+    }
+    // the sides swap: the next mover's stones are `own` from here on
+    const uint64_t mv = group8_legal(to_lane(p, L), to_lane(o, L), L);
+    if (!live || L.l8 != 0)
+        return;
+    const bool was_done = done[b] != 0;
+    int stones = stone_num[b] + (placed ? 1 : 0);                // stone_num += 1 per stone placed
+    const bool passing = !placed && !was_done;                   // the mover had no move
+    if (passing && pass_flg[b] != 0)
+        stones = 64;                                             // a pass after a pass ends the game
+    if (!was_done)
+        pass_flg[b] = passing ? 1 : 0;
+    stone_num[b] = stones;
+    bool dn = was_done;
+    if (close_pair) {                                            // `while stone_num < 64` per pair of turns
+        dn = dn || stones >= 64;
+        done[b] = dn ? 1 : 0;
+    }
+    own[b] = p;
+    opp[b] = o;
+    legal[b] = dn ? 0ull : mv;
+    active_out[b] = (mv != 0ull && !dn) ? 1 : 0;
+}
+
 // One thread per float4 of the (n,2,8,8) tensor: 32 threads cover the 512 B
 // of one board, so a wave writes 1 KiB contiguous (fully coalesced stores).
 // index: optional gather list (row b of the output encodes board index[b]).
@@ -218,6 +265,20 @@ int iago_apply_moves(uint64_t *own, uint64_t *opp, const int8_t *action, int64_t
     hipLaunchKernelGGL(apply_moves_kernel, dim3(grid_for(n * 8)), dim3(BLOCK), 0,
                        (hipStream_t)stream, own, opp, action, n);
     return iago_check_launch("iago_apply_moves");
+}
+
+int iago_play_turn(uint64_t *own, uint64_t *opp, const int8_t *action, const uint8_t *active, int32_t *stone_num,
+                   uint8_t *pass_flg, uint8_t *done, int close_pair, uint64_t *legal, uint8_t *active_next, int64_t n,
+                   void *stream)
+{
+    if (n < 0 || (n > 0 && (!own || !opp || !action || !active || !stone_num || !pass_flg || !done || !legal ||
+                            !active_next)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_play_turn: null pointer or negative n");
+    if (n == 0)
+        return IAGO_OK;
+    hipLaunchKernelGGL(play_turn_kernel, dim3(grid_for(n * 8)), dim3(BLOCK), 0, (hipStream_t)stream, own, opp, action,
+                       active, stone_num, pass_flg, done, close_pair, legal, active_next, n);
+    return iago_check_launch("iago_play_turn");
 }
 
 int iago_encode_planes(const uint64_t *own, const uint64_t *opp, float *planes, int64_t n,

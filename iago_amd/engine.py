@@ -790,8 +790,8 @@ class SelfPlayEngine(object):
             opp = opp | handicap
         m.tree.reset()
         stone_num = torch.full((B,), 4, dtype=torch.int32, device=dev)  # game.py:32
-        pass_flg = torch.zeros(B, dtype=torch.bool, device=dev)
-        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        pass_flg = torch.zeros(B, dtype=torch.uint8, device=dev)
+        done = torch.zeros(B, dtype=torch.uint8, device=dev)
         res = SelfPlayResult()
         T = self.max_turns
         if record:
@@ -801,11 +801,10 @@ class SelfPlayEngine(object):
             res.valid = torch.zeros((T, B), dtype=torch.uint8, device=dev)
             res.move = torch.full((T, B), -1, dtype=torch.int8, device=dev)
         res.mover = []
-        def next_active():
-            return ((ops.legal_moves(own, opp) != 0) & ~done).to(torch.uint8)
-
+        legal = ops.legal_moves(own, opp)
+        active = (legal != 0).to(torch.uint8)
+        legal_next, active_next = torch.empty_like(legal), torch.empty_like(active)
         t = 0
-        active = next_active()
         counts = m.search_counts(active).tolist()
         while t < T:
             # ONE readback per move (below): the flags of this move's search, the check of its
@@ -817,18 +816,13 @@ class SelfPlayEngine(object):
                 res.own[t], res.opp[t], res.valid[t], res.move[t] = own, opp, active, mv
                 res.pi[t] = visits * active.reshape(B, 1).to(torch.int32)
             res.mover.append(1 if t % 2 == 0 else 2)
-            ops.apply_moves(own, opp, mv)
-            placed = active.bool()
-            stone_num = stone_num + placed.to(torch.int32)
-            passing = ~placed & ~done
-            stone_num = torch.where(passing & pass_flg, torch.full_like(stone_num, 64), stone_num)
-            pass_flg = torch.where(done, pass_flg, passing)
-            m.update_with_move(mv, (~done).to(torch.uint8))  # game.py:84,108,140
-            own, opp = opp, own
+            m.update_with_move(mv, done ^ 1)  # game.py:84,108,140 (the games not yet done)
+            # the move, stone_num / pass_flg, `while game.stone_num < 64` once per pair of turns
+            # (game.py:117-142,253-255), the swap of sides, the next mover's legal moves
+            ops.play_turn(own, opp, mv, active, stone_num, pass_flg, done, t % 2 == 1, legal_next, active_next)
+            legal, legal_next = legal_next, legal
+            active, active_next = active_next, active
             t += 1
-            if t % 2 == 0:  # `while game.stone_num < 64` once per pair of turns (game.py:253-255)
-                done = done | (stone_num >= 64)
-            active = next_active()
             back = torch.cat([m.error_flags(), (mv == -2).any().to(torch.int64).reshape(1),
                               done.all().to(torch.int64).reshape(1), m.search_counts(active)]).tolist()
             m.raise_errors(back[:4])

@@ -59,6 +59,25 @@ def apply_moves(own, opp, action):
     return own, opp
 
 
+def play_turn(own, opp, action, active, stone_num, pass_flg, done, close_pair, legal, active_next):
+    """One turn of n lockstep games in place (iago_play_turn): the move, stone_num / pass_flg /
+    done, the swap of sides (own = the next mover afterwards), the next mover's legal moves and
+    the next turn's `active`.  uint8 flags, int32 stone_num, int8 action."""
+    n = own.numel()
+    for name, t in (("opp", opp), ("action", action), ("active", active), ("stone_num", stone_num),
+                    ("pass_flg", pass_flg), ("done", done), ("legal", legal), ("active_next", active_next)):
+        if t.numel() != n:
+            raise ValueError("play_turn: %s has %d entries, expected %d" % (name, t.numel(), n))
+    if active.data_ptr() == active_next.data_ptr():
+        raise ValueError("play_turn: active and active_next may not alias")
+    check(_lib.lib().iago_play_turn(_dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp"),
+                                    _dev(action, torch.int8, "action"), _dev(active, torch.uint8, "active"),
+                                    _dev(stone_num, torch.int32, "stone_num"), _dev(pass_flg, torch.uint8, "pass_flg"),
+                                    _dev(done, torch.uint8, "done"), 1 if close_pair else 0,
+                                    _dev(legal, torch.int64, "legal"), _dev(active_next, torch.uint8, "active_next"),
+                                    n, _stream()), "iago_play_turn")
+
+
 def encode_planes(own, opp, out=None):
     """(n,2,8,8) float32 planes, channel 0 = opp, channel 1 = own (game.py:168-174)."""
     n = own.numel()

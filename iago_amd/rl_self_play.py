@@ -25,37 +25,34 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
     if handicap is not None:
         opp = opp | handicap
     stone_num = torch.full((B,), 4, dtype=torch.int32, device=device)  # src/rl_self_play.py:20
-    pass_flg = torch.zeros(B, dtype=torch.bool, device=device)
-    done = torch.zeros(B, dtype=torch.bool, device=device)
+    pass_flg = torch.zeros(B, dtype=torch.uint8, device=device)
+    done = torch.zeros(B, dtype=torch.uint8, device=device)
     rec_own, rec_opp, rec_act = [], [], []
     nan_seen = torch.zeros((), dtype=torch.bool, device=device)
+    legal = ops.legal_moves(own, opp)          # of the mover; 0 for a finished game from turn 1 on
+    active = (legal != 0).to(torch.uint8)
+    legal_next, active_next = torch.empty_like(legal), torch.empty_like(active)
     t = 0
     while t < ops.IAGO_MAX_TURNS:
         color = 1 if t % 2 == 0 else 2
-        legal = ops.legal_moves(own, opp)
-        active = (legal != 0) & ~done
         with torch.no_grad():
             probs = (model1 if color == 1 else model2)(ops.encode_planes(own, opp))
         u = next(uniforms) if (uniforms is not None and bool(active.any().item())) else None
-        a = ops.sample_moves(probs.to(torch.float32).contiguous(),
-                             torch.where(active, legal, torch.zeros_like(legal)), uniforms=u,
+        a = ops.sample_moves(probs.to(torch.float32).contiguous(), legal, uniforms=u,
                              seed=seed, id_base=game_id_base, step=t)
         nan_seen = nan_seen | (a > 63).any()
         if color == 1:
             rec_own.append(own.clone())
             rec_opp.append(opp.clone())
             rec_act.append(a.clone())
-        ops.apply_moves(own, opp, a)
-        stone_num = stone_num + active.to(torch.int32)
-        passing = ~active & ~done
-        stone_num = torch.where(passing & pass_flg, torch.full_like(stone_num, 64), stone_num)
-        pass_flg = torch.where(done, pass_flg, passing)
-        own, opp = opp, own
+        # the move, stone_num / pass_flg / done (`while stone_num < 64` per pair of turns,
+        # src/rl_self_play.py:28-30,130-145), the swap of sides and the next mover's moves
+        ops.play_turn(own, opp, a, active, stone_num, pass_flg, done, t % 2 == 1, legal_next, active_next)
+        legal, legal_next = legal_next, legal
+        active, active_next = active_next, active
         t += 1
-        if t % 2 == 0:  # `while stone_num < 64` per pair of turns (src/rl_self_play.py:28-30)
-            done = done | (stone_num >= 64)
-            if bool(done.all().item()):
-                break
+        if t % 2 == 0 and bool(done.all().item()):
+            break
     p1, p2 = (own, opp) if t % 2 == 0 else (opp, own)
     if bool(nan_seen.item()):
         # iago_sample_moves returns 64 when no cell's CDF exceeds u: NaN probabilities.

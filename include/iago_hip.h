@@ -81,6 +81,24 @@ IAGO_API int iago_legal_moves(const uint64_t *own, const uint64_t *opp, uint64_t
 IAGO_API int iago_apply_moves(uint64_t *own, uint64_t *opp, const int8_t *action, int64_t n, void *stream);
 
 /*
+ * One turn of the reference's game loops for n lockstep games -- Game.turn inside Game.__call__
+ * (src/rl_self_play.py:130-145,27-31; game.py:117-142,253-255; mcts_self_play.py:124-134,25-29;
+ * GameEnv.step's bookkeeping rl_env.py:41-74) -- in one launch:
+ *   game b's mover places action[b] where active[b] != 0 (iago_apply_moves; otherwise it has no
+ *   move and passes); stone_num += 1 per stone placed; a pass directly after a pass sets
+ *   stone_num = 64; pass_flg = "this turn was a pass" (games already done keep theirs);
+ *   with close_pair != 0 (the second turn of a `while stone_num < 64` pair) done |= stone_num >= 64;
+ *   the sides swap IN MEMORY (own = the next mover's stones on return);
+ *   legal[b] = the next mover's legal moves (0 for a game that is done), active_next[b] =
+ *   legal[b] != 0 (the `active` of the next call).
+ * stone_num int32, pass_flg / done / active / active_next uint8, action int8 (-1 = pass); active and
+ * active_next may not alias.
+ */
+IAGO_API int iago_play_turn(uint64_t *own, uint64_t *opp, const int8_t *action, const uint8_t *active,
+                            int32_t *stone_num, uint8_t *pass_flg, uint8_t *done, int close_pair,
+                            uint64_t *legal, uint8_t *active_next, int64_t n, void *stream);
+
+/*
  * planes: float32 (n,2,8,8) NCHW; channel 0 = opp (the opponent of the side
  * to move), channel 1 = own.  Replaces GameFunctions.make_state_var(state,
  * color) (game.py:168-174; copies mcts_self_play.py:91-97,

@@ -191,3 +191,58 @@ def test_encode_planes_indexed_matches_gather():
     ops.encode_planes_indexed(own.cuda(), opp.cuda(), idx.cuda(), out)
     want = ops.encode_planes(own[idx].cuda(), opp[idx].cuda())
     assert torch.equal(out[:6], want) and float(out[6:].abs().sum()) == 0.0
+
+
+def test_play_turn_equals_the_separate_calls(ops):
+    """iago_play_turn (move + stone_num / pass_flg / done + swap of sides + the next mover's legal
+    moves in one launch; Game.turn inside `while stone_num < 64: turn(c); turn(3 - c)`,
+    src/rl_self_play.py:27-31,130-145, game.py:117-142,253-255) against iago_legal_moves,
+    iago_apply_moves and the bookkeeping written out with tensor operations, over whole games of
+    random legal moves from random positions: every array identical after every turn."""
+    n = 3000
+    own_np, opp_np = random_positions(n, seed=77)
+    own_np[:100], opp_np[:100] = 0x0000000810000000, 0x0000001008000000
+    own_np[100:110], opp_np[100:110] = 1, 1 << 63            # nobody can move: double pass at once
+    g = torch.Generator(device="cuda").manual_seed(5)
+    # reference state (tensor operations) and fused state
+    ro, rp = ops.bits_to_tensor(own_np), ops.bits_to_tensor(opp_np)
+    fo, fp = ro.clone(), rp.clone()
+    r_stones = torch.tensor([bin(int(a) | int(b)).count("1") for a, b in zip(own_np, opp_np)], dtype=torch.int32,
+                            device="cuda")
+    f_stones = r_stones.clone()
+    r_pass = torch.zeros(n, dtype=torch.bool, device="cuda")
+    r_done = torch.zeros(n, dtype=torch.bool, device="cuda")
+    f_pass = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    f_done = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    f_legal = ops.legal_moves(fo, fp)
+    f_active = (f_legal != 0).to(torch.uint8)
+    f_legal2, f_active2 = torch.empty_like(f_legal), torch.empty_like(f_active)
+    equal = torch.full((n, 64), 1.0 / 64, dtype=torch.float32, device="cuda")
+    for t in range(130):
+        legal = ops.legal_moves(ro, rp)
+        active = (legal != 0) & ~r_done
+        masked = torch.where(active, legal, torch.zeros_like(legal))
+        assert torch.equal(masked, f_legal) and torch.equal(active.to(torch.uint8), f_active), t
+        u = torch.rand(n, generator=g, device="cuda", dtype=torch.float64)
+        a = ops.sample_moves(equal, masked, uniforms=u, seed=1, id_base=0, step=t)   # a random legal move, -1 = pass
+        # the separate calls (what rl_self_play.play_batch did before the fused turn)
+        ops.apply_moves(ro, rp, a)
+        r_stones = r_stones + active.to(torch.int32)
+        passing = ~active & ~r_done
+        r_stones = torch.where(passing & r_pass, torch.full_like(r_stones, 64), r_stones)
+        r_pass = torch.where(r_done, r_pass, passing)
+        ro, rp = rp, ro
+        if t % 2 == 1:
+            r_done = r_done | (r_stones >= 64)
+        # the fused turn
+        ops.play_turn(fo, fp, a, f_active, f_stones, f_pass, f_done, t % 2 == 1, f_legal2, f_active2)
+        f_legal, f_legal2 = f_legal2, f_legal
+        f_active, f_active2 = f_active2, f_active
+        assert torch.equal(fo, ro) and torch.equal(fp, rp), t
+        assert torch.equal(f_stones, r_stones) and torch.equal(f_pass.bool(), r_pass), t
+        assert torch.equal(f_done.bool(), r_done), t
+        if t % 2 == 1 and bool(r_done.all().item()):
+            break
+    assert bool(r_done.all().item()) and t < 129
+    with pytest.raises(ValueError):
+        ops.play_turn(fo, fp, a, f_active, f_stones, f_pass, f_done, True, f_legal, f_active)   # aliased flags
