@@ -26,8 +26,7 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = ops._stream   # the current HIP stream as a void*
 
 
 def suggest_capacity(n_sims, n_thr=15, moves=64, branching=12):
