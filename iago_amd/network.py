@@ -165,9 +165,25 @@ class SLPolicy(nn.Module, _NpzMixin):
         key = tuple((c.weight._version, c.weight.data_ptr(), c.bias._version) for c in ws)
         hit = self.__dict__.get("_split3_cache")
         if hit is None or hit[0] != key:
-            hit = (key, [ops.split_weights3(c.weight) + (c.bias.detach().float().contiguous(),) for c in ws])
+            pieces = ops.split_weights3_many([c.weight for c in ws])
+            layers = [p3 + (c.bias.detach().float().contiguous(),) for p3, c in zip(pieces, ws)]
+            hit = (key, layers, None)
             self.__dict__["_split3_cache"] = hit
         return hit[1]
+
+    def _split3_template(self):
+        """iago_policy_split3_args with this module's weights, rebuilt when they change."""
+        from . import ops
+        layers = self._split3_layers()
+        small = (self.block1.conv.weight, self.block1.conv.bias, self.conv9.weight, self.bias10.b)
+        key2 = tuple((t._version, t.data_ptr()) for t in small)
+        hit = self.__dict__["_split3_cache"]
+        if hit[2] is None or hit[2][0] != key2:
+            tmpl = ops.policy_split3_prepare(self.block1.conv.weight, self.block1.conv.bias, layers,
+                                             self.conv9.weight, self.bias10.b)
+            hit = (hit[0], hit[1], (key2, tmpl))
+            self.__dict__["_split3_cache"] = hit
+        return hit[2][1]
 
     def _overflow_flag(self, device):
         """Device word the three-piece kernel raises when an activation leaves the f16 range
@@ -202,10 +218,9 @@ class SLPolicy(nn.Module, _NpzMixin):
         rows = own.numel() if n is None else n
         scratch = self._split3_scratch(own.device, rows) if self.split3_parts > 1 else None
         with torch.no_grad():
-            return ops.policy_forward_split3(own, opp, self.block1.conv.weight, self.block1.conv.bias,
-                                             self._split3_layers(), self.conv9.weight, self.bias10.b,
-                                             n=n, index=index, n_dev=n_dev, overflow=overflow,
-                                             parts=self.split3_parts, scratch=scratch)
+            return ops.policy_forward_split3_prepared(self._split3_template(), own, opp, n=n, index=index,
+                                                      n_dev=n_dev, overflow=overflow, parts=self.split3_parts,
+                                                      scratch=scratch)
 
     def _split3_scratch(self, device, rows):
         """The buffer a multi-launch forward parks the boards' activations in: one per stream

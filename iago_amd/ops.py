@@ -292,7 +292,73 @@ def split_weights3(weight):
     return hi.contiguous(), mid.contiguous(), lo.contiguous()
 
 
+def split_weights3_many(weights):
+    """split_weights3 of several conv weights with the elementwise work of equally shaped ones
+    done on one stacked tensor (a training loop re-splits all 7 blocks after every update)."""
+    out = [None] * len(weights)
+    groups = {}
+    for i, w in enumerate(weights):
+        groups.setdefault(tuple(w.shape), []).append(i)
+    for shape, idx in groups.items():
+        cout, cin, kh, kw = shape
+        if (kh, kw) != (3, 3) or cin % 16 or cout != 128:
+            raise ValueError("split_weights3: need (128, 16k, 3, 3) weights")
+        w = torch.stack([weights[i].detach().to(torch.float32) for i in idx])          # L, co, ci, ky, kx
+        w = w.permute(0, 3, 4, 1, 2).reshape(len(idx), 3, 3, cout, cin // 16, 16).permute(0, 4, 1, 2, 3, 5).contiguous()
+        hi = w.to(torch.float16)
+        r1 = (w - hi.to(torch.float32)) * 2048.0
+        mid = r1.to(torch.float16)
+        lo = ((r1 - mid.to(torch.float32)) * 2048.0).to(torch.float16)
+        for j, i in enumerate(idx):
+            out[i] = (hi[j], mid[j], lo[j])
+    return out
+
+
 POLICY_SCRATCH_ROW_BYTES = 50176   # a board's LDS image in iago_policy_forward_split3 (64 rows of 784 B)
+
+
+def policy_split3_prepare(w1, b1, layers, w9, b10):
+    """The weight half of iago_policy_split3_args, checked once: a template that
+    policy_forward_split3_prepared copies per call.  The caller keeps the tensors alive."""
+    a = _lib.PolicySplit3Args()
+    if len(layers) != 7 or tuple(w1.shape) != (64, 2, 3, 3) or w9.numel() != 128 or b10.numel() != 64:
+        raise ValueError("policy_forward_split3: unexpected shapes")
+    a.w1, a.b1 = _dev(w1, torch.float32, "w1").value, _dev(b1, torch.float32, "b1").value
+    for k, (w_hi, w_mid, w_lo, bias) in enumerate(layers):
+        if w_hi.shape != ((4 if k == 0 else 8), 3, 3, 128, 16):
+            raise ValueError("policy_forward_split3: layer %d: weight blocks %s" % (k, tuple(w_hi.shape)))
+        a.w_hi[k] = _dev(w_hi, torch.float16, "w_hi").value
+        a.w_mid[k] = _dev(w_mid, torch.float16, "w_mid").value
+        a.w_lo[k] = _dev(w_lo, torch.float16, "w_lo").value
+        a.bias[k] = _dev(bias, torch.float32, "bias").value
+    a.w9 = _dev(w9.reshape(128), torch.float32, "w9").value
+    a.b10 = _dev(b10, torch.float32, "b10").value
+    return a
+
+
+def policy_forward_split3_prepared(template, own, opp, n=None, index=None, n_dev=None, overflow=None, parts=1,
+                                   scratch=None):
+    """policy_forward_split3 with the weights of policy_split3_prepare."""
+    a = _lib.PolicySplit3Args.from_buffer_copy(template)
+    n = own.numel() if n is None else n
+    if index is not None:
+        n = min(n, index.numel())
+        a.index = _dev(index, torch.int64, "index").value
+    if n_dev is not None:
+        a.n_dev = _dev(n_dev, torch.int32, "n_dev").value
+    a.own, a.opp = _dev(own, torch.int64, "own").value, _dev(opp, torch.int64, "opp").value
+    a.n = n
+    probs = torch.empty((n, 64), dtype=torch.float32, device=own.device)
+    a.probs = probs.data_ptr()
+    if parts > 1:
+        if scratch is None or scratch.numel() < n * POLICY_SCRATCH_ROW_BYTES:
+            raise ValueError("policy_forward_split3: parts > 1 needs a scratch buffer of n x %d bytes"
+                             % POLICY_SCRATCH_ROW_BYTES)
+        a.parts, a.scratch = parts, _dev(scratch, torch.uint8, "scratch").value
+    f = _flag(overflow)
+    a.overflow = f.value if f is not None else None
+    check(_lib.lib().iago_policy_forward_split3(C.byref(a), _stream()), "iago_policy_forward_split3")
+    return probs
 
 
 def policy_forward_split3(own, opp, w1, b1, layers, w9, b10, n=None, index=None, n_dev=None, overflow=None,
