@@ -109,7 +109,7 @@ def cpu_baseline(w, b, budget_s=10.0):
             "board_steps_per_game": steps / games, "one_core_games_per_sec": one_core}
 
 
-def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=False, use_graph=True):
+def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=False, use_graph=True, n_thr=15):
     """BASELINE configs[2]: PV-MCTS self-play, `n_games` lockstep games per GPU,
     `n_sims` playouts per move, SLPolicy + Value with random-init weights
     (Chainer-default LeCunNormal, seed 0), reference constants lmbda=0.5,
@@ -125,8 +125,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     value = network.Value().cuda().eval()
     value.split_f16 = not value_f32
     m = engine.BatchedMCTS(n_games, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0,
-                           n_thr=15, capacity=engine.suggest_capacity(n_sims, 15), seed=7,
-                           game_id_base=rank * n_games, use_graph=use_graph)
+                           n_thr=n_thr, seed=7, game_id_base=rank * n_games, use_graph=use_graph,
+                           capacity=engine.suggest_capacity(n_sims, n_thr, moves=64 if full_games else n_turns + 4))
     eng = engine.SelfPlayEngine(m, max_turns=(128 if full_games else n_turns))
     m.enable_stats()
     m.warmup()                 # MIOpen kernel selection for every batch bucket
@@ -186,7 +186,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
                            "f32: hand-written conv3x3_f32 / policy_head kernels (batches <= 192); MIOpen above"),
            "roofline": _mcts_roofline(val, pol, dt, world, value_f32, policy.split3),
            "config": "BASELINE configs[2]: PV-MCTS %d sims/move, %d games per GPU, SLPolicy+Value "
-                     "random init fp32, lmbda=0.5 c_puct=1 n_thr=15" % (n_sims, n_games),
+                     "random init fp32, lmbda=0.5 c_puct=1 n_thr=%d" % (n_sims, n_games, n_thr),
+           "n_thr": n_thr,
            "tree_pool_bytes_per_gpu": m.tree.bytes(), "tree_traffic_rank0": m.tree_bytes(),
            "tree_nodes_used_max": int(m.tree.n_nodes.max().item()),
            "tree_capacity": m.tree.capacity}
@@ -198,21 +199,43 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     return out
 
 
-def trunk_kernel_profile():
-    """The Value trunk kernel alone, from the committed rocprofv3 passes of the PV-MCTS leg
-    (tools/profile_mcts.sh -> profiles/*_mcts_pmc_summary.json, newest tag): average duration
-    and executed f16 MFMA FLOP/s of one launch on 1024 boards (7 layers, 3 MFMAs per product)."""
+MFMA_FLOP_32x32x16 = 2 * 32 * 32 * 16    # one v_mfma_f32_32x32x16_f16 wave-instruction
+MIN_PROFILE_LAUNCHES = 100
+
+
+def net_kernel_profiles():
+    """The two net kernels that ARE on the timed path of the PV-MCTS leg -- value_rollout_kernel
+    (the leaf evaluation: one-board Value walks + the rollouts) and policy_resident_kernel (the
+    look-ahead batches) -- from the newest committed FULL-GAME eager profile of the leg
+    (tools/profile_mcts.sh -> profiles/*_mcts_fullgame_pmc_summary.json): rocprofv3's average
+    duration and the executed f16 MFMA FLOP/s = SQ_INSTS_MFMA x 32,768 / duration against the
+    2.5 PFLOP/s dense peak.  A kernel with fewer than 100 launches in the profile is refused
+    (a one-launch sample of a variant off the path had been reported here)."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mcts_pmc_summary.json")))
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mcts_fullgame_pmc_summary.json")))
     for path in reversed(paths):
         with open(path) as f:
-            k = json.load(f).get("kernels", {}).get("trunk_resident_kernel")
-        if k and "avg_us" in k:
-            flops = 1024 * 3 * 122_683_392
-            a = flops / (k["avg_us"] * 1e-6) / 1e12
-            return {"kernel": "trunk_resident_kernel", "rocprof_avg_us": k["avg_us"], "boards": 1024,
-                    "executed_tflops": a, "frac_of_2500": a / 2500.0,
-                    "hbm_bytes_per_launch": k.get("hbm_bytes_per_launch"), "profile": os.path.basename(path)}
+            prof = json.load(f)
+        ks = prof.get("kernels", {})
+        out = {}
+        for name in ("value_rollout_kernel", "policy_resident_kernel", "descend_kernel", "mix_backup_path_kernel"):
+            k = ks.get(name)
+            if not k or k.get("calls", 0) < MIN_PROFILE_LAUNCHES or k.get("pmc_launches", 0) < MIN_PROFILE_LAUNCHES:
+                continue
+            e = {"launches": k["calls"], "rocprof_avg_us": k["avg_us"],
+                 "hbm_bytes_per_launch": k.get("hbm_bytes_per_launch")}
+            if k.get("SQ_INSTS_MFMA"):
+                tf = k["SQ_INSTS_MFMA"] * MFMA_FLOP_32x32x16 / (k["avg_us"] * 1e-6) / 1e12
+                e.update({"mfma_insts_per_launch": k["SQ_INSTS_MFMA"], "executed_tflops": tf,
+                          "bound": "mfma", "peak": 2500.0, "frac": tf / 2500.0})
+            elif k.get("hbm_bytes_per_launch"):
+                gb = k["hbm_bytes_per_launch"] / (k["avg_us"] * 1e-6) / 1e9
+                e.update({"bound": "hbm", "achieved_gb_per_s": gb, "peak": HBM_PEAK_GBS, "frac": gb / HBM_PEAK_GBS})
+            out[name] = e
+        if "value_rollout_kernel" in out and "policy_resident_kernel" in out:
+            out["profile"] = os.path.basename(path)
+            out["command"] = prof.get("command")
+            return out
     return None
 
 
@@ -235,11 +258,104 @@ def _mcts_roofline(leaf, pol, dt, world, value_f32, policy_split3=False):  # lea
             "note": "loop level: executed f16 MFMA FLOPs of both nets' trunks (evaluations actually run: "
                     "the value cache skips re-evaluations of a leaf, the policy look-ahead also evaluates "
                     "leaves that never expand) over the WHOLE leg's wall time (tree kernels and rollouts "
-                    "included); the Value trunk kernel alone: trunk_kernel.  The one-board-per-workgroup "
+                    "included); the net kernels on the timed path, per launch: `kernels` (committed full-game "
+                    "rocprofv3 profile, >= 100 launches each).  The one-board-per-workgroup "
                     "launches of the search (Value 3.9 MB, SLPolicy 5.8 MB of weights per board into ONE CU) "
                     "are bound by that CU's L2 bandwidth (~70 GB/s: 56 of 69 us, 83 of 113 us), not by the "
                     "matrix pipe (DESIGN.md section 5)",
-            "trunk_kernel": trunk_kernel_profile()}
+            "kernels": net_kernel_profiles()}
+
+
+def cpu_workers(kind, budget_s):
+    """the reference's own execution model "on P = os.cpu_count() independent
+    worker processes, P stated" -- the reference is one single-threaded Python process per game
+    (MCTS.py:139-147, mcts_self_play.py:25-29), so P of them side by side is what the host's
+    cores give it.  P = host_cores() copies of this script in --cpu-worker mode (CHILD processes
+    that never touch the GPU), all timing the same `budget_s` window that starts at a common wall
+    clock instant after their imports; the aggregate is the sum of their counts over the window."""
+    import subprocess
+    P = min(host_cores(), 64)
+    start_at = time.time() + 20.0        # imports + warm-up of the slowest worker
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", kind,
+                               "--cpu-worker-budget", str(budget_s), "--cpu-worker-start", repr(start_at),
+                               "--cpu-worker-seed", str(i)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                              env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1"))
+             for i in range(P)]
+    rows = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=600)
+        if pr.returncode == 0 and out.strip():
+            rows.append(json.loads(out.strip().splitlines()[-1]))
+    if len(rows) != P:
+        return {"error": "%d of %d CPU workers finished" % (len(rows), P)}
+    window = max(r["seconds"] for r in rows)
+    late = max(r["late_s"] for r in rows)
+    return {"count": sum(r["count"] for r in rows), "seconds": window, "processes": P, "max_start_lag_s": late,
+            "steps": sum(r.get("steps", 0) for r in rows)}
+
+
+def cpu_worker_main(kind, budget_s, start_at, seed):
+    """One worker of cpu_workers(): warm up, wait for the common start, run for budget_s."""
+    w, b = shipped_rollout_weights()
+    torch.set_num_threads(1)
+    count = steps = 0
+    if kind == "python_loops":
+        from iago_amd import network
+        from oracle import py_loops
+        ro = network.RolloutPolicy().eval()
+        with torch.no_grad():
+            ro.conv1.weight.copy_(torch.from_numpy(w.reshape(1, 2, 3, 3)))
+            ro.bias2.b.copy_(torch.from_numpy(b))
+
+        def policy(x):
+            with torch.no_grad():
+                return ro(torch.from_numpy(x)).numpy()
+
+        s0 = np.zeros((8, 8), np.float32)
+        s0[4, 3] = s0[3, 4] = 1
+        s0[3, 3] = s0[4, 4] = 2
+        rs = np.random.RandomState(seed)
+
+        def unit():
+            return 1, py_loops.simulate(s0, 1, policy, rs)[1]
+    elif kind == "mcts":
+        from iago_amd import network
+        from oracle import mcts_py
+        from oracle import oracle as orc
+        torch.manual_seed(0)
+        policy_net, value_net = network.SLPolicy().eval(), network.Value().eval()
+        counter = [seed << 24]
+
+        def pol(x):
+            with torch.no_grad():
+                return policy_net(torch.from_numpy(x)).numpy().reshape(64)
+
+        def val(x):
+            with torch.no_grad():
+                return value_net(torch.from_numpy(x)).numpy().reshape(1)[0]
+
+        def roll(state, color):
+            counter[0] += 1
+            return orc.simulate(state, color, w, b, seed=3, game_id=counter[0])[0]
+
+        m = mcts_py.MCTS(pol, val, roll, lmbda=0.5, c_puct=1, n_thr=15)
+
+        def unit():   # 20 playouts of the worker's own game tree from the start position
+            m.get_move(orc.initial_state(), 1, 20)
+            return 20, 0
+    else:
+        raise SystemExit("unknown --cpu-worker kind %r" % kind)
+    unit()                                  # warm-up
+    late = max(0.0, time.time() - start_at)
+    while time.time() < start_at:
+        time.sleep(0.01)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        c, st = unit()
+        count += c
+        steps += st
+    print(json.dumps({"count": count, "steps": steps, "seconds": time.perf_counter() - t0, "late_s": late}), flush=True)
 
 
 def mcts_cpu_baseline(n_sims=600):
@@ -277,9 +393,19 @@ def mcts_cpu_baseline(n_sims=600):
         dt = time.perf_counter() - t0
     finally:
         torch.set_num_threads(nthreads)
-    return {"value": n_sims / dt, "unit": "leaf-evals/s", "cores": 1, "kind": "port",
-            "sample": "%d playouts of one game from the start position, oracle/mcts_py.py + "
-                      "torch-CPU fp32 nets (1 thread) + C rollout, %.1f s" % (n_sims, dt)}
+    out = {"value": n_sims / dt, "unit": "leaf-evals/s", "cores": 1, "kind": "port",
+           "sample": "%d playouts of one game from the start position, oracle/mcts_py.py + "
+                     "torch-CPU fp32 nets (1 thread) + C rollout, %.1f s" % (n_sims, dt)}
+    pw = cpu_workers("mcts", 6.0)
+    if "error" in pw:
+        out["all_cores"] = pw
+    else:
+        out["all_cores"] = {"value": pw["count"] / pw["seconds"], "unit": "leaf-evals/s", "cores": pw["processes"],
+                            "kind": "port",
+                            "sample": "%d independent single-threaded worker processes (one game tree each, the "
+                                      "same restatement), %d playouts in a common %.1f s window"
+                                      % (pw["processes"], pw["count"], pw["seconds"])}
+    return out
 
 
 def mcts_b1_leg(n_sims=200):
@@ -389,10 +515,19 @@ def python_loop_baseline(w, b, budget_s=4.0):
         dt = time.perf_counter() - t0
     finally:
         torch.set_num_threads(nthreads)
-    return {"value": games / dt, "unit": "games/s", "cores": 1, "kind": "port",
-            "sample": "%d rollout-policy games, oracle/py_loops.py (Python loops over a numpy board, "
-                      "torch-CPU B=1 policy calls), %.1f s" % (games, dt),
-            "board_steps_per_game": steps / max(games, 1)}
+    out = {"value": games / dt, "unit": "games/s", "cores": 1, "kind": "port",
+           "sample": "%d rollout-policy games, oracle/py_loops.py (Python loops over a numpy board, "
+                     "torch-CPU B=1 policy calls), %.1f s" % (games, dt),
+           "board_steps_per_game": steps / max(games, 1)}
+    pw = cpu_workers("python_loops", 4.0)
+    if "error" in pw:
+        out["all_cores"] = pw
+    else:
+        out["all_cores"] = {"value": pw["count"] / pw["seconds"], "unit": "games/s", "cores": pw["processes"],
+                            "kind": "port",
+                            "sample": "%d independent single-threaded worker processes, %d games in a common "
+                                      "%.1f s window" % (pw["processes"], pw["count"], pw["seconds"])}
+    return out
 
 
 class RolloutRounds(object):
@@ -632,6 +767,42 @@ def rollout_leg(args, world, rank, dist):
     return out, (w, b)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started without torch.distributed.run: N copies of this
+    script as CHILD processes, one per GPU (RANK = LOCAL_RANK = 0..N-1, rendezvous on
+    127.0.0.1 at a free port), started before this process makes any HIP call -- a process
+    that has initialised the GPU must never exec or fork another GPU program on this pool.
+    Rank 0 inherits stdout and prints the ONE JSON line; the other ranks' stdout goes to
+    stderr.  Returns the exit status: 0 when every rank returned 0, else the first failure
+    (the remaining ranks are then terminated by PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    status = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 128 - rc
+                for q in live:          # a rank died: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -660,19 +831,36 @@ def main():
     ap.add_argument("--mcts-eager", action="store_true",
                     help="PV-MCTS leg: plain launches instead of hipGraph replay (rocprofv3 does not "
                          "attribute kernels launched from a graph)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks as child processes even for --gpus 1 (what --gpus N > 1 does "
+                         "when no launcher has set WORLD_SIZE)")
     ap.add_argument("--mcts-value-f32", action="store_true",
                     help="PV-MCTS leg: MIOpen float32 convolutions for the Value net instead of the "
                          "split-f16 MFMA kernels")
+    ap.add_argument("--nthr1-turns", type=int, default=8,
+                    help="PV-MCTS with n_thr = 1 (SURVEY.md 8d: the policy net inside every playout): turns of "
+                         "the bounded sample, 0 = skip")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-budget", type=float, default=4.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-start", type=float, default=0.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-seed", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:   # a CPU-baseline worker process (cpu_workers): never touches the GPU
+        cpu_worker_main(args.cpu_worker, args.cpu_worker_budget, args.cpu_worker_start, args.cpu_worker_seed)
+        return
     if args.rollout_only:
-        args.mcts_turns, args.train_iters, args.no_cpu_baseline = 0, 0, True
+        args.mcts_turns, args.train_iters, args.no_cpu_baseline, args.nthr1_turns = 0, 0, True, 0
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher
+        # (nothing in it has touched the GPU yet) and exits with its ranks' status
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (torch.distributed.run "
+                         "--nproc-per-node %d, or no launcher at all)" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (any N)
@@ -696,6 +884,21 @@ def main():
         ref = mcts_leg(args.mcts_games, args.mcts_sims, 4, False, world, rank, dist, value_f32=True)
         mcts["value_f32_sample"] = {k: ref[k] for k in ("leaf_evals_per_sec", "leaf_evals", "seconds",
                                                         "turns_played", "value_conv")}
+    nthr1 = None
+    if mcts is not None and args.nthr1_turns > 0 and not args.mcts_only and not args.mcts_value_f32:
+        # "also report n_thr = 1" (MCTS.py:80,109): every leaf expands at its
+        # second visit, so the look-ahead cannot apply (no visits to run ahead of) and the policy net
+        # sits inside every playout: select, pending, policy_resident_kernel x 2 on the expanding
+        # leaves, expand, continued select, fresh_leaves, value_rollout_kernel, mix_backup -- one
+        # hipGraph replay per playout.  Bounded sample: the first turns of the same 1024 games
+        r1 = mcts_leg(args.mcts_games, args.mcts_sims, args.nthr1_turns, False, world, rank, dist, n_thr=1,
+                      use_graph=not args.mcts_eager)
+        nthr1 = {k: r1[k] for k in ("leaf_evals_per_sec", "leaf_evals", "policy_evals", "value_evals", "seconds",
+                                    "turns_played", "sims_per_move", "games_per_gpu", "n_thr", "policy_lookahead",
+                                    "value_cache", "tree_nodes_used_max", "tree_capacity", "config")}
+        nthr1["sample"] = "the first %d turns of the games (bounded sample), policy net inside every playout" \
+                          % args.nthr1_turns
+        nthr1["default_n_thr15_leaf_evals_per_sec"] = mcts["leaf_evals_per_sec"]
     train = reinforce_leg(args.train_iters, world, rank, dist) if args.train_iters > 0 else None
     b1 = mcts_b1_leg() if (mcts is not None and rank == 0 and not args.mcts_only) else None
 
@@ -721,7 +924,15 @@ def main():
             if key in head:
                 line[key] = head[key]
         if mcts is not None:
+            # the north star's second metric as top-level scalars (the driver's `parsed` keeps scalars
+            # only): PV-MCTS configs[2], split-f16 Value + three-piece SLPolicy, whole job over all ranks
+            line["leaf_evals_per_sec"] = mcts["leaf_evals_per_sec"]
+            if "games_per_sec" in mcts:
+                line["mcts_games_per_sec"] = mcts["games_per_sec"]
             line["mcts"] = mcts
+        if nthr1 is not None:
+            line["mcts_nthr1"] = nthr1
+            line["leaf_evals_per_sec_nthr1"] = nthr1["leaf_evals_per_sec"]
         if train is not None:
             line["reinforce"] = train
         if b1 is not None:

@@ -67,7 +67,7 @@ class PolicySplit3Args(C.Structure):
         ("w1", C.c_void_p), ("b1", C.c_void_p),
         ("w_hi", C.c_void_p * 7), ("w_mid", C.c_void_p * 7), ("w_lo", C.c_void_p * 7), ("bias", C.c_void_p * 7),
         ("w9", C.c_void_p), ("b10", C.c_void_p), ("probs", C.c_void_p), ("overflow", C.c_void_p),
-        ("parts", C.c_int32), ("reserved", C.c_int32), ("scratch", C.c_void_p),
+        ("parts", C.c_int32), ("scratch_rows", C.c_int32), ("scratch", C.c_void_p),
     ]
 
 
@@ -78,6 +78,7 @@ class MctsLookahead(C.Structure):
         ("cache", C.c_void_p), ("q_count", C.c_void_p), ("q_capacity", C.c_int32), ("path_stride", C.c_int32),
         ("q_own", C.c_void_p), ("q_opp", C.c_void_p), ("q_game", C.c_void_p), ("q_seq", C.c_void_p),
         ("error", C.c_void_p), ("clear_word", C.c_void_p), ("path", C.c_void_p), ("path_len", C.c_void_p),
+        ("z_log", C.c_void_p), ("z_log_n", C.c_void_p), ("z_log_rows", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -104,7 +105,7 @@ class MctsTree(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 5   # iago_abi_version() of the include/iago_hip.h these bindings mirror
+ABI_VERSION = 6   # iago_abi_version() of the include/iago_hip.h these bindings mirror
 
 
 def lib():

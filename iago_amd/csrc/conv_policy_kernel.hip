@@ -57,6 +57,9 @@ struct PolicyParams {
     // travels between the launches through `scratch` [n][64 * RS]
     int layer_lo, layer_hi;
     uint4 *scratch;
+    // a launch covers the rows [row_lo, row_hi) of the batch; row r parks its image in scratch slot
+    // r - row_lo (the host runs a long batch as chunks of `scratch_rows` rows: bounded scratch)
+    int64_t row_lo, row_hi;
 };
 
 // (conv_trunk_kernel.hip) ds_read_b128 serves lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}
@@ -91,7 +94,7 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
         *(uint4 *)(T + 64 * RS + tid * 16) = make_uint4(0, 0, 0, 0);
     bool saturated = false;
     if (P.layer_lo > 0) {
-        const uint4 *src = P.scratch + row_id * (64 * RS / 16);
+        const uint4 *src = P.scratch + (row_id - P.row_lo) * (64 * RS / 16);
         for (int e = tid; e < 64 * RS / 16; e += 256)
             *(uint4 *)(T + e * 16) = src[e];
     } else {
@@ -277,7 +280,7 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
     if (P.overflow && saturated)
         *P.overflow = 1u;
     if (P.layer_hi < 7) { // the next launch goes on from this image
-        uint4 *dst = P.scratch + row_id * (64 * RS / 16);
+        uint4 *dst = P.scratch + (row_id - P.row_lo) * (64 * RS / 16);
         for (int e = tid; e < 64 * RS / 16; e += 256)
             dst[e] = *(const uint4 *)(T + e * 16);
         return;
@@ -316,10 +319,10 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void policy_resident_kernel(PolicyParams P)
 {
-    int64_t n_rows = P.n;
+    int64_t n_rows = P.row_hi;
     if (P.n_dev)
-        n_rows = min(P.n, (int64_t)*P.n_dev);
-    for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        n_rows = min(n_rows, (int64_t)*P.n_dev);
+    for (int64_t row = P.row_lo + blockIdx.x; row < n_rows; row += gridDim.x) {
         policy_item(P, row);
         __syncthreads(); // the next pass re-stages the LDS image the head just read
     }
@@ -369,7 +372,7 @@ int iago_policy_forward_split3(const iago_policy_split3_args *a, void *stream)
         const long v = e ? atol(e) : 256;
         return (int64_t)(v < 1 ? 1 : v > 1024 ? 1024 : v);
     }();
-    const unsigned grid = (unsigned)(a->n < cap ? a->n : cap);
+
     // parts > 1: the 7 convolution blocks as that many launches of 7 / parts blocks each (short
     // launches leave the CUs to the other stream's kernels sooner), the boards' LDS images
     // travelling through `scratch`
@@ -378,10 +381,20 @@ int iago_policy_forward_split3(const iago_policy_split3_args *a, void *stream)
         return iago_fail(IAGO_ERR_INVALID, "iago_policy_forward_split3: parts > 1 needs a 16-byte aligned scratch "
                                            "buffer of n x 50,176 bytes");
     P.scratch = (uint4 *)a->scratch;
-    for (int p = 0; p < parts; p++) {
-        P.layer_lo = 7 * p / parts;
-        P.layer_hi = 7 * (p + 1) / parts;
-        hipLaunchKernelGGL(policy_resident_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, P);
+    // scratch_rows > 0: the scratch holds that many rows; a longer batch runs as chunks of
+    // scratch_rows rows, each chunk its `parts` launches (launches of one stream run in order, so
+    // the chunks may share the buffer).  With a device-side count the chunks past it exit at once
+    const int64_t chunk = (parts > 1 && a->scratch_rows > 0 && a->scratch_rows < a->n) ? a->scratch_rows : a->n;
+    for (int64_t lo = 0; lo < a->n; lo += chunk) {
+        P.row_lo = lo;
+        P.row_hi = lo + chunk < a->n ? lo + chunk : a->n;
+        const int64_t rows = P.row_hi - P.row_lo;
+        const unsigned grid = (unsigned)(rows < cap ? rows : cap);
+        for (int p = 0; p < parts; p++) {
+            P.layer_lo = 7 * p / parts;
+            P.layer_hi = 7 * (p + 1) / parts;
+            hipLaunchKernelGGL(policy_resident_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, P);
+        }
     }
     return iago_check_launch("iago_policy_forward_split3");
 }

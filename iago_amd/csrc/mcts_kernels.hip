@@ -373,7 +373,20 @@ struct Lookahead {
     int32_t *clear_word;        // optional: set to 0 by the backup (the fresh-leaf count of the next descent)
     int32_t *path, *path_len;   // optional: the nodes of a game's last descent, root first ([n_games][path_stride])
     int32_t path_stride;
+    int8_t *z_log;              // optional [z_log_rows][n_games]: the rollout result the backup mixed in, one
+    int32_t *z_log_n;           // row per playout of a game (z_log_n [n_games] = rows written so far)
+    int32_t z_log_rows;
 };
+
+// Diagnostic record of the parity tests (tests/test_mcts_production_gpu.py): the z every playout of
+// game g backed up, in playout order -- what the oracle's rollout_fn replays.
+__device__ __forceinline__ void log_z(const Lookahead &A, int64_t g, int64_t n_games, int8_t zg)
+{
+    const int k = A.z_log_n[g];
+    A.z_log_n[g] = k + 1;
+    if (k < A.z_log_rows)
+        A.z_log[(int64_t)k * n_games + g] = zg;
+}
 
 __global__ __launch_bounds__(BLOCK) void mix_backup_lookahead_kernel(
     Tree T, const uint8_t *__restrict__ active, const int32_t *__restrict__ cur_node,
@@ -408,6 +421,8 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_lookahead_kernel(
     leaf_value[g] = lv;
     if (!active[g])
         return;
+    if (A.z_log && lmbda > 0.0f)
+        log_z(A, g, T.n_games, z[g]);
     const int leaf = cur_node[g];
     int node = leaf;
     for (int depth = 0; node >= 0 && depth <= MAX_DEPTH; depth++) {
@@ -476,6 +491,8 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_path_kernel(
         leaf_value[g] = lv;
     if (!act)
         return;
+    if (A.z_log && lmbda > 0.0f && r == 0u)
+        log_z(A, g, T.n_games, z[g]);
     // lane 0 decides the queueing from the leaf's count BEFORE this playout (+ 1 = after it)
     int leaf_n = 0, leaf_tag = 0;
     if (r == 0u) {
@@ -772,7 +789,13 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
         if (fresh_index) {
             const float c = __uint_as_float(vbits);
             if (c != c) {
-                fresh_index[atomicAdd(fresh_count, 1)] = g;
+                // (at most one entry per game and playout; a count the previous backup did not clear
+                // -- a playout aborted between descent and backup -- must not run past the list)
+                const int pos = atomicAdd(fresh_count, 1);
+                if (pos < T.n_games)
+                    fresh_index[pos] = g;
+                else
+                    T.overflow[g] = 1;
                 if (fresh_total)
                     atomicAdd((unsigned long long *)fresh_total, 1ull);
             }
@@ -1142,6 +1165,11 @@ int lookahead_of(const iago_mcts_lookahead *a, Lookahead &A, const char *who)
     A.path_len = a->path_len;
     A.path_stride = a->path_stride;
     if (A.path && (!A.path_len || a->path_stride < 8))
+        return iago_fail(IAGO_ERR_INVALID, who);
+    A.z_log = a->z_log_rows > 0 ? a->z_log : nullptr;
+    A.z_log_n = a->z_log_n;
+    A.z_log_rows = a->z_log_rows;
+    if (A.z_log && !A.z_log_n)
         return iago_fail(IAGO_ERR_INVALID, who);
     return IAGO_OK;
 }

@@ -29,6 +29,23 @@ def shard_range(n_games, rank=None, world=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _staged(group=None):
+    """True when the collectives of `group` cannot take device tensors (gloo: world-size > 1
+    rehearsals on ONE GPU, where RCCL refuses two ranks on the same device; gloo implements
+    all-gather for host memory only): payloads then travel through host copies.  The nccl
+    (= RCCL) backend takes the device tensors as they are."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(recv, send, group=None):
+    if send.is_cuda and _staged(group):
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(r, send.cpu(), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+
+
 def gather_tuples(fields, group=None):
     """All-gather per-rank tuple arrays (dict name -> tensor, same length along
     dim 0 on a rank, lengths may differ between ranks).  Returns a dict of
@@ -49,8 +66,7 @@ def gather_tuples(fields, group=None):
         if fields[k].shape[0] != n:
             raise ValueError("field %s has %d rows, expected %d" % (k, fields[k].shape[0], n))
     counts = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, torch.tensor([n], dtype=torch.int64, device=dev),
-                                group=group)
+    _all_gather_into(counts, torch.tensor([n], dtype=torch.int64, device=dev), group)
     counts = counts.cpu().tolist()
     nmax = max(counts)
     # pack every field's rows as bytes, 8-byte aligned segments
@@ -69,7 +85,7 @@ def gather_tuples(fields, group=None):
     for (k, t, row_bytes, seg), o in zip(segs, offs):
         send[o:o + row_bytes * n] = t.view(-1).view(torch.uint8)
     recv = torch.empty(world * off, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    _all_gather_into(recv, send, group)
     out = {}
     for (k, t, row_bytes, seg), o in zip(segs, offs):
         parts = []
@@ -88,7 +104,12 @@ def broadcast_tensors(tensors, src=0, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1 or not tensors:
         return
     flat = torch.cat([t.detach().contiguous().view(-1).view(torch.uint8) for t in tensors])
-    dist.broadcast(flat, src, group=group)
+    if flat.is_cuda and _staged(group):
+        host = flat.cpu()
+        dist.broadcast(host, src, group=group)
+        flat.copy_(host)
+    else:
+        dist.broadcast(flat, src, group=group)
     off = 0
     with torch.no_grad():
         for t in tensors:

@@ -153,7 +153,8 @@ class BatchedMCTS(object):
 
     def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
                  n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False,
-                 sync_free=None, lookahead=None, lookahead_slots=None, value_cache=None, lookahead_overlap=None):
+                 sync_free=None, lookahead=None, lookahead_slots=None, value_cache=None, lookahead_overlap=None,
+                 z_log_rows=0):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         self.n_games = n_games
@@ -232,6 +233,8 @@ class BatchedMCTS(object):
             j -= 1   # n_thr leaves no room to queue the leaves that much earlier
         self.lookahead_overlap = j
         margin = self.lookahead + max(self.lookahead_overlap - 1, 0)
+        if z_log_rows and not self.lookahead:
+            raise ValueError("z_log_rows needs the look-ahead playout (rollout_hook serves the other paths)")
         if self.lookahead and not (can and self.n_thr > margin):
             raise ValueError("lookahead needs the sync-free playout, a policy net with "
                              "forward_counted_boards and n_thr > lookahead (+ overlap - 1)")
@@ -254,6 +257,10 @@ class BatchedMCTS(object):
             self._la_path_len = torch.zeros(n_games, dtype=torch.int32, **kw) if use_path else None
             # two queues: the playouts of a group fill one while the other one's batch is in flight
             self._la_queues, self._la = [], []
+            # diagnostic record of the parity tests: the z every playout of a game backed up, in
+            # playout order (iago_mcts_lookahead.z_log); works in graph mode, unlike rollout_hook
+            self.z_log = torch.zeros((z_log_rows, n_games), dtype=torch.int8, **kw) if z_log_rows else None
+            self.z_log_n = torch.zeros(n_games, dtype=torch.int32, **kw) if z_log_rows else None
             for _ in range(2):
                 q = dict(count=torch.zeros(1, dtype=torch.int32, **kw), own=torch.zeros(Q, dtype=torch.int64, **kw),
                          opp=torch.zeros(Q, dtype=torch.int64, **kw), game=torch.zeros(Q, dtype=torch.int32, **kw),
@@ -270,6 +277,8 @@ class BatchedMCTS(object):
                 if self._la_path is not None:
                     a.path, a.path_len = self._la_path.data_ptr(), self._la_path_len.data_ptr()
                     a.path_stride = self.PATH_STRIDE
+                if self.z_log is not None:
+                    a.z_log, a.z_log_n, a.z_log_rows = self.z_log.data_ptr(), self.z_log_n.data_ptr(), z_log_rows
                 self._la_queues.append(q)
                 self._la.append(a)
             self._la_cur = 0   # the queue the playouts fill
@@ -580,10 +589,18 @@ class BatchedMCTS(object):
         # MIOpen's choice for this shape, weight layouts cached per weight version) must not
         # happen under capture.  Neither touches the trees.
         if self.lmbda < 1.0 and self.value_cache:
+            # (through the very entry point the capture records -- iago_value_rollout when the leaf
+            # evaluation is fused -- with an empty fresh list: the value rows do nothing, the
+            # rollouts write self.z, which every playout overwrites before it is read)
             self._fresh_count.zero_()
+            both = (self.fused_leaf_eval and self.lmbda > 0.0 and self.rollout_weights is not None
+                    and not self.rollout_weights.log_form)
+            ro = ops.rollout_prepare(self.cur_own, self.cur_opp, self.rollout_weights, seed=self.seed,
+                                     id_base=self.game_id_base, stream_id=0, stream_id_dev=self._sim_dev,
+                                     out=self._rollout_out) if both else None
             with torch.no_grad():
                 self.value_fn.forward_boards_counted(self.cur_own, self.cur_opp, self._fresh_idx,
-                                                     self._fresh_count, self.v)
+                                                     self._fresh_count, self.v, rollout=ro)
         elif self.lmbda < 1.0:
             ops.encode_planes(self.cur_own, self.cur_opp, out=self.planes)
             with torch.no_grad():
@@ -591,8 +608,15 @@ class BatchedMCTS(object):
                 if fb is None or fb(self.cur_own, self.cur_opp) is None:
                     self.value_fn(self.planes)
         if self.policy_fn is not None:
+            # the entry point _expand_pending_counted / _flush_lookahead take: the board-fed forward
+            # (three-piece kernel: weight split, argument template, scratch buffer, kernel
+            # attributes) when the policy has one, the planes-fed float32 kernels otherwise
             self._pend_count.zero_()
-            self._policy_counted(self._policy_in[:self.n_games], self._pend_count)
+            fb = getattr(self.policy_fn, "forward_counted_boards", None)
+            if fb is not None:
+                fb(self.cur_own, self.cur_opp, self._pend_idx, self.n_games, self._pend_count)
+            else:
+                self._policy_counted(self._policy_in[:self.n_games], self._pend_count)
         torch.cuda.synchronize()
         if self.lookahead:
             self._flush_lookahead(0)  # (queues empty: allocations and one-time setup only)
@@ -669,6 +693,9 @@ class BatchedMCTS(object):
                 if self._value_key is not None:
                     self.tree.v.fill_(float("nan"))
                 self._value_key = key
+            # (the descent appends to the fresh-leaf list through this count and the backup clears
+            # it: a playout aborted between the two must not leave a stale count behind)
+            self._fresh_count.zero_()
         if used > self.tree.capacity // 2 and used > self._live_after_compaction * 5 // 4:
             # a pool is half full: free the nodes that subtree reuse left behind (what the
             # reference's garbage collector does after MCTS.py:149-152) before this search adds
@@ -736,6 +763,26 @@ class BatchedMCTS(object):
         bak = 20 * (lv + self.n_leaf_evals)
         return {"select": sel, "backup": bak, "levels": lv, "children_scored": ch}
 
+    def memory_bytes(self):
+        """Device memory this engine holds, by part: the tree pools (22 B per node, 26 B with the
+        value cache; twice that once compact() has allocated its second pool), the look-ahead's
+        prior cache ([game][slot][64] float32) and queues, the recorded paths, and the policy
+        net's scratch for its multi-launch forward (network.SLPolicy.SPLIT3_SCRATCH_ROWS x 50,176 B
+        = 205 MB per stream that calls it -- the search uses up to three: eager, capture, side
+        stream -- bounded whatever n_games is; longer batches run in chunks)."""
+        out = {"tree": self.tree.bytes() + (self.tree.v.numel() * 4 if self.tree.v is not None else 0)}
+        if getattr(self.tree, "_scratch", None) is not None:
+            out["tree_compaction_pool"] = out["tree"] + self.tree._order.numel() * 4
+        if self.lookahead:
+            out["prior_cache"] = self._la_cache.numel() * 4 + self._la_cache_seq.numel() * 4
+            out["queues"] = sum(t.numel() * t.element_size() for q in self._la_queues for t in q.values())
+            if self._la_path is not None:
+                out["paths"] = self._la_path.numel() * 4
+        pool = getattr(self.policy_fn, "__dict__", {}).get("_split3_scratch_pool", {})
+        out["policy_scratch"] = sum(b.numel() for k, b in pool.items() if k != "retired") + \
+            sum(b.numel() for b in pool.get("retired", ()))
+        return out
+
     def best_move(self, active=None, want_visits=True):
         """argmax visit count of the root's children, first wins (MCTS.py:147)."""
         check(_lib.lib().iago_mcts_best_move(self.tree.ref(),
@@ -766,8 +813,10 @@ class SelfPlayResult(object):
         sign = torch.tensor([1 if c == 1 else -1 for c in self.mover], dtype=torch.int8,
                             device=self.z.device).reshape(T, 1)
         zz = (self.z.reshape(1, B) * sign).reshape(-1)
+        colour = torch.tensor(list(self.mover), dtype=torch.int8, device=self.z.device).reshape(T, 1).expand(T, B)
         return dict(own=self.own.reshape(-1)[m], opp=self.opp.reshape(-1)[m],
-                    pi=self.pi.reshape(-1, 64)[m], z=zz[m], move=self.move.reshape(-1)[m])
+                    pi=self.pi.reshape(-1, 64)[m], z=zz[m], move=self.move.reshape(-1)[m],
+                    colour=colour.reshape(-1)[m])
 
 
 class SelfPlayEngine(object):

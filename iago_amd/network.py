@@ -222,11 +222,22 @@ class SLPolicy(nn.Module, _NpzMixin):
                                                       n_dev=n_dev, overflow=overflow, parts=self.split3_parts,
                                                       scratch=scratch)
 
+    # rows of a multi-launch forward's scratch buffer: 4096 x 50,176 B = 205 MB per stream that
+    # calls the net, whatever the batch (a longer batch runs as chunks of this many rows)
+    SPLIT3_SCRATCH_ROWS = 4096
+
+    def release_scratch(self):
+        """Drop the scratch buffers of forwards that no captured graph refers to any more (the
+        search engine calls it before it re-captures)."""
+        self.__dict__.pop("_split3_scratch_pool", None)
+
     def _split3_scratch(self, device, rows):
         """The buffer a multi-launch forward parks the boards' activations in: one per stream
-        (calls on different streams must not share it), kept for the module's lifetime -- a
-        captured hipGraph of the search engine holds its address."""
+        (calls on different streams must not share it), min(rows, SPLIT3_SCRATCH_ROWS) rows,
+        kept until release_scratch() -- a captured hipGraph of the search engine holds its
+        address."""
         from . import ops
+        rows = min(rows, self.SPLIT3_SCRATCH_ROWS)
         key = (str(device), torch.cuda.current_stream(device).cuda_stream)
         pool = self.__dict__.setdefault("_split3_scratch_pool", {})
         buf = pool.get(key)

@@ -351,14 +351,22 @@ def policy_forward_split3_prepared(template, own, opp, n=None, index=None, n_dev
     probs = torch.empty((n, 64), dtype=torch.float32, device=own.device)
     a.probs = probs.data_ptr()
     if parts > 1:
-        if scratch is None or scratch.numel() < n * POLICY_SCRATCH_ROW_BYTES:
-            raise ValueError("policy_forward_split3: parts > 1 needs a scratch buffer of n x %d bytes"
-                             % POLICY_SCRATCH_ROW_BYTES)
-        a.parts, a.scratch = parts, _dev(scratch, torch.uint8, "scratch").value
+        _set_scratch(a, parts, scratch, n)
     f = _flag(overflow)
     a.overflow = f.value if f is not None else None
     check(_lib.lib().iago_policy_forward_split3(C.byref(a), _stream()), "iago_policy_forward_split3")
     return probs
+
+
+def _set_scratch(a, parts, scratch, n):
+    """parts > 1: scratch = uint8 [rows][POLICY_SCRATCH_ROW_BYTES]; a batch of more than `rows`
+    rows runs as chunks of `rows` (iago_policy_split3_args.scratch_rows)."""
+    rows = 0 if scratch is None else scratch.numel() // POLICY_SCRATCH_ROW_BYTES
+    if rows < 1:
+        raise ValueError("policy_forward_split3: parts > 1 needs a scratch buffer of (rows, %d) bytes"
+                         % POLICY_SCRATCH_ROW_BYTES)
+    a.parts, a.scratch = parts, _dev(scratch, torch.uint8, "scratch").value
+    a.scratch_rows = min(rows, n, 0x7FFFFFFF)
 
 
 def policy_forward_split3(own, opp, w1, b1, layers, w9, b10, n=None, index=None, n_dev=None, overflow=None,
@@ -390,12 +398,9 @@ def policy_forward_split3(own, opp, w1, b1, layers, w9, b10, n=None, index=None,
     probs = torch.empty((n, 64), dtype=torch.float32, device=own.device)
     a.probs = probs.data_ptr()
     if parts > 1:
-        # parts launches; scratch: uint8 [>= n][POLICY_SCRATCH_ROW_BYTES], not shared with a call on
+        # parts launches (per chunk of the scratch's rows); scratch not shared with a call on
         # another stream (the launches of a call, and the calls of a stream, run in order)
-        if scratch is None or scratch.numel() < n * POLICY_SCRATCH_ROW_BYTES:
-            raise ValueError("policy_forward_split3: parts > 1 needs a scratch buffer of n x %d bytes"
-                             % POLICY_SCRATCH_ROW_BYTES)
-        a.parts, a.scratch = parts, _dev(scratch, torch.uint8, "scratch").value
+        _set_scratch(a, parts, scratch, n)
     f = _flag(overflow)
     a.overflow = f.value if f is not None else None
     check(_lib.lib().iago_policy_forward_split3(C.byref(a), _stream()), "iago_policy_forward_split3")

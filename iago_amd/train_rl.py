@@ -152,7 +152,9 @@ class ReinforceTrainer(object):
 
     def sync_replicas(self):
         """Every rank takes rank 0's parameters and Adam moments."""
-        ts = [p.data for p in self.model1.parameters()]
+        # (the parameters themselves, not their .data: broadcast_tensors copies under no_grad,
+        # which bumps p._version -- the key of every cached weight layout and captured graph)
+        ts = list(self.model1.parameters())
         for n, _ in self.model1.named_parameters():
             ts.extend(self.opt.state[n])
         idist.broadcast_tensors(ts)
@@ -191,18 +193,47 @@ class ReinforceTrainer(object):
         wins = idist.gather_tuples(dict(win=(r["z"] == 1).to(torch.int8)))["win"]
         return tup, int(wins.sum().item())
 
+    def _update(self, own, opp, actions, rewards):
+        """src/train_rl.py:55-66 on a gathered batch: loss, backward, Adam step; every replica
+        then takes rank 0's parameters (one collective)."""
+        self.model1.train()
+        for p in self.model1.parameters():
+            p.grad = None
+        loss = reinforce_loss(self.model1, own, opp, actions, rewards, pad_to=512)
+        loss.backward()
+        self.opt.update()
+        idist.broadcast_tensors(list(self.model1.parameters()))  # replicas stay identical
+        return loss
+
+    def step_from_tuples(self, tup, colour=None):
+        """One REINFORCE update from the tuples of a PV-MCTS self-play round (BASELINE
+        configs[4]: "self-play feeding train_rl.py REINFORCE update on gathered (s, pi, z)"):
+        tup = engine.SelfPlayResult.tuples() of THIS rank's games -- own / opp (the searched
+        position, own = the mover), move (the move played = argmax of pi), z (the game's result
+        from the mover's view), colour (1 / 2).  The rows of all ranks are all-gathered
+        (idist.gather_tuples: the reference's list concatenation, src/train_rl.py:48-51) and go
+        through the same loss as a policy-vs-policy set (src/train_rl.py:55-66: x = the mover's
+        planes, y = the action, r = the result).  colour = 1 keeps the learner's plies only, as
+        the reference records them (src/rl_self_play.py:134-138); None = both colours (in PV-MCTS
+        self-play both sides are the learner).  The win rate / snapshot gating of step() belongs
+        to games against a pool opponent and is not touched.  Returns dict(loss, n_tuples)."""
+        keep = slice(None)
+        if colour is not None:
+            keep = tup["colour"] == colour
+        g = idist.gather_tuples(dict(own=tup["own"][keep], opp=tup["opp"][keep],
+                                     action=tup["move"][keep], z=tup["z"][keep]))
+        if g["z"].numel() == 0:
+            raise ValueError("step_from_tuples: no tuples")
+        loss = self._update(g["own"], g["opp"], g["action"], g["z"])
+        out = dict(loss=float(loss.item()), n_tuples=int(g["z"].numel()))
+        self.log.append(out)
+        return out
+
     def step(self):
         """One set + one update; returns dict(rate, loss, saved)."""
         model2 = self.pick_opponent()
         tup, result = self.play_set(model2)
-        self.model1.train()
-        for p in self.model1.parameters():
-            p.grad = None
-        loss = reinforce_loss(self.model1, tup["own"], tup["opp"], tup["action"], tup["z"],
-                              pad_to=512)
-        loss.backward()
-        self.opt.update()
-        idist.broadcast_tensors([p.data for p in self.model1.parameters()])  # replicas stay identical
+        loss = self._update(tup["own"], tup["opp"], tup["action"], tup["z"])
         rate = result / (2 * self.N)
         saved = False
         if rate > 0.5:                                             # src/train_rl.py:71-72

@@ -64,6 +64,7 @@ def generate(model_sl, model_rl, n_games, stop_num=None, seed=0, game_id_base=0,
     every_cell = torch.full((B,), -1, dtype=torch.int64, device=device)
     equal = torch.full((B, 64), 1.0 / 64, dtype=torch.float32, device=device)
     it = iter(draws) if draws is not None else None
+    nan_seen = torch.zeros((), dtype=torch.bool, device=device)
 
     def u_next():
         return torch.tensor([next(it)], dtype=torch.float64, device=device)
@@ -90,6 +91,10 @@ def generate(model_sl, model_rl, n_games, stop_num=None, seed=0, game_id_base=0,
             # np.random.choice(64, p=softmax(...)): unmasked = every cell "legal"
             a1 = ops.sample_moves(p, every_cell, uniforms=u_next() if it is not None else None,
                                   seed=seed, id_base=game_id_base, step=t, stream_id=0)
+            # iago_sample_moves returns 64 for a row whose probabilities hold NaN / inf (the
+            # reference's un-shifted softmax overflows for saturated nets and np.random.choice
+            # then raises, value_self_play.py:143): remembered here, raised after the loop
+            nan_seen = nan_seen | (movers & (a1 > 63)).any()
             ok = ((legal >> a1.to(torch.int64).clamp(0, 63)) & 1).bool() & (a1 >= 0) & (a1 < 64)
             need_fallback = movers & ~ok
             a2 = a1
@@ -131,6 +136,8 @@ def generate(model_sl, model_rl, n_games, stop_num=None, seed=0, game_id_base=0,
             finished = finished | over
         if bool(finished.all().item()):
             break
+    if bool(nan_seen.item()):
+        raise ValueError("probabilities contain NaN")   # numpy.random.choice's message
     if not bool(finished.all().item()):
         raise RuntimeError("value_self_play.generate: a game did not finish in %d turns" % MAX_TURNS)
     if it is not None and next(it, None) is not None:

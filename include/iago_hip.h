@@ -320,8 +320,11 @@ typedef struct iago_policy_split3_args {
     float *probs;
     uint32_t *overflow;
     int32_t parts;          /* 0 / 1: one launch; 2..7: the 7 blocks as that many launches of 7 / parts blocks */
-    int32_t reserved;
-    void *scratch;          /* parts > 1: [n][50,176] bytes, a board's activations between the launches */
+    int32_t scratch_rows;   /* parts > 1: rows the scratch holds; 0 = n.  A batch of more rows runs as chunks of
+                               scratch_rows rows (each chunk its `parts` launches), so the scratch stays bounded
+                               whatever n is */
+    void *scratch;          /* parts > 1: [scratch_rows or n][50,176] bytes, a board's activations between the
+                               launches */
 } iago_policy_split3_args;
 IAGO_API int iago_policy_forward_split3(const iago_policy_split3_args *args, void *stream);
 /*
@@ -574,6 +577,14 @@ typedef struct iago_mcts_lookahead {
                               by side instead of climbing through `parent`.  A descent deeper than path_stride
                               sets the game's `overflow` */
     int32_t *path_len;
+    int8_t *z_log;         /* optional diagnostic record [z_log_rows][n_games] (z_log_rows = 0: none):
+                              iago_mcts_mix_backup_lookahead stores the rollout result z it mixed into the leaf
+                              value (MCTS.py:124-125) of game g's k-th playout since z_log_n[g] was zeroed in row
+                              k, and counts in z_log_n [n_games] -- what a replay of the search through the
+                              reference's MCTS.playout needs from Simulate (tests/test_mcts_production_gpu.py) */
+    int32_t *z_log_n;
+    int32_t z_log_rows;
+    int32_t reserved;
 } iago_mcts_lookahead;
 IAGO_API int iago_mcts_mix_backup_lookahead(const iago_mcts_tree *tree, const uint8_t *active,
                                             const int32_t *cur_node, const uint64_t *cur_own,

@@ -1,0 +1,106 @@
+"""R-independence on the real kernels: what DESIGN.md section 6 promises -- "results do not depend
+on the number of GPUs" -- checked with two ranks running the HIP engine (two fresh child
+processes on the one GPU of the box, gloo; tests/dist_gpu_worker.py) against one rank playing
+all the games; and bench.py's own launcher (`--gpus N` without torch.distributed.run).
+The reference's analogue of the exchange: list concatenation, src/train_rl.py:48-51."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_gpu_worker.py")
+
+
+def run_world(world, *args):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, WORKER, *[str(a) for a in args]], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0, err[-3000:]
+
+
+def canonical(npz, keys, by):
+    order = np.lexsort(tuple(npz[k] for k in reversed(by)))
+    return {k: npz[k][order] for k in keys}
+
+
+def test_selfplay_two_ranks_equal_one_rank(tmp_path):
+    """SelfPlayEngine (production defaults: hipGraph, look-ahead, value cache) on 2 x 32 games vs
+    1 x 64: the gathered (s, pi, z) tuples are identical row for row -- Philox streams are keyed
+    by the global game id, a net's output for a board does not depend on its batch."""
+    one, two = str(tmp_path / "w1.npz"), str(tmp_path / "w2.npz")
+    run_world(1, "selfplay", 64, 24, one)
+    run_world(2, "selfplay", 64, 24, two)
+    a, b = np.load(one), np.load(two)
+    keys = ("own", "opp", "pi", "z", "move", "colour", "game", "turn")
+    ca, cb = canonical(a, keys, ("game", "turn")), canonical(b, keys, ("game", "turn"))
+    assert len(ca["z"]) > 64 * 40
+    for k in keys:
+        assert np.array_equal(ca[k], cb[k]), k
+    # rank 0's rows first, then rank 1's (gather_tuples): games 0..31 before 32..63
+    first_hi = int(np.argmax(b["game"] >= 32))
+    assert np.all(b["game"][:first_hi] < 32) and np.all(b["game"][first_hi:] >= 32)
+    assert np.array_equal(a["final_z"][np.argsort(a["final_game"])], b["final_z"][np.argsort(b["final_game"])])
+    assert int(a["leaf_evals"]) > 0
+
+
+def test_reinforce_two_ranks_equal_one_rank(tmp_path):
+    """ReinforceTrainer.step() x 3 and one step_from_tuples() of PV-MCTS tuples, 2 ranks vs 1:
+    same gathered tuples, same win rates, parameters allclose 1e-6, replicas bit-identical after
+    the broadcast (the ranks start from DIFFERENT random replicas and seeds: rank 0's win)."""
+    run_world(1, "reinforce", 3, tmp_path / "w1")
+    run_world(2, "reinforce", 3, tmp_path / "w2")
+    one = np.load(str(tmp_path / "w1.rank0.npz"))
+    r0, r1 = np.load(str(tmp_path / "w2.rank0.npz")), np.load(str(tmp_path / "w2.rank1.npz"))
+    params = [k for k in one.files if "/" in k]
+    assert len(params) == 18
+    for k in params:
+        assert np.array_equal(r0[k], r1[k]), k                       # replicas: bit-identical
+        assert np.allclose(one[k], r0[k], rtol=0, atol=1e-6), k      # 2 ranks vs 1
+    assert np.array_equal(one["rates"], r0["rates"]) and np.array_equal(r0["rates"], r1["rates"])
+    assert np.array_equal(one["n_tuples"], r0["n_tuples"])
+    assert np.allclose(one["losses"], r0["losses"], rtol=1e-5, atol=1e-7)
+    assert int(one["adam_t"]) == int(r0["adam_t"]) == 4
+    assert int(one["mcts_tuples"]) == int(r0["mcts_tuples"]) > 0
+    assert np.allclose(one["mcts_loss"], r0["mcts_loss"], rtol=1e-5, atol=1e-7)
+    for i in range(3):   # the gathered tuples of every set: the same rows (rank order = game order)
+        for k in ("own", "opp", "action", "z"):
+            assert np.array_equal(one["set%d_%s" % (i, k)].shape, r0["set%d_%s" % (i, k)].shape), (i, k)
+        for src in (r0, r1):
+            a = np.stack([one["set%d_%s" % (i, k)].astype(np.int64) for k in ("own", "opp", "action", "z")])
+            b = np.stack([src["set%d_%s" % (i, k)].astype(np.int64) for k in ("own", "opp", "action", "z")])
+            assert np.array_equal(a[:, np.lexsort(a[::-1])], b[:, np.lexsort(b[::-1])]), i
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` as the driver runs it, without a launcher: the spawn path
+    (forced with --spawn for N = 1, all this box has) starts the rank as a child process with
+    RANK / WORLD_SIZE / MASTER_* set, that rank runs the whole bench over the nccl (= RCCL)
+    backend and prints the ONE JSON line."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "20",
+                          "--warmup", "5", "--rollout-only"], cwd=ROOT, capture_output=True, text=True,
+                         timeout=600, env={k: v for k, v in os.environ.items()
+                                           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 1e6
+    assert "rccl all-gather" in line["config"]["tuple_allgather"]   # the rank ran under a process group
+    # a rank that fails takes the launcher's exit status with it
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--boards", "-5",
+                          "--rollout-only"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0

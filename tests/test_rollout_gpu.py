@@ -383,3 +383,63 @@ def test_lpb_agrees_with_8lane_kernel_statistically(ops):
         assert float(same.float().mean()) > 0.995
     assert torch.equal(ops.judge(b.final_own, b.final_opp), b.z)
     assert torch.equal(ops.judge(c.final_own, c.final_opp), c.z)
+
+
+# ------------------------------------------------- the production instance, directly
+# rollout_row_kernel<false> (no trace pointer, no recorded uniforms) is what bench.py times and
+# what the leaf evaluation of a PV-MCTS playout runs; every test above records a trace and
+# therefore launches the <true> instance.  z, final boards and turn counts need no trace.
+def run_production(ops, own, opp, weights=None, **kw):
+    res = ops.rollout(ops.bits_to_tensor(own) if isinstance(own, np.ndarray) else own,
+                      ops.bits_to_tensor(opp) if isinstance(opp, np.ndarray) else opp,
+                      weights, want_final=True, want_turns=True, **kw)
+    torch.cuda.synchronize()
+    assert res.trace is None
+    return res
+
+
+@pytest.mark.parametrize("n,seed,id_base", [(1, 1, 0), (300, 3, 1000), (4096, 6, 70000)])
+def test_production_instance_uniform_policy_bit_exact(ops, n, seed, id_base):
+    """rollout_row_kernel<false> against orc.random_playout game for game: z, final boards and
+    turn counts (uniform policy: the arithmetic is exact, so the games are the oracle's)."""
+    own, opp = random_positions(min(n, 512), seed=seed)
+    reps = (n + len(own) - 1) // len(own)
+    own, opp = np.tile(own, reps)[:n], np.tile(opp, reps)[:n]
+    own[: n // 2] = 0x0000000810000000  # standard start, colour 1 to move
+    opp[: n // 2] = 0x0000001008000000
+    res = run_production(ops, own, opp, None, seed=seed, id_base=id_base)
+    z, nt = res.z.cpu().numpy(), res.n_turns.cpu().numpy()
+    fo, fp = ops.tensor_to_bits(res.final_own), ops.tensor_to_bits(res.final_opp)
+    for b in range(n):
+        oz, final, otr = orc.random_playout(state_of(own[b], opp[b]), 1, seed=seed, game_id=id_base + b)
+        assert z[b] == oz, b
+        assert nt[b] == len(otr), b
+        assert (int(fo[b]), int(fp[b])) == orc.state_to_bits(final), b
+
+
+@pytest.mark.parametrize("which", ["shipped", "random"])
+def test_production_instance_equals_traced_instance(ops, which):
+    """Shipped (and seeded random) RolloutPolicy weights, 4096 boards from the start position
+    (BASELINE configs[1], the launch bench.py times) + 4096 mid-game positions: the <false>
+    instance returns exactly what the <true> instance -- the one the replay tests hold against
+    the oracle turn by turn -- returns for the same Philox keys."""
+    g = load_json("simulate.json")
+    w, bvec = (g["shipped_w"], g["shipped_b"]) if which == "shipped" else (g["w"], g["b"])
+    weights = ops.RolloutWeights(w, bvec)
+    n = 4096
+    own = np.full(n, 0x0000000810000000, np.uint64)
+    opp = np.full(n, 0x0000001008000000, np.uint64)
+    mo, mp = random_positions(512, seed=23)
+    for o, p, base in ((own, opp, 0), (np.tile(mo, 8), np.tile(mp, 8), 12345)):
+        prod = run_production(ops, o, p, weights, seed=2024, id_base=base, stream_id=3)
+        z, fo, fp, nt, tr = run(ops, o, p, weights, seed=2024, id_base=base, stream_id=3)
+        assert np.array_equal(prod.z.cpu().numpy(), z)
+        assert np.array_equal(ops.tensor_to_bits(prod.final_own), fo)
+        assert np.array_equal(ops.tensor_to_bits(prod.final_opp), fp)
+        assert np.array_equal(prod.n_turns.cpu().numpy(), nt)
+    # ... and a sample of those production games replayed through the oracle's rules from the
+    # traced twin (same games, as just shown): legal sets, flips, passes, termination, z
+    k = 300
+    sampled, exact = replay_check(o[:k], p[:k], z[:k], fo[:k], fp[:k], nt[:k], tr[:, :k], w, bvec,
+                                  lambda b, t: orc.uniform(2024, 12345 + b, t, 3))
+    assert sampled > 5000 and exact >= sampled - 3

@@ -1,21 +1,34 @@
 #!/bin/bash
-# rocprofv3 kernel stats + PMC of the PV-MCTS leg (bounded sample: the first 4 turns of
-# 1024 games x 100 playouts, eager launches -- rocprofv3 does not attribute kernels
-# launched from a hipGraph): gpurun_out/prof_<tag>_mcts/
+# rocprofv3 kernel stats + PMC of the PV-MCTS leg with eager launches (rocprofv3 does not
+# attribute kernels launched from a hipGraph).
+#   tools/profile_mcts.sh <tag>        bounded sample: the first 4 turns of 1024 games x 100 playouts
+#   tools/profile_mcts.sh <tag> full   the games played to the end (>= 6,000 launches per playout kernel):
+#                                      what bench.py's mcts.roofline.kernels reads (*_mcts_fullgame_*)
+# -> gpurun_out/prof_<tag>_mcts[_fullgame]/ ; summary.json = tools/summarize_mcts_profile.py
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
+MODE=${2:-first4}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/prof_${TAG}_mcts
+if [ "$MODE" = "full" ]; then TURNS=-1; SUF=_mcts_fullgame; else TURNS=4; SUF=_mcts; fi
+OUT=$REPO/gpurun_out/prof_${TAG}${SUF}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --large-boards 0 --train-iters 0 --mcts-turns 4 --mcts-eager --mcts-only"
+ARGS="--gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --large-boards 0 --train-iters 0 --mcts-turns $TURNS --mcts-eager --mcts-only"
 echo "python3 bench.py $ARGS" > "$OUT/command.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py $ARGS > "$OUT/trace.log" 2>&1
-for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
+# one pass per counter group (MI355X_MICROARCH.md: PMC in runs of their own, no trace domains);
+# the last three groups are the L2 / fabric side of the one-board walks
+for C in FETCH_SIZE WRITE_SIZE \
+  "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" \
+  "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" \
+  "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$N" -- python3 $REPO/bench.py $ARGS > "$OUT/pmc_$N.log" 2>&1
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$N" -- python3 $REPO/bench.py $ARGS > "$OUT/pmc_$N.log" 2>&1 \
+    || echo "pass $N failed (see pmc_$N.log)"
 done
 find "$OUT" -name "*_kernel_trace.csv" -delete
 find "$OUT" -name "*.db" -delete
 python3 $REPO/tools/summarize_mcts_profile.py "$OUT" > "$OUT/summary.json"
+# the counter CSVs of a full game are tens of MB: keep the summary and the stats
+if [ "$MODE" = "full" ]; then find "$OUT" -name "*_counter_collection.csv" -delete; fi
 du -sh "$OUT"
