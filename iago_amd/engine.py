@@ -813,10 +813,16 @@ class SelfPlayResult(object):
         sign = torch.tensor([1 if c == 1 else -1 for c in self.mover], dtype=torch.int8,
                             device=self.z.device).reshape(T, 1)
         zz = (self.z.reshape(1, B) * sign).reshape(-1)
-        colour = torch.tensor(list(self.mover), dtype=torch.int8, device=self.z.device).reshape(T, 1).expand(T, B)
+        dev = self.z.device
+        colour = torch.tensor(list(self.mover), dtype=torch.int8, device=dev).reshape(T, 1).expand(T, B)
+        # (global game id, turn) of a row: the key that puts the gathered rows of any number of
+        # ranks into ONE canonical order (train_rl.ReinforceTrainer.step_from_tuples)
+        game = (torch.arange(B, dtype=torch.int32, device=dev) + int(getattr(self, "game_id_base", 0))).reshape(1, B)
+        turn = torch.arange(T, dtype=torch.int32, device=dev).reshape(T, 1)
         return dict(own=self.own.reshape(-1)[m], opp=self.opp.reshape(-1)[m],
                     pi=self.pi.reshape(-1, 64)[m], z=zz[m], move=self.move.reshape(-1)[m],
-                    colour=colour.reshape(-1)[m])
+                    colour=colour.reshape(-1)[m], game=game.expand(T, B).reshape(-1)[m],
+                    turn=turn.expand(T, B).reshape(-1)[m])
 
 
 class SelfPlayEngine(object):
@@ -841,6 +847,7 @@ class SelfPlayEngine(object):
         pass_flg = torch.zeros(B, dtype=torch.uint8, device=dev)
         done = torch.zeros(B, dtype=torch.uint8, device=dev)
         res = SelfPlayResult()
+        res.game_id_base = m.game_id_base
         T = self.max_turns
         if record:
             res.own = torch.zeros((T, B), dtype=torch.int64, device=dev)

@@ -99,6 +99,13 @@ def _atomic_savez(path, arrays):
     os.replace(tmp, final)
 
 
+def _canonical(gathered):
+    """Gathered tuple rows (rank 0's first, then rank 1's, ...) in the order of their `key`
+    column: independent of how the games were sharded.  The key column is dropped."""
+    order = torch.argsort(gathered["key"], stable=True)
+    return {k: v[order] for k, v in gathered.items() if k != "key"}
+
+
 def reinforce_loss(model, own, opp, actions, rewards, pad_to=None):
     """src/train_rl.py:55-64.  own/opp: recorded learner positions (own = the
     learner = mover); the reference rebuilds planes [x==1, x==2] from the
@@ -188,8 +195,14 @@ class ReinforceTrainer(object):
                                     seed=self.seed, game_id_base=self.set_index * n_total + lo)
         valid = (r["action"] >= 0)                       # (T1, B): the learner moved
         z = r["z"].reshape(1, -1).expand_as(r["action"])
-        tup = idist.gather_tuples(dict(own=r["own"][valid], opp=r["opp"][valid],
-                                       action=r["action"][valid], z=z[valid]))
+        T1, B = r["action"].shape
+        # row key = (turn, global game): sorted by it the gathered batch is the one a single rank
+        # playing all 2N games records (turn-major), whatever the number of ranks -- the update then
+        # sums the same rows in the same order
+        key = (torch.arange(T1, device=valid.device).reshape(T1, 1) * n_total
+               + torch.arange(lo, hi, device=valid.device).reshape(1, B))
+        tup = _canonical(idist.gather_tuples(dict(own=r["own"][valid], opp=r["opp"][valid],
+                                                  action=r["action"][valid], z=z[valid], key=key[valid])))
         wins = idist.gather_tuples(dict(win=(r["z"] == 1).to(torch.int8)))["win"]
         return tup, int(wins.sum().item())
 
@@ -220,8 +233,9 @@ class ReinforceTrainer(object):
         keep = slice(None)
         if colour is not None:
             keep = tup["colour"] == colour
-        g = idist.gather_tuples(dict(own=tup["own"][keep], opp=tup["opp"][keep],
-                                     action=tup["move"][keep], z=tup["z"][keep]))
+        key = tup["turn"].to(torch.int64) * (1 << 32) + tup["game"].to(torch.int64)
+        g = _canonical(idist.gather_tuples(dict(own=tup["own"][keep], opp=tup["opp"][keep],
+                                                action=tup["move"][keep], z=tup["z"][keep], key=key[keep])))
         if g["z"].numel() == 0:
             raise ValueError("step_from_tuples: no tuples")
         loss = self._update(g["own"], g["opp"], g["action"], g["z"])

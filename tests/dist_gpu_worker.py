@@ -35,13 +35,8 @@ def selfplay(n_games, n_sims, out):
     m = engine.BatchedMCTS(hi - lo, policy, value, shipped_rollout(ops), n_thr=15, capacity=4096, seed=7,
                            game_id_base=lo, use_graph=True)
     res = engine.SelfPlayEngine(m).play(n_sims)
-    tup = res.tuples()
-    # (global game id, turn) of every row: the canonical order the comparison sorts by
-    T, B = res.valid.shape
-    keep = res.valid.reshape(-1).bool()
-    game = (torch.arange(B, device="cuda") + lo).reshape(1, B).expand(T, B).reshape(-1)[keep]
-    turn = torch.arange(T, device="cuda").reshape(T, 1).expand(T, B).reshape(-1)[keep]
-    tup["game"], tup["turn"] = game.to(torch.int32), turn.to(torch.int32)
+    tup = res.tuples()      # with the (global game id, turn) of every row: the comparison sorts by it
+    B = res.valid.shape[1]
     got = gather_tuples(tup)
     zs = gather_tuples(dict(z=res.z, game=(torch.arange(B, device="cuda") + lo).to(torch.int32)))
     if dist.get_rank() == 0:
@@ -54,6 +49,12 @@ def reinforce(n_steps, prefix):
     import torch.distributed as dist
     from iago_amd import network
     from iago_amd.train_rl import ReinforceTrainer
+    # MIOpen's default weight-gradient kernels accumulate with atomics: two runs of the SAME rank
+    # count already differ in the last bit of a gradient, and Adam's m / (sqrt(v) + eps) turns
+    # that into +-alpha wherever a gradient entry is noise (measured: 2e-4 after 4 updates).  The
+    # comparison of 1 vs 2 ranks therefore asks for deterministic convolution algorithms
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
     torch.manual_seed(100 + dist.get_rank())  # DIFFERENT initial replicas: sync_replicas must fix that
     tr = ReinforceTrainer(network.SLPolicy(), pool_dir=None, N=32, seed=3 + dist.get_rank())
     recorded = []
