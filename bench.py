@@ -135,6 +135,7 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
         from iago_amd.dist import gather_tuples
         gather_tuples(warm.tuples())   # (RCCL sets up a collective of a new size class on its first use)
     m.n_leaf_evals = m.n_policy_evals = 0
+    m._value_total.zero_()
     m.stats.zero_()
     torch.cuda.synchronize()
     if dist is not None:
@@ -196,6 +197,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
         if gathered is not None:
             out["gathered_tuples"] = int(gathered["z"].numel())
             out["play_seconds_rank0"] = t_play   # the rest of `seconds`: packing + all-gather of the tuples + barrier
+    out["device_memory_bytes"] = m.memory_bytes()
+    m.close()   # the captured graphs go now, not whenever the garbage collector finds the engine
     return out
 
 
@@ -427,6 +430,7 @@ def mcts_b1_leg(n_sims=200):
     a = m.get_move(state, 1)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    m._m.close()
     return {"playouts_per_sec": n_sims / dt, "ms_per_playout": dt / n_sims * 1e3,
             "sims": n_sims, "move": int(a), "hipgraph": True}
 
@@ -855,6 +859,12 @@ def main():
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher
         # (nothing in it has touched the GPU yet) and exits with its ranks' status
         sys.exit(spawn_ranks(args.gpus))
+    # stdout carries ONE line, rank 0's JSON: whatever a library prints there (RCCL's version banner
+    # at communicator creation, MIOpen notices) goes to stderr instead -- file descriptor 1 points
+    # at stderr for the whole run and the line is written to the original descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -942,7 +952,8 @@ def main():
             line["cpu_baseline"]["python_loops_one_core"] = python_loop_baseline(w, b)
             if mcts is not None:
                 mcts["cpu_baseline"] = mcts_cpu_baseline()
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -582,7 +582,28 @@ class BatchedMCTS(object):
                 key.append(id(fn))
         return tuple(key)
 
+    def close(self):
+        """Drop the captured graphs (and with them their private memory pools) now.  An engine
+        holds reference cycles (the trees' reset hooks), so without this its graphs live until the
+        cyclic garbage collector runs -- which must not happen while ANOTHER engine captures:
+        destroying a graph is not permitted while a stream of the process is capturing."""
+        self._graph = self._graph_long = self._graph_key = None
+
     def _capture(self):
+        """Record the playout launches into hipGraphs.  The cyclic garbage collector is held
+        off for the duration: a collected torch.cuda.CUDAGraph of some other, unreferenced engine
+        would be destroyed inside the capture, which HIP refuses (hipErrorStreamCaptureUnsupported)."""
+        import gc
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_graphs()
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _capture_graphs(self):
         if self.rollout_hook is not None:
             raise ValueError("rollout_hook is not available in graph mode")
         # one eager evaluation of both nets first: lazy one-time setup (kernel attributes,
