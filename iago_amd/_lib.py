@@ -31,7 +31,7 @@ SYMBOLS = [
     "iago_leaf_values",
     "iago_mcts_backup", "iago_mcts_mix_backup", "iago_mcts_best_move", "iago_mcts_advance_root", "iago_mcts_compact",
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
-    "iago_mcts_fresh_leaves", "iago_mcts_descend",
+    "iago_mcts_fresh_leaves", "iago_mcts_descend", "iago_value_rollout_async",
 ]
 
 
@@ -71,6 +71,18 @@ class PolicySplit3Args(C.Structure):
     ]
 
 
+class MctsAsync(C.Structure):
+    """Mirror of iago_mcts_async (include/iago_hip.h)."""
+    _fields_ = [
+        ("parts", C.c_int32), ("reserved", C.c_int32), ("wait", C.c_void_p), ("done", C.c_void_p),
+        ("roll", C.c_void_p), ("fq_index", C.c_void_p), ("fq_count", C.c_void_p), ("step", C.c_void_p),
+        ("n_sims", C.c_void_p), ("scratch", C.c_void_p),
+    ]
+
+
+VALUE_IMAGE_BYTES = 33792   # IAGO_VALUE_IMAGE_BYTES
+
+
 class MctsLookahead(C.Structure):
     """Mirror of iago_mcts_lookahead (include/iago_hip.h)."""
     _fields_ = [
@@ -79,6 +91,7 @@ class MctsLookahead(C.Structure):
         ("q_own", C.c_void_p), ("q_opp", C.c_void_p), ("q_game", C.c_void_p), ("q_seq", C.c_void_p),
         ("error", C.c_void_p), ("clear_word", C.c_void_p), ("path", C.c_void_p), ("path_len", C.c_void_p),
         ("z_log", C.c_void_p), ("z_log_n", C.c_void_p), ("z_log_rows", C.c_int32), ("reserved", C.c_int32),
+        ("async_", C.c_void_p),
     ]
 
 

@@ -44,10 +44,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); // a 16-byte pie
 typedef float f32x4 __attribute__((ext_vector_type(4)));        // (HIP's float4 / uint4 structs end up in scratch)
 
 constexpr int TB = 4;           // boards per workgroup
-#ifndef IAGO_CONV_CS
-#define IAGO_CONV_CS 2
-#endif
-constexpr int CS = IAGO_CONV_CS; // waves per board: each owns 128 / CS output channels
+constexpr int CS = 2;            // waves per board: each owns 128 / CS output channels
 constexpr int NI = 4 / CS;       // 32-channel blocks per wave
 constexpr int THREADS = 64 * TB * CS;
 constexpr int XQ = 512 / THREADS;                 // X pieces per thread and hi/lo

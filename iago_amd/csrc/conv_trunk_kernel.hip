@@ -60,7 +60,27 @@ struct TrunkRParams {
     const int64_t *index;       // optional gather list: row b = board index[b] of own / opp, value to out[index[b]]
     const int32_t *n_dev;       // optional device-side row count: only the first min(n, *n_dev) rows
     int32_t count_lo, count_hi; // this launch runs iff count_lo < rows <= count_hi (variant choice on the device)
+    // FUSED only: a launch may run the layers [layer_lo, layer_hi) of blocks 2..8 alone -- block1
+    // comes with layer_lo == 0, the head with layer_hi == n_layers; in between a board's 64 cell rows
+    // (IMG bytes) travel through scratch [row][IMG] (the game-asynchronous steps' pieces)
+    int32_t layer_lo, layer_hi;
+    char *scratch;
 };
+constexpr int IMG = 64 * RS; // == IAGO_VALUE_IMAGE_BYTES
+
+// What a workgroup's walk takes its rows from and how far it goes (FUSED): by value, in registers --
+// the kernel parameters themselves stay untouched in the kernarg segment (a kernel that edits its
+// TrunkRParams gets a private copy in scratch memory: 384 bytes per lane).
+struct Piece {
+    const int64_t *index;
+    const int32_t *n_dev;
+    char *scratch;
+    int layer_lo, layer_hi;
+};
+__device__ __forceinline__ Piece whole_walk(const TrunkRParams &P)
+{
+    return Piece{P.index, P.n_dev, P.scratch, P.layer_lo, P.layer_hi};
+}
 
 constexpr int head_lds(int tb) { return (9 * 64 * tb + 64 * tb + 128 * tb) * 4; } // tap maps, block9 output, fc terms
 constexpr int lds_alloc_fused(int tb) { return lds_alloc(tb) + head_lds(tb); }
@@ -79,7 +99,7 @@ extern __shared__ __align__(16) char trunk_lds[];
 
 // The work of one workgroup on the TB boards (rows) b0 .. b0 + TB - 1 of n_rows.
 template <bool FUSED, int TB>
-__device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t b0, const int64_t n_rows)
+__device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W, const int64_t b0, const int64_t n_rows)
 {
     constexpr int NT = 2 * TB;      // 32-cell tiles of a wave: TB boards x 2 halves
     constexpr int NPAIR = (TB + 1) / 2; // board pairs (address sets)
@@ -90,7 +110,27 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t 
     if (tid < TB * (ZB / 16))
         *(uint4 *)(T + (tid / (ZB / 16)) * BS + 64 * RS + (tid % (ZB / 16)) * 16) = make_uint4(0, 0, 0, 0);
     bool saturated = false;
-    if constexpr (FUSED) {
+    constexpr bool PIECES = FUSED && TB <= 2; // (the 4-board variant only ever runs whole walks)
+    if (PIECES && W.layer_lo > 0) {
+        // a later piece of the walk: the boards' rows as the previous piece left them (all of a
+        // thread's loads in flight together, then its LDS stores)
+        constexpr int PER = (TB * (IMG / 16) + 255) / 256;
+        uint4 img[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int e = min(tid + i * 256, TB * (IMG / 16) - 1);
+            const int board = e / (IMG / 16), off = e - board * (IMG / 16);
+            const int64_t row = min(b0 + board, n_rows - 1);
+            img[i] = ((const uint4 *)(W.scratch + row * IMG))[off];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int e = tid + i * 256;
+            const int board = e / (IMG / 16), off = e - board * (IMG / 16);
+            if (e < TB * (IMG / 16))
+                *(uint4 *)(T + board * BS + off * 16) = img[i];
+        }
+    } else if constexpr (FUSED) {
         // block1 (3x3, 2 -> 64, bias, ReLU; network.py:66-70) straight into T: the arithmetic of
         // value_stem_kernel (conv_kernels.hip) -- same FMA order, same split -- per (board,
         // cell = lane, 8 output channels = 16 bytes of a row); the channel group is wave-uniform
@@ -99,7 +139,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t 
 #pragma unroll
         for (int board = 0; board < TB; board++) {
             const int64_t row = min(b0 + board, n_rows - 1);
-            const int64_t b = P.index ? P.index[row] : row;
+            const int64_t b = W.index ? W.index[row] : row;
             const float *pl = P.planes + b * 128;
             const uint64_t bits0 = P.planes ? 0ull : P.opp[b], bits1 = P.planes ? 0ull : P.own[b];
 #pragma unroll
@@ -198,14 +238,10 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t 
 #pragma unroll
         for (int pr = 0; pr < NPAIR; pr++)
             wrow[pr][j] = (uint32_t)((32 * j + lane_cell) * RS + pr * 2 * BS);
-#ifdef TRUNK_EXP_STAMPS // timing experiments only (tools/exp_trunk_variants.sh): s_memtime per phase
-    unsigned long long stamps[3 * MAX_LAYERS + 1];
-#define STAMP(i) stamps[i] = __builtin_readcyclecounter()
-#else
 #define STAMP(i)
-#endif
 
-    for (int L = 0; L < P.n_layers; L++) {
+    const int L_lo = PIECES ? W.layer_lo : 0, L_hi = PIECES ? W.layer_hi : P.n_layers;
+    for (int L = L_lo; L < L_hi; L++) {
         STAMP(3 * L);
         const int n_chunks = L == 0 ? (P.cin0 >> 4) : 8;
         // this lane's A operand: output channel 32 wv + r, input channels 8 h .. 8 h + 7 of
@@ -248,10 +284,8 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t 
             for (int tap = 0; tap < 9; tap++) {
                 const int s = c * 9 + tap;
                 const int s2 = min(s + 2, n_steps - 1); // the last two prefetches repeat the last k-step
-#ifndef TRUNK_EXP_NO_A // (timing experiments only: tools/exp_trunk_variants.sh)
                 a_hi[(tap + 2) % 3] = wh[(int64_t)s2 * 256];
                 a_lo[(tap + 2) % 3] = wl[(int64_t)s2 * 256];
-#endif
                 const half8 ah = __builtin_bit_cast(half8, a_hi[tap % 3]);
                 const half8 al = __builtin_bit_cast(half8, a_lo[tap % 3]);
 #pragma unroll
@@ -259,10 +293,8 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t 
                     const int tile = tap * NT + j8, cur = tile % 3, nxt = (tile + 2) % 3;
                     // (past the last chunk: harmless reads 32 B further in the same rows)
                     const char *p = b_addr(tile + 2);
-#ifndef TRUNK_EXP_NO_B
                     bh[nxt] = *(const half8 *)p;
                     bl[nxt] = *(const half8 *)(p + 256);
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                     acc_main[j8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cur], acc_main[j8], 0, 0, 0);
                     acc_cross[j8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[cur], acc_cross[j8], 0, 0, 0);
@@ -304,9 +336,6 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t 
         // NaN survives in the sum) instead of a compare per value.
         float vmax = 0.0f;
         f2 vsum = (f2){0.0f, 0.0f};
-#ifdef TRUNK_EXP_NO_EPI
-        if (acc_main[0][0] == 12345.0f)
-#endif
 #pragma unroll
         for (int j8 = 0; j8 < NT; j8++) {
             const int bb = j8 >> 1, j = j8 & 1;
@@ -340,6 +369,15 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t 
     if (P.overflow && saturated)
         *P.overflow = 1u;
 
+    if (PIECES && W.layer_hi < P.n_layers) {
+        // the next piece of the walk goes on from these rows
+        for (int e = tid; e < TB * (IMG / 16); e += 256) {
+            const int board = e / (IMG / 16), off = e - board * (IMG / 16);
+            if (b0 + board < n_rows)
+                ((uint4 *)(W.scratch + (b0 + board) * IMG))[off] = *(const uint4 *)(T + board * BS + off * 16);
+        }
+        return;
+    }
     if constexpr (FUSED) {
         // ---- block9 (3x3, 128 -> 1, bias, ReLU) + fc10 + fc11 (network.py:78-96, train=False) on
         // the activations still in T.  The 3x3 convolution with ONE output channel as a 1x1
@@ -446,7 +484,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t 
                 v += hv[j4].w;
             }
             const int64_t row = b0 + tid;
-            P.out[P.index ? P.index[row] : row] = v;
+            P.out[W.index ? W.index[row] : row] = v;
         }
         return;
     }
@@ -460,29 +498,23 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const int64_t 
             P.y_lo[b * 1024 + (e & 1023)] = *(const uint4 *)(src + 256);
         }
     }
-#ifdef TRUNK_EXP_STAMPS
-    __syncthreads();
-    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
-        for (int i = 0; i <= 3 * P.n_layers; i++)
-            ((unsigned long long *)P.y_hi)[(blockIdx.x ? 64 : 0) + i] = stamps[i] - stamps[0];
-#endif
 }
 
 // Workgroup `bid` of `nb` walks its rows with that stride (one pass unless the grid was capped:
 // the device-counted launch of the value cache, iago_value_forward_split).
 template <bool FUSED, int TB>
-__device__ __forceinline__ void trunk_walk(const TrunkRParams &P, const int64_t bid, const int64_t nb)
+__device__ __forceinline__ void trunk_walk(const TrunkRParams &P, const Piece &W, const int64_t bid, const int64_t nb)
 {
     int64_t n_rows = P.n;
     if constexpr (FUSED) {
         // device-side row count and variant choice: uniform over the launch, before any barrier
-        if (P.n_dev)
-            n_rows = min(P.n, (int64_t)*P.n_dev);
+        if (W.n_dev)
+            n_rows = min(P.n, (int64_t)*W.n_dev);
         if (n_rows <= P.count_lo || n_rows > P.count_hi)
             return;
     }
     for (int64_t b0 = bid * TB; b0 < n_rows; b0 += nb * TB) {
-        trunk_item<FUSED, TB>(P, b0, n_rows);
+        trunk_item<FUSED, TB>(P, W, b0, n_rows);
         __syncthreads(); // the next pass re-stages the LDS image the head just read
     }
 }
@@ -490,7 +522,7 @@ __device__ __forceinline__ void trunk_walk(const TrunkRParams &P, const int64_t 
 template <bool FUSED, int TB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void trunk_resident_kernel(TrunkRParams P)
 {
-    trunk_walk<FUSED, TB>(P, blockIdx.x, gridDim.x);
+    trunk_walk<FUSED, TB>(P, whole_walk(P), blockIdx.x, gridDim.x);
 }
 
 // The leaf evaluation of a playout (MCTS.py:123-125) in ONE launch: workgroups 0 .. n_ro-1 play
@@ -513,9 +545,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int64_t nb = (int64_t)gridDim.x - n_ro;
     const int64_t n_rows = min(P.n, (int64_t)*P.n_dev);
     if (n_rows <= nb)
-        trunk_walk<true, 1>(P, blockIdx.x - n_ro, nb);
+        trunk_walk<true, 1>(P, whole_walk(P), blockIdx.x - n_ro, nb);
     else
-        trunk_walk<true, 2>(P, blockIdx.x - n_ro, nb);
+        trunk_walk<true, 2>(P, whole_walk(P), blockIdx.x - n_ro, nb);
+}
+
+// The leaf evaluation of one GAME-ASYNCHRONOUS step (iago_value_rollout_async, include/iago_hip.h)
+// in one launch: workgroups 0 .. n_ro-1 play the rollouts of the games that descended in this step
+// (mask, per-game Philox stream ids); then, oldest queue first, `parts` groups of NV workgroups:
+// group p walks the leaves queued p steps ago through piece p of the Value net (block1 + the first
+// layers | ... | the last layers + the head), a board's rows parked in the queue row's scratch
+// between two pieces.  Every workgroup's work is a fraction of a whole walk, so the launch is as
+// long as ONE piece (or one rollout), not as one walk: the value net has left the steps' critical
+// chain.  One board per workgroup while a queue's rows fit its NV workgroups, two above (the pair
+// shares the weight stream).
+constexpr int ASYNC_NV = 64; // value workgroups per piece: parts * NV + the rollouts' 64 <= 256 CUs + slack
+struct AsyncParams {
+    int32_t parts;
+    const int64_t *fq_index; // [parts][n]
+    const int32_t *fq_count; // [parts]
+    const uint32_t *step;
+    char *scratch;           // [parts][n][IMG]
+    uint64_t bounds;         // byte p = first layer of piece p (byte `parts` = 7): piece p = layers [b[p], b[p + 1])
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void value_rollout_async_kernel(
+    TrunkRParams P, iago_row::HwParams R, AsyncParams Y, uint32_t n_ro)
+{
+    if (blockIdx.x < n_ro) {
+        iago_row::rollout_row_body<false, true>(R, blockIdx.x);
+        return;
+    }
+    const uint32_t x = blockIdx.x - n_ro;
+    const int part = Y.parts - 1 - (int)(x / ASYNC_NV); // the oldest queue's workgroups are dispatched first
+    const int64_t bid = x % ASYNC_NV;
+    const uint32_t row = (*Y.step + (uint32_t)(Y.parts - part)) % (uint32_t)Y.parts; // == (step - part) mod parts
+    Piece W;
+    W.index = Y.fq_index + (int64_t)row * P.n;
+    W.n_dev = Y.fq_count + row;
+    W.scratch = Y.scratch + (int64_t)row * P.n * IMG;
+    W.layer_lo = (Y.bounds >> (8 * part)) & 0xFF;
+    W.layer_hi = (Y.bounds >> (8 * part + 8)) & 0xFF;
+    const int64_t n_rows = min(P.n, (int64_t)*W.n_dev);
+    if (n_rows <= ASYNC_NV)
+        trunk_walk<true, 1>(P, W, bid, ASYNC_NV);
+    else
+        trunk_walk<true, 2>(P, W, bid, ASYNC_NV);
 }
 
 } // namespace
@@ -551,10 +626,10 @@ int iago_launch_trunk_resident(const iago_conv_split_layer *layers, int32_t n_la
     P.n_dev = nullptr;
     P.count_lo = 0;
     P.count_hi = 0x7fffffff;
-#ifndef TRUNK_EXP_TB // boards per workgroup (timing experiments build 1 / 2: tools/exp_trunk_variants.sh)
-#define TRUNK_EXP_TB 4
-#endif
-    constexpr int TB = TRUNK_EXP_TB;
+    P.layer_lo = 0;
+    P.layer_hi = n_layers;
+    P.scratch = nullptr;
+    constexpr int TB = 4; // boards per workgroup
     static std::atomic<uint64_t> configured{0};
     if (iago_reserve_lds((const void *)trunk_resident_kernel<false, TB>, lds_alloc(TB), configured,
                          "iago_conv3x3_split_trunk: cannot reserve 134 KB of LDS"))
@@ -629,6 +704,9 @@ static int value_params_of(const iago_value_split_args *a, TrunkRParams &P)
         return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: a gather list needs the boards, not planes");
     P.index = a->index;
     P.n_dev = a->n_dev;
+    P.layer_lo = 0;
+    P.layer_hi = 7;
+    P.scratch = nullptr;
     return IAGO_OK;
 }
 
@@ -716,4 +794,53 @@ int iago_value_rollout(const iago_value_split_args *a, const iago_rollout_args *
     hipLaunchKernelGGL(value_rollout_kernel, dim3(n_ro + n_val), dim3(256), lds_alloc_fused(2), (hipStream_t)stream, P, R,
                        n_ro);
     return iago_check_launch("iago_value_rollout");
+}
+
+int iago_value_rollout_async(const iago_value_split_args *a, const iago_rollout_args *ro, const iago_mcts_async *y,
+                             void *stream)
+{
+    if (!a || !ro || !y)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_rollout_async: null args");
+    if (y->parts < 2 || y->parts > IAGO_ASYNC_MAX_PARTS || !y->wait || !y->done || !y->roll || !y->fq_index ||
+        !y->fq_count || !y->step || !y->n_sims || !y->scratch || ((uintptr_t)y->scratch & 15u))
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_rollout_async: incomplete iago_mcts_async (scratch 16-byte aligned)");
+    if (a->n < 1 || !a->own || !a->opp || a->planes)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_rollout_async: the value net takes the boards (own, opp) of "
+                                           "the n games");
+    if (ro->n != a->n || ro->n > 0x7fffffffll || !ro->own || !ro->opp || !ro->z || !ro->table ||
+        ((uintptr_t)ro->table & 15u) || ro->log_form || ro->trace || ro->uniforms || ro->throughput_hint != 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_rollout_async: product-form rollout of the same n games without "
+                                           "trace / uniforms expected");
+    iago_value_split_args a2 = *a;
+    a2.index = nullptr;
+    a2.n_dev = nullptr;
+    TrunkRParams P;
+    if (const int rc = value_params_of(&a2, P))
+        return rc;
+    P.count_lo = 0;
+    P.count_hi = 0x7fffffff;
+    static std::atomic<uint64_t> configured{0};
+    if (iago_reserve_lds((const void *)value_rollout_async_kernel, lds_alloc_fused(2), configured,
+                         "iago_value_rollout_async: cannot reserve 80 KB of LDS"))
+        return IAGO_ERR_HIP;
+    iago_row::HwParams R = iago_row::hw_params_of(ro);
+    R.mask = y->roll;
+    R.stream_ids = y->done;
+    AsyncParams Y;
+    Y.parts = y->parts;
+    Y.fq_index = y->fq_index;
+    Y.fq_count = y->fq_count;
+    Y.step = y->step;
+    Y.scratch = (char *)y->scratch;
+    // pieces of (nearly) equal work in units of a 128 -> 128 layer: block1 0.3, block 2 (64 -> 128) 0.5,
+    // blocks 3..8 1 each, head 0.3
+    static const int8_t B2[3] = {0, 4, 7}, B3[4] = {0, 3, 5, 7}, B4[5] = {0, 2, 4, 6, 7};
+    const int8_t *B = y->parts == 2 ? B2 : y->parts == 3 ? B3 : B4;
+    Y.bounds = 0;
+    for (int i = 0; i <= y->parts; i++)
+        Y.bounds |= (uint64_t)(uint8_t)B[i] << (8 * i);
+    const unsigned n_ro = (unsigned)((ro->n + (iago_row::HW_BLOCK / 16) - 1) / (iago_row::HW_BLOCK / 16));
+    hipLaunchKernelGGL(value_rollout_async_kernel, dim3(n_ro + (unsigned)(y->parts * ASYNC_NV)), dim3(256),
+                       lds_alloc_fused(2), (hipStream_t)stream, P, R, Y, n_ro);
+    return iago_check_launch("iago_value_rollout_async");
 }

@@ -376,6 +376,14 @@ struct Lookahead {
     int8_t *z_log;              // optional [z_log_rows][n_games]: the rollout result the backup mixed in, one
     int32_t *z_log_n;           // row per playout of a game (z_log_n [n_games] = rows written so far)
     int32_t z_log_rows;
+    // game-asynchronous steps (iago_mcts_async, include/iago_hip.h); y_wait == nullptr: lockstep playouts
+    int32_t y_parts;
+    int32_t *y_wait, *y_done;
+    uint8_t *y_roll;
+    int64_t *y_fq_index;
+    int32_t *y_fq_count;
+    uint32_t *y_step;
+    const int32_t *y_n_sims;
 };
 
 // Diagnostic record of the parity tests (tests/test_mcts_production_gpu.py): the z every playout of
@@ -464,12 +472,36 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_path_kernel(
     const uint32_t r = threadIdx.x & 7u;
     if (gtid == 0 && counter)
         *counter += 1u;
-    if (gtid == 0 && A.clear_word)
+    if (gtid == 0 && A.clear_word && !A.y_wait)
         *A.clear_word = 0;
+    if (A.y_wait && gtid == 0) {
+        // the step is over: the queue row the last piece of the value net has just drained is the
+        // one the next step's descent appends to
+        const uint32_t s = *A.y_step;
+        A.y_fq_count[(s + 1u) % (uint32_t)A.y_parts] = 0;
+        *A.y_step = s + 1u;
+    }
     if (g >= T.n_games)
         return;
     const int64_t base = g * (int64_t)T.capacity;
-    const bool act = active[g] != 0;
+    bool act = active[g] != 0;
+    if (A.y_wait) {
+        // a game completes a playout in this step when its leaf had a stored value (it descended
+        // in this step: roll) or when the value it has been waiting for has arrived (wait == 1)
+        const int w = A.y_wait[g];
+        if (w > 1) {
+            if (r == 0u)
+                A.y_wait[g] = w - 1;
+            act = false;
+        } else if (w == 1) {
+            if (r == 0u)
+                A.y_wait[g] = 0;
+        } else {
+            act = act && A.y_roll[g] != 0;
+        }
+        if (act && r == 0u)
+            A.y_done[g] += 1;
+    }
     const int leaf = cur_node[g];
     float vg = (lmbda < 1.0f) ? v[g] : 0.0f;
     if (T.v && lmbda < 1.0f && act) {
@@ -487,7 +519,7 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_path_kernel(
     const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * vg : 0.0f;
     const float b = (lmbda > 0.0f) ? (float)((double)lmbda * (double)z[g]) : 0.0f;
     const float lv = a + b;
-    if (r == 0u)
+    if (r == 0u && (act || !A.y_wait))
         leaf_value[g] = lv;
     if (!act)
         return;
@@ -616,7 +648,7 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
     Tree T, const uint64_t *__restrict__ root_own, const uint64_t *__restrict__ root_opp,
     const uint8_t *__restrict__ active, float c_puct, int n_thr, int32_t *__restrict__ cur_node,
     uint64_t *__restrict__ cur_own, uint64_t *__restrict__ cur_opp, uint64_t *__restrict__ legal_out,
-    int32_t *__restrict__ stats, Lookahead A, int64_t *__restrict__ fresh_index, int32_t *__restrict__ fresh_count,
+    int32_t *__restrict__ stats, Lookahead A, int64_t *fresh_index, int32_t *fresh_count,
     int64_t *__restrict__ fresh_total)
 {
     int st_levels = 0, st_children = 0;
@@ -624,7 +656,17 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
     const int64_t g = gtid >> 3;
     const Lane8 L = make_lane8(threadIdx.x);
     const uint32_t r = L.l8;
-    const bool live = g < T.n_games && active[g] != 0;
+    bool live = g < T.n_games && active[g] != 0;
+    if (A.y_wait) {
+        // a game-asynchronous step: the games that wait for a value and the games that have
+        // completed the search's playouts sit this step out
+        live = live && A.y_wait[g] == 0 && A.y_done[g] < *A.y_n_sims;
+        if (g < T.n_games && r == 0u)
+            A.y_roll[g] = live ? 1 : 0;
+        const uint32_t row = *A.y_step % (uint32_t)A.y_parts;
+        fresh_index = A.y_fq_index + (int64_t)row * T.n_games;
+        fresh_count = A.y_fq_count + row;
+    }
     const int64_t base = live ? g * (int64_t)T.capacity : 0;
 
     // The descent is a chain of dependent loads (a level cannot start before the previous one
@@ -796,6 +838,8 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
                     fresh_index[pos] = g;
                 else
                     T.overflow[g] = 1;
+                if (A.y_wait)
+                    A.y_wait[g] = A.y_parts; // the value arrives with the last piece, parts - 1 steps on
                 if (fresh_total)
                     atomicAdd((unsigned long long *)fresh_total, 1ull);
             }
@@ -1171,6 +1215,21 @@ int lookahead_of(const iago_mcts_lookahead *a, Lookahead &A, const char *who)
     A.z_log_rows = a->z_log_rows;
     if (A.z_log && !A.z_log_n)
         return iago_fail(IAGO_ERR_INVALID, who);
+    A.y_wait = nullptr;
+    A.y_parts = 0;
+    if (const iago_mcts_async *y = a->async) {
+        if (y->parts < 2 || y->parts > IAGO_ASYNC_MAX_PARTS || !y->wait || !y->done || !y->roll || !y->fq_index ||
+            !y->fq_count || !y->step || !y->n_sims || !A.path)
+            return iago_fail(IAGO_ERR_INVALID, who);
+        A.y_parts = y->parts;
+        A.y_wait = y->wait;
+        A.y_done = y->done;
+        A.y_roll = y->roll;
+        A.y_fq_index = y->fq_index;
+        A.y_fq_count = y->fq_count;
+        A.y_step = y->step;
+        A.y_n_sims = y->n_sims;
+    }
     return IAGO_OK;
 }
 } // namespace
@@ -1257,6 +1316,8 @@ int iago_mcts_descend(const iago_mcts_tree *tree, const uint64_t *root_own, cons
         return IAGO_ERR_INVALID;
     if (!root_own || !root_opp || !active || !cur_node || !cur_own || !cur_opp || !legal)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_descend: null pointer");
+    if (A.y_wait && !tree->v)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_descend: game-asynchronous steps need the tree's value cache");
     if (fresh_index && (!fresh_count || !tree->v))
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_descend: the fresh-leaf list needs its count word and the "
                                            "tree's value cache");

@@ -30,13 +30,7 @@ using namespace iago;
 
 namespace {
 
-#ifndef IAGO_LPB_BLOCK
-#define IAGO_LPB_BLOCK 256
-#endif
-#ifndef IAGO_LPB_ATTR
-#define IAGO_LPB_ATTR
-#endif
-constexpr int BLOCK = IAGO_LPB_BLOCK;
+constexpr int BLOCK = 256; // (64- / 128- / 512-thread blocks and 5-6 waves per SIMD measured equal or slower: LABNOTES.md)
 constexpr int SLOTS = 34; // an Othello position has at most 33 legal moves
 
 struct LpbParams {
@@ -292,48 +286,17 @@ __device__ __forceinline__ void fill_slots(Slots &S, const Padded &To, const Pad
     }
 }
 
-// ---- re-binning (IAGO_LPB_REBIN): the slot descent of a wave runs to the wave's MAXIMUM
-// number of legal moves (~15) while a board has 8.8 on average.  Every turn the boards of a
-// block are therefore counting-sorted by their number of legal moves through LDS (the whole
-// per-board state travels: boards, guard-column strings, Philox words, flags, home index), so
-// that a wave holds boards of similar mobility (sum of the wave maxima x0.73 at 256 boards per
-// block).  Results are written by home index: games are bit-identical to the unsorted kernel.
-#ifndef IAGO_LPB_REBIN
-#define IAGO_LPB_REBIN 0
-#endif
-constexpr bool REBIN = IAGO_LPB_REBIN != 0;
-#ifndef IAGO_LPB_REBIN_PERIOD
-#define IAGO_LPB_REBIN_PERIOD 1
-#endif
-#ifndef IAGO_LPB_REBIN_IDENT
-#define IAGO_LPB_REBIN_IDENT 0
-#endif
-constexpr int N_STAGE = REBIN ? 5 * BLOCK : 1;
-
-// inclusive prefix sum over the 64 lanes of a wave (row_shr 1/2/4/8, row_bcast 15 / 31)
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31
-    return v;
-}
-
-__global__ __launch_bounds__(BLOCK) IAGO_LPB_ATTR void rollout_lpb_kernel(LpbParams P)
+// (Round 2 measured a per-turn counting sort of a block's boards by their number of legal moves,
+// so that a wave holds boards of similar mobility: bit-identical games, 751 vs 813 M games/s --
+// rejected, LABNOTES.md; the variant is in the history at commit b61d6ed.)
+__global__ __launch_bounds__(BLOCK) void rollout_lpb_kernel(LpbParams P)
 {
     __shared__ float ct[N_CT]; // [plane][512]
     __shared__ float be[64];   // exp'ed biases
-    __shared__ uint4 stage[N_STAGE];
-    __shared__ uint32_t hist[2][64]; // bins 0..33: boards per number of legal moves; 63: finished
     for (uint32_t i = threadIdx.x; i < (uint32_t)N_CT; i += BLOCK)
         ct[i] = P.blob[OFF_CT + i];
     if (threadIdx.x < 64) {
         be[threadIdx.x] = P.blob[OFF_BIAS + threadIdx.x];
-        hist[0][threadIdx.x] = 0u;
-        hist[1][threadIdx.x] = 0u;
     }
     __syncthreads();
 
@@ -344,7 +307,6 @@ __global__ __launch_bounds__(BLOCK) IAGO_LPB_ATTR void rollout_lpb_kernel(LpbPar
     uint32_t stones = (uint32_t)__popcll(own | opp);
     uint32_t pass_flg = 0u, nt = 0u;
     uint32_t done = (!live || stones >= 64u) ? 1u : 0u; // `while stone_num < 64`
-    uint32_t home = threadIdx.x;                        // the board's slot in the launch arrays
     const uint32_t stream_id = P.stream_id + (P.stream_id_dev ? *P.stream_id_dev : 0u);
     uint32_t rw[4] = {0, 0, 0, 0};
     const ShiftAmounts SA = opaque_shift_amounts();
@@ -354,62 +316,13 @@ __global__ __launch_bounds__(BLOCK) IAGO_LPB_ATTR void rollout_lpb_kernel(LpbPar
         uint64_t ro = rev64(own), rp = rev64(opp);
         uint64_t legal = legal_moves_1(own, opp, ro, rp, SA);
 
-        if (REBIN && (t % IAGO_LPB_REBIN_PERIOD) == 0u) {
-            uint32_t *h = hist[(t / IAGO_LPB_REBIN_PERIOD) & 1u];
-            const uint32_t key = done ? 0u : (uint32_t)__popcll(legal);
-            const uint32_t rank = atomicAdd(&h[key], 1u);
-            if (done)
-                atomicAdd(&h[63], 1u);
-            if (threadIdx.x < 64)
-                hist[((t / IAGO_LPB_REBIN_PERIOD) & 1u) ^ 1u][threadIdx.x] = 0u; // next turn's bins
-            __syncthreads();
-            if (h[63] >= (uint32_t)BLOCK)
-                break; // every board of the block has finished
-            const uint32_t lane = threadIdx.x & 63u;
-            const uint32_t cnt = (lane < 34u) ? h[lane] : 0u;
-            const uint32_t excl = wave_scan_add(cnt) - cnt;
-            const uint32_t first = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(key << 2), (int)excl);
-            // rotate the sorted order by block: the heavy quarter must not always be wave 3
-            const uint32_t pos = IAGO_LPB_REBIN_IDENT ? threadIdx.x + ((first + rank) >> 16)
-                                                      : (first + rank + 64u * blockIdx.x) & (uint32_t)(BLOCK - 1);
-            const uint32_t flags = home | (done << 16) | (pass_flg << 17) | ((uint32_t)live << 18);
-            stage[pos] = make_uint4((uint32_t)own, (uint32_t)(own >> 32), (uint32_t)opp, (uint32_t)(opp >> 32));
-            stage[BLOCK + pos] = make_uint4((uint32_t)To.w01, (uint32_t)(To.w01 >> 32), (uint32_t)To.w12,
-                                            (uint32_t)(To.w12 >> 32));
-            stage[2 * BLOCK + pos] = make_uint4((uint32_t)Tp.w01, (uint32_t)(Tp.w01 >> 32), (uint32_t)Tp.w12,
-                                                (uint32_t)(Tp.w12 >> 32));
-            stage[3 * BLOCK + pos] = make_uint4(rw[0], rw[1], rw[2], rw[3]);
-            stage[4 * BLOCK + pos] = make_uint4((uint32_t)legal, (uint32_t)(legal >> 32), flags, stones | (nt << 8));
-            __syncthreads();
-            const uint4 a0 = stage[threadIdx.x], a1 = stage[BLOCK + threadIdx.x],
-                        a2 = stage[2 * BLOCK + threadIdx.x], a3 = stage[3 * BLOCK + threadIdx.x],
-                        a4 = stage[4 * BLOCK + threadIdx.x];
-            own = ((uint64_t)a0.y << 32) | a0.x;
-            opp = ((uint64_t)a0.w << 32) | a0.z;
-            To.w01 = ((uint64_t)a1.y << 32) | a1.x;
-            To.w12 = ((uint64_t)a1.w << 32) | a1.z;
-            Tp.w01 = ((uint64_t)a2.y << 32) | a2.x;
-            Tp.w12 = ((uint64_t)a2.w << 32) | a2.z;
-            rw[0] = a3.x, rw[1] = a3.y, rw[2] = a3.z, rw[3] = a3.w;
-            legal = ((uint64_t)a4.y << 32) | a4.x;
-            home = a4.z & 0xFFFFu;
-            done = (a4.z >> 16) & 1u;
-            pass_flg = (a4.z >> 17) & 1u;
-            live = (a4.z >> 18) & 1u;
-            stones = a4.w & 0xFFu;
-            nt = a4.w >> 8;
-            ro = rev64(own), rp = rev64(opp);
-        }
-        const int64_t bh = REBIN ? (int64_t)blockIdx.x * BLOCK + home : b;
-        const bool wave_idle = REBIN && __builtin_amdgcn_ballot_w64(done == 0u) == 0ull;
-        if (!wave_idle) {
         // ---- uniform of this turn: word t&3 of Philox counter (rid, t>>2, stream, 0)
         float u;
         if (P.uniforms) {
-            u = live ? P.uniforms[(int64_t)t * P.n + bh] : 0.0f;
+            u = live ? P.uniforms[(int64_t)t * P.n + b] : 0.0f;
         } else {
             if ((t & 3u) == 0u) {
-                rw[0] = P.id_base + (uint32_t)bh;
+                rw[0] = P.id_base + (uint32_t)b;
                 rw[1] = t >> 2;
                 rw[2] = stream_id;
                 rw[3] = 0u;
@@ -453,7 +366,7 @@ __global__ __launch_bounds__(BLOCK) IAGO_LPB_ATTR void rollout_lpb_kernel(LpbPar
         stones = max(stones + play, (passing & pass_flg) << 6); // mcts_self_play.py:126-133
         pass_flg = (pass_flg & done) | passing;
         if (P.trace && live_turn)
-            P.trace[(int64_t)t * P.n + bh] = play ? (uint8_t)action : (uint8_t)IAGO_TRACE_PASS;
+            P.trace[(int64_t)t * P.n + b] = play ? (uint8_t)action : (uint8_t)IAGO_TRACE_PASS;
         own = nopp; // the other side moves next (finished boards swap an even number of times)
         opp = nown;
         // the guard-column strings follow incrementally: only the changed cells are spread
@@ -466,26 +379,15 @@ __global__ __launch_bounds__(BLOCK) IAGO_LPB_ATTR void rollout_lpb_kernel(LpbPar
             Tp.w12 = oldTo.w12 | D.w12;
         }
         nt += live_turn;
-        } else {
-            // a wave of finished boards: only the side swap of the turn (keeps the parity)
-            const uint64_t x = own;
-            own = opp;
-            opp = x;
-            const Padded X = To;
-            To = Tp;
-            Tp = X;
-        }
         if (t & 1u) { // `while stone_num < 64` once per pair of turns
             done |= stones >> 6;
-            if constexpr (!REBIN) {
-                if (__builtin_amdgcn_ballot_w64(done == 0u) == 0ull)
-                    break;
-            }
+            if (__builtin_amdgcn_ballot_w64(done == 0u) == 0ull)
+                break;
         }
     }
 
     if (live) {
-        const int64_t bo = REBIN ? (int64_t)blockIdx.x * BLOCK + home : b;
+        const int64_t bo = b;
         const int d = __popcll(own) - __popcll(opp);
         P.z[bo] = (int8_t)((d > 0) - (d < 0));
         if (P.final_own)

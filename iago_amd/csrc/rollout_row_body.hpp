@@ -30,6 +30,10 @@ struct HwParams {
     uint64_t *final_opp;
     uint8_t *n_turns;
     uint8_t *trace;
+    // game-asynchronous search steps (iago_value_rollout_async): only the boards with mask[b] != 0
+    // are played (the others keep their z), board b draws from Philox stream stream_id + stream_ids[b]
+    const uint8_t *mask;
+    const int32_t *stream_ids;
 };
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -138,21 +142,15 @@ __device__ __forceinline__ uint64_t flips_hw(uint64_t o, uint64_t p, uint32_t po
     const uint64_t t = x + 1ull;
     const uint64_t cand = bitop64<TT_A_NB_C>(p, t, M); // the opponent run the carry went through
     const uint64_t of = bitop64<TT_ABC>(t, M, o);
-#ifdef ROW_OLD_OK
-    const uint32_t zz = (uint32_t)of | (uint32_t)(of >> 32);
-    const uint32_t ok = (uint32_t)((int32_t)(0u - zz) >> 31); // all ones iff bracketed
-    const uint64_t okm = ((uint64_t)ok << 32) | ok;
-    return reduce_dirs(cand & okm);
-#else
     return reduce_dirs(of ? cand : 0ull); // kept iff an own stone brackets the run
-#endif
 }
 
 // DIAG: the instance of the parity tests (the launch records the action of every turn and / or
 // takes its uniforms from a buffer); a wave alone on its SIMD pays a full issue slot for every
 // instruction, scalar ones and branches included, so the production instance does not even
 // test those pointers.
-template <bool DIAG>
+// ASYNC: the per-board mask and stream ids of HwParams (prologue only; the turn loop is the same).
+template <bool DIAG, bool ASYNC = false>
 __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32_t block_id)
 {
     // T4[orientation][kernel row][plane][row half][5 window bits] -> factors of the 4 cells
@@ -161,9 +159,6 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
     // m << 3, cells 4-7.  Reversed orientation = the 180-degree rotated kernel: kernel row
     // 2 - ky, the window's columns mirrored (oriented column c = true column 7 - c), the
     // other half of the true row -- whose four factors then already are in true order.
-#ifdef ROW_EXP_STAMPS // diagnostic build (tools/exp_row_stamps.py): phases of a wave's life
-    const uint64_t st0 = __builtin_amdgcn_s_memtime();
-#endif
     __shared__ f4 t4[N_T4];
     // the table's global loads go out first (3 per thread, all in flight together); lane
     // constants, the board loads and the first Philox blocks are computed under their latency
@@ -183,9 +178,6 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
         }
         stg[i] = *(const f4 *)(P.blob + OFF_E + (((sky * 2u + pl) * 2u + shf) * 256u + byte) * 4u);
     }
-#ifdef ROW_EXP_STAMPS
-    const uint64_t st1 = __builtin_amdgcn_s_memtime();
-#endif
     const uint32_t lane = threadIdx.x & 63u;
     LaneHw L;
     L.l = lane & 15u;
@@ -216,13 +208,17 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
     for (uint32_t j = 0; j < 4; j++)
         L.bit[j] = rev ? 4u * q + 3u - j : 4u * q + j;
     L.bias = *(const f4 *)(P.blob + OFF_BIAS + 4u * L.l);
-    const uint32_t stream_id = P.stream_id + (P.stream_id_dev ? *P.stream_id_dev : 0u);
+    uint32_t stream_id = P.stream_id + (P.stream_id_dev ? *P.stream_id_dev : 0u);
     const char *const tb = (const char *)t4;
     uint32_t m1f0;
     asm("v_mov_b32 %0, 0x1f0" : "=v"(m1f0));
 
     const int64_t b = (int64_t)block_id * (HW_BLOCK / 16) + (threadIdx.x >> 4);
-    const bool live = b < P.n;
+    bool live = b < P.n;
+    if constexpr (ASYNC) {
+        live = live && P.mask[b] != 0;
+        stream_id += live ? (uint32_t)P.stream_ids[b] : 0u;
+    }
     uint64_t own = live ? P.own[b] : 0ull; // side to move, in this lane's orientation below
     uint64_t opp = live ? P.opp[b] : 0ull;
     uint32_t stones = (uint32_t)__popcll(own | opp);
@@ -238,11 +234,9 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
     uint32_t rw[4] = {P.id_base + (uint32_t)b, L.l, stream_id, 0u};
     auto draw = [&]() __attribute__((always_inline)) {
         philox4x32_10(rw, P.key0, P.key1);
-#ifndef ROW_OLD_DRAW
 #pragma unroll
         for (int i = 0; i < 4; i++)
             rw[i] = __float_as_uint((float)(rw[i] >> 8) * (1.0f / 16777216.0f));
-#endif
     };
     if (!(DIAG && P.uniforms))
         draw();
@@ -250,27 +244,17 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
     for (uint32_t i = 0; i < (uint32_t)(N_T4 / HW_BLOCK); i++)
         t4[threadIdx.x + i * HW_BLOCK] = stg[i];
     __syncthreads();
-#ifdef ROW_EXP_STAMPS
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    const uint64_t st2 = __builtin_amdgcn_s_memtime();
-#endif
     // A lone wave fetches its instruction stream in 32-byte windows, and an 8-byte instruction
     // that straddles two of them costs extra: the loop's speed moves by +-1 % with its offset
-    // in that grid (tools/exp_row_variants.sh, ROW_PAD4 = 0..7: 25.99 .. 26.57 us).  The loop
+    // in that grid (measured in round 2, offsets 0..7: 25.99 .. 26.57 us).  The loop
     // head is therefore pinned to the grid and shifted by the best of the 8 offsets.
-#ifndef ROW_PAD4
 #define ROW_PAD4 1
-#endif
 #define ROW_PAD_STR(n) ROW_PAD_STR2(n)
 #define ROW_PAD_STR2(n) ".p2align 5\n .rept " #n "\n s_nop 0\n .endr"
     asm volatile(ROW_PAD_STR(ROW_PAD4));
     for (uint32_t t4 = 0; t4 < (uint32_t)IAGO_MAX_TURNS; t4 += 4) {
         float u4[4];
-#ifdef ROW_OLD_UNI
-        if (__builtin_expect(P.uniforms != nullptr, 0)) {
-#else
         if (DIAG && P.uniforms) {
-#endif
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 u4[i] = live ? P.uniforms[(int64_t)(t4 + i) * P.n + b] : 0.0f;
@@ -285,11 +269,7 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
             const int src = (int)(((lane & 48u) + ((t4 >> 2) & 15u)) << 2);
 #pragma unroll
             for (int i = 0; i < 4; i++)
-#ifdef ROW_OLD_DRAW
-                u4[i] = (float)((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rw[i]) >> 8) * (1.0f / 16777216.0f);
-#else
                 u4[i] = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rw[i]));
-#endif
         }
         bool any_live = true;
         auto turn = [&](const int i) {
@@ -427,11 +407,6 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
             break;
     }
 
-#ifdef ROW_EXP_STAMPS
-    const uint64_t st3 = __builtin_amdgcn_s_memtime();
-    own = (st1 - st0) | ((st2 - st1) << 21) | ((st3 - st2) << 42);
-    opp = st0;
-#endif
     if (live && L.l == 0u) {
         const int d = __popcll(own) - __popcll(opp);
         P.z[b] = (int8_t)((d > 0) - (d < 0));
@@ -463,6 +438,8 @@ inline HwParams hw_params_of(const iago_rollout_args *a)
     P.final_opp = a->final_opp;
     P.n_turns = a->n_turns;
     P.trace = a->trace;
+    P.mask = nullptr;
+    P.stream_ids = nullptr;
     return P;
 }
 

@@ -154,7 +154,7 @@ class BatchedMCTS(object):
     def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
                  n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False,
                  sync_free=None, lookahead=None, lookahead_slots=None, value_cache=None, lookahead_overlap=None,
-                 z_log_rows=0):
+                 z_log_rows=0, async_steps=None, async_parts=None):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         self.n_games = n_games
@@ -296,6 +296,53 @@ class BatchedMCTS(object):
             self.tree.reset_hooks = [reset_lookahead]
         self.tree.reset_hooks = list(getattr(self.tree, "reset_hooks", ())) + [
             lambda mask: setattr(self, "_live_after_compaction", 0)]
+        # Game-asynchronous steps (iago_mcts_async in include/iago_hip.h): a game whose leaf has a
+        # stored value completes its playout in the step; a game whose leaf is fresh waits `parts`
+        # steps while the value net walks its board piece by piece beside the other games' steps.
+        # Same trees (tests/test_mcts_production_gpu.py runs both schedules against the oracle).
+        # Default OFF: measured slower than lockstep playouts as long as every search ends in
+        # lockstep -- a 100-playout search needs ~200 steps of ~105 us because the game with the most
+        # fresh leaves sets the step count (LABNOTES.md, round 3); async_steps=True / IAGO_ASYNC=1
+        # selects it.
+        import os as _os3
+        can_async = bool(self.lookahead and self.value_cache and getattr(self, "fused_descent", False)
+                         and getattr(self, "_la_path", None) is not None and self.fused_leaf_eval
+                         and 0.0 < self.lmbda < 1.0 and rollout_weights is not None and not rollout_weights.log_form
+                         and getattr(value_fn, "forward_boards_async", None) is not None)
+        if async_steps is None:
+            async_steps = can_async and _os3.environ.get("IAGO_ASYNC", "0") == "1"
+        if async_steps and not can_async:
+            raise ValueError("async_steps needs the look-ahead playout with the value cache, the one-launch descent, "
+                             "the path backup, the fused leaf evaluation (0 < lmbda < 1, product-form rollout "
+                             "weights) and a value net with forward_boards_async")
+        self.async_steps = bool(async_steps)
+        self.n_steps = 0              # game-asynchronous steps run so far
+        if self.async_steps:
+            parts = int(async_parts if async_parts is not None else _os3.environ.get("IAGO_ASYNC_PARTS", "3"))
+            if not 2 <= parts <= 4:
+                raise ValueError("async_parts must be 2, 3 or 4")
+            self.async_parts = parts
+            self._a_wait = torch.zeros(n_games, dtype=torch.int32, **kw)
+            self._a_done = torch.zeros(n_games, dtype=torch.int32, **kw)
+            self._a_roll = torch.zeros(n_games, dtype=torch.uint8, **kw)
+            self._a_fq_index = torch.zeros((parts, n_games), dtype=torch.int64, **kw)
+            self._a_fq_count = torch.zeros(parts, dtype=torch.int32, **kw)
+            self._a_step = torch.zeros(1, dtype=torch.int32, **kw)
+            self._a_nsims = torch.zeros(1, dtype=torch.int32, **kw)
+            self._a_scratch = torch.empty((parts, n_games, _lib.VALUE_IMAGE_BYTES), dtype=torch.uint8, **kw)
+            y = _lib.MctsAsync()
+            y.parts = parts
+            y.wait, y.done, y.roll = self._a_wait.data_ptr(), self._a_done.data_ptr(), self._a_roll.data_ptr()
+            y.fq_index, y.fq_count = self._a_fq_index.data_ptr(), self._a_fq_count.data_ptr()
+            y.step, y.n_sims, y.scratch = self._a_step.data_ptr(), self._a_nsims.data_ptr(), self._a_scratch.data_ptr()
+            self._async = y
+            # the look-ahead state of the asynchronous steps: the lockstep one + the pointer
+            self._la_async = []
+            for a in self._la:
+                b = _lib.MctsLookahead.from_buffer_copy(a)
+                b.async_ = C.addressof(y)
+                self._la_async.append(b)
+            self._async_hint = {}     # n_sims -> steps the last such search needed
         self._g_own = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._g_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
         self._g_active = torch.zeros(n_games, dtype=torch.uint8, **kw)
@@ -488,6 +535,29 @@ class BatchedMCTS(object):
         self._select(own, opp, self._pending, False)  # MCTS.py:121: recurse into the same node
         self._evaluate_and_backup(active, stream_id=stream_id, stream_id_dev=stream_id_dev, counter=counter)
 
+    def _step_async(self, own, opp, active):
+        """One game-asynchronous step for every game of `active`: descent of the games that are not
+        waiting, leaf evaluation (rollouts of those games + one piece of the value net per queue of
+        fresh leaves), backup of the games whose playout completes in this step."""
+        L = _lib.lib()
+        check(L.iago_mcts_descend(self.tree.ref(), _p(own), _p(opp), _p(active), self.c_puct, self.n_thr,
+                                  _p(self.cur_node), _p(self.cur_own), _p(self.cur_opp), _p(self.legal),
+                                  _p(self.stats) if self.stats is not None else None, C.byref(self._la_async[0]),
+                                  None, None, _p(self._value_total), _stream()), "iago_mcts_descend")
+        ro = self.__dict__.get("_async_rollout")
+        if ro is None or ro._keep[2] is not self.rollout_weights:
+            # (marshalled once: the Philox stream of game g's playout is stream base + done[g], the
+            # base in the device word the search sets)
+            ro = self._async_rollout = ops.rollout_prepare(
+                self.cur_own, self.cur_opp, self.rollout_weights, seed=self.seed, id_base=self.game_id_base,
+                stream_id=0, stream_id_dev=self._sim_dev, out=self._rollout_out)
+        with torch.no_grad():
+            self.value_fn.forward_boards_async(self.cur_own, self.cur_opp, self.v, ro, C.byref(self._async))
+        check(L.iago_mcts_mix_backup_lookahead(
+            self.tree.ref(), _p(active), _p(self.cur_node), _p(self.cur_own), _p(self.cur_opp), _p(self.v), _p(self.z),
+            self.lmbda, _p(self.leaf_value), None, C.byref(self._la_async[self._la_cur]), _stream()),
+            "iago_mcts_mix_backup_lookahead")
+
     def _flush_lookahead(self, which=0):
         """The policy net on the leaves of queue `which` (one batch), its outputs into the prior
         cache; the queue is empty afterwards."""
@@ -498,7 +568,7 @@ class BatchedMCTS(object):
                                                 _stream()), "iago_mcts_store_priors")
         q["count"].zero_()
 
-    def _lookahead_block(self, own, opp, active, stream_ids):
+    def _lookahead_block(self, own, opp, active, stream_ids, async_=False):
         """Two groups of K playouts.  On entry queue 1 may hold the leaves of the previous block's
         second group and queue 0 is empty; on exit the same.  With lookahead_overlap = j > 0 the
         batch of the previous group runs on the side stream beside the first j playouts of a group
@@ -516,7 +586,9 @@ class BatchedMCTS(object):
             for i in range(K):
                 if j and i == j:
                     main.wait_stream(self._la_side)
-                if stream_ids is None:
+                if async_:
+                    self._step_async(own, opp, active)
+                elif stream_ids is None:
                     self._playout_lookahead(own, opp, active, stream_id=0, stream_id_dev=self._sim_dev,
                                             counter=self._sim_dev)
                 else:
@@ -567,6 +639,7 @@ class BatchedMCTS(object):
         """What the captured graph baked in: device pointers and versions of every weight
         (and of the layouts cached from them), the rollout table, the scalar arguments."""
         key = [self.lmbda, self.c_puct, self.n_thr, self.lookahead, self.lookahead_overlap, self.value_cache,
+               self.async_steps,
                getattr(self, "fused_descent", False), self.fused_leaf_eval,
                self.stats.data_ptr() if self.stats is not None else 0,
                self.rollout_weights.table.data_ptr() if self.rollout_weights is not None else 0]
@@ -643,6 +716,15 @@ class BatchedMCTS(object):
             self._flush_lookahead(0)  # (queues empty: allocations and one-time setup only)
             self._flush_lookahead(1)
             torch.cuda.synchronize()
+        if self.async_steps:
+            # the asynchronous step's own entry points, once, on empty queues and no game rolled
+            self._a_wait.zero_()
+            self._a_done.zero_()
+            self._a_roll.zero_()
+            self._a_fq_count.zero_()
+            self._a_nsims.zero_()
+            self._step_async(self._g_own, self._g_opp, torch.zeros_like(self._g_active))
+            torch.cuda.synchronize()
         self._graph_long = None
         if self.lookahead and self.graph_blocks > 1:
             # the same block several times over: a replay costs tens of microseconds on the
@@ -651,12 +733,12 @@ class BatchedMCTS(object):
             self._graph_long = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_long):
                 for _ in range(self.graph_blocks):
-                    self._lookahead_block(self._g_own, self._g_opp, self._g_active, None)
+                    self._lookahead_block(self._g_own, self._g_opp, self._g_active, None, async_=self.async_steps)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             if self.lookahead:
-                # 2 K playouts and the policy batches of the leaves they queue: ONE replay
-                self._lookahead_block(self._g_own, self._g_opp, self._g_active, None)
+                # 2 K playouts (or steps) and the policy batches of the leaves they queue: ONE replay
+                self._lookahead_block(self._g_own, self._g_opp, self._g_active, None, async_=self.async_steps)
             else:
                 self._select(self._g_own, self._g_opp, self._g_active, True)
                 self._expand_pending_counted(self._g_own, self._g_opp, self._g_active)
@@ -693,6 +775,59 @@ class BatchedMCTS(object):
         self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
         self.n_leaf_evals += n_active * n_sims
 
+    def _search_async(self, own, opp, active, n_sims, n_active):
+        """n_sims playouts per active game as game-asynchronous steps: blocks of 2 K steps (one
+        graph replay each, or the same launches eagerly) until every game has completed its
+        playouts.  The number of steps depends on how often the games met fresh leaves, so the
+        host reads one word back after the expected number of blocks and adds blocks while a
+        game is behind; steps after the last game has finished do nothing."""
+        if self.use_graph:
+            key = self._graph_state()
+            if self._graph is None or key != self._graph_key:
+                self._graph = None
+                self._capture()
+                self._graph_key = key
+            self._g_own.copy_(own)
+            self._g_opp.copy_(opp)
+            self._g_active.copy_(active)
+            own, opp, act = self._g_own, self._g_opp, self._g_active
+        else:
+            act = active
+        self._a_wait.zero_()
+        self._a_done.zero_()
+        self._a_roll.zero_()
+        self._a_fq_count.zero_()
+        self._a_nsims.fill_(n_sims)
+        self._sim_dev.fill_(self.sim_counter - (1 << 32) if self.sim_counter >= (1 << 31) else self.sim_counter)
+        block = 2 * self.lookahead
+        want = self._async_hint.get(n_sims, n_sims + (self.async_parts - 1) * (n_sims // 5 + 1))
+        steps = 0
+        checks = 0
+        while True:
+            n_blocks = max(1, -(-(want - steps) // block))
+            steps += n_blocks * block
+            if self.use_graph:
+                if self._graph_long is not None:
+                    for _ in range(n_blocks // self.graph_blocks):
+                        self._graph_long.replay()
+                    n_blocks %= self.graph_blocks
+                for _ in range(n_blocks):
+                    self._graph.replay()
+            else:
+                for _ in range(n_blocks):
+                    self._lookahead_block(own, opp, act, None, async_=True)
+            checks += 1
+            behind = bool(((self._a_done < n_sims) & (act != 0)).any().item())   # the search's host sync
+            if not behind:
+                break
+            want = steps + block
+        # one check: the estimate was enough (try one block less next time); more: remember the need
+        self._async_hint[n_sims] = max(n_sims, steps - block) if checks == 1 else steps
+        self.n_steps += steps
+        self._lookahead_tail(own, opp, act, 0, None)   # the last group's policy batch: both queues end empty
+        self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
+        self.n_leaf_evals += n_active * n_sims
+
     def search_counts(self, active):
         """Device tensor int64[2]: games in `active`, nodes of the fullest pool -- what search()
         reads back before it starts (a caller that batches its readbacks passes them in)."""
@@ -726,7 +861,9 @@ class BatchedMCTS(object):
             self.tree.compact()
             self.n_compactions += 1
             self._live_after_compaction = int(self.tree.n_nodes.max().item())
-        if self.use_graph:
+        if self.async_steps and self.rollout_hook is None:
+            self._search_async(own, opp, active, n_sims, n_active)
+        elif self.use_graph:
             self._search_graph(own, opp, active, n_sims, n_active)
         elif self.lookahead:
             block = 2 * self.lookahead

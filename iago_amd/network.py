@@ -416,6 +416,21 @@ class Value(nn.Module, _NpzMixin):
                                        overflow=self._overflow_flag(own.device), index=index, n_dev=n_dev, out=out,
                                        rollout=rollout)
 
+    def forward_boards_async(self, own, opp, out, rollout, async_ref):
+        """One game-asynchronous search step's leaf evaluation (iago_value_rollout_async): the
+        rollouts of the games that descended in this step + one piece of this net for every queue
+        of fresh leaves; values of the leaves whose last piece ran land in out[game]."""
+        if not (self.split_f16 and own.is_cuda and not self.training and not torch.is_grad_enabled()
+                and not torch.is_autocast_enabled()):
+            raise ValueError("forward_boards_async: CUDA boards, eval mode, split_f16")
+        from . import ops
+        layers = [self._split_weights(k) + (getattr(self, "block%d" % k).conv.bias,) for k in range(2, 9)]
+        return ops.value_forward_split((own, opp), self.block1.conv.weight, self.block1.conv.bias, layers,
+                                       self._head_weights(), self.block9.conv.weight, self.block9.conv.bias,
+                                       self.fc10.weight, self.fc11.weight,
+                                       overflow=self._overflow_flag(own.device), out=out, rollout=rollout,
+                                       async_ref=async_ref)
+
     def forward_boards(self, own, opp):
         """forward(make_state_var(...)) for int64 bitboards (own = side to move) without the
         planes tensor, when the split-f16 path applies; None otherwise."""

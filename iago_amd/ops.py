@@ -421,7 +421,7 @@ def split_head_weights(w9):
 
 
 def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None, index=None, n_dev=None,
-                        out=None, rollout=None):
+                        out=None, rollout=None, async_ref=None):
     """The whole Value net in one launch (iago_value_forward_split).  x: float32 planes
     (n, 2, 8, 8) or a pair (own, opp) of int64 bitboards (own = side to move); layers: the 7
     (w_hi, w_lo, bias) of blocks 2..8 (split_weights); head: split_head_weights(w9).
@@ -466,7 +466,12 @@ def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None
     a.out = _dev(out, torch.float32, "out").value
     f = _flag(overflow)
     a.overflow = f.value if f is not None else None
-    if rollout is not None:
+    if async_ref is not None:
+        # one game-asynchronous step's leaf evaluation: the rollouts of the games that descended and
+        # one piece of the value net for every queue of fresh leaves (iago_value_rollout_async)
+        check(_lib.lib().iago_value_rollout_async(C.byref(a), rollout.ref, async_ref, _stream()),
+              "iago_value_rollout_async")
+    elif rollout is not None:
         check(_lib.lib().iago_value_rollout(C.byref(a), rollout.ref, _stream()), "iago_value_rollout")
     else:
         check(_lib.lib().iago_value_forward_split(C.byref(a), _stream()), "iago_value_forward_split")

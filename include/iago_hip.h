@@ -558,6 +558,41 @@ IAGO_API int iago_mcts_compact(const iago_mcts_tree *tree, const iago_mcts_tree 
  * next_seq [n_games] (zeroed with the trees), cache_seq [n_games][slots] (-1), cache
  * [n_games][slots][64] float32, the queue arrays [q_capacity].
  */
+/*
+ * Game-asynchronous search steps.  MCTS.playout (MCTS.py:105-133) is sequential INSIDE a game --
+ * playout i + 1 selects on the statistics playout i backed up -- but the games of a batch are
+ * independent, and only ~1 playout in 6 ends on a leaf whose value_func (MCTS.py:97-103) has not
+ * been computed yet.  In lockstep every playout of every game waits for those evaluations (one
+ * board's walk through the Value net on one CU: ~70 us of a ~125 us playout).  With this state a
+ * search advances in STEPS: per step every game that is not waiting descends
+ * (iago_mcts_descend); a game whose leaf has a stored value completes its playout in the same step
+ * (rollout, iago_mcts_mix_backup_lookahead); a game whose leaf is fresh is queued for the value net
+ * and WAITS `parts` steps while the net walks its board in `parts` pieces, one per step's
+ * iago_value_rollout_async launch (each piece a few layers, the board's activations parked in
+ * `scratch` in between), beside the rollouts of the games that go on; its playout completes in the
+ * step its value arrives.  A game's sequence of playouts -- leaves, values, rollouts (Philox stream
+ * id = stream base + the game's own playout count), backups, expansions -- is exactly the lockstep
+ * one; only the interleaving between games changes: trees are bit-identical.
+ * All arrays caller-owned device memory: wait / done [n_games] int32 (zeroed before a search),
+ * roll [n_games] uint8, fq_index [parts][n_games], fq_count [parts] (zeroed before a search), step
+ * (one word, any value), n_sims (one word: playouts per game of this search), scratch
+ * [parts][n_games][IAGO_VALUE_IMAGE_BYTES].
+ */
+#define IAGO_VALUE_IMAGE_BYTES 33792   /* a board's activations between two pieces: 64 cells x 528 B */
+#define IAGO_ASYNC_MAX_PARTS 4
+typedef struct iago_mcts_async {
+    int32_t parts;           /* pieces of the value net = steps a fresh leaf waits: 2..IAGO_ASYNC_MAX_PARTS */
+    int32_t reserved;
+    int32_t *wait;           /* steps until the game's value arrives (0 = not waiting) */
+    int32_t *done;           /* playouts the game has completed in this search */
+    uint8_t *roll;           /* the game descended in this step (its leaf is rolled out) */
+    int64_t *fq_index;       /* the games queued at step s in row (s mod parts) */
+    int32_t *fq_count;
+    uint32_t *step;          /* step counter (iago_mcts_mix_backup_lookahead increments it) */
+    const int32_t *n_sims;
+    void *scratch;
+} iago_mcts_async;
+
 typedef struct iago_mcts_lookahead {
     int32_t trigger, slots;
     int32_t *next_seq;
@@ -585,6 +620,9 @@ typedef struct iago_mcts_lookahead {
     int32_t *z_log_n;
     int32_t z_log_rows;
     int32_t reserved;
+    const iago_mcts_async *async; /* optional: iago_mcts_descend and iago_mcts_mix_backup_lookahead run one
+                                     game-asynchronous STEP instead of one lockstep playout (`active` is then
+                                     the search's mask; `counter` and `clear_word` are not used) */
 } iago_mcts_lookahead;
 IAGO_API int iago_mcts_mix_backup_lookahead(const iago_mcts_tree *tree, const uint8_t *active,
                                             const int32_t *cur_node, const uint64_t *cur_own,
@@ -626,6 +664,17 @@ IAGO_API int iago_mcts_descend(const iago_mcts_tree *tree, const uint64_t *root_
                                uint64_t *cur_own, uint64_t *cur_opp, uint64_t *legal, int32_t *stats,
                                const iago_mcts_lookahead *la, int64_t *fresh_index, int32_t *fresh_count,
                                int64_t *fresh_total, void *stream);
+
+/*
+ * The leaf evaluation of one game-asynchronous step in ONE launch: the rollouts
+ * (Simulate, mcts_self_play.py:9-134) of the games that descended in this step (async->roll; game
+ * g draws from Philox stream rollout->stream_id (+ *stream_id_dev) + async->done[g]) and, for the
+ * leaves queued 0 .. parts-1 steps ago, piece 0 .. parts-1 of the Value net (iago_value_forward_split's
+ * arithmetic, bit-identical values; piece parts-1 writes value->out[game]).  value->index / n_dev
+ * are ignored (the queues of `async` take their place); value->n = n_games.
+ */
+IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const iago_rollout_args *rollout,
+                                      const iago_mcts_async *async, void *stream);
 
 #ifdef __cplusplus
 }

@@ -90,16 +90,22 @@ def _positions(G, golden_rules):
     return own, opp
 
 
+@pytest.mark.parametrize("async_steps", [False, True])
 @pytest.mark.parametrize("n_sims,n_sims2,G", [(100, 60, 320), (400, 37, 64)])
-def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_sims, n_sims2, G):
+def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_sims, n_sims2, G, async_steps):
+    """async_steps=False: lockstep playouts, the default and what bench.py times.  True: the same
+    search as game-asynchronous steps (iago_mcts_async: a game with a fresh leaf waits while the value
+    net walks its board in 3 pieces beside the other games' steps) -- the same trees, bit for bit."""
     engine, ops, policy, value, rw = shipped
     own, opp = _positions(G, golden_rules)
     cap = engine.suggest_capacity(n_sims + n_sims2, 15, moves=2)
     m = engine.BatchedMCTS(G, policy, value, rw, lmbda=0.5, c_puct=1.0, n_thr=15, capacity=cap, seed=5,
-                           game_id_base=1000, use_graph=True, z_log_rows=max(n_sims, n_sims2))
+                           game_id_base=1000, use_graph=True, z_log_rows=max(n_sims, n_sims2),
+                           async_steps=async_steps)
     # what bench.py's mcts_leg runs
     assert m.use_graph and m.sync_free and m.lookahead == 4 and m.lookahead_overlap == 2
     assert m.value_cache and m.fused_descent and m.fused_leaf_eval and m._la_path is not None
+    assert m.async_steps == async_steps and (not async_steps or m.async_parts == 3)
     assert policy.split3 and policy.split3_parts == 2 and value.split_f16
     o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
     active = torch.ones(G, dtype=torch.uint8, device="cuda")
@@ -162,15 +168,16 @@ def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_si
     value.check_saturation()
 
 
-def test_production_self_play_games_vs_oracle(shipped):
+@pytest.mark.parametrize("async_steps", [False, True])
+def test_production_self_play_games_vs_oracle(shipped, async_steps):
     """Whole self-play games through SelfPlayEngine at the production defaults (what bench.py's
     PV-MCTS leg times), 20 playouts per move (n_thr = 15 needs > 15): every game's move list and
     result equal the oracle's selfplay_game (game.py:117-142 turn structure) fed the recorded z."""
     engine, ops, policy, value, rw = shipped
     G, n_sims = 8, 24
     m = engine.BatchedMCTS(G, policy, value, rw, n_thr=15, capacity=4096, seed=11, use_graph=True,
-                           z_log_rows=128 * n_sims)
-    assert m.lookahead == 4 and m.value_cache
+                           z_log_rows=128 * n_sims, async_steps=async_steps)
+    assert m.lookahead == 4 and m.value_cache and m.async_steps == async_steps
     res = engine.SelfPlayEngine(m).play(n_sims)
     moves = res.move.cpu().numpy()           # (T, G), -1 = pass / finished
     valid = res.valid.cpu().numpy()

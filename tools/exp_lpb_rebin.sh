@@ -1,4 +1,6 @@
 # Variants of the lane-per-board rollout kernel with per-turn re-binning of a block's boards by
+# NOTE (round 3): the -D variants this script builds (ROW_PAD4 / ROW_OLD_* / IAGO_LPB_* / TRUNK_EXP_*) were removed from
+# the product sources; they live in the history: run this from a checkout of commit b61d6ed.
 # mobility (IAGO_LPB_REBIN).  bash tools/exp_lpb_rebin.sh build   (here; needs iago_amd/_obj from
 # `python -m iago_amd.build`), then on the GPU box: bash tools/exp_lpb_rebin.sh run
 cd ${GRAFT_REPO_ROOT:-/root/repo}

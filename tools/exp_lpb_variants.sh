@@ -1,4 +1,6 @@
 # Builds variants of the lane-per-board rollout kernel (block size, waves per SIMD) HERE
+# NOTE (round 3): the -D variants this script builds (ROW_PAD4 / ROW_OLD_* / IAGO_LPB_* / TRUNK_EXP_*) were removed from
+# the product sources; they live in the history: run this from a checkout of commit b61d6ed.
 # and benches each on the GPU box:  bash tools/exp_lpb_variants.sh build ; gpurun -- 'bash tools/exp_lpb_variants.sh run'
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 VARIANTS="b256: b128:-DIAGO_LPB_BLOCK=128 b64:-DIAGO_LPB_BLOCK=64 b256w5:-DIAGO_LPB_ATTR=__attribute__((amdgpu_waves_per_eu(5,5))) b64w5:-DIAGO_LPB_BLOCK=64|-DIAGO_LPB_ATTR=__attribute__((amdgpu_waves_per_eu(5,5))) b64w6:-DIAGO_LPB_BLOCK=64|-DIAGO_LPB_ATTR=__attribute__((amdgpu_waves_per_eu(6,6)))"

@@ -1,4 +1,6 @@
 """Diagnostic: phases of a wave's life in the 16-lanes-per-board rollout kernel
+# NOTE (round 3): the -D variant code this script builds (ROW_EXP_* / TRUNK_EXP_* / ROW_OLD_*) was removed from the
+# product sources; it lives in the history: run this from a checkout of commit b61d6ed.
 (-DROW_EXP_STAMPS build): table staging, setup (loads, Philox), the turn loop."""
 import os, sys, subprocess, json, shutil
 import numpy as np, torch

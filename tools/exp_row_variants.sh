@@ -1,4 +1,6 @@
 # Variants of the 16-lane rollout kernel by -D flags: build here, time on the GPU box.
+# NOTE (round 3): the -D variants this script builds (ROW_PAD4 / ROW_OLD_* / IAGO_LPB_* / TRUNK_EXP_*) were removed from
+# the product sources; they live in the history: run this from a checkout of commit b61d6ed.
 #   bash tools/exp_row_variants.sh build "name:-DFLAG ..." ; gpurun -- 'bash tools/exp_row_variants.sh run "name ..."'
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 if [ "$1" = build ]; then

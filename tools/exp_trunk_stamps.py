@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NOTE (round 3): the -D variant code this script builds (ROW_EXP_* / TRUNK_EXP_* / ROW_OLD_*) was removed from the
+# product sources; it lives in the history: run this from a checkout of commit b61d6ed.
 """Per-phase cycle stamps of the LDS-resident trunk (library built with -DTRUNK_EXP_STAMPS):
 IAGO_HIP_LIB=tools/_build/trunk_stamps.so python3 tools/exp_trunk_stamps.py"""
 import os, sys

@@ -1,4 +1,6 @@
 # Timing-only variants of the LDS-resident trunk kernel (an operand stream or the epilogue
+# NOTE (round 3): the -D variants this script builds (ROW_PAD4 / ROW_OLD_* / IAGO_LPB_* / TRUNK_EXP_*) were removed from
+# the product sources; they live in the history: run this from a checkout of commit b61d6ed.
 # removed: wrong results, right cost):  bash tools/exp_trunk_variants.sh build ; gpurun -- 'bash tools/exp_trunk_variants.sh run'
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 VARIANTS="base: noA:-DTRUNK_EXP_NO_A noB:-DTRUNK_EXP_NO_B noEpi:-DTRUNK_EXP_NO_EPI noAB:-DTRUNK_EXP_NO_A|-DTRUNK_EXP_NO_B stamps:-DTRUNK_EXP_STAMPS"
