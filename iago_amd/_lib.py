@@ -110,15 +110,16 @@ class ValueSplitArgs(C.Structure):
 class MctsTree(C.Structure):
     """Mirror of iago_mcts_tree (include/iago_hip.h)."""
     _fields_ = [
-        ("n_games", C.c_int64), ("capacity", C.c_int32), ("reserved", C.c_int32),
-        ("parent", C.c_void_p), ("first_child", C.c_void_p), ("n_children", C.c_void_p),
-        ("action", C.c_void_p), ("n_visits", C.c_void_p), ("q", C.c_void_p), ("p", C.c_void_p),
-        ("n_nodes", C.c_void_p), ("root", C.c_void_p), ("overflow", C.c_void_p), ("v", C.c_void_p),
+        ("n_games", C.c_int64), ("capacity", C.c_int32), ("has_v", C.c_int32),
+        ("nodes", C.c_void_p), ("n_nodes", C.c_void_p), ("root", C.c_void_p), ("overflow", C.c_void_p),
     ]
 
 
+NODE_WORDS = 8   # sizeof(iago_mcts_node) / 4: n_visits, q, p, v, first_child, parent, action | n_children << 8, reserved
+
+
 _lib = None
-ABI_VERSION = 6   # iago_abi_version() of the include/iago_hip.h these bindings mirror
+ABI_VERSION = 7   # iago_abi_version() of the include/iago_hip.h these bindings mirror
 
 
 def lib():

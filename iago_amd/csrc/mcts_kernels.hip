@@ -31,15 +31,15 @@ typedef iago_mcts_tree Tree;
 
 __device__ __forceinline__ void init_node(const Tree &T, int64_t i, int parent, int action, float p)
 {
-    T.parent[i] = parent;
-    T.first_child[i] = -1;
-    T.n_children[i] = 0;
-    T.action[i] = (int8_t)action;
-    T.n_visits[i] = 0;
-    T.q[i] = 0.0f;
-    T.p[i] = p;
-    if (T.v)
-        T.v[i] = __builtin_nanf(""); // value_func(node) not evaluated yet
+    T.nodes[i].parent = parent;
+    T.nodes[i].first_child = -1;
+    T.nodes[i].n_children = 0;
+    T.nodes[i].action = (int8_t)action;
+    T.nodes[i].n_visits = 0;
+    T.nodes[i].q = 0.0f;
+    T.nodes[i].p = p;
+    if (T.has_v)
+        T.nodes[i].v = __builtin_nanf(""); // value_func(node) not evaluated yet
 }
 
 __global__ __launch_bounds__(BLOCK) void reset_kernel(Tree T, const uint8_t *__restrict__ mask)
@@ -107,12 +107,12 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(
     }
     bool descending = live;
     for (int depth = 0; depth < MAX_DEPTH; depth++) {
-        const int fc = descending ? T.first_child[base + node] : -1;
+        const int fc = descending ? T.nodes[base + node].first_child : -1;
         descending = descending && fc >= 0; // leaf reached (MCTS.py:107)
         if (__builtin_amdgcn_ballot_w64(descending) == 0ull)
             break;
-        const int k = descending ? (int)T.n_children[base + node] : 0;
-        const int pn = descending ? T.n_visits[base + node] : 0;
+        const int k = descending ? (int)T.nodes[base + node].n_children : 0;
+        const int pn = descending ? T.nodes[base + node].n_visits : 0;
         st_levels += descending ? 1 : 0;
         st_children += k;
         const double sq = sqrt((double)pn); // np.sqrt(parent.n_visits), MCTS.py:49
@@ -120,9 +120,9 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(
         int best_i = 0x7fffffff;
         for (int j = (int)L.l8; j < k; j += 8) {
             const int64_t c = base + fc + j;
-            const float cp = c_puct * T.p[c];                        // float32, MCTS.py:49
-            const double u = (double)cp * sq / (0.01 + (double)T.n_visits[c]);
-            const double v = (double)T.q[c] + u;                     // get_value, MCTS.py:75-76
+            const float cp = c_puct * T.nodes[c].p;                        // float32, MCTS.py:49
+            const double u = (double)cp * sq / (0.01 + (double)T.nodes[c].n_visits);
+            const double v = (double)T.nodes[c].q + u;                     // get_value, MCTS.py:75-76
             if (v > best_v) { // strict: the first maximum wins (python max, MCTS.py:46)
                 best_v = v;
                 best_i = j;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(
         argmax_step<DPP_XOR2>(best_v, best_i);
         argmax_step<DPP_HALF_MIRROR>(best_v, best_i);
         const int child = fc + best_i;
-        const int a = descending ? (int)T.action[base + child] : -1;
+        const int a = descending ? (int)T.nodes[base + child].action : -1;
         // GameFunctions.place_stone(state, action, c); c = 3 - c  (MCTS.py:131-132)
         const uint64_t f =
             group8_flips(to_lane(own, L), to_lane(opp, L), (uint32_t)a & 63u, L);
@@ -150,13 +150,13 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(
     }
     // leaf: expansion test (MCTS.py:109) and its legal moves (MCTS.py:111)
     const uint64_t legal = group8_legal(to_lane(own, L), to_lane(opp, L), L);
-    if (live && L.l8 == 0 && descending && T.first_child[base + node] >= 0)
+    if (live && L.l8 == 0 && descending && T.nodes[base + node].first_child >= 0)
         T.overflow[g] = 1; // path longer than MAX_DEPTH: reported like a full pool
     if (live && L.l8 == 0) {
         cur_node[g] = node;
         cur_own[g] = own;
         cur_opp[g] = opp;
-        const bool ne = T.first_child[base + node] < 0 && T.n_visits[base + node] >= n_thr;
+        const bool ne = T.nodes[base + node].first_child < 0 && T.nodes[base + node].n_visits >= n_thr;
         needs_expand[g] = ne ? 1 : 0;
         legal_out[g] = legal;
         if (stats) {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(Tree T, const int32_t *__
     const int k = lg ? __popcll(lg) : 1;
     // lane 0 allocates k nodes; every lane of the group learns the start
     uint32_t fc1 = 0; // first child + 1, 0 = no room / already expanded
-    if (live && r == 0u && T.first_child[base + node] < 0) {
+    if (live && r == 0u && T.nodes[base + node].first_child < 0) {
         const int at = T.n_nodes[g];
         if (at + k <= T.capacity) {
             T.n_nodes[g] = at + k;
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(Tree T, const int32_t *__
         }
     }
     if (r == 0u) {
-        T.first_child[base + node] = fc;
-        T.n_children[base + node] = (uint8_t)k;
+        T.nodes[base + node].first_child = fc;
+        T.nodes[base + node].n_children = (uint8_t)k;
     }
 }
 
@@ -246,11 +246,11 @@ __global__ __launch_bounds__(BLOCK) void backup_kernel(Tree T, const uint8_t *__
     const float lv = leaf_value[g];
     int node = cur_node[g];
     for (int depth = 0; node >= 0 && depth <= MAX_DEPTH; depth++) {
-        const int n = T.n_visits[base + node] + 1; // MCTS.py:61
-        const float q = T.q[base + node];
-        T.n_visits[base + node] = n;
-        T.q[base + node] = q + (lv - q) / (float)n; // MCTS.py:63
-        node = T.parent[base + node];               // MCTS.py:71-72, same value, no sign flip
+        const int n = T.nodes[base + node].n_visits + 1; // MCTS.py:61
+        const float q = T.nodes[base + node].q;
+        T.nodes[base + node].n_visits = n;
+        T.nodes[base + node].q = q + (lv - q) / (float)n; // MCTS.py:63
+        node = T.nodes[base + node].parent;               // MCTS.py:71-72, same value, no sign flip
     }
 }
 
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_kernel(Tree T, const uint8_t
     // whose values are in v[g] and are stored now; the others take the stored value
     const int64_t base = g * (int64_t)T.capacity;
     float vg = (lmbda < 1.0f) ? v[g] : 0.0f;
-    if (T.v && lmbda < 1.0f && active[g]) {
-        float *slot = T.v + base + cur_node[g];
+    if (T.has_v && lmbda < 1.0f && active[g]) {
+        float *slot = &T.nodes[base + cur_node[g]].v;
         const float cached = *slot;
         if (cached != cached)
             *slot = vg;
@@ -290,11 +290,11 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_kernel(Tree T, const uint8_t
         return;
     int node = cur_node[g];
     for (int depth = 0; node >= 0 && depth <= MAX_DEPTH; depth++) {
-        const int n = T.n_visits[base + node] + 1; // MCTS.py:61
-        const float q = T.q[base + node];
-        T.n_visits[base + node] = n;
-        T.q[base + node] = q + (lv - q) / (float)n; // MCTS.py:63
-        node = T.parent[base + node];
+        const int n = T.nodes[base + node].n_visits + 1; // MCTS.py:61
+        const float q = T.nodes[base + node].q;
+        T.nodes[base + node].n_visits = n;
+        T.nodes[base + node].q = q + (lv - q) / (float)n; // MCTS.py:63
+        node = T.nodes[base + node].parent;
     }
 }
 
@@ -307,15 +307,15 @@ __global__ __launch_bounds__(BLOCK) void best_move_kernel(Tree T, const uint8_t 
         return;
     const int64_t base = g * (int64_t)T.capacity;
     const int root = T.root[g];
-    const int fc = T.first_child[base + root];
-    const int k = fc >= 0 ? (int)T.n_children[base + root] : 0;
+    const int fc = T.nodes[base + root].first_child;
+    const int k = fc >= 0 ? (int)T.nodes[base + root].n_children : 0;
     int best = -2, best_n = -1;
     if (visits)
         for (int a = 0; a < 64; a++)
             visits[g * 64 + a] = 0;
     for (int j = 0; j < k; j++) {
-        const int n = T.n_visits[base + fc + j];
-        const int a = (int)T.action[base + fc + j];
+        const int n = T.nodes[base + fc + j].n_visits;
+        const int a = (int)T.nodes[base + fc + j].action;
         if (n > best_n) { // first maximum wins (MCTS.py:147)
             best_n = n;
             best = a;
@@ -334,13 +334,13 @@ __global__ __launch_bounds__(BLOCK) void advance_root_kernel(Tree T, const uint8
         return;
     const int64_t base = g * (int64_t)T.capacity;
     const int root = T.root[g];
-    const int fc = T.first_child[base + root];
-    const int k = fc >= 0 ? (int)T.n_children[base + root] : 0;
+    const int fc = T.nodes[base + root].first_child;
+    const int k = fc >= 0 ? (int)T.nodes[base + root].n_children : 0;
     const int a = (int)move[g];
     for (int j = 0; j < k; j++) {
-        if ((int)T.action[base + fc + j] == a) { // last_move in self.root.children (MCTS.py:150)
+        if ((int)T.nodes[base + fc + j].action == a) { // last_move in self.root.children (MCTS.py:150)
             T.root[g] = fc + j;
-            T.parent[base + fc + j] = -1; // self.root.parent = None (MCTS.py:152)
+            T.nodes[base + fc + j].parent = -1; // self.root.parent = None (MCTS.py:152)
             return;
         }
     }
@@ -414,8 +414,8 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_lookahead_kernel(
     // whose values are in v[g] and are stored now; the others take the stored value
     const int64_t base = g * (int64_t)T.capacity;
     float vg = (lmbda < 1.0f) ? v[g] : 0.0f;
-    if (T.v && lmbda < 1.0f && active[g]) {
-        float *slot = T.v + base + cur_node[g];
+    if (T.has_v && lmbda < 1.0f && active[g]) {
+        float *slot = &T.nodes[base + cur_node[g]].v;
         const float cached = *slot;
         if (cached != cached)
             *slot = vg;
@@ -434,20 +434,20 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_lookahead_kernel(
     const int leaf = cur_node[g];
     int node = leaf;
     for (int depth = 0; node >= 0 && depth <= MAX_DEPTH; depth++) {
-        const int n = T.n_visits[base + node] + 1; // MCTS.py:61
-        const float q = T.q[base + node];
-        T.n_visits[base + node] = n;
-        T.q[base + node] = q + (lv - q) / (float)n; // MCTS.py:63
-        node = T.parent[base + node];
+        const int n = T.nodes[base + node].n_visits + 1; // MCTS.py:61
+        const float q = T.nodes[base + node].q;
+        T.nodes[base + node].n_visits = n;
+        T.nodes[base + node].q = q + (lv - q) / (float)n; // MCTS.py:63
+        node = T.nodes[base + node].parent;
     }
     // the leaf of this playout crosses the trigger exactly once (it gains one visit per playout
     // that ends on it): queue its position for the next flush
-    if (T.n_visits[base + leaf] == A.trigger && T.first_child[base + leaf] == -1) {
+    if (T.nodes[base + leaf].n_visits == A.trigger && T.nodes[base + leaf].first_child == -1) {
         const int pos = atomicAdd(A.q_count, 1);
         if (pos < A.q_capacity) {
             const int seq = A.next_seq[g];
             A.next_seq[g] = seq + 1;
-            T.first_child[base + leaf] = -2 - seq;
+            T.nodes[base + leaf].first_child = -2 - seq;
             A.q_own[pos] = cur_own[g];
             A.q_opp[pos] = cur_opp[g];
             A.q_game[pos] = (int32_t)g;
@@ -504,9 +504,9 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_path_kernel(
     }
     const int leaf = cur_node[g];
     float vg = (lmbda < 1.0f) ? v[g] : 0.0f;
-    if (T.v && lmbda < 1.0f && act) {
+    if (T.has_v && lmbda < 1.0f && act) {
         // (every lane reads the slot, lane 0 fills it: the loads of a wave come before its stores)
-        float *slot = T.v + base + leaf;
+        float *slot = &T.nodes[base + leaf].v;
         const float cached = *slot;
         if (cached != cached) {
             if (r == 0u)
@@ -528,24 +528,25 @@ __global__ __launch_bounds__(BLOCK) void mix_backup_path_kernel(
     // lane 0 decides the queueing from the leaf's count BEFORE this playout (+ 1 = after it)
     int leaf_n = 0, leaf_tag = 0;
     if (r == 0u) {
-        leaf_n = T.n_visits[base + leaf];
-        leaf_tag = T.first_child[base + leaf];
+        leaf_n = T.nodes[base + leaf].n_visits;
+        leaf_tag = T.nodes[base + leaf].first_child;
     }
     const int len = A.path_len[g];
     const int32_t *path = A.path + g * (int64_t)A.path_stride;
     for (int d = (int)r; d < len; d += 8) {
         const int node = path[d];
-        const int n = T.n_visits[base + node] + 1; // MCTS.py:61
-        const float q = T.q[base + node];
-        T.n_visits[base + node] = n;
-        T.q[base + node] = q + (lv - q) / (float)n; // MCTS.py:63
+        uint2 *nq = (uint2 *)&T.nodes[base + node]; // (n_visits, Q): one 8-byte load, one 8-byte store
+        const uint2 old = *nq;
+        const int n = (int)old.x + 1;                // MCTS.py:61
+        const float q = __uint_as_float(old.y);
+        *nq = make_uint2((uint32_t)n, __float_as_uint(q + (lv - q) / (float)n)); // MCTS.py:63
     }
     if (r == 0u && leaf_n + 1 == A.trigger && leaf_tag == -1) {
         const int pos = atomicAdd(A.q_count, 1);
         if (pos < A.q_capacity) {
             const int seq = A.next_seq[g];
             A.next_seq[g] = seq + 1;
-            T.first_child[base + leaf] = -2 - seq;
+            T.nodes[base + leaf].first_child = -2 - seq;
             A.q_own[pos] = cur_own[g];
             A.q_opp[pos] = cur_opp[g];
             A.q_game[pos] = (int32_t)g;
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(BLOCK) void expand_cached_kernel(Tree T, const uint
     const int node = live ? cur_node[g] : 0;
     const uint64_t lg = live ? legal[g] : 0ull;
     const int k = lg ? __popcll(lg) : 1;
-    const int tag = live ? T.first_child[base + node] : 0;
+    const int tag = live ? T.nodes[base + node].first_child : 0;
     uint32_t fc1 = 0; // first child + 1, 0 = no room / already expanded
     if (live && r == 0u && tag < 0) {
         const int at = T.n_nodes[g];
@@ -632,8 +633,8 @@ __global__ __launch_bounds__(BLOCK) void expand_cached_kernel(Tree T, const uint
         }
     }
     if (r == 0u) {
-        T.first_child[base + node] = fc;
-        T.n_children[base + node] = (uint8_t)k;
+        T.nodes[base + node].first_child = fc;
+        T.nodes[base + node].n_children = (uint8_t)k;
     }
 }
 
@@ -675,17 +676,17 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
     // loaded anyway -- and the stored value); the argmax butterfly carries them along, so the
     // winner's move and the next level's header arrive with the winner's index.
     int node = 0, fc = -1, k = 0, nv = 0;
-    uint32_t vbits = 0; // T.v[node] (the value cache), NaN = not evaluated
+    uint32_t vbits = 0; // T.nodes[node].v (the value cache), NaN = not evaluated
     uint64_t own = 0, opp = 0;
     if (live) {
         node = T.root[g];
         own = root_own[g];
         opp = root_opp[g];
-        fc = T.first_child[base + node];
-        k = (int)T.n_children[base + node];
-        nv = T.n_visits[base + node];
-        if (T.v)
-            vbits = __float_as_uint(T.v[base + node]);
+        const uint4 s0 = ((const uint4 *)&T.nodes[base + node])[0], l0 = ((const uint4 *)&T.nodes[base + node])[1];
+        fc = (int)l0.x;
+        k = (int)((l0.z >> 8) & 0xFFu);
+        nv = (int)s0.x;
+        vbits = s0.w;
     }
     int32_t *const path = (A.path && live) ? A.path + g * (int64_t)A.path_stride : nullptr;
     int path_n = 0;
@@ -740,8 +741,8 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
                         }
                     }
                     if (r == 0u) {
-                        T.first_child[base + node] = nf;
-                        T.n_children[base + node] = (uint8_t)kn;
+                        T.nodes[base + node].first_child = nf;
+                        T.nodes[base + node].n_children = (uint8_t)kn;
                     }
                     fc = nf;
                     k = kn;
@@ -764,12 +765,16 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
             const int j1 = j0 + 8;
             const bool two = j1 < kk;
             const int64_t c0 = base + fc + j0, c1 = two ? base + fc + j1 : c0;
-            const float p0 = T.p[c0], q0 = T.q[c0], p1 = T.p[c1], q1 = T.q[c1];
-            const int n0 = T.n_visits[c0], n1 = T.n_visits[c1];
-            const int f0 = T.first_child[c0], f1 = T.first_child[c1];
-            const uint32_t a0 = (uint32_t)(uint8_t)T.action[c0] | ((uint32_t)T.n_children[c0] << 8);
-            const uint32_t a1 = (uint32_t)(uint8_t)T.action[c1] | ((uint32_t)T.n_children[c1] << 8);
-            const uint32_t w0 = T.v ? __float_as_uint(T.v[c0]) : 0u, w1 = T.v ? __float_as_uint(T.v[c1]) : 0u;
+            // a child's record as two 16-byte loads: (n_visits, Q, P, v) | (first_child, parent, action |
+            // n_children << 8, -) -- one 32-byte sector per child
+            const uint4 s0 = ((const uint4 *)&T.nodes[c0])[0], l0 = ((const uint4 *)&T.nodes[c0])[1];
+            const uint4 s1 = ((const uint4 *)&T.nodes[c1])[0], l1 = ((const uint4 *)&T.nodes[c1])[1];
+            const float p0 = __uint_as_float(s0.z), q0 = __uint_as_float(s0.y);
+            const float p1 = __uint_as_float(s1.z), q1 = __uint_as_float(s1.y);
+            const int n0 = (int)s0.x, n1 = (int)s1.x;
+            const int f0 = (int)l0.x, f1 = (int)l1.x;
+            const uint32_t a0 = l0.z & 0xFFFFu, a1 = l1.z & 0xFFFFu;
+            const uint32_t w0 = s0.w, w1 = s1.w;
             {
                 const float cp = c_puct * p0;                          // float32, MCTS.py:49
                 const double u = (double)cp * sq / (0.01 + (double)n0);
@@ -869,16 +874,16 @@ __global__ __launch_bounds__(64) void compact_plan_kernel(Tree T, Tree S, const 
     const int64_t base = g * (int64_t)T.capacity;
     int32_t *q = order + base;
     q[0] = T.root[g];
-    S.parent[base] = -1;
+    S.nodes[base].parent = -1;
     int head = 0, tail = 1;
     while (head < tail) {
         const int o = q[head];
-        const int fc = T.first_child[base + o];
-        const int k = fc >= 0 ? (int)T.n_children[base + o] : 0;
-        S.first_child[base + head] = k ? tail : fc; // (fc < 0: an unexpanded leaf keeps its prior-cache tag)
+        const int fc = T.nodes[base + o].first_child;
+        const int k = fc >= 0 ? (int)T.nodes[base + o].n_children : 0;
+        S.nodes[base + head].first_child = k ? tail : fc; // (fc < 0: an unexpanded leaf keeps its prior-cache tag)
         for (int j = 0; j < k; j++) {
             q[tail + j] = fc + j;
-            S.parent[base + tail + j] = head;
+            S.nodes[base + tail + j].parent = head;
         }
         tail += k;
         head++;
@@ -893,13 +898,13 @@ __global__ __launch_bounds__(BLOCK) void compact_gather_kernel(Tree T, Tree S, c
     const int64_t base = g * (int64_t)T.capacity;
     for (int i = threadIdx.x; i < count; i += BLOCK) {
         const int64_t o = base + order[base + i];
-        S.n_children[base + i] = T.n_children[o];
-        S.action[base + i] = T.action[o];
-        S.n_visits[base + i] = T.n_visits[o];
-        S.q[base + i] = T.q[o];
-        S.p[base + i] = T.p[o];
-        if (T.v && S.v)
-            S.v[base + i] = T.v[o];
+        S.nodes[base + i].n_children = T.nodes[o].n_children;
+        S.nodes[base + i].action = T.nodes[o].action;
+        S.nodes[base + i].n_visits = T.nodes[o].n_visits;
+        S.nodes[base + i].q = T.nodes[o].q;
+        S.nodes[base + i].p = T.nodes[o].p;
+        if (T.has_v && S.has_v)
+            S.nodes[base + i].v = T.nodes[o].v;
     }
 }
 
@@ -909,15 +914,15 @@ __global__ __launch_bounds__(BLOCK) void compact_commit_kernel(Tree T, Tree S)
     const int count = S.n_nodes[g];
     const int64_t base = g * (int64_t)T.capacity;
     for (int i = threadIdx.x; i < count; i += BLOCK) {
-        T.parent[base + i] = S.parent[base + i];
-        T.first_child[base + i] = S.first_child[base + i];
-        T.n_children[base + i] = S.n_children[base + i];
-        T.action[base + i] = S.action[base + i];
-        T.n_visits[base + i] = S.n_visits[base + i];
-        T.q[base + i] = S.q[base + i];
-        T.p[base + i] = S.p[base + i];
-        if (T.v && S.v)
-            T.v[base + i] = S.v[base + i];
+        T.nodes[base + i].parent = S.nodes[base + i].parent;
+        T.nodes[base + i].first_child = S.nodes[base + i].first_child;
+        T.nodes[base + i].n_children = S.nodes[base + i].n_children;
+        T.nodes[base + i].action = S.nodes[base + i].action;
+        T.nodes[base + i].n_visits = S.nodes[base + i].n_visits;
+        T.nodes[base + i].q = S.nodes[base + i].q;
+        T.nodes[base + i].p = S.nodes[base + i].p;
+        if (T.has_v && S.has_v)
+            T.nodes[base + i].v = S.nodes[base + i].v;
     }
     if (threadIdx.x == 0 && count >= 0) {
         T.n_nodes[g] = count;
@@ -931,8 +936,8 @@ int check_tree(const Tree *t, const char *who)
 {
     if (!t)
         return iago_fail(IAGO_ERR_INVALID, who);
-    if (t->n_games < 0 || t->capacity < 1 || !t->parent || !t->first_child || !t->n_children ||
-        !t->action || !t->n_visits || !t->q || !t->p || !t->n_nodes || !t->root || !t->overflow)
+    if (t->n_games < 0 || t->capacity < 1 || !t->nodes || ((uintptr_t)t->nodes & 31u) || !t->n_nodes || !t->root ||
+        !t->overflow)
         return iago_fail(IAGO_ERR_INVALID, who);
     return IAGO_OK;
 }
@@ -1003,7 +1008,7 @@ __global__ __launch_bounds__(1024) void fresh_leaves_kernel(Tree T, const uint8_
         const int g = g0 + tid;
         bool p = false;
         if (g < n && active[g] != 0) {
-            const float c = T.v[(int64_t)g * T.capacity + cur_node[g]];
+            const float c = T.nodes[(int64_t)g * T.capacity + cur_node[g]].v;
             p = c != c;
         }
         const unsigned long long m = __ballot(p);
@@ -1169,7 +1174,7 @@ int iago_mcts_compact(const iago_mcts_tree *tree, const iago_mcts_tree *scratch,
     if (check_tree(tree, "iago_mcts_compact: bad tree") || check_tree(scratch, "iago_mcts_compact: bad scratch tree"))
         return IAGO_ERR_INVALID;
     if (!order || scratch->n_games != tree->n_games || scratch->capacity != tree->capacity ||
-        scratch->parent == tree->parent || scratch->n_visits == tree->n_visits)
+        scratch->nodes == tree->nodes)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_compact: scratch must be a second pool of the same shape");
     if (tree->n_games == 0)
         return IAGO_OK;
@@ -1295,7 +1300,7 @@ int iago_mcts_fresh_leaves(const iago_mcts_tree *tree, const uint8_t *active, co
 {
     if (check_tree(tree, "iago_mcts_fresh_leaves: bad tree"))
         return IAGO_ERR_INVALID;
-    if (!tree->v || !active || !cur_node || !index || !count)
+    if (!tree->has_v || !active || !cur_node || !index || !count)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_fresh_leaves: null pointer (the tree needs its value cache `v`)");
     if (tree->n_games > 0x7fffffffll)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_fresh_leaves: too many games");
@@ -1316,9 +1321,9 @@ int iago_mcts_descend(const iago_mcts_tree *tree, const uint64_t *root_own, cons
         return IAGO_ERR_INVALID;
     if (!root_own || !root_opp || !active || !cur_node || !cur_own || !cur_opp || !legal)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_descend: null pointer");
-    if (A.y_wait && !tree->v)
+    if (A.y_wait && !tree->has_v)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_descend: game-asynchronous steps need the tree's value cache");
-    if (fresh_index && (!fresh_count || !tree->v))
+    if (fresh_index && (!fresh_count || !tree->has_v))
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_descend: the fresh-leaf list needs its count word and the "
                                            "tree's value cache");
     if (n_thr < 1)

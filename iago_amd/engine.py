@@ -43,35 +43,35 @@ def suggest_capacity(n_sims, n_thr=15, moves=64, branching=12):
 
 
 class TreePool(object):
-    """Device memory of the per-game search trees (iago_mcts_tree)."""
-
-    FIELDS = ("parent", "first_child", "n_children", "action", "n_visits", "q", "p", "n_nodes", "root", "overflow")
+    """Device memory of the per-game search trees (iago_mcts_tree): ONE array of 32-byte node
+    records (iago_mcts_node); `n_visits`, `q`, `p`, `v`, `first_child`, `parent`, `action`,
+    `n_children` are strided views of it (read them with .cpu(), fill them in place)."""
 
     def __init__(self, n_games, capacity, device="cuda", value_cache=False):
         if not torch.cuda.is_available():
             raise _lib.IagoError("TreePool needs a HIP device (no CPU fallback)")
-        n = n_games * capacity
-        kw = dict(device=device)
         self.n_games, self.capacity = n_games, capacity
-        # value_func(node) once evaluated, NaN before (iago_mcts_fresh_leaves); None = no cache
-        self.v = torch.full((n,), float("nan"), dtype=torch.float32, **kw) if value_cache else None
-        self.parent = torch.empty(n, dtype=torch.int32, **kw)
-        self.first_child = torch.empty(n, dtype=torch.int32, **kw)
-        self.n_children = torch.empty(n, dtype=torch.uint8, **kw)
-        self.action = torch.empty(n, dtype=torch.int8, **kw)
-        self.n_visits = torch.empty(n, dtype=torch.int32, **kw)
-        self.q = torch.empty(n, dtype=torch.float32, **kw)
-        self.p = torch.empty(n, dtype=torch.float32, **kw)
-        self.n_nodes = torch.zeros(n_games, dtype=torch.int32, **kw)
-        self.root = torch.zeros(n_games, dtype=torch.int32, **kw)
-        self.overflow = torch.zeros(n_games, dtype=torch.int32, **kw)
-        t = MctsTree()
-        t.n_games, t.capacity = n_games, capacity
-        for f in self.FIELDS:
-            setattr(t, f, getattr(self, f).data_ptr())
-        t.v = self.v.data_ptr() if self.v is not None else None
-        self.c = t
+        self._alloc(device, value_cache)
         self.reset()
+
+    def _alloc(self, device, value_cache):
+        n = self.n_games * self.capacity
+        kw = dict(device=device)
+        self.nodes = torch.zeros((n, _lib.NODE_WORDS), dtype=torch.int32, **kw)
+        f32, i8 = self.nodes.view(torch.float32), self.nodes.view(torch.int8)
+        self.n_visits, self.q, self.p = self.nodes[:, 0], f32[:, 1], f32[:, 2]
+        # value_func(node) once evaluated, NaN before (iago_mcts_fresh_leaves); None = no cache
+        self.v = f32[:, 3] if value_cache else None
+        self.first_child, self.parent = self.nodes[:, 4], self.nodes[:, 5]
+        self.action, self.n_children = i8[:, 24], self.nodes.view(torch.uint8)[:, 25]
+        self.n_nodes = torch.zeros(self.n_games, dtype=torch.int32, **kw)
+        self.root = torch.zeros(self.n_games, dtype=torch.int32, **kw)
+        self.overflow = torch.zeros(self.n_games, dtype=torch.int32, **kw)
+        t = MctsTree()
+        t.n_games, t.capacity, t.has_v = self.n_games, self.capacity, 1 if value_cache else 0
+        t.nodes = self.nodes.data_ptr()
+        t.n_nodes, t.root, t.overflow = self.n_nodes.data_ptr(), self.root.data_ptr(), self.overflow.data_ptr()
+        self.c = t
 
     def ref(self):
         return C.byref(self.c)
@@ -83,28 +83,18 @@ class TreePool(object):
             hook(mask)
 
     def bytes(self):
-        return sum(getattr(self, f).numel() * getattr(self, f).element_size()
-                   for f in ("parent", "first_child", "n_children", "action", "n_visits", "q", "p"))
+        return self.nodes.numel() * 4
 
     def compact(self, mask=None):
         """Garbage collection (iago_mcts_compact): the live subtree of every game (mask: uint8
         per game, None = all) re-laid from index 0; the nodes abandoned by subtree reuse are
         freed.  A second pool and an index array are allocated on first use."""
         if getattr(self, "_scratch", None) is None:
-            dev = self.parent.device
             sc = TreePool.__new__(TreePool)
             sc.n_games, sc.capacity = self.n_games, self.capacity
-            for f in self.FIELDS:
-                setattr(sc, f, torch.empty_like(getattr(self, f)))
-            sc.v = torch.empty_like(self.v) if self.v is not None else None
-            t = MctsTree()
-            t.n_games, t.capacity = self.n_games, self.capacity
-            for f in self.FIELDS:
-                setattr(t, f, getattr(sc, f).data_ptr())
-            t.v = sc.v.data_ptr() if sc.v is not None else None
-            sc.c = t
+            sc._alloc(self.nodes.device, self.v is not None)
             self._scratch = sc
-            self._order = torch.empty(self.n_games * self.capacity, dtype=torch.int32, device=dev)
+            self._order = torch.empty(self.n_games * self.capacity, dtype=torch.int32, device=self.nodes.device)
         check(_lib.lib().iago_mcts_compact(self.ref(), self._scratch.ref(), _p(self._order),
                                            _p(mask) if mask is not None else None, _stream()),
               "iago_mcts_compact")
@@ -112,8 +102,11 @@ class TreePool(object):
     def dump(self, g, max_depth=6):
         """Host copy of game g's tree in the format of oracle.mcts_py.dump_tree."""
         lo, hi = g * self.capacity, g * self.capacity + int(self.n_nodes[g].item())
-        arr = {f: getattr(self, f)[lo:hi].cpu().numpy()
-               for f in ("first_child", "n_children", "action", "n_visits", "q", "p")}
+        rec = self.nodes[lo:hi].cpu()
+        f32, i8 = rec.view(torch.float32), rec.view(torch.int8)
+        arr = {"first_child": rec[:, 4].numpy(), "n_children": rec.view(torch.uint8)[:, 25].numpy(),
+               "action": i8[:, 24].numpy(), "n_visits": rec[:, 0].numpy(), "q": f32[:, 1].numpy(),
+               "p": f32[:, 2].numpy()}
 
         def rec(i, depth):
             d = dict(n=int(arr["n_visits"][i]), Q=float(arr["q"][i]), P=float(arr["p"][i]),
@@ -928,7 +921,7 @@ class BatchedMCTS(object):
         net's scratch for its multi-launch forward (network.SLPolicy.SPLIT3_SCRATCH_ROWS x 50,176 B
         = 205 MB per stream that calls it -- the search uses up to three: eager, capture, side
         stream -- bounded whatever n_games is; longer batches run in chunks)."""
-        out = {"tree": self.tree.bytes() + (self.tree.v.numel() * 4 if self.tree.v is not None else 0)}
+        out = {"tree": self.tree.bytes()}
         if getattr(self.tree, "_scratch", None) is not None:
             out["tree_compaction_pool"] = out["tree"] + self.tree._order.numel() * 4
         if self.lookahead:

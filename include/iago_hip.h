@@ -395,31 +395,40 @@ IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n
 /* ------------------------------------------------------------------- MCTS */
 
 /*
- * Device-resident search trees of `n_games` lockstep games, struct-of-arrays.
- * Game g owns nodes [g*capacity, (g+1)*capacity); node ids stored in the
- * arrays are LOCAL to the game (0 .. capacity-1).  Replaces the reference's
- * dict-of-Node tree (MCTS.py:10-76): parent / children{action: Node} /
- * n_visits / Q / P.  The children of a node are stored contiguously in
- * ascending action order (the reference's dict insertion order, MCTS.py:34-36),
- * so "first maximum wins" (MCTS.py:46,147) is "lowest child index wins".
+ * Device-resident search trees of `n_games` lockstep games.  Game g owns nodes
+ * [g*capacity, (g+1)*capacity) of ONE array of 32-byte records; node ids stored in the records are
+ * LOCAL to the game (0 .. capacity-1).  Replaces the reference's dict-of-Node tree
+ * (MCTS.py:10-76): parent / children{action: Node} / n_visits / Q / P.  The children of a node are
+ * stored contiguously in ascending action order (the reference's dict insertion order,
+ * MCTS.py:34-36), so "first maximum wins" (MCTS.py:46,147) is "lowest child index wins".
  * dtypes follow the reference under numpy >= 2: Q, P float32; scores float64.
+ * Layout (round 3; struct-of-arrays before): what scoring a child reads -- n_visits, Q, P and the
+ * stored value -- is the first 16 bytes of its record, the links the descent carries along
+ * (first_child, action, n_children) the second 16: one 32-byte sector per child instead of
+ * one sector in each of seven arrays.
  */
+typedef struct iago_mcts_node {
+    int32_t n_visits;      /* MCTS.py:14 */
+    float q;               /* MCTS.py:15,63 */
+    float p;               /* prior + 0.1 (MCTS.py:19) */
+    float v;               /* value_func(node) once evaluated, NaN before (the value cache, see
+                              iago_mcts_fresh_leaves); maintained only when the tree's has_v is set */
+    int32_t first_child;   /* local id of child 0, -1 = leaf (MCTS.py:24-25), <= -2: look-ahead tag */
+    int32_t parent;        /* local id, -1 = root (MCTS.py:12,21) */
+    int8_t action;         /* move leading to the node; -1 = pass child (MCTS.py:114) */
+    uint8_t n_children;
+    uint16_t reserved0;
+    int32_t reserved1;
+} iago_mcts_node;
+
 typedef struct iago_mcts_tree {
     int64_t n_games;
     int32_t capacity;      /* nodes per game */
-    int32_t reserved;
-    int32_t *parent;       /* [n_games*capacity] local id, -1 = root (MCTS.py:12,21) */
-    int32_t *first_child;  /* local id of child 0, -1 = leaf (MCTS.py:24-25) */
-    uint8_t *n_children;
-    int8_t *action;        /* move leading to the node; -1 = pass child (MCTS.py:114) */
-    int32_t *n_visits;     /* MCTS.py:14 */
-    float *q;              /* MCTS.py:15,63 */
-    float *p;              /* prior + 0.1 (MCTS.py:19) */
+    int32_t has_v;         /* 1: the value cache (node.v) is in use */
+    iago_mcts_node *nodes; /* [n_games*capacity], 32-byte aligned */
     int32_t *n_nodes;      /* [n_games] nodes allocated so far */
     int32_t *root;         /* [n_games] local id of the current root */
     int32_t *overflow;     /* [n_games] set to 1 when an expansion did not fit */
-    float *v;              /* optional [n_games*capacity]: value_func(node) once evaluated, NaN before
-                              (the value cache, see iago_mcts_fresh_leaves); NULL = no cache */
 } iago_mcts_tree;
 
 /*
