@@ -444,7 +444,7 @@ def reinforce_leg(n_iters, world, rank, dist):
     from iago_amd.train_rl import ReinforceTrainer
     torch.manual_seed(0)
     tr = ReinforceTrainer(network.SLPolicy(), pool_dir=None, N=32, seed=rank)
-    for _ in range(2):
+    for _ in range(4):
         tr.step()  # warm-up: MIOpen forward/backward kernel selection, allocator, weight-layout caches
     torch.cuda.synchronize()
     if dist is not None:

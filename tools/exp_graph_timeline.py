@@ -74,8 +74,14 @@ a = buf[:2 * n].cpu().numpy().reshape(n, 2)
 lab, t = a[:, 0], a[:, 1].astype(np.float64) * 0.01   # us (100 MHz)
 seg = collections.defaultdict(list)
 last = {}
+n_eval = 0
 for L, x in zip(lab, t):
     L = int(L)
+    if L == V1 and D1 in last:
+        # by the playout's place in its look-ahead group of 4: the policy batch of the previous
+        # group runs beside playouts 0 and 1 (lookahead_overlap = 2)
+        seg["leaf evaluation, playout %d of its group" % (n_eval % 4)].append(x - last[D1])
+        n_eval += 1
     if L == D1 and D0 in last:
         seg["descent"].append(x - last[D0])
     if L == V1 and D1 in last:
