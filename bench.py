@@ -577,6 +577,7 @@ class RolloutRounds(object):
 def rollout_leg(args, world, rank, dist):
     """The headline leg; returns the dict of measurements rank 0 prints."""
     from iago_amd import _lib, ops
+    from iago_amd.dist import all_gather_into   # (= dist.all_gather_into_tensor under nccl)
     B, K, W = args.boards, args.steps, args.warmup
     w, b = shipped_rollout_weights()
     weights = ops.RolloutWeights(w, b)
@@ -651,7 +652,7 @@ def rollout_leg(args, world, rank, dist):
             played[x].record(main)
             with torch.cuda.stream(comm):
                 comm.wait_event(played[x])
-                dist.all_gather_into_tensor(gathered[buf][:world * nfill], rr.bufs[buf][:nfill])
+                all_gather_into(gathered[buf][:world * nfill], rr.bufs[buf][:nfill])
                 shipped[x].record(comm)
     span1.record(main)
     if use_gather:
@@ -693,8 +694,9 @@ def rollout_leg(args, world, rank, dist):
     achieved = alg / (kernel_ms * 1e-3) / 1e9
     pmc = measured_pmc(B)
     out = {
-        "exchange": "rccl all-gather of the finished tuples on a side stream, one per %d steps "
-                    "(%.1f MB per rank)" % (S, S * B * 18 / 1e6),
+        "exchange": "%s all-gather of the finished tuples on a side stream, one per %d steps "
+                    "(%.1f MB per rank)" % ("rccl" if dist is None or dist.get_backend() == "nccl" else dist.get_backend(),
+                                            S, S * B * 18 / 1e6),
         "value": games / dt, "ms_per_step": dt / (R * K) * 1e3, "repeats": R,
         "timed_region_s": dt, "board_steps_per_game": steps_per_game,
         "board_steps_per_sec": steps_per_game * games / dt,
@@ -871,14 +873,20 @@ def main():
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (torch.distributed.run "
                          "--nproc-per-node %d, or no launcher at all)" % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # (rehearsal of the N > 1 path on a one-GPU box, tests/test_dist_gpu.py: IAGO_BENCH_BACKEND=gloo
+    # with every rank on IAGO_BENCH_DEVICE=0 -- RCCL refuses two ranks on one device)
+    backend = os.environ.get("IAGO_BENCH_BACKEND", "nccl")
+    device = int(os.environ.get("IAGO_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (any N)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     B, K, W = args.boards, args.steps, args.warmup
     head, (w, b) = rollout_leg(args, world, rank, dist)

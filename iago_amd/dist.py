@@ -37,7 +37,8 @@ def _staged(group=None):
     return dist.get_backend(group) == "gloo"
 
 
-def _all_gather_into(recv, send, group=None):
+def all_gather_into(recv, send, group=None):
+    """dist.all_gather_into_tensor; under gloo (one-GPU rehearsals) device payloads travel through host copies."""
     if send.is_cuda and _staged(group):
         r = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_gather_into_tensor(r, send.cpu(), group=group)
@@ -66,7 +67,7 @@ def gather_tuples(fields, group=None):
         if fields[k].shape[0] != n:
             raise ValueError("field %s has %d rows, expected %d" % (k, fields[k].shape[0], n))
     counts = torch.empty(world, dtype=torch.int64, device=dev)
-    _all_gather_into(counts, torch.tensor([n], dtype=torch.int64, device=dev), group)
+    all_gather_into(counts, torch.tensor([n], dtype=torch.int64, device=dev), group)
     counts = counts.cpu().tolist()
     nmax = max(counts)
     # pack every field's rows as bytes, 8-byte aligned segments
@@ -85,7 +86,7 @@ def gather_tuples(fields, group=None):
     for (k, t, row_bytes, seg), o in zip(segs, offs):
         send[o:o + row_bytes * n] = t.view(-1).view(torch.uint8)
     recv = torch.empty(world * off, dtype=torch.uint8, device=dev)
-    _all_gather_into(recv, send, group)
+    all_gather_into(recv, send, group)
     out = {}
     for (k, t, row_bytes, seg), o in zip(segs, offs):
         parts = []

@@ -103,3 +103,27 @@ def test_bench_starts_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--boards", "-5",
                           "--rollout-only"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py --gpus 2 started the way the driver starts it (no launcher: it spawns its ranks),
+    every leg, with both ranks on the one GPU of the box over gloo (IAGO_BENCH_BACKEND / _DEVICE:
+    RCCL refuses two ranks on one device): the N > 1 code of the bench -- global game ids per rank,
+    the side-stream all-gather of the round buffers and its "ranks played different games" check, the
+    max-over-ranks timing, the PV-MCTS leg's sharded engines and tuple gather, the sharded REINFORCE
+    leg -- runs and prints ONE line with whole-job values."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(IAGO_BENCH_BACKEND="gloo", IAGO_BENCH_DEVICE="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--mcts-games", "128", "--mcts-turns", "6", "--nthr1-turns", "0", "--train-iters", "2"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["games_per_step"] == 2 * 4096 and "gloo all-gather" in line["config"]["tuple_allgather"]
+    assert abs(line["value"] - 2 * 4096 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    assert line["mcts"]["leaf_evals"] == 2 * 128 * 100 * line["mcts"]["turns_played"]   # both ranks' playouts
+    assert line["leaf_evals_per_sec"] == line["mcts"]["leaf_evals_per_sec"] > 0
+    assert line["reinforce"]["iters"] == 2 and "cpu_baseline" not in line   # CPU baselines are N = 1 figures
