@@ -905,13 +905,13 @@ class BatchedMCTS(object):
         self.stats = torch.zeros((self.n_games, 2), dtype=torch.int32, device=self.cur_own.device)
 
     def tree_bytes(self):
-        """Algorithmic bytes moved on the tree arrays so far:
-        select reads first_child/n_children/n_visits (9 B) per level and
-        (n, Q, P) = 12 B per child scored + 1 B action; backup reads and writes
-        (n, Q) and reads parent = 20 B per level (+ the leaf itself)."""
+        """Algorithmic bytes moved on the tree arrays so far, for the 32-byte
+        node records: the descent reads one record per level (the node's header) and one per child
+        scored; the backup reads and writes (n_visits, Q) = 8 + 8 B per node of the path (the levels
+        + the leaf itself)."""
         lv, ch = (int(x) for x in self.stats.to(torch.int64).sum(dim=0).tolist())
-        sel = 10 * lv + 12 * ch + 8 * self.n_leaf_evals
-        bak = 20 * (lv + self.n_leaf_evals)
+        sel = 32 * (lv + ch) + 32 * self.n_leaf_evals
+        bak = 16 * (lv + self.n_leaf_evals)
         return {"select": sel, "backup": bak, "levels": lv, "children_scored": ch}
 
     def memory_bytes(self):

@@ -98,6 +98,50 @@ def test_one_training_set_on_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_step_from_pv_mcts_tuples_gpu():
+    """BASELINE configs[4] as it is worded: PV-MCTS self-play tuples feed the REINFORCE update.
+    64 games x 20 playouts per move -> SelfPlayResult.tuples() (own, opp, move, z from the mover's view)
+    -> ReinforceTrainer.step_from_tuples: the loss equals the float64 numpy restatement of
+    src/train_rl.py:55-66 on exactly those rows (x = the mover's planes, y = the move, r = z), one
+    Adam step is taken, and colour = 1 restricts the batch to the learner's plies as the reference
+    records them (src/rl_self_play.py:134-138)."""
+    import json
+    import os
+    from iago_amd import engine, ops
+    from iago_amd.train_rl import ReinforceTrainer
+    from tests.conftest import GOLDEN
+    params = nets_np.random_params("sl", 21)
+    model = network.SLPolicy().load_npz(params)
+    tr = ReinforceTrainer(model, pool_dir=None, N=32, seed=4)
+    torch.manual_seed(3)
+    value = network.Value().cuda().eval()
+    with open(os.path.join(GOLDEN, "simulate.json")) as f:
+        g = json.load(f)
+    tr.model1.eval()
+    m = engine.BatchedMCTS(64, tr.model1, value, ops.RolloutWeights(g["shipped_w"], g["shipped_b"]), n_thr=15,
+                           capacity=4096, seed=2, use_graph=True)
+    res = engine.SelfPlayEngine(m, max_turns=10).play(20)
+    tup = res.tuples()
+    n = int(tup["z"].numel())
+    assert n == 64 * 10 and set(tup) >= {"own", "opp", "move", "z", "colour", "game", "turn"}
+    # float64 restatement on the same rows, in the canonical (turn, game) order the trainer sorts into
+    order = np.lexsort((tup["game"].cpu().numpy(), tup["turn"].cpu().numpy()))
+    own, opp = ops.tensor_to_bits(tup["own"])[order], ops.tensor_to_bits(tup["opp"])[order]
+    x = np.stack([orc.make_state_var(orc.bits_to_state(int(o), int(p)), 1)[0] for o, p in zip(own, opp)])
+    y = tup["move"].cpu().numpy().astype(np.int64)[order]
+    r = tup["z"].cpu().numpy().astype(np.float64)[order]
+    assert np.all(y >= 0) and set(np.unique(r)) <= {-1.0, 0.0, 1.0}
+    want = numpy_loss(params, x, y, r)
+    before = {k: v.copy() for k, v in tr.model1.npz_dict().items()}
+    out = tr.step_from_tuples(tup)
+    assert out["n_tuples"] == n and abs(out["loss"] - want) < 1e-5, (out["loss"], want)
+    assert tr.opt.t == 1 and any(not np.array_equal(before[k], v) for k, v in tr.model1.npz_dict().items())
+    # the learner's plies only
+    one = tr.step_from_tuples(tup, colour=1)
+    assert one["n_tuples"] == int((tup["colour"] == 1).sum().item()) == 64 * 5 and tr.opt.t == 2
+
+
+@pytest.mark.gpu
 def test_supervised_trainers_gpu():
     """train_policy / train_value loops: losses against numpy restatements, and a
     few epochs on a learnable synthetic set make the loss fall."""
