@@ -99,7 +99,7 @@ for mode in (False, True):
         torch.cuda.synchronize()
         for k in range(3):
             acc[k] += ev[k].elapsed_time(ev[k + 1])
-        rows.append((int(m._a_fq_count.sum().item()), int(m._a_roll.sum().item()),
+        rows.append((tuple(m._a_fq_count.tolist()), int(m._a_roll.sum().item()),
                      round(ev[1].elapsed_time(ev[2]) * 1e3, 1)))
         m._la_queues[0]["count"].zero_()   # (no flush here: the queue would overflow)
     print("per step us: descent %.1f  leaf-eval %.1f  backup %.1f" % tuple(1e3 * a / N for a in acc))
