@@ -58,6 +58,8 @@ def lib():
         L.orc_simulate.restype = C.c_int
         L.orc_random_playout.argtypes = [fp, C.c_int, C.c_uint64, C.c_uint32, u8p, ip]
         L.orc_random_playout.restype = C.c_int
+        L.orc_random_playout_stream.argtypes = [fp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, u8p, ip]
+        L.orc_random_playout_stream.restype = C.c_int
         L.orc_simulate_batch.argtypes = [fp, C.c_int, fp, fp, C.c_uint64, C.c_uint32, C.c_int,
                                          C.POINTER(C.c_int8)]
         L.orc_simulate_batch.restype = C.c_long
@@ -181,11 +183,14 @@ def simulate(state, color, w, b, uniforms=None, seed=0, game_id=0):
     return z, s, tr
 
 
-def random_playout(state, color, seed=0, game_id=0):
+def random_playout(state, color, seed=0, game_id=0, stream=0):
+    """Uniformly random legal moves to the end (Simulate's turn structure, mcts_self_play.py:25-29,124-134)
+    from Philox stream `stream` of (seed, game_id).  Returns (z from `color`'s view, final state, trace)."""
     s = _state(state).copy()
     trace = (C.c_uint8 * 160)()
     nt = C.c_int(0)
-    z = lib().orc_random_playout(_f(s), int(color), int(seed), int(game_id), trace, C.byref(nt))
+    z = lib().orc_random_playout_stream(_f(s), int(color), int(seed), int(game_id) & 0xFFFFFFFF,
+                                        int(stream) & 0xFFFFFFFF, trace, C.byref(nt))
     tr = [(-1 if trace[i] == 0xFF else trace[i]) for i in range(nt.value)]
     return z, s, tr
 

@@ -345,8 +345,18 @@ ORC_API int orc_simulate(float *state, int color, const float *w18, const float 
  * workload of SURVEY.md section 6): action = actions[floor(u * n)].
  * Used for traces and as a CPU baseline of the pure rules path.
  */
+ORC_API int orc_random_playout_stream(float *state, int color, uint64_t seed, uint32_t game_id, uint32_t stream,
+                                      uint8_t *trace, int *n_turns);
 ORC_API int orc_random_playout(float *state, int color, uint64_t seed, uint32_t game_id,
                                uint8_t *trace, int *n_turns)
+{
+    return orc_random_playout_stream(state, color, seed, game_id, 0, trace, n_turns);
+}
+
+/* The same game drawn from Philox stream `stream` of (seed, game_id): a search rolls the leaf of its
+ * i-th playout out on stream i (the build's keying; the reference draws from numpy's global state). */
+ORC_API int orc_random_playout_stream(float *state, int color, uint64_t seed, uint32_t game_id, uint32_t stream,
+                                      uint8_t *trace, int *n_turns)
 {
     int empties = 0;
     for (int k = 0; k < 64; k++)
@@ -359,7 +369,7 @@ ORC_API int orc_random_playout(float *state, int color, uint64_t seed, uint32_t 
             int actions[64];
             int n = orc_legal_actions(state, c, actions);
             if (n > 0) {
-                float u = orc_uniform(seed, game_id, (uint32_t)t, 0);
+                float u = orc_uniform(seed, game_id, (uint32_t)t, stream);
                 int k = (int)(u * (float)n);
                 if (k >= n)
                     k = n - 1;

@@ -193,3 +193,58 @@ def test_production_self_play_games_vs_oracle(shipped, async_steps):
         assert got == want_moves, g
         assert z[g] == want_z, g
         assert next(it, None) is None, g     # the oracle consumed exactly the playouts the GPU ran
+
+
+@pytest.mark.parametrize("n_thr,n_sims,n_sims2", [(15, 100, 44), (1, 60, 30)])
+def test_production_search_with_uniform_rollouts_needs_no_replay(shipped, golden_rules, n_thr, n_sims, n_sims2):
+    """The whole playout reproduced by the oracle ITSELF, rollouts included: with the uniform rollout
+    policy (arithmetic exact in float32: tests/test_rollout_gpu.py) the oracle plays Simulate from the
+    same Philox stream the kernel draws from -- stream id = the search's playout counter -- instead of
+    being fed recorded results.  n_thr = 15: the production path (hipGraph, look-ahead, value cache,
+    fused descent / leaf evaluation, path backup).  n_thr = 1: the configuration of bench.py's
+    `mcts_nthr1` leg -- no look-ahead possible, the policy net inside every playout
+    (select, pending, policy_resident_kernel on the expanding leaves, expand, continued select,
+    fresh_leaves, value_rollout_kernel, mix_backup), one hipGraph replay per playout."""
+    engine, ops, policy, value, _ = shipped
+    G, seed, base = 48, 9, 500
+    own, opp = _positions(G, golden_rules)
+    cap = engine.suggest_capacity(n_sims + n_sims2, n_thr, moves=2)
+    m = engine.BatchedMCTS(G, policy, value, ops.uniform_weights(), lmbda=0.5, c_puct=1.0, n_thr=n_thr, capacity=cap,
+                           seed=seed, game_id_base=base, use_graph=True)
+    assert m.use_graph and m.value_cache and m.fused_leaf_eval and m.lookahead == (4 if n_thr == 15 else 0)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    active = torch.ones(G, dtype=torch.uint8, device="cuda")
+    m.search(o, p, active, n_sims)
+    move = m.best_move(active)[0].cpu().numpy()
+    probe = NetProbe(ops, policy, value)
+    checked = list(range(0, 8)) + list(range(G // 2 - 2, G // 2 + 4))
+    oracles = {}
+
+    def rollout_of(g, counter):
+        def fn(state, color):
+            z = orc.random_playout(state, color, seed=seed, game_id=base + g, stream=counter[0])[0]
+            counter[0] += 1
+            return z
+        return fn
+
+    for g in checked:
+        counter = [0]     # the engine's playout counter: one Philox stream per playout of the engine's life
+        om = mcts_py.MCTS(probe.policy_fn, probe.value_fn, rollout_of(g, counter), lmbda=0.5, c_puct=1.0, n_thr=n_thr)
+        want_move = om.get_move(state_of(own[g], opp[g]), 1, n_sims)
+        assert counter[0] == n_sims
+        _cmp_tree(m.tree.dump(g, max_depth=64), mcts_py.dump_tree(om.root, max_depth=64), "g%d" % g)
+        assert move[g] == (-2 if want_move is None else want_move), g
+        oracles[g] = (om, counter)
+    mv = torch.from_numpy(np.where(move == -2, -1, move).astype(np.int8)).cuda()
+    m.update_with_move(mv, active.clone())
+    o2, p2 = o.clone(), p.clone()
+    ops.apply_moves(o2, p2, mv)
+    m.search(p2, o2, active, n_sims2)
+    for g, (om, counter) in oracles.items():
+        a = int(mv[g].item())
+        om.update_with_move(a)
+        s = state_of(own[g], opp[g])
+        orc.place_stone(s, a, 1)
+        om.get_move(s, 2, n_sims2)
+        assert counter[0] == n_sims + n_sims2
+        _cmp_tree(m.tree.dump(g, max_depth=64), mcts_py.dump_tree(om.root, max_depth=64), "g%d'" % g)
