@@ -10,6 +10,19 @@ import torch
 from . import boards, engine, ops
 
 
+def _move_probs(model, own, opp):
+    """model(make_state_var(...)) for every board.  An SLPolicy module is evaluated by its one-launch
+    three-piece kernel straight from the boards: one board per workgroup, so a board's distribution
+    does not depend on how many boards are in the batch -- the games a rank plays do not depend on how
+    the games were sharded (the planes-fed float32 kernels pick their tiling by batch size and agree
+    only to ~1e-6).  Any other callable sees the planes, as in the reference."""
+    with torch.no_grad():
+        fb = getattr(model, "forward_boards_split3", None)
+        if fb is not None and getattr(model, "split3", False) and not getattr(model, "training", False):
+            return fb(own, opp)
+        return model(ops.encode_planes(own, opp))
+
+
 def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, uniforms=None,
                device="cuda"):
     """n_games lockstep games.  handicap: optional (n_games,) int64 bit masks of
@@ -35,8 +48,7 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
     t = 0
     while t < ops.IAGO_MAX_TURNS:
         color = 1 if t % 2 == 0 else 2
-        with torch.no_grad():
-            probs = (model1 if color == 1 else model2)(ops.encode_planes(own, opp))
+        probs = _move_probs(model1 if color == 1 else model2, own, opp)
         u = next(uniforms) if (uniforms is not None and bool(active.any().item())) else None
         a = ops.sample_moves(probs.to(torch.float32).contiguous(), legal, uniforms=u,
                              seed=seed, id_base=game_id_base, step=t)
