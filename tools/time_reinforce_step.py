@@ -4,10 +4,15 @@ from iago_amd import network
 from iago_amd.train_rl import ReinforceTrainer
 import iago_amd.train_rl as T
 torch.manual_seed(0)
+import os
+if os.environ.get("BENCHMARK") == "1":
+    torch.backends.cudnn.benchmark = True
 tr = ReinforceTrainer(network.SLPolicy(), pool_dir=None, N=32, seed=0)
+t0 = time.perf_counter()
 for _ in range(3):
     tr.step()
 torch.cuda.synchronize()
+print("3 warm-up steps: %.1f s" % (time.perf_counter() - t0))
 def timed(f, *a):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(*a); torch.cuda.synchronize(); return r, (time.perf_counter() - t0) * 1e3
 for it in range(4):
