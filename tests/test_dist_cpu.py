@@ -83,3 +83,39 @@ def test_gather_tuples_single_process_is_identity():
     t = dict(a=torch.arange(5), b=torch.ones(5, 3))
     out = gather_tuples(t)
     assert out["a"] is t["a"] and out["b"] is t["b"]
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """`python bench.py --gpus 2` without a launcher starts its ranks as child processes and exits
+    with their status: on this GPU-less container every rank fails at its first HIP call, and the
+    launcher must come back promptly with a non-zero status and nothing on stdout."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU (the -m gpu tests run the launcher for real)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rollout-only"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert out.stdout.strip() == ""
+
+
+def test_bench_refuses_thin_kernel_profiles(tmp_path, monkeypatch):
+    """mcts.roofline.kernels comes from a committed full-game profile and refuses kernels with fewer
+    than 100 launches (a one-launch sample had been reported)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    k = {"calls": 500, "pmc_launches": 500, "avg_us": 90.0, "SQ_INSTS_MFMA": 1.8e6, "hbm_bytes_per_launch": 3e7}
+    thin = dict(k, calls=1, pmc_launches=1)
+    (prof / "r98_mcts_fullgame_pmc_summary.json").write_text(json.dumps(
+        {"command": "x", "kernels": {"value_rollout_kernel": k, "policy_resident_kernel": k}}))
+    (prof / "r99_mcts_fullgame_pmc_summary.json").write_text(json.dumps(
+        {"command": "y", "kernels": {"value_rollout_kernel": thin, "policy_resident_kernel": k}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got = bench.net_kernel_profiles()
+    assert got["profile"] == "r98_mcts_fullgame_pmc_summary.json"      # the newer one is refused
+    v = got["value_rollout_kernel"]
+    assert v["launches"] == 500 and abs(v["executed_tflops"] - 1.8e6 * 32768 / 90e-6 / 1e12) < 1e-6
+    assert abs(v["frac"] - v["executed_tflops"] / 2500.0) < 1e-12
