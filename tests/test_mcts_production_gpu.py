@@ -248,3 +248,53 @@ def test_production_search_with_uniform_rollouts_needs_no_replay(shipped, golden
         om.get_move(s, 2, n_sims2)
         assert counter[0] == n_sims + n_sims2
         _cmp_tree(m.tree.dump(g, max_depth=64), mcts_py.dump_tree(om.root, max_depth=64), "g%d'" % g)
+
+
+def test_production_self_play_uniform_rollouts_no_replay(shipped):
+    """Whole PV-MCTS self-play games (SelfPlayEngine at the production defaults) reproduced by the oracle
+    with nothing replayed: uniform rollout policy, the oracle plays every leaf rollout itself from the
+    Philox stream of that playout -- stream id = (turn of the game) x n_sims + playout, the engine's
+    playout counter (every turn of the lockstep loop runs one search of n_sims playouts)."""
+    engine, ops, policy, value, _ = shipped
+    G, n_sims, seed, base = 8, 24, 13, 70
+    m = engine.BatchedMCTS(G, policy, value, ops.uniform_weights(), n_thr=15, capacity=4096, seed=seed,
+                           game_id_base=base, use_graph=True)
+    assert m.lookahead == 4 and m.value_cache and m.use_graph
+    res = engine.SelfPlayEngine(m).play(n_sims)
+    moves, valid, z = res.move.cpu().numpy(), res.valid.cpu().numpy(), res.z.cpu().numpy()
+    f1, f2 = ops.tensor_to_bits(res.final_p1), ops.tensor_to_bits(res.final_p2)
+    probe = NetProbe(ops, policy, value)
+    for g in range(G):
+        counter = [0]
+
+        def roll(state, color, g=g, counter=counter):
+            zz = orc.random_playout(state, color, seed=seed, game_id=base + g, stream=counter[0])[0]
+            counter[0] += 1
+            return zz
+
+        om = mcts_py.MCTS(probe.policy_fn, probe.value_fn, roll, lmbda=0.5, c_puct=1.0, n_thr=15)
+        # game.py:117-142,253-255 with both colours driven by MCTS.get_move (oracle.mcts_py.selfplay_game),
+        # the turn counted for the stream ids
+        state = orc.initial_state()
+        stone_num, pass_flg, t, want = 4, False, 0, []
+        while stone_num < 64:
+            for color in (1, 2):
+                acts = orc.legal_actions(state, color)
+                if len(acts) > 0:
+                    counter[0] = t * n_sims
+                    a = om.get_move(state, color, n_sims)
+                    om.update_with_move(a)
+                    orc.place_stone(state, a, color)
+                    stone_num += 1
+                    pass_flg = False
+                    want.append(a)
+                else:
+                    if pass_flg:
+                        stone_num = 64
+                    pass_flg = True
+                    om.update_with_move(-1)
+                    want.append(-1)
+                t += 1
+        got = [int(moves[k, g]) if valid[k, g] else -1 for k in range(len(want))]
+        assert got == want, g
+        assert z[g] == orc.judge(state, 1) and orc.state_to_bits(state) == (int(f1[g]), int(f2[g])), g
