@@ -947,6 +947,11 @@ def main():
             line["leaf_evals_per_sec"] = mcts["leaf_evals_per_sec"]
             if "games_per_sec" in mcts:
                 line["mcts_games_per_sec"] = mcts["games_per_sec"]
+            ks = (mcts.get("roofline") or {}).get("kernels") or {}
+            for name, key in (("value_rollout_kernel", "mcts_value_kernel_mfma_frac"),
+                              ("policy_resident_kernel", "mcts_policy_kernel_mfma_frac")):
+                if name in ks and "frac" in ks[name]:
+                    line[key] = ks[name]["frac"]    # executed f16 MFMA FLOP/s of the kernel / 2.5 PF (committed profile)
             line["mcts"] = mcts
         if nthr1 is not None:
             line["mcts_nthr1"] = nthr1
