@@ -11,6 +11,7 @@ n_thr simulations, no sign flip in backup, pass = action -1, subtree reuse.
 The wall-clock budget (10 s per move, MCTS.py:142) becomes a simulation count.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -172,8 +173,7 @@ class BatchedMCTS(object):
         self._fresh_count = torch.zeros(1, dtype=torch.int32, **kw)
         self._value_total = torch.zeros(1, dtype=torch.int64, **kw)  # value-net evaluations, on the device
         self._value_key = None
-        import os as _os
-        self.fused_leaf_eval = _os.environ.get("IAGO_FUSED_LEAF_EVAL", "1") != "0"
+        self.fused_leaf_eval = os.environ.get("IAGO_FUSED_LEAF_EVAL", "1") != "0"
         self.cur_node = torch.zeros(n_games, dtype=torch.int32, **kw)
         self.cur_own = torch.zeros(n_games, dtype=torch.int64, **kw)
         self.cur_opp = torch.zeros(n_games, dtype=torch.int64, **kw)
@@ -199,8 +199,7 @@ class BatchedMCTS(object):
             raise ValueError("use_graph needs the sync-free playout (a policy with forward_counted)")
         self.use_graph, self._graph, self._graph_key = bool(use_graph), None, None
         # look-ahead blocks (of 2 K playouts) per replay of the long graph (tuning knob: DESIGN.md)
-        import os as _os2
-        self.graph_blocks = max(1, int(_os2.environ.get("IAGO_GRAPH_BLOCKS", "4")))
+        self.graph_blocks = max(1, int(os.environ.get("IAGO_GRAPH_BLOCKS", "4")))
         self._graph_long = None
         self.n_compactions = 0
         self._live_after_compaction = 0
@@ -210,7 +209,6 @@ class BatchedMCTS(object):
         # board-fed policy net applies and n_thr leaves room for it; 0 = the net runs inside the
         # playout that expands (the reference's order of evaluation).  Same trees either way.
         can = (self.sync_free and getattr(policy_fn, "forward_counted_boards", None) is not None)
-        import os
         if lookahead is None:
             k = int(os.environ.get("IAGO_LOOKAHEAD", "4"))   # (tuning knob: tools/)
             lookahead = k if (can and self.n_thr > k + 1) else 0
@@ -297,13 +295,12 @@ class BatchedMCTS(object):
         # lockstep -- a 100-playout search needs ~200 steps of ~105 us because the game with the most
         # fresh leaves sets the step count (LABNOTES.md, round 3); async_steps=True / IAGO_ASYNC=1
         # selects it.
-        import os as _os3
         can_async = bool(self.lookahead and self.value_cache and getattr(self, "fused_descent", False)
                          and getattr(self, "_la_path", None) is not None and self.fused_leaf_eval
                          and 0.0 < self.lmbda < 1.0 and rollout_weights is not None and not rollout_weights.log_form
                          and getattr(value_fn, "forward_boards_async", None) is not None)
         if async_steps is None:
-            async_steps = can_async and _os3.environ.get("IAGO_ASYNC", "0") == "1"
+            async_steps = can_async and os.environ.get("IAGO_ASYNC", "0") == "1"
         if async_steps and not can_async:
             raise ValueError("async_steps needs the look-ahead playout with the value cache, the one-launch descent, "
                              "the path backup, the fused leaf evaluation (0 < lmbda < 1, product-form rollout "
@@ -311,7 +308,7 @@ class BatchedMCTS(object):
         self.async_steps = bool(async_steps)
         self.n_steps = 0              # game-asynchronous steps run so far
         if self.async_steps:
-            parts = int(async_parts if async_parts is not None else _os3.environ.get("IAGO_ASYNC_PARTS", "3"))
+            parts = int(async_parts if async_parts is not None else os.environ.get("IAGO_ASYNC_PARTS", "3"))
             if not 2 <= parts <= 4:
                 raise ValueError("async_parts must be 2, 3 or 4")
             self.async_parts = parts
