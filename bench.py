@@ -166,7 +166,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     # leaves that never expand)
     flops = val * 122_994_944 + pol * 122_847_232
     out = {"leaf_evals_per_sec": leaf / dt, "leaf_evals": int(leaf), "policy_evals": int(pol),
-           "value_evals": int(val),
+           "value_evals": int(val), "value_inline": int(m.n_value_inline), "value_ahead": int(m.n_value_ahead),
+           "async_steps": int(m.n_steps) if m.async_steps else None,
            "leaf_eval_definition": "one leaf-eval = one playout (MCTS.py:105-133) ending in the leaf "
                                    "evaluation of MCTS.py:123-127: value_func(leaf) + rollout + backup; "
                                    "value_func is a pure function of the position, computed at a leaf's "

@@ -32,6 +32,7 @@ SYMBOLS = [
     "iago_mcts_backup", "iago_mcts_mix_backup", "iago_mcts_best_move", "iago_mcts_advance_root", "iago_mcts_compact",
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
     "iago_mcts_fresh_leaves", "iago_mcts_descend", "iago_value_rollout_async",
+    "iago_value_forward_batch", "iago_mcts_value_ahead_rows", "iago_mcts_value_ahead_store",
 ]
 
 
@@ -91,7 +92,17 @@ class MctsLookahead(C.Structure):
         ("q_own", C.c_void_p), ("q_opp", C.c_void_p), ("q_game", C.c_void_p), ("q_seq", C.c_void_p),
         ("error", C.c_void_p), ("clear_word", C.c_void_p), ("path", C.c_void_p), ("path_len", C.c_void_p),
         ("z_log", C.c_void_p), ("z_log_n", C.c_void_p), ("z_log_rows", C.c_int32), ("reserved", C.c_int32),
-        ("async_", C.c_void_p),
+        ("async_", C.c_void_p), ("value_ahead", C.c_void_p),
+    ]
+
+
+class MctsValueAhead(C.Structure):
+    """Mirror of iago_mcts_value_ahead (include/iago_hip.h)."""
+    _fields_ = [
+        ("x_capacity", C.c_int32), ("row_capacity", C.c_int32), ("x_count", C.c_void_p),
+        ("x_game", C.c_void_p), ("x_node", C.c_void_p), ("x_own", C.c_void_p), ("x_opp", C.c_void_p),
+        ("row_count", C.c_void_p), ("row_own", C.c_void_p), ("row_opp", C.c_void_p), ("row_node", C.c_void_p),
+        ("row_v", C.c_void_p), ("total", C.c_void_p),
     ]
 
 
@@ -119,7 +130,7 @@ NODE_WORDS = 8   # sizeof(iago_mcts_node) / 4: n_visits, q, p, v, first_child, p
 
 
 _lib = None
-ABI_VERSION = 7   # iago_abi_version() of the include/iago_hip.h these bindings mirror
+ABI_VERSION = 8   # iago_abi_version() of the include/iago_hip.h these bindings mirror
 
 
 def lib():
@@ -196,6 +207,10 @@ def lib():
     L.iago_mcts_expand_cached.argtypes = [tp, vp, vp, vp, vp, lp, vp, vp]
     L.iago_mcts_fresh_leaves.argtypes = [tp, vp, vp, vp, vp, vp, vp]
     L.iago_mcts_descend.argtypes = [tp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, vp, lp, vp, vp, vp, vp]
+    L.iago_value_forward_batch.argtypes = [C.POINTER(ValueSplitArgs), i32, i32, vp]
+    vap = C.POINTER(MctsValueAhead)
+    L.iago_mcts_value_ahead_rows.argtypes = [tp, vap, vp]
+    L.iago_mcts_value_ahead_store.argtypes = [tp, vap, vp]
     for name in SYMBOLS[3:]:
         getattr(L, name).restype = C.c_int
     _lib = L

@@ -559,7 +559,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // long as ONE piece (or one rollout), not as one walk: the value net has left the steps' critical
 // chain.  One board per workgroup while a queue's rows fit its NV workgroups, two above (the pair
 // shares the weight stream).
-constexpr int ASYNC_NV = 64; // value workgroups per piece: parts * NV + the rollouts' 64 <= 256 CUs + slack
+// value workgroups per piece (parts * NV + the rollouts' 64 <= 256 CUs + slack; tuning knob IAGO_ASYNC_NV: with
+// the value look-ahead few leaves are evaluated in place, and every workgroup of this launch needs a CU
+// of its own to start on, beside the look-ahead's batches)
+static int iago_async_nv()
+{
+    static const int v = [] {
+        const char *e = getenv("IAGO_ASYNC_NV");
+        const int n = e ? atoi(e) : 64;
+        return n < 1 ? 1 : (n > 64 ? 64 : n);
+    }();
+    return v;
+}
 struct AsyncParams {
     int32_t parts;
     const int64_t *fq_index; // [parts][n]
@@ -570,7 +581,7 @@ struct AsyncParams {
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void value_rollout_async_kernel(
-    TrunkRParams P, iago_row::HwParams R, AsyncParams Y, uint32_t n_ro)
+    TrunkRParams P, iago_row::HwParams R, AsyncParams Y, uint32_t n_ro, uint32_t ASYNC_NV)
 {
     if (blockIdx.x < n_ro) {
         iago_row::rollout_row_body<false, true>(R, blockIdx.x);
@@ -769,6 +780,47 @@ int iago_value_forward_split(const iago_value_split_args *a, void *stream)
     return iago_check_launch("iago_value_forward_split");
 }
 
+int iago_value_forward_batch(const iago_value_split_args *a, int32_t boards_per_workgroup, int32_t max_workgroups,
+                             void *stream)
+{
+    if (a && a->n == 0)
+        return IAGO_OK;
+    if (!a || !a->n_dev || max_workgroups < 1 ||
+        (boards_per_workgroup != 1 && boards_per_workgroup != 2 && boards_per_workgroup != 4))
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_batch: a device-side row count, 1 / 2 / 4 boards per "
+                                           "workgroup and max_workgroups >= 1 expected");
+    TrunkRParams P;
+    if (const int rc = value_params_of(a, P))
+        return rc;
+    P.count_lo = 0;
+    P.count_hi = 0x7fffffff;
+    static std::atomic<uint64_t> configured4{0}, configured2{0}, configured1{0};
+    const int tb = boards_per_workgroup;
+    int64_t grid = (a->n + tb - 1) / tb;
+    if (grid > max_workgroups)
+        grid = max_workgroups;
+    if (tb == 4) {
+        if (iago_reserve_lds((const void *)trunk_resident_kernel<true, 4>, lds_alloc_fused(4), configured4,
+                             "iago_value_forward_batch: cannot reserve 148 KB of LDS"))
+            return IAGO_ERR_HIP;
+        hipLaunchKernelGGL((trunk_resident_kernel<true, 4>), dim3((unsigned)grid), dim3(256), lds_alloc_fused(4),
+                           (hipStream_t)stream, P);
+    } else if (tb == 2) {
+        if (iago_reserve_lds((const void *)trunk_resident_kernel<true, 2>, lds_alloc_fused(2), configured2,
+                             "iago_value_forward_batch: cannot reserve 75 KB of LDS"))
+            return IAGO_ERR_HIP;
+        hipLaunchKernelGGL((trunk_resident_kernel<true, 2>), dim3((unsigned)grid), dim3(256), lds_alloc_fused(2),
+                           (hipStream_t)stream, P);
+    } else {
+        if (iago_reserve_lds((const void *)trunk_resident_kernel<true, 1>, lds_alloc_fused(1), configured1,
+                             "iago_value_forward_batch: cannot reserve 39 KB of LDS"))
+            return IAGO_ERR_HIP;
+        hipLaunchKernelGGL((trunk_resident_kernel<true, 1>), dim3((unsigned)grid), dim3(256), lds_alloc_fused(1),
+                           (hipStream_t)stream, P);
+    }
+    return iago_check_launch("iago_value_forward_batch");
+}
+
 int iago_value_rollout(const iago_value_split_args *a, const iago_rollout_args *ro, void *stream)
 {
     if (!a || !ro)
@@ -840,7 +892,8 @@ int iago_value_rollout_async(const iago_value_split_args *a, const iago_rollout_
     for (int i = 0; i <= y->parts; i++)
         Y.bounds |= (uint64_t)(uint8_t)B[i] << (8 * i);
     const unsigned n_ro = (unsigned)((ro->n + (iago_row::HW_BLOCK / 16) - 1) / (iago_row::HW_BLOCK / 16));
-    hipLaunchKernelGGL(value_rollout_async_kernel, dim3(n_ro + (unsigned)(y->parts * ASYNC_NV)), dim3(256),
-                       lds_alloc_fused(2), (hipStream_t)stream, P, R, Y, n_ro);
+    const unsigned nv = (unsigned)iago_async_nv();
+    hipLaunchKernelGGL(value_rollout_async_kernel, dim3(n_ro + (unsigned)y->parts * nv), dim3(256),
+                       lds_alloc_fused(2), (hipStream_t)stream, P, R, Y, n_ro, nv);
     return iago_check_launch("iago_value_rollout_async");
 }

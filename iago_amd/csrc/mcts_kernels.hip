@@ -384,6 +384,11 @@ struct Lookahead {
     int32_t *y_fq_count;
     uint32_t *y_step;
     const int32_t *y_n_sims;
+    // value look-ahead (iago_mcts_value_ahead); va_x_count == nullptr: off
+    int32_t *va_x_count;
+    int32_t va_x_capacity;
+    int32_t *va_x_game, *va_x_node;
+    uint64_t *va_x_own, *va_x_opp;
 };
 
 // Diagnostic record of the parity tests (tests/test_mcts_production_gpu.py): the z every playout of
@@ -743,6 +748,17 @@ __global__ __launch_bounds__(BLOCK) void descend_kernel(
                     if (r == 0u) {
                         T.nodes[base + node].first_child = nf;
                         T.nodes[base + node].n_children = (uint8_t)kn;
+                        if (A.va_x_count) {
+                            // value look-ahead: the new children will be first-visited during this
+                            // node's next visits (a full queue drops the hint)
+                            const int pos = atomicAdd(A.va_x_count, 1);
+                            if (pos < A.va_x_capacity) {
+                                A.va_x_game[pos] = (int32_t)g;
+                                A.va_x_node[pos] = node;
+                                A.va_x_own[pos] = own;
+                                A.va_x_opp[pos] = opp;
+                            }
+                        }
                     }
                     fc = nf;
                     k = kn;
@@ -927,6 +943,89 @@ __global__ __launch_bounds__(BLOCK) void compact_commit_kernel(Tree T, Tree S)
     if (threadIdx.x == 0 && count >= 0) {
         T.n_nodes[g] = count;
         T.root[g] = 0;
+    }
+}
+
+// ---- value look-ahead (iago_mcts_value_ahead_rows / _store).  8 lanes per queued node: its
+// legal moves in ascending order are its children in pool order (Node.expand, MCTS.py:27-37);
+// every child without a stored value becomes a row of the value net's next batch.
+struct ValueAhead {
+    int32_t x_capacity, row_capacity;
+    int32_t *x_count;
+    const int32_t *x_game, *x_node;
+    const uint64_t *x_own, *x_opp;
+    int32_t *row_count;
+    uint64_t *row_own, *row_opp;
+    int64_t *row_node;
+    float *row_v;
+    int64_t *total;
+};
+
+__global__ __launch_bounds__(BLOCK) void value_ahead_rows_kernel(Tree T, ValueAhead V)
+{
+    const int count = min(*V.x_count, V.x_capacity);
+    const Lane8 L = make_lane8(threadIdx.x);
+    for (int64_t e = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 3; e < (((int64_t)count + 31) & ~31ll);
+         e += ((int64_t)gridDim.x * BLOCK) >> 3) {
+        // (the loop bound is rounded up to a whole workgroup's 32 entries: the 8 lanes of a group
+        // and the groups of a wave run the cross-lane primitives together)
+        const bool live = e < count;
+        const int64_t g = live ? V.x_game[e] : 0;
+        const int node = live ? V.x_node[e] : 0;
+        const uint64_t own = live ? V.x_own[e] : 0ull, opp = live ? V.x_opp[e] : 0ull;
+        const int64_t base = g * (int64_t)T.capacity;
+        const int fc = live ? T.nodes[base + node].first_child : -1;
+        const int k = fc >= 0 ? (int)T.nodes[base + node].n_children : 0;
+        uint64_t lg = group8_legal(to_lane(own, L), to_lane(opp, L), L);
+        // (a node of a finished position has one pass child: the same stones, the other side to move)
+        const bool pass = lg == 0ull;
+        int j = 0;
+        // wave-uniform trip count: the longest list of the wave's groups
+        while (__builtin_amdgcn_ballot_w64(live && j < k) != 0ull) {
+            const bool on = live && j < k;
+            const int a = pass ? -1 : (lg ? (int)__builtin_ctzll(lg) : 0);
+            const uint64_t f = group8_flips(to_lane(own, L), to_lane(opp, L), (uint32_t)a & 63u, L);
+            if (on && L.l8 == 0u) {
+                const int64_t c = base + fc + j;
+                const float cv = T.nodes[c].v;
+                if (cv != cv) {
+                    uint64_t no = own, np_ = opp;
+                    if (a >= 0) {
+                        const uint64_t bit = 1ull << (a & 63);
+                        no = own | f | bit;
+                        np_ = opp & ~f & ~bit;
+                    }
+                    const int pos = atomicAdd(V.row_count, 1);
+                    if (pos < V.row_capacity) {
+                        V.row_own[pos] = np_; // the child's mover is the other side (MCTS.py:131-132)
+                        V.row_opp[pos] = no;
+                        V.row_node[pos] = c;
+                    }
+                }
+            }
+            lg &= lg - 1ull;
+            j++;
+        }
+    }
+}
+
+// (separate launch: the count is final only when every workgroup of the rows kernel is done)
+__global__ void value_ahead_clamp_kernel(ValueAhead V)
+{
+    const int n = min(*V.row_count, V.row_capacity);
+    *V.row_count = n;
+    if (V.total)
+        *V.total += n;
+}
+
+__global__ __launch_bounds__(BLOCK) void value_ahead_store_kernel(Tree T, ValueAhead V)
+{
+    const int count = min(*V.row_count, V.row_capacity);
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (int64_t)gridDim.x * BLOCK) {
+        float *slot = &T.nodes[V.row_node[i]].v;
+        const float cur = *slot;
+        if (cur != cur) // (a visit in the meantime has stored the same number)
+            *slot = V.row_v[i];
     }
 }
 
@@ -1220,6 +1319,20 @@ int lookahead_of(const iago_mcts_lookahead *a, Lookahead &A, const char *who)
     A.z_log_rows = a->z_log_rows;
     if (A.z_log && !A.z_log_n)
         return iago_fail(IAGO_ERR_INVALID, who);
+    A.va_x_count = nullptr;
+    A.va_x_capacity = 0;
+    A.va_x_game = A.va_x_node = nullptr;
+    A.va_x_own = A.va_x_opp = nullptr;
+    if (const iago_mcts_value_ahead *v = a->value_ahead) {
+        if (v->x_capacity < 1 || !v->x_count || !v->x_game || !v->x_node || !v->x_own || !v->x_opp)
+            return iago_fail(IAGO_ERR_INVALID, who);
+        A.va_x_count = v->x_count;
+        A.va_x_capacity = v->x_capacity;
+        A.va_x_game = v->x_game;
+        A.va_x_node = v->x_node;
+        A.va_x_own = v->x_own;
+        A.va_x_opp = v->x_opp;
+    }
     A.y_wait = nullptr;
     A.y_parts = 0;
     if (const iago_mcts_async *y = a->async) {
@@ -1334,6 +1447,59 @@ int iago_mcts_descend(const iago_mcts_tree *tree, const uint64_t *root_own, cons
                        root_own, root_opp, active, c_puct, n_thr, cur_node, cur_own, cur_opp, legal, stats, A,
                        fresh_index, fresh_count, fresh_total);
     return iago_check_launch("iago_mcts_descend");
+}
+
+} // extern "C"
+
+namespace {
+int value_ahead_of(const iago_mcts_tree *tree, const iago_mcts_value_ahead *v, ValueAhead &V, const char *who)
+{
+    if (!v || v->x_capacity < 1 || v->row_capacity < 1 || !v->x_count || !v->x_game || !v->x_node || !v->x_own ||
+        !v->x_opp || !v->row_count || !v->row_own || !v->row_opp || !v->row_node || !v->row_v || !tree->has_v)
+        return iago_fail(IAGO_ERR_INVALID, who);
+    V.x_capacity = v->x_capacity;
+    V.row_capacity = v->row_capacity;
+    V.x_count = v->x_count;
+    V.x_game = v->x_game;
+    V.x_node = v->x_node;
+    V.x_own = v->x_own;
+    V.x_opp = v->x_opp;
+    V.row_count = v->row_count;
+    V.row_own = v->row_own;
+    V.row_opp = v->row_opp;
+    V.row_node = v->row_node;
+    V.row_v = v->row_v;
+    V.total = v->total;
+    return IAGO_OK;
+}
+} // namespace
+
+extern "C" {
+
+int iago_mcts_value_ahead_rows(const iago_mcts_tree *tree, const iago_mcts_value_ahead *va, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_value_ahead_rows: bad tree"))
+        return IAGO_ERR_INVALID;
+    ValueAhead V;
+    if (value_ahead_of(tree, va, V, "iago_mcts_value_ahead_rows: incomplete iago_mcts_value_ahead (the tree needs "
+                                    "its value cache `v`)"))
+        return IAGO_ERR_INVALID;
+    // (a fixed small grid: the queue holds a few dozen nodes per playout)
+    hipLaunchKernelGGL(value_ahead_rows_kernel, dim3(32), dim3(BLOCK), 0, (hipStream_t)stream, *tree, V);
+    hipLaunchKernelGGL(value_ahead_clamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, V);
+    return iago_check_launch("iago_mcts_value_ahead_rows");
+}
+
+int iago_mcts_value_ahead_store(const iago_mcts_tree *tree, const iago_mcts_value_ahead *va, void *stream)
+{
+    if (check_tree(tree, "iago_mcts_value_ahead_store: bad tree"))
+        return IAGO_ERR_INVALID;
+    ValueAhead V;
+    if (value_ahead_of(tree, va, V, "iago_mcts_value_ahead_store: incomplete iago_mcts_value_ahead (the tree needs "
+                                    "its value cache `v`)"))
+        return IAGO_ERR_INVALID;
+    hipLaunchKernelGGL(value_ahead_store_kernel, dim3(16), dim3(BLOCK), 0, (hipStream_t)stream, *tree, V);
+    return iago_check_launch("iago_mcts_value_ahead_store");
 }
 
 } // extern "C"

@@ -148,7 +148,7 @@ class BatchedMCTS(object):
     def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
                  n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False,
                  sync_free=None, lookahead=None, lookahead_slots=None, value_cache=None, lookahead_overlap=None,
-                 z_log_rows=0, async_steps=None, async_parts=None):
+                 z_log_rows=0, async_steps=None, async_parts=None, value_ahead=None):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         self.n_games = n_games
@@ -275,6 +275,53 @@ class BatchedMCTS(object):
             self._la_cur = 0   # the queue the playouts fill
             prio = int(os.environ.get("IAGO_SIDE_PRIORITY", "0"))
             self._la_side = torch.cuda.Stream(device=device, priority=prio) if self.lookahead_overlap else None
+            # Value look-ahead (iago_mcts_value_ahead in include/iago_hip.h): the descent queues every
+            # node it expands; once per group of K playouts the children that have no value yet go
+            # through the value net as ONE batch on the side stream and the results land in the
+            # children's records, so that their first visits find a stored value instead of walking
+            # the net on the playouts' critical path.  Same trees (a child visited before its value
+            # has landed is evaluated in place as before).  Default OFF -- measured slower (round 4,
+            # LABNOTES.md): in lockstep ONE game without a stored value still puts a 70 us one-board
+            # walk on every playout's critical path (1024 games x 16 % fresh leaves x 53 % misses = ~85
+            # per playout), and with game-asynchronous steps the extra evaluations (children that are
+            # never visited, or visited before their value lands: +50 % rows) make the side stream the
+            # bound.  value_ahead=True / IAGO_VALUE_AHEAD=1 selects it.
+            can_va = bool(self.value_cache and self.fused_descent and self._la_side is not None
+                          and getattr(value_fn, "forward_boards_batch", None) is not None)
+            if value_ahead is None:
+                value_ahead = can_va and os.environ.get("IAGO_VALUE_AHEAD", "0") == "1"
+            if value_ahead and not can_va:
+                raise ValueError("value_ahead needs the value cache, the one-launch descent, lookahead_overlap > 0 "
+                                 "and a value net with forward_boards_batch")
+            self.value_ahead = bool(value_ahead)
+            if self.value_ahead:
+                self.va_boards = int(os.environ.get("IAGO_VALUE_AHEAD_BOARDS", "2"))      # boards per workgroup
+                self.va_grid = int(os.environ.get("IAGO_VALUE_AHEAD_GRID", "176"))        # workgroup cap of a batch
+                xcap, rcap = n_games * K, max(4096, 8 * n_games * K)
+                self._va_total = torch.zeros(1, dtype=torch.int64, **kw)   # rows the batches have evaluated
+                self._va_row_count = torch.zeros(1, dtype=torch.int32, **kw)
+                self._va_rows = dict(own=torch.zeros(rcap, dtype=torch.int64, **kw),
+                                     opp=torch.zeros(rcap, dtype=torch.int64, **kw),
+                                     node=torch.zeros(rcap, dtype=torch.int64, **kw),
+                                     v=torch.zeros(rcap, dtype=torch.float32, **kw))
+                self._va_x, self._va = [], []
+                for a in self._la:
+                    x = dict(count=torch.zeros(1, dtype=torch.int32, **kw), game=torch.zeros(xcap, dtype=torch.int32, **kw),
+                             node=torch.zeros(xcap, dtype=torch.int32, **kw), own=torch.zeros(xcap, dtype=torch.int64, **kw),
+                             opp=torch.zeros(xcap, dtype=torch.int64, **kw))
+                    v = _lib.MctsValueAhead()
+                    v.x_capacity, v.row_capacity = xcap, rcap
+                    v.x_count, v.x_game, v.x_node = x["count"].data_ptr(), x["game"].data_ptr(), x["node"].data_ptr()
+                    v.x_own, v.x_opp = x["own"].data_ptr(), x["opp"].data_ptr()
+                    v.row_count = self._va_row_count.data_ptr()
+                    v.row_own, v.row_opp = self._va_rows["own"].data_ptr(), self._va_rows["opp"].data_ptr()
+                    v.row_node, v.row_v = self._va_rows["node"].data_ptr(), self._va_rows["v"].data_ptr()
+                    v.total = self._va_total.data_ptr()
+                    a.value_ahead = C.addressof(v)
+                    self._va_x.append(x)
+                    self._va.append(v)
+                self._ev_priors = torch.cuda.Event()
+                self._ev_rows = torch.cuda.Event()
 
             def reset_lookahead(mask):
                 if mask is None:
@@ -285,6 +332,7 @@ class BatchedMCTS(object):
                     self._la_next_seq[m] = 0
                     self._la_cache_seq[m] = -1
             self.tree.reset_hooks = [reset_lookahead]
+        self.value_ahead = bool(getattr(self, "value_ahead", False))
         self.tree.reset_hooks = list(getattr(self.tree, "reset_hooks", ())) + [
             lambda mask: setattr(self, "_live_after_compaction", 0)]
         # Game-asynchronous steps (iago_mcts_async in include/iago_hip.h): a game whose leaf has a
@@ -352,8 +400,20 @@ class BatchedMCTS(object):
 
     @property
     def n_value_evals(self):
-        """Value-net evaluations so far (with the value cache: first visits of leaves only)."""
+        """Value-net evaluations executed so far: with the value cache the first visits of leaves that
+        had no stored value (n_value_inline) + the rows of the value look-ahead's batches
+        (n_value_ahead)."""
+        return self.n_value_inline + self.n_value_ahead if self.value_cache else self.n_leaf_evals
+
+    @property
+    def n_value_inline(self):
+        """Evaluations on the playouts' critical path (a leaf visited before it had a value)."""
         return int(self._value_total.item()) if self.value_cache else self.n_leaf_evals
+
+    @property
+    def n_value_ahead(self):
+        """Rows the value look-ahead's batches have evaluated (hits, duplicates and never-visited)."""
+        return int(self._va_total.item()) if self.value_ahead else 0
 
     @n_policy_evals.setter
     def n_policy_evals(self, value):
@@ -510,7 +570,8 @@ class BatchedMCTS(object):
             # select, expand from the cache, continue, list the leaves without a value: one launch
             check(L.iago_mcts_descend(self.tree.ref(), _p(own), _p(opp), _p(active), self.c_puct, self.n_thr,
                                       _p(self.cur_node), _p(self.cur_own), _p(self.cur_opp), _p(self.legal),
-                                      _p(self.stats) if self.stats is not None else None, C.byref(self._la[0]),
+                                      _p(self.stats) if self.stats is not None else None,
+                                      C.byref(self._la[self._la_cur]),   # (the group's queue of expanded nodes)
                                       _p(self._fresh_idx) if self.value_cache else None,
                                       _p(self._fresh_count) if self.value_cache else None,
                                       _p(self._value_total) if self.value_cache else None, _stream()),
@@ -532,7 +593,8 @@ class BatchedMCTS(object):
         L = _lib.lib()
         check(L.iago_mcts_descend(self.tree.ref(), _p(own), _p(opp), _p(active), self.c_puct, self.n_thr,
                                   _p(self.cur_node), _p(self.cur_own), _p(self.cur_opp), _p(self.legal),
-                                  _p(self.stats) if self.stats is not None else None, C.byref(self._la_async[0]),
+                                  _p(self.stats) if self.stats is not None else None,
+                                  C.byref(self._la_async[self._la_cur]),
                                   None, None, _p(self._value_total), _stream()), "iago_mcts_descend")
         ro = self.__dict__.get("_async_rollout")
         if ro is None or ro._keep[2] is not self.rollout_weights:
@@ -558,7 +620,23 @@ class BatchedMCTS(object):
                                                 _stream()), "iago_mcts_store_priors")
         q["count"].zero_()
 
-    def _lookahead_block(self, own, opp, active, stream_ids, async_=False):
+    def _flush_value_ahead(self, which, rows_event=None):
+        """The value look-ahead's batch for the nodes queue `which` holds: one row per child without a
+        value, the value net on the rows, the results into the children's records.  rows_event: recorded
+        once the queue has been consumed (the next group may then append to it)."""
+        L = _lib.lib()
+        va, rows = self._va[which], self._va_rows
+        self._va_row_count.zero_()
+        check(L.iago_mcts_value_ahead_rows(self.tree.ref(), C.byref(va), _stream()), "iago_mcts_value_ahead_rows")
+        self._va_x[which]["count"].zero_()
+        if rows_event is not None:
+            rows_event.record()
+        with torch.no_grad():
+            self.value_fn.forward_boards_batch(rows["own"], rows["opp"], self._va_row_count, rows["v"],
+                                               self.va_boards, self.va_grid)
+        check(L.iago_mcts_value_ahead_store(self.tree.ref(), C.byref(va), _stream()), "iago_mcts_value_ahead_store")
+
+    def _lookahead_block(self, own, opp, active, stream_ids, async_=False, last=True):
         """Two groups of K playouts.  On entry queue 1 may hold the leaves of the previous block's
         second group and queue 0 is empty; on exit the same.  With lookahead_overlap = j > 0 the
         batch of the previous group runs on the side stream beside the first j playouts of a group
@@ -567,15 +645,25 @@ class BatchedMCTS(object):
         iterator of 2 K Philox stream ids."""
         K, j = self.lookahead, self.lookahead_overlap
         main = torch.cuda.current_stream()
+        va = self.value_ahead
         for grp in (0, 1):
             self._la_cur = grp
             if j:
                 self._la_side.wait_stream(main)
                 with torch.cuda.stream(self._la_side):
                     self._flush_lookahead(1 - grp)
+                    if va:
+                        # the value batch of the previous group's expansions goes on beside this whole
+                        # group; the playouts only wait for the priors (playout j) and, before the next
+                        # group appends to the queue, for the rows kernel that consumes it
+                        self._ev_priors.record()
+                        self._flush_value_ahead(1 - grp, self._ev_rows)
             for i in range(K):
                 if j and i == j:
-                    main.wait_stream(self._la_side)
+                    if va:
+                        main.wait_event(self._ev_priors)
+                    else:
+                        main.wait_stream(self._la_side)
                 if async_:
                     self._step_async(own, opp, active)
                 elif stream_ids is None:
@@ -585,6 +673,10 @@ class BatchedMCTS(object):
                     self._playout_lookahead(own, opp, active, stream_id=next(stream_ids))
             if not j:
                 self._flush_lookahead(grp)
+            if va:
+                main.wait_event(self._ev_rows)
+        if va and last:
+            main.wait_stream(self._la_side)   # (a captured graph ends with every stream joined)
         self._la_cur = 0
 
     def _lookahead_tail(self, own, opp, active, n, stream_ids):
@@ -592,6 +684,8 @@ class BatchedMCTS(object):
         a batch after every K of them and at the end (one stream); both queues end empty."""
         if self.lookahead_overlap:
             self._flush_lookahead(1)
+        if self.value_ahead:
+            self._flush_value_ahead(1)
         self._la_cur = 0
         for i in range(n):
             if stream_ids is None:
@@ -601,6 +695,8 @@ class BatchedMCTS(object):
                 self._playout_lookahead(own, opp, active, stream_id=next(stream_ids))
             if (i + 1) % self.lookahead == 0 or i + 1 == n:
                 self._flush_lookahead(0)
+                if self.value_ahead:
+                    self._flush_value_ahead(0)
 
     def simulate(self, own, opp, active, n_active=None):
         """One MCTS.playout for every active game (eager launches)."""
@@ -608,6 +704,8 @@ class BatchedMCTS(object):
             self._la_cur = 0
             self._playout_lookahead(own, opp, active, stream_id=self.sim_counter)
             self._flush_lookahead(0)  # a lone playout flushes at once: the queues are empty between calls
+            if self.value_ahead:
+                self._flush_value_ahead(0)
             self.sim_counter = (self.sim_counter + 1) & 0xFFFFFFFF
             if n_active is not None:
                 self.n_leaf_evals += n_active
@@ -629,7 +727,7 @@ class BatchedMCTS(object):
         """What the captured graph baked in: device pointers and versions of every weight
         (and of the layouts cached from them), the rollout table, the scalar arguments."""
         key = [self.lmbda, self.c_puct, self.n_thr, self.lookahead, self.lookahead_overlap, self.value_cache,
-               self.async_steps,
+               self.async_steps, self.value_ahead,
                getattr(self, "fused_descent", False), self.fused_leaf_eval,
                self.stats.data_ptr() if self.stats is not None else 0,
                self.rollout_weights.table.data_ptr() if self.rollout_weights is not None else 0]
@@ -705,6 +803,10 @@ class BatchedMCTS(object):
         if self.lookahead:
             self._flush_lookahead(0)  # (queues empty: allocations and one-time setup only)
             self._flush_lookahead(1)
+            if self.value_ahead:
+                self._flush_value_ahead(0)
+                with torch.cuda.stream(self._la_side):
+                    self._flush_value_ahead(1)
             torch.cuda.synchronize()
         if self.async_steps:
             # the asynchronous step's own entry points, once, on empty queues and no game rolled
@@ -722,8 +824,9 @@ class BatchedMCTS(object):
             # the one-block graph
             self._graph_long = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_long):
-                for _ in range(self.graph_blocks):
-                    self._lookahead_block(self._g_own, self._g_opp, self._g_active, None, async_=self.async_steps)
+                for b in range(self.graph_blocks):
+                    self._lookahead_block(self._g_own, self._g_opp, self._g_active, None, async_=self.async_steps,
+                                          last=b + 1 == self.graph_blocks)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             if self.lookahead:
@@ -912,8 +1015,8 @@ class BatchedMCTS(object):
         return {"select": sel, "backup": bak, "levels": lv, "children_scored": ch}
 
     def memory_bytes(self):
-        """Device memory this engine holds, by part: the tree pools (22 B per node, 26 B with the
-        value cache; twice that once compact() has allocated its second pool), the look-ahead's
+        """Device memory this engine holds, by part: the tree pools (32-byte node records;
+        twice that once compact() has allocated its second pool), the look-ahead's
         prior cache ([game][slot][64] float32) and queues, the recorded paths, and the policy
         net's scratch for its multi-launch forward (network.SLPolicy.SPLIT3_SCRATCH_ROWS x 50,176 B
         = 205 MB per stream that calls it -- the search uses up to three: eager, capture, side
@@ -926,6 +1029,8 @@ class BatchedMCTS(object):
             out["queues"] = sum(t.numel() * t.element_size() for q in self._la_queues for t in q.values())
             if self._la_path is not None:
                 out["paths"] = self._la_path.numel() * 4
+        if self.value_ahead:
+            out["value_ahead"] = sum(t.numel() * t.element_size() for d in self._va_x + [self._va_rows] for t in d.values())
         pool = getattr(self.policy_fn, "__dict__", {}).get("_split3_scratch_pool", {})
         out["policy_scratch"] = sum(b.numel() for k, b in pool.items() if k != "retired") + \
             sum(b.numel() for b in pool.get("retired", ()))

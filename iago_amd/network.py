@@ -416,6 +416,22 @@ class Value(nn.Module, _NpzMixin):
                                        overflow=self._overflow_flag(own.device), index=index, n_dev=n_dev, out=out,
                                        rollout=rollout)
 
+    def forward_boards_batch(self, own, opp, n_dev, out, boards_per_workgroup=2, max_workgroups=192):
+        """The net on boards 0 .. *n_dev (device-side count) of own / opp, values to out[i], as a batch
+        OFF the playouts' critical path (the search's value look-ahead): boards_per_workgroup boards
+        share a workgroup's weight stream, at most max_workgroups workgroups walk the rows
+        (iago_value_forward_batch).  Bit-identical per board to every other split-f16 forward."""
+        if not (self.split_f16 and own.is_cuda and not self.training and not torch.is_grad_enabled()
+                and not torch.is_autocast_enabled()):
+            raise ValueError("forward_boards_batch: CUDA boards, eval mode, split_f16")
+        from . import ops
+        layers = [self._split_weights(k) + (getattr(self, "block%d" % k).conv.bias,) for k in range(2, 9)]
+        return ops.value_forward_split((own, opp), self.block1.conv.weight, self.block1.conv.bias, layers,
+                                       self._head_weights(), self.block9.conv.weight, self.block9.conv.bias,
+                                       self.fc10.weight, self.fc11.weight,
+                                       overflow=self._overflow_flag(own.device), n_dev=n_dev, out=out,
+                                       batch=(boards_per_workgroup, max_workgroups))
+
     def forward_boards_async(self, own, opp, out, rollout, async_ref):
         """One game-asynchronous search step's leaf evaluation (iago_value_rollout_async): the
         rollouts of the games that descended in this step + one piece of this net for every queue

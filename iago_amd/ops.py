@@ -421,14 +421,16 @@ def split_head_weights(w9):
 
 
 def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None, index=None, n_dev=None,
-                        out=None, rollout=None, async_ref=None):
+                        out=None, rollout=None, async_ref=None, batch=None):
     """The whole Value net in one launch (iago_value_forward_split).  x: float32 planes
     (n, 2, 8, 8) or a pair (own, opp) of int64 bitboards (own = side to move); layers: the 7
     (w_hi, w_lo, bias) of blocks 2..8 (split_weights); head: split_head_weights(w9).
     index / n_dev (boards only): evaluate boards index[0 .. min(n, *n_dev)) and write their
     values to out[index[i]] (out: (n_boards,) float32, the other entries untouched).
     rollout: a PreparedRollout (rollout_prepare) to play in the SAME launch (iago_value_rollout:
-    the leaf evaluation of a playout, value net on the listed leaves + rollout of all)."""
+    the leaf evaluation of a playout, value net on the listed leaves + rollout of all).
+    batch = (boards per workgroup, max workgroups): the device-counted batch form for work off the
+    playouts' critical path (iago_value_forward_batch; n_dev required)."""
     a = _lib.ValueSplitArgs()
     if isinstance(x, tuple):
         own, opp = x
@@ -473,6 +475,9 @@ def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None
               "iago_value_rollout_async")
     elif rollout is not None:
         check(_lib.lib().iago_value_rollout(C.byref(a), rollout.ref, _stream()), "iago_value_rollout")
+    elif batch is not None:
+        check(_lib.lib().iago_value_forward_batch(C.byref(a), int(batch[0]), int(batch[1]), _stream()),
+              "iago_value_forward_batch")
     else:
         check(_lib.lib().iago_value_forward_split(C.byref(a), _stream()), "iago_value_forward_split")
     return out

@@ -377,6 +377,16 @@ typedef struct iago_value_split_args {
     const int32_t *n_dev;  /* optional device-side row count: only the first min(n, *n_dev) rows */
 } iago_value_split_args;
 IAGO_API int iago_value_forward_split(const iago_value_split_args *args, void *stream);
+/*
+ * The same net on a batch whose row count is known only on the device (args->n_dev required,
+ * args->n = the buffers' capacity), for work OFF the playouts' critical path (the value
+ * look-ahead): `boards_per_workgroup` (1, 2 or 4) boards share a workgroup's weight stream and at
+ * most `max_workgroups` workgroups walk the rows with the grid's stride, so that the launch leaves
+ * the rest of the chip to the kernels of the playouts beside it.  Same products in the same order
+ * per board as iago_value_forward_split: bit-identical values.
+ */
+IAGO_API int iago_value_forward_batch(const iago_value_split_args *args, int32_t boards_per_workgroup,
+                                      int32_t max_workgroups, void *stream);
 
 /*
  * The leaf evaluation of a playout (MCTS.py:123-125) in ONE launch: iago_rollout of all leaves
@@ -602,6 +612,40 @@ typedef struct iago_mcts_async {
     void *scratch;
 } iago_mcts_async;
 
+/*
+ * Value look-ahead.  value_func(state) (MCTS.py:97-103) is a pure function of the position, and
+ * under Node.select's score (MCTS.py:44-49,75-76: u = c_puct*P*sqrt(N)/(0.01+n) with P >= 0.1) an
+ * unvisited child outscores every visited one, so the children of a node that has just expanded
+ * are first-visited one after the other during the node's next visits -- each of those visits ends
+ * on a leaf without a stored value (the value cache's NaN), i.e. on a one-board walk of the value
+ * net on the playouts' critical path.  With this state iago_mcts_descend records every node it
+ * expands (x_* queue: game, node, the node's position), iago_mcts_value_ahead_rows turns the
+ * queued nodes into one row per child that has no value yet (the child's position, own = side to
+ * move there, and the global index of its record), the caller runs the value net on the rows as
+ * ONE batch off the critical path (iago_value_forward_batch -> row_v) and
+ * iago_mcts_value_ahead_store writes the results into the children's `v` -- exactly the number the
+ * first visit would have computed (the net's output for a board does not depend on its batch), so
+ * the trees are bit-identical; a child that is visited before its value has landed is evaluated
+ * in place as before.  Everything here is a hint: a full queue drops entries, nothing is reported.
+ * Arrays caller-owned: x_* [x_capacity], row_* [row_capacity], the count words zeroed by the caller
+ * (x_count after iago_mcts_value_ahead_rows has consumed the queue, row_count before it runs).
+ * The queues must be drained (rows + net + store) before iago_mcts_compact / iago_mcts_reset /
+ * a change of the value net's weights: rows address nodes by pool index.
+ */
+typedef struct iago_mcts_value_ahead {
+    int32_t x_capacity, row_capacity;
+    int32_t *x_count;
+    int32_t *x_game, *x_node;     /* game and local id of an expanded node */
+    uint64_t *x_own, *x_opp;      /* its position, own = side to move (the children's mover is the other side) */
+    int32_t *row_count;
+    uint64_t *row_own, *row_opp;  /* a child's position, own = side to move at the child */
+    int64_t *row_node;            /* game * capacity + local id of the child */
+    float *row_v;                 /* the value net's output for the row */
+    int64_t *total;               /* optional: rows produced so far (accumulated by iago_mcts_value_ahead_rows) */
+} iago_mcts_value_ahead;
+IAGO_API int iago_mcts_value_ahead_rows(const iago_mcts_tree *tree, const iago_mcts_value_ahead *va, void *stream);
+IAGO_API int iago_mcts_value_ahead_store(const iago_mcts_tree *tree, const iago_mcts_value_ahead *va, void *stream);
+
 typedef struct iago_mcts_lookahead {
     int32_t trigger, slots;
     int32_t *next_seq;
@@ -632,6 +676,8 @@ typedef struct iago_mcts_lookahead {
     const iago_mcts_async *async; /* optional: iago_mcts_descend and iago_mcts_mix_backup_lookahead run one
                                      game-asynchronous STEP instead of one lockstep playout (`active` is then
                                      the search's mask; `counter` and `clear_word` are not used) */
+    const struct iago_mcts_value_ahead *value_ahead; /* optional: iago_mcts_descend queues every node it expands
+                                     for the value look-ahead (below) */
 } iago_mcts_lookahead;
 IAGO_API int iago_mcts_mix_backup_lookahead(const iago_mcts_tree *tree, const uint8_t *active,
                                             const int32_t *cur_node, const uint64_t *cur_own,

@@ -90,18 +90,22 @@ def _positions(G, golden_rules):
     return own, opp
 
 
-@pytest.mark.parametrize("async_steps", [False, True])
+@pytest.mark.parametrize("async_steps,value_ahead", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("n_sims,n_sims2,G", [(100, 60, 320), (400, 37, 64)])
-def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_sims, n_sims2, G, async_steps):
+def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_sims, n_sims2, G, async_steps,
+                                                     value_ahead):
     """async_steps=False: lockstep playouts, the default and what bench.py times.  True: the same
     search as game-asynchronous steps (iago_mcts_async: a game with a fresh leaf waits while the value
-    net walks its board in 3 pieces beside the other games' steps) -- the same trees, bit for bit."""
+    net walks its board in 3 pieces beside the other games' steps) -- the same trees, bit for bit.
+    value_ahead=True: the children of every expanded node get their values from batches on the side
+    stream (iago_mcts_value_ahead) -- again the same trees."""
     engine, ops, policy, value, rw = shipped
     own, opp = _positions(G, golden_rules)
     cap = engine.suggest_capacity(n_sims + n_sims2, 15, moves=2)
     m = engine.BatchedMCTS(G, policy, value, rw, lmbda=0.5, c_puct=1.0, n_thr=15, capacity=cap, seed=5,
                            game_id_base=1000, use_graph=True, z_log_rows=max(n_sims, n_sims2),
-                           async_steps=async_steps)
+                           async_steps=async_steps, value_ahead=value_ahead)
+    assert m.value_ahead == value_ahead and (not value_ahead or m.n_value_ahead == 0)
     # what bench.py's mcts_leg runs
     assert m.use_graph and m.sync_free and m.lookahead == 4 and m.lookahead_overlap == 2
     assert m.value_cache and m.fused_descent and m.fused_leaf_eval and m._la_path is not None
@@ -120,6 +124,7 @@ def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_si
     assert int(m.tree.n_nodes[5].item()) == 1 and int(m.tree.n_visits[5 * cap].item()) == 0
     # the value net ran on a fraction of the leaves only (the cache), the policy a few visits ahead
     assert 0 < m.n_value_evals < 0.6 * m.n_leaf_evals and m.n_policy_evals > 0
+    assert (m.n_value_ahead > 0) == value_ahead
 
     probe = NetProbe(ops, policy, value)
     checked = [g for g in list(range(0, 12)) + list(range(G // 2 - 2, G // 2 + 6)) if g != 5]
