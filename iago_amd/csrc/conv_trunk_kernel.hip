@@ -238,11 +238,9 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
 #pragma unroll
         for (int pr = 0; pr < NPAIR; pr++)
             wrow[pr][j] = (uint32_t)((32 * j + lane_cell) * RS + pr * 2 * BS);
-#define STAMP(i)
 
     const int L_lo = PIECES ? W.layer_lo : 0, L_hi = PIECES ? W.layer_hi : P.n_layers;
     for (int L = L_lo; L < L_hi; L++) {
-        STAMP(3 * L);
         const int n_chunks = L == 0 ? (P.cin0 >> 4) : 8;
         // this lane's A operand: output channel 32 wv + r, input channels 8 h .. 8 h + 7 of
         // the k-step's chunk; a k-step (chunk, tap) is 128 x 32 B further
@@ -321,7 +319,6 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                     addr[pr][j][tap] -= 32u * (uint32_t)n_chunks;
 
         // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T
-        STAMP(3 * L + 1);
         // bias of the 16 channels this lane finishes: 32 wv + 8 q + 4 h + t
         f2 bia[8];
 #pragma unroll
@@ -362,10 +359,8 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
         }
         // beyond the f16 range, or NaN (the clamp would hide it)
         saturated |= !(vmax <= 65000.0f) || !(vsum.x + vsum.y == vsum.x + vsum.y);
-        STAMP(3 * L + 2);
         __syncthreads();
     }
-    STAMP(3 * P.n_layers);
     if (P.overflow && saturated)
         *P.overflow = 1u;
 

@@ -78,22 +78,6 @@ __device__ __forceinline__ void add8(Row8 &e, const float4 lo, const float4 hi)
     e.d += (f2){hi.z, hi.w};
 }
 
-// Diagnostic build only (-DEXP_STAMPS, tools/exp_stamps.py): s_memtime stamps at the
-// segment boundaries of a turn; the sums leave through final_own/final_opp.  Never
-// defined in the shipped library.
-#ifdef EXP_STAMPS
-#define STAMP(i)                                                                      \
-    do {                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                            \
-        unsigned long long t_;                                                        \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
-        __builtin_amdgcn_sched_barrier(0);                                            \
-        G.seg[i] += t_ - G.last;                                                      \
-        G.last = t_;                                                                  \
-    } while (0)
-#else
-#define STAMP(i)
-#endif
 
 // Per-board state carried across turns (replicated in the 8 lanes of the group).
 struct Game {
@@ -104,9 +88,6 @@ struct Game {
     // the VALU (compare results routed through SGPR masks and SALU logic cost a
     // VALU->SALU->VALU round trip per term)
     uint32_t pass_flg, done;
-#ifdef EXP_STAMPS
-    unsigned long long seg[6], last;
-#endif
 };
 
 template <bool PRODUCT>
@@ -133,14 +114,12 @@ __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t
         tb[2 * ky + 1] = lds_f4(to + 1024);
     }
 
-    STAMP(0); // window + E-read issue
     // ---- legal moves of the side to move
     const uint64_t o = to_lane(G.own, L), p = to_lane(G.opp, L);
     const uint64_t legal = group8_legal(o, p, L);
     const uint32_t has = min(1u, (uint32_t)legal | (uint32_t)(legal >> 32)); // 0/1
     const uint32_t lr = (uint32_t)(legal >> (8u * r)) & 0xFFu;
 
-    STAMP(1); // movegen + LM issue
     // ---- unnormalised probabilities e[x] of row r, zero on illegal cells
     Row8 E;
     E.a = (f2){bias[0], bias[1]};
@@ -215,10 +194,8 @@ __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t
     }
     action &= 63u;
 
-    STAMP(3); // cumsum, scan, count, fix-up
     // ---- flips and board update (branch-free)
     const uint64_t f = group8_flips(o, p, action, L);
-    STAMP(4); // flips
     const uint32_t live_turn = G.done ^ 1u;
     const uint32_t play = has & live_turn;
     const uint32_t passing = (has ^ 1u) & live_turn;
@@ -242,7 +219,6 @@ __device__ __forceinline__ void play_turn(Game &G, const float u, const uint32_t
     // `while stone_num < 64` is evaluated once per pair of turns (mcts_self_play.py:26-28)
     if (t & 1u)
         G.done |= G.stones >> 6;
-    STAMP(5); // update
 }
 
 template <bool PRODUCT>
@@ -285,11 +261,6 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
         G.pass_flg = 0u;
         G.done = (!live || G.stones >= 64u) ? 1u : 0u; // `while stone_num < 64` (mcts_self_play.py:26)
         G.nt = 0;
-#ifdef EXP_STAMPS
-        for (int i = 0; i < 6; i++)
-            G.seg[i] = 0;
-        G.last = __builtin_amdgcn_s_memtime();
-#endif
         const uint32_t rid = P.id_base + (uint32_t)b;
         uint32_t rw[4] = {0, 0, 0, 0};
 
@@ -334,14 +305,6 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P)
                 P.final_opp[b] = G.opp;
             if (P.n_turns)
                 P.n_turns[b] = (uint8_t)G.nt;
-#ifdef EXP_STAMPS
-            if (P.final_own && P.final_opp) { // diagnostic build: segment cycle sums, 21 bits each
-                P.final_own[b] = (G.seg[0] & 0x1FFFFF) | ((G.seg[1] & 0x1FFFFF) << 21) |
-                                 ((G.seg[2] & 0x1FFFFF) << 42);
-                P.final_opp[b] = (G.seg[3] & 0x1FFFFF) | ((G.seg[4] & 0x1FFFFF) << 21) |
-                                 ((G.seg[5] & 0x1FFFFF) << 42);
-            }
-#endif
         }
     }
 }
