@@ -205,6 +205,25 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
 
 MFMA_FLOP_32x32x16 = 2 * 32 * 32 * 16    # one v_mfma_f32_32x32x16_f16 wave-instruction
 MIN_PROFILE_LAUNCHES = 100
+F16_PEAK_TF, F32_MATRIX_PEAK_TF = 2500.0, 157.3    # MI355X_MICROARCH.md: dense f16 MFMA / f32 matrix
+VALUE_FLOP, POLICY_FLOP = 122_994_944, 122_847_232   # algorithmic FLOPs per evaluation
+# wave-level MFMA instructions one evaluated board executes in the search's net kernels: blocks 2..8 =
+# (36 + 6 x 72) k-steps x (2 tiles x 3 or 6 MFMAs) x 4 waves (+ the Value head's 8 x 2 x 3 on one wave)
+VALUE_MFMA_PER_BOARD = 468 * 6 * 4 + 48
+POLICY_MFMA_PER_BOARD = 468 * 12 * 4
+
+
+def csrc_sha16():
+    """Identity of the kernel sources (iago_amd/csrc/*, include/iago_hip.h): what a committed rocprofv3
+    summary must carry (tools/summarize_mcts_profile.py writes it) to be quoted beside measured numbers."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    here = os.path.dirname(os.path.abspath(__file__))   # (the sources of THIS file's tree, wherever ROOT points)
+    for path in sorted(glob.glob(os.path.join(here, "iago_amd", "csrc", "*"))) + [os.path.join(here, "include", "iago_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def net_kernel_profiles():
@@ -214,9 +233,17 @@ def net_kernel_profiles():
     (tools/profile_mcts.sh -> profiles/*_mcts_fullgame_pmc_summary.json): rocprofv3's average
     duration and the executed f16 MFMA FLOP/s = SQ_INSTS_MFMA x 32,768 / duration against the
     2.5 PFLOP/s dense peak.  A kernel with fewer than 100 launches in the profile is refused
-    (a one-launch sample of a variant off the path had been reported here)."""
+    (a one-launch sample of a variant off the path had been reported here).
+    These are numbers of a COMMITTED profile, not of this run: the entry names the profile and says
+    whether it was taken on the kernel sources of this tree (`current`: its csrc_sha16 equals
+    csrc_sha16() now); a stale profile is still listed, marked, and its fractions are not lifted to
+    the top-level line.  Per kernel, beside the executed f16 MFMA rate: the evaluated boards per
+    launch (MFMA instructions / instructions per board), the USEFUL rate = boards x SURVEY 8(d)'s
+    FLOPs per evaluation / duration, as fraction of the f16 peak and as multiple of the float32
+    matrix peak, and the bytes a CU pulls from L2 per evaluation (TCP_TCC_READ_REQ x 128 B)."""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mcts_fullgame_pmc_summary.json")))
+    now = csrc_sha16()
     for path in reversed(paths):
         with open(path) as f:
             prof = json.load(f)
@@ -231,7 +258,19 @@ def net_kernel_profiles():
             if k.get("SQ_INSTS_MFMA"):
                 tf = k["SQ_INSTS_MFMA"] * MFMA_FLOP_32x32x16 / (k["avg_us"] * 1e-6) / 1e12
                 e.update({"mfma_insts_per_launch": k["SQ_INSTS_MFMA"], "executed_tflops": tf,
-                          "bound": "mfma", "peak": 2500.0, "frac": tf / 2500.0})
+                          "bound": "mfma", "peak": F16_PEAK_TF, "frac": tf / F16_PEAK_TF})
+                per_board, flop = {"value_rollout_kernel": (VALUE_MFMA_PER_BOARD, VALUE_FLOP),
+                                   # (a launch of the two-launch forward walks half a net)
+                                   "policy_resident_kernel": (POLICY_MFMA_PER_BOARD / 2, POLICY_FLOP / 2)}.get(name, (0, 0))
+                if per_board:
+                    boards = k["SQ_INSTS_MFMA"] / per_board
+                    useful = boards * flop / (k["avg_us"] * 1e-6) / 1e12
+                    e.update({"boards_per_launch": boards, "useful_tflops": useful,
+                              "useful_frac_f16_peak": useful / F16_PEAK_TF,
+                              "useful_x_f32_matrix_peak": useful / F32_MATRIX_PEAK_TF})
+                    if k.get("TCP_TCC_READ_REQ_sum"):
+                        per_eval = k["TCP_TCC_READ_REQ_sum"] * 128.0 / boards
+                        e["l2_to_cu_bytes_per_eval"] = per_eval * (2 if name == "policy_resident_kernel" else 1)
             elif k.get("hbm_bytes_per_launch"):
                 gb = k["hbm_bytes_per_launch"] / (k["avg_us"] * 1e-6) / 1e9
                 e.update({"bound": "hbm", "achieved_gb_per_s": gb, "peak": HBM_PEAK_GBS, "frac": gb / HBM_PEAK_GBS})
@@ -239,6 +278,12 @@ def net_kernel_profiles():
         if "value_rollout_kernel" in out and "policy_resident_kernel" in out:
             out["profile"] = os.path.basename(path)
             out["command"] = prof.get("command")
+            out["profile_csrc_sha16"] = prof.get("csrc_sha16")
+            out["current"] = prof.get("csrc_sha16") == now
+            out["provenance"] = ("committed rocprofv3 profile of an earlier run of this command, %s"
+                                 % ("taken on these kernel sources" if out["current"] else
+                                    "STALE: taken on other kernel sources (csrc_sha16 %s, now %s)"
+                                    % (prof.get("csrc_sha16"), now)))
             return out
     return None
 
@@ -253,7 +298,12 @@ def _mcts_roofline(leaf, pol, dt, world, value_f32, policy_split3=False):  # lea
         return {"bound": "mfma", "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
                 "flops_per_leaf_eval": 122_994_944, "flops_per_policy_eval": 122_847_232}
     a = (leaf * 3 + (pol * 6 if policy_split3 else 0)) * 122_683_392 / dt / 1e12 / world
+    useful = (leaf * VALUE_FLOP + pol * POLICY_FLOP) / dt / 1e12 / world
     return {"bound": "mfma", "achieved": a, "peak": 2500.0, "unit": "TFLOP/s", "frac": a / 2500.0,
+            # the same loop in SURVEY 8(d)'s algorithmic FLOPs (one multiply-add per product, whatever the
+            # number of f16 pieces it is executed in)
+            "useful_tflops": useful, "useful_frac_f16_peak": useful / F16_PEAK_TF,
+            "useful_x_f32_matrix_peak": useful / F32_MATRIX_PEAK_TF,
             "dtype": "f16 MFMA operands (split f32), f32 accumulate",
             "mfma_flops_per_leaf_eval": 3 * 122_683_392,
             "mfma_flops_per_policy_eval": (6 * 122_683_392 if policy_split3 else 0),
@@ -436,14 +486,31 @@ def mcts_b1_leg(n_sims=200):
             "sims": n_sims, "move": int(a), "hipgraph": True}
 
 
-def reinforce_leg(n_iters, world, rank, dist):
+def miopen_find_db_state():
+    """MIOpen's user find-db decides which backward-convolution solvers the REINFORCE update runs on:
+    on a fresh box (no tuned entries) the immediate-mode fallback solvers take ~40 ms per update, once
+    any process has run a find (torch.backends.cudnn.benchmark = True: ~110 s of tuning, not done here)
+    ~10 ms (LABNOTES.md, round 3).  'warm' = the user db holds find records for this GPU."""
+    import glob
+    home = os.environ.get("MIOPEN_USER_DB_PATH") or os.path.join(os.path.expanduser("~"), ".config", "miopen")
+    files = [f for f in glob.glob(os.path.join(home, "**", "*.ufdb.txt"), recursive=True) if os.path.getsize(f) > 0]
+    return "warm" if files else "cold"
+
+
+def reinforce_leg(n_iters, world, rank, dist, mcts_rounds=1):
     """BASELINE configs[4] in miniature: `n_iters` iterations of the REINFORCE loop
     (src/train_rl.py:28-81): one set of 2N = 64 SLPolicy-vs-SLPolicy games sharded
     over the ranks, all-gather of the (state, action, z) tuples, one update on
-    every rank.  Random-init SLPolicy (seed 0), opponent = the current weights."""
-    from iago_amd import network
+    every rank.  Random-init SLPolicy (seed 0), opponent = the current weights.
+    Then, as configs[4] words it ("self-play feeding train_rl.py REINFORCE update on gathered
+    (s, pi, z)"), `mcts_rounds` rounds of PV-MCTS self-play (64 games sharded over the ranks, 20
+    playouts per move, the learner as the search's policy net) -> SelfPlayResult.tuples() ->
+    ReinforceTrainer.step_from_tuples (src/train_rl.py:55-66 on the gathered rows)."""
+    from iago_amd import engine, network, ops
+    from iago_amd.dist import shard_range
     from iago_amd.train_rl import ReinforceTrainer
     torch.manual_seed(0)
+    db_before = miopen_find_db_state()
     tr = ReinforceTrainer(network.SLPolicy(), pool_dir=None, N=32, seed=rank)
     for _ in range(4):
         tr.step()  # warm-up: MIOpen forward/backward kernel selection, allocator, weight-layout caches
@@ -458,10 +525,49 @@ def reinforce_leg(n_iters, world, rank, dist):
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    return {"iters_per_sec": n_iters / dt, "games_per_sec": 64 * n_iters / dt,
-            "tuples_per_iter": tuples / n_iters, "iters": n_iters,
-            "config": "64 policy-vs-policy games per set (SLPolicy, random init, fp32) + "
-                      "double-softmax REINFORCE update, ChainerAdam + WD 5e-4"}
+    out = {"iters_per_sec": n_iters / dt, "games_per_sec": 64 * n_iters / dt,
+           "tuples_per_iter": tuples / n_iters, "iters": n_iters, "ms_per_iter": dt / n_iters * 1e3,
+           # the figure depends on this state (19 sets/s cold, 45 warm on one MI355X): stated, not hidden
+           "miopen_find_db": db_before,
+           "config": "64 policy-vs-policy games per set (SLPolicy, random init, fp32) + "
+                     "double-softmax REINFORCE update, ChainerAdam + WD 5e-4"}
+    if mcts_rounds > 0:
+        w, b = shipped_rollout_weights()
+        games, sims = 64, 20
+        lo, hi = shard_range(games, rank, world)
+        value = network.Value().cuda().eval()
+        m = engine.BatchedMCTS(hi - lo, tr.model1, value, ops.RolloutWeights(w, b), n_thr=15,
+                               capacity=engine.suggest_capacity(sims, 15), seed=1, game_id_base=lo, use_graph=True)
+        sp = engine.SelfPlayEngine(m)
+
+        def one():
+            tr.model1.eval()
+            res = sp.play(sims)     # (the engine re-captures its graph: the weights changed)
+            return tr.step_from_tuples(res.tuples())
+
+        one()                       # warm-up round
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        leaf0, n_tup, loss = m.n_leaf_evals, 0, None
+        for _ in range(mcts_rounds):
+            r = one()
+            n_tup += r["n_tuples"]
+            loss = r["loss"]
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt2 = time.perf_counter() - t0
+        out["mcts_fed"] = {"rounds": mcts_rounds, "rounds_per_sec": mcts_rounds / dt2, "seconds": dt2,
+                           "tuples_per_round": n_tup / mcts_rounds, "loss": loss,
+                           "leaf_evals_rank0": m.n_leaf_evals - leaf0,
+                           "config": "%d PV-MCTS self-play games per round (sharded over the ranks), %d playouts per "
+                                     "move, learner = the search's policy net -> tuples (own, opp, move, z) of both "
+                                     "colours -> step_from_tuples (gather, canonical order, REINFORCE update)"
+                                     % (games, sims)}
+        m.close()
+    return out
 
 
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2  # wave64 VALU instructions/ns: 1024 SIMD-32s, 2 cycles each
@@ -844,6 +950,9 @@ def main():
     ap.add_argument("--mcts-value-f32", action="store_true",
                     help="PV-MCTS leg: MIOpen float32 convolutions for the Value net instead of the "
                          "split-f16 MFMA kernels")
+    ap.add_argument("--mcts400-turns", type=int, default=4,
+                    help="PV-MCTS at 400 playouts per move (one GPU's share of BASELINE configs[3]): turns of the "
+                         "bounded sample, 0 = skip")
     ap.add_argument("--nthr1-turns", type=int, default=8,
                     help="PV-MCTS with n_thr = 1 (SURVEY.md 8d: the policy net inside every playout): turns of "
                          "the bounded sample, 0 = skip")
@@ -856,7 +965,7 @@ def main():
         cpu_worker_main(args.cpu_worker, args.cpu_worker_budget, args.cpu_worker_start, args.cpu_worker_seed)
         return
     if args.rollout_only:
-        args.mcts_turns, args.train_iters, args.no_cpu_baseline, args.nthr1_turns = 0, 0, True, 0
+        args.mcts_turns, args.train_iters, args.no_cpu_baseline, args.nthr1_turns, args.mcts400_turns = 0, 0, True, 0, 0
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher
@@ -918,6 +1027,17 @@ def main():
         nthr1["sample"] = "the first %d turns of the games (bounded sample), policy net inside every playout" \
                           % args.nthr1_turns
         nthr1["default_n_thr15_leaf_evals_per_sec"] = mcts["leaf_evals_per_sec"]
+    m400 = None
+    if mcts is not None and args.mcts400_turns > 0 and not args.mcts_only and not args.mcts_value_f32:
+        # BASELINE configs[3] at one GPU's share: the reference's 10 s budget per move (MCTS.py:80,139-147) as
+        # 400 playouts, `--mcts-games` games per GPU; bounded sample of the first turns (a full game at 400
+        # playouts is ~4 s: tools/time_value_ahead.py with SIMS=400), with the tuple gather when N > 1
+        r4 = mcts_leg(args.mcts_games, 400, args.mcts400_turns, False, world, rank, dist, use_graph=not args.mcts_eager)
+        m400 = {k: r4[k] for k in ("leaf_evals_per_sec", "leaf_evals", "policy_evals", "value_evals", "seconds",
+                                   "turns_played", "sims_per_move", "games_per_gpu", "tree_nodes_used_max",
+                                   "tree_capacity", "config")}
+        m400["config"] = m400["config"].replace("configs[2]", "configs[3] (one GPU's share)")
+        m400["sample"] = "the first %d turns of the games (bounded sample)" % args.mcts400_turns
     train = reinforce_leg(args.train_iters, world, rank, dist) if args.train_iters > 0 else None
     b1 = mcts_b1_leg() if (mcts is not None and rank == 0 and not args.mcts_only) else None
 
@@ -948,17 +1068,35 @@ def main():
             line["leaf_evals_per_sec"] = mcts["leaf_evals_per_sec"]
             if "games_per_sec" in mcts:
                 line["mcts_games_per_sec"] = mcts["games_per_sec"]
-            ks = (mcts.get("roofline") or {}).get("kernels") or {}
-            for name, key in (("value_rollout_kernel", "mcts_value_kernel_mfma_frac"),
-                              ("policy_resident_kernel", "mcts_policy_kernel_mfma_frac")):
-                if name in ks and "frac" in ks[name]:
-                    line[key] = ks[name]["frac"]    # executed f16 MFMA FLOP/s of the kernel / 2.5 PF (committed profile)
+            rl = mcts.get("roofline") or {}
+            if "useful_tflops" in rl:
+                line["mcts_useful_tflops"] = rl["useful_tflops"]                # measured in this run
+                line["mcts_useful_frac_f16_peak"] = rl["useful_frac_f16_peak"]
+                line["mcts_executed_frac_f16_peak"] = rl["frac"]
+            ks = rl.get("kernels") or {}
+            if ks:
+                # per-kernel fractions come from a COMMITTED profile (named here), and only from one taken
+                # on the kernel sources of this tree
+                line["mcts_kernel_profile"] = ks.get("profile")
+                line["mcts_kernel_profile_current"] = bool(ks.get("current"))
+            for name, key in (("value_rollout_kernel", "mcts_value_kernel"), ("policy_resident_kernel", "mcts_policy_kernel")):
+                if ks.get("current") and name in ks and "frac" in ks[name]:
+                    line[key + "_mfma_frac_committed_profile"] = ks[name]["frac"]
+                    if "useful_frac_f16_peak" in ks[name]:
+                        line[key + "_useful_frac_committed_profile"] = ks[name]["useful_frac_f16_peak"]
             line["mcts"] = mcts
+        if m400 is not None:
+            line["mcts400"] = m400
+            line["leaf_evals_per_sec_400"] = m400["leaf_evals_per_sec"]
         if nthr1 is not None:
             line["mcts_nthr1"] = nthr1
             line["leaf_evals_per_sec_nthr1"] = nthr1["leaf_evals_per_sec"]
         if train is not None:
             line["reinforce"] = train
+            line["reinforce_iters_per_sec"] = train["iters_per_sec"]
+            line["reinforce_miopen_find_db"] = train["miopen_find_db"]
+            if "mcts_fed" in train:
+                line["reinforce_mcts_fed_rounds_per_sec"] = train["mcts_fed"]["rounds_per_sec"]
         if b1 is not None:
             line["mcts_single_game"] = b1
         if not args.no_cpu_baseline and world == 1:  # the CPU baselines are N = 1 figures

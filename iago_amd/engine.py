@@ -749,17 +749,30 @@ class BatchedMCTS(object):
         cyclic garbage collector runs -- which must not happen while ANOTHER engine captures:
         destroying a graph is not permitted while a stream of the process is capturing."""
         self._graph = self._graph_long = self._graph_key = None
+        self._scratch_refs = None
 
     def _capture(self):
         """Record the playout launches into hipGraphs.  The cyclic garbage collector is held
         off for the duration: a collected torch.cuda.CUDAGraph of some other, unreferenced engine
         would be destroyed inside the capture, which HIP refuses (hipErrorStreamCaptureUnsupported)."""
         import gc
+        self._graph = self._graph_long = None
+        self._scratch_refs = None
         gc.collect()
+        # (this engine's old graphs are gone and with them its hold on the scratch buffers of the
+        # policy's multi-launch forward: the module drops its own references -- 205 MB per calling
+        # stream that a re-capture-per-update loop would otherwise pile up -- and the warm-up below
+        # allocates what the new capture needs.  Another engine that shares the module keeps the
+        # buffers ITS graphs address alive through its own _scratch_refs)
+        rel = getattr(self.policy_fn, "release_scratch", None)
+        if rel is not None:
+            rel()
         was_enabled = gc.isenabled()
         gc.disable()
         try:
             self._capture_graphs()
+            pool = getattr(self.policy_fn, "__dict__", {}).get("_split3_scratch_pool", {})
+            self._scratch_refs = [b for k, b in pool.items() if k != "retired"] + list(pool.get("retired", ()))
         finally:
             if was_enabled:
                 gc.enable()

@@ -227,8 +227,9 @@ class SLPolicy(nn.Module, _NpzMixin):
     SPLIT3_SCRATCH_ROWS = 4096
 
     def release_scratch(self):
-        """Drop the scratch buffers of forwards that no captured graph refers to any more (the
-        search engine calls it before it re-captures)."""
+        """Drop this module's references to the scratch buffers of its multi-launch forwards.
+        engine.BatchedMCTS._capture calls it before every (re-)capture; an engine keeps the buffers
+        its own captured graphs address alive itself (BatchedMCTS._scratch_refs)."""
         self.__dict__.pop("_split3_scratch_pool", None)
 
     def _split3_scratch(self, device, rows):

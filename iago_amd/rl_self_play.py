@@ -31,7 +31,13 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
 
     Returns dict: own/opp (T1,B) int64 recorded learner positions (own = colour
     1 = the mover), action (T1,B) int8 (-1 where that game did not move),
-    z (B,) int8 from colour 1's view, final_p1/final_p2, n_turns."""
+    z (B,) int8 from colour 1's view, final_p1/final_p2, n_turns.
+
+    Shard-independence of the games (a rank's games do not depend on how many other games share
+    its batch) holds for SLPolicy modules in eval mode with `split3` on (one board per workgroup);
+    that kernel clamps activations at 65000, so both models' saturation flags are read once at the
+    end of the batch and a saturated net raises here (the reference's float32 range is unbounded:
+    set `model.split3 = False` for such weights) instead of playing on from clamped priors."""
     B = n_games
     own = torch.full((B,), engine.START_OWN, dtype=torch.int64, device=device)
     opp = torch.full((B,), engine.START_OPP, dtype=torch.int64, device=device)
@@ -66,6 +72,9 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
         if t % 2 == 0 and bool(done.all().item()):
             break
     p1, p2 = (own, opp) if t % 2 == 0 else (opp, own)
+    for model in (model1, model2):
+        if getattr(model, "check_saturation", None) is not None:
+            model.check_saturation()   # raises and clears the flag (one readback per model and batch)
     if bool(nan_seen.item()):
         # iago_sample_moves returns 64 when no cell's CDF exceeds u: NaN probabilities.
         # numpy.random.choice raises here in the reference (src/rl_self_play.py:122)

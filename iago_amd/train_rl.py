@@ -234,6 +234,18 @@ class ReinforceTrainer(object):
         if colour is not None:
             keep = tup["colour"] == colour
         key = tup["turn"].to(torch.int64) * (1 << 32) + tup["game"].to(torch.int64)
+        if idist.world_size() > 1:
+            # the canonical order needs globally unique game ids: every rank must have built its
+            # engine with its own game_id_base (idist.shard_range); with the default 0 everywhere the
+            # ranks also play IDENTICAL games, whose duplicate rows would silently enter the update
+            gm = tup["game"].to(torch.int64)
+            span = torch.stack([gm.min(), gm.max()]) if gm.numel() else torch.tensor([1, 0], device=key.device)
+            spans = idist.gather_tuples(dict(lo=span[:1], hi=span[1:]))
+            lo, hi = spans["lo"].tolist(), spans["hi"].tolist()
+            live = sorted((a, b) for a, b in zip(lo, hi) if a <= b)
+            if any(live[i][1] >= live[i + 1][0] for i in range(len(live) - 1)):
+                raise ValueError("step_from_tuples: the ranks' game id ranges overlap (%s): build every rank's "
+                                 "BatchedMCTS with game_id_base = iago_amd.dist.shard_range(n_games)[0]" % live)
         g = _canonical(idist.gather_tuples(dict(own=tup["own"][keep], opp=tup["opp"][keep],
                                                 action=tup["move"][keep], z=tup["z"][keep], key=key[keep])))
         if g["z"].numel() == 0:

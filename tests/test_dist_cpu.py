@@ -54,14 +54,17 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_gather_tuples_world2_gloo():
-    world, port = 2, 29000 + os.getpid() % 2000
+@pytest.mark.parametrize("world", [2, 8])
+def test_gather_tuples_gloo(world):
+    """world 8 = the driver's node: 11 games over 8 ranks (shards of 1 and 2 games, some of them
+    without a tuple), an 8-way ragged gather, empty shards on 7 ranks, the replica broadcast."""
+    port = 29000 + (os.getpid() + 7 * world) % 2000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(4)]
+    got = [q.get(timeout=240) for _ in range(2 * world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -69,7 +72,7 @@ def test_gather_tuples_world2_gloo():
     want_own = [g * 1000 + k for g, k in rows]
     want_z = [(g % 3) - 1 for g, k in rows]
     full = [x for x in got if len(x) == 5]
-    assert len(full) == 2
+    assert len(full) == world
     for rank, own, pisum, z, shape in full:
         assert own == want_own and z == want_z
         assert shape == (len(rows), 64)
@@ -119,3 +122,17 @@ def test_bench_refuses_thin_kernel_profiles(tmp_path, monkeypatch):
     v = got["value_rollout_kernel"]
     assert v["launches"] == 500 and abs(v["executed_tflops"] - 1.8e6 * 32768 / 90e-6 / 1e12) < 1e-6
     assert abs(v["frac"] - v["executed_tflops"] / 2500.0) < 1e-12
+    # useful figures: boards per launch from the MFMA count, SURVEY 8(d)'s FLOPs per evaluation
+    boards = 1.8e6 / bench.VALUE_MFMA_PER_BOARD
+    assert abs(v["boards_per_launch"] - boards) < 1e-9
+    assert abs(v["useful_tflops"] - boards * bench.VALUE_FLOP / 90e-6 / 1e12) < 1e-6
+    assert abs(v["useful_frac_f16_peak"] - v["useful_tflops"] / 2500.0) < 1e-12
+    # provenance: a profile without the hash of the kernel sources it was taken on is
+    # STALE and says so; one that carries the current hash is `current`
+    assert got["current"] is False and "STALE" in got["provenance"]
+    (prof / "r97_mcts_fullgame_pmc_summary.json").write_text(json.dumps(
+        {"command": "z", "csrc_sha16": bench.csrc_sha16(),
+         "kernels": {"value_rollout_kernel": k, "policy_resident_kernel": k}}))
+    os.remove(str(prof / "r98_mcts_fullgame_pmc_summary.json"))
+    got = bench.net_kernel_profiles()
+    assert got["profile"] == "r97_mcts_fullgame_pmc_summary.json" and got["current"] is True

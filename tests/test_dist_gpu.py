@@ -27,9 +27,17 @@ def run_world(world, *args):
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, WORKER, *[str(a) for a in args]], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    for p in procs:
-        out, err = p.communicate(timeout=900)
-        assert p.returncode == 0, err[-3000:]
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=900)
+            assert p.returncode == 0, err[-3000:]
+    finally:
+        # a rank that failed (or a timeout) leaves the others blocked in a gloo collective, holding the
+        # GPU: end every rank that is still running, by PID
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait(timeout=60)
 
 
 def canonical(npz, keys, by):
@@ -55,6 +63,24 @@ def test_selfplay_two_ranks_equal_one_rank(tmp_path):
     assert np.all(b["game"][:first_hi] < 32) and np.all(b["game"][first_hi:] >= 32)
     assert np.array_equal(a["final_z"][np.argsort(a["final_game"])], b["final_z"][np.argsort(b["final_game"])])
     assert int(a["leaf_evals"]) > 0
+
+
+def test_selfplay_six_ranks_equal_one_rank(tmp_path):
+    """The same with SIX ranks on the one GPU (the most GPU processes this pool lets one job run; the
+    driver's node has 8 GPUs): 6 x 11 games = 1 x 66 games row for row, a six-way ragged gather."""
+    one, six = str(tmp_path / "w1.npz"), str(tmp_path / "w6.npz")
+    run_world(1, "selfplay", 66, 24, one)
+    run_world(6, "selfplay", 66, 24, six)
+    a, b = np.load(one), np.load(six)
+    keys = ("own", "opp", "pi", "z", "move", "colour", "game", "turn")
+    ca, cb = canonical(a, keys, ("game", "turn")), canonical(b, keys, ("game", "turn"))
+    assert len(ca["z"]) > 66 * 40
+    for k in keys:
+        assert np.array_equal(ca[k], cb[k]), k
+    # gather_tuples: rank r's rows before rank r + 1's -- the global game ids never decrease across blocks
+    blocks = b["game"] // 11
+    assert np.all(np.diff(blocks) >= 0) and set(blocks.tolist()) == set(range(6))
+    assert np.array_equal(a["final_z"][np.argsort(a["final_game"])], b["final_z"][np.argsort(b["final_game"])])
 
 
 def test_reinforce_two_ranks_equal_one_rank(tmp_path):
@@ -115,7 +141,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(IAGO_BENCH_BACKEND="gloo", IAGO_BENCH_DEVICE="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-                          "--mcts-games", "128", "--mcts-turns", "6", "--nthr1-turns", "0", "--train-iters", "2"],
+                          "--mcts-games", "128", "--mcts-turns", "6", "--nthr1-turns", "0", "--mcts400-turns", "2", "--train-iters", "2"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -127,3 +153,71 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert line["mcts"]["leaf_evals"] == 2 * 128 * 100 * line["mcts"]["turns_played"]   # both ranks' playouts
     assert line["leaf_evals_per_sec"] == line["mcts"]["leaf_evals_per_sec"] > 0
     assert line["reinforce"]["iters"] == 2 and "cpu_baseline" not in line   # CPU baselines are N = 1 figures
+    assert line["mcts400"]["leaf_evals"] == 2 * 128 * 400 * 2 and line["leaf_evals_per_sec_400"] > 0
+    assert line["reinforce"]["mcts_fed"]["rounds"] == 1 and line["reinforce_miopen_find_db"] in ("cold", "warm")
+
+
+SIX = ["--gpus", "6", "--steps", "20", "--warmup", "5", "--boards", "4096", "--mcts-games", "32", "--mcts-turns", "4",
+       "--nthr1-turns", "0", "--mcts400-turns", "0", "--train-iters", "1", "--large-boards", "0"]
+
+
+def _rehearsal_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(IAGO_BENCH_BACKEND="gloo", IAGO_BENCH_DEVICE="0")
+    return env
+
+
+def test_bench_six_ranks_rehearsal_on_one_gpu():
+    """bench.py --gpus N at the largest world this pool allows on one box (6 GPU processes; the
+    driver's first 8-rank run cannot be debugged): self-spawned ranks, one rendezvous, six engines'
+    pools and six MIOpen caches warming at once, six-way ragged gathers, the "ranks played different
+    games" assertion six ways -- ONE line with whole-job values."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SIX, cwd=ROOT, capture_output=True,
+                         text=True, timeout=1100, env=_rehearsal_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 6 and line["scaling"] == "weak"
+    assert line["config"]["games_per_step"] == 6 * 4096 and "gloo all-gather" in line["config"]["tuple_allgather"]
+    assert abs(line["value"] - 6 * 4096 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    assert line["mcts"]["leaf_evals"] == 6 * 32 * 100 * line["mcts"]["turns_played"] and line["mcts"]["turns_played"] == 4
+    assert line["reinforce"]["iters"] == 1 and line["reinforce"]["mcts_fed"]["rounds"] == 1
+    assert line["reinforce"]["mcts_fed"]["tuples_per_round"] > 64 * 40      # all 64 games of the round, gathered
+    assert "cpu_baseline" not in line
+
+
+def test_bench_launcher_propagates_a_killed_rank():
+    """One of six running ranks is killed (SIGKILL, by PID): the launcher ends the other five -- they
+    would wait in a collective forever -- and exits non-zero with nothing on stdout."""
+    import signal
+    import time
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + SIX, cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, env=_rehearsal_env())
+    try:
+        kids = []
+        for _ in range(600):        # the ranks are this launcher's direct children
+            time.sleep(0.1)
+            kids = []
+            for d in os.listdir("/proc"):
+                if d.isdigit():
+                    try:
+                        with open("/proc/%s/stat" % d) as f:
+                            if int(f.read().rsplit(")", 1)[1].split()[1]) == p.pid:
+                                kids.append(int(d))
+                    except (OSError, ValueError, IndexError):
+                        pass
+            if len(kids) == 6 or p.poll() is not None:
+                break
+        assert len(kids) == 6 and p.poll() is None
+        time.sleep(20.0)            # let them get into the run (import, rendezvous, first launches)
+        assert p.poll() is None
+        os.kill(sorted(kids)[3], signal.SIGKILL)
+        out, err = p.communicate(timeout=120)
+        assert p.returncode != 0
+        assert out.strip() == ""
+        time.sleep(1.0)
+        assert not [k for k in kids if os.path.exists("/proc/%d" % k)]     # no rank left behind
+    finally:
+        if p.poll() is None:
+            p.kill()

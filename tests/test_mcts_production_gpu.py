@@ -173,16 +173,19 @@ def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_si
     value.check_saturation()
 
 
-@pytest.mark.parametrize("async_steps", [False, True])
+@pytest.mark.parametrize("async_steps", [False, True, 2, 4])
 def test_production_self_play_games_vs_oracle(shipped, async_steps):
     """Whole self-play games through SelfPlayEngine at the production defaults (what bench.py's
     PV-MCTS leg times), 20 playouts per move (n_thr = 15 needs > 15): every game's move list and
     result equal the oracle's selfplay_game (game.py:117-142 turn structure) fed the recorded z."""
     engine, ops, policy, value, rw = shipped
     G, n_sims = 8, 24
+    # (True: the default 3 pieces; 2 / 4: the other layer splits and queue rotations of the value net's walk)
+    parts = async_steps if async_steps not in (False, True) else None
     m = engine.BatchedMCTS(G, policy, value, rw, n_thr=15, capacity=4096, seed=11, use_graph=True,
-                           z_log_rows=128 * n_sims, async_steps=async_steps)
-    assert m.lookahead == 4 and m.value_cache and m.async_steps == async_steps
+                           z_log_rows=128 * n_sims, async_steps=bool(async_steps), async_parts=parts)
+    assert m.lookahead == 4 and m.value_cache and m.async_steps == bool(async_steps)
+    assert not async_steps or m.async_parts == (parts or 3)
     res = engine.SelfPlayEngine(m).play(n_sims)
     moves = res.move.cpu().numpy()           # (T, G), -1 = pass / finished
     valid = res.valid.cpu().numpy()

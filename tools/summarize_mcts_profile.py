@@ -58,5 +58,8 @@ for k in KERNELS:
             d["l2_read_gb_per_s_per_workgroup_64B_req"] = d["l2_read_bytes_per_launch_64B_req"] / wgs / d["avg_us"] / 1e3
             d["l2_read_gb_per_s_per_workgroup_128B_req"] = d["l2_read_bytes_per_launch_128B_req"] / wgs / d["avg_us"] / 1e3
 cmd = os.path.join(src, "command.txt")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402  (csrc_sha16: the kernel sources this profile was taken on)
 print(json.dumps({"command": open(cmd).read().strip() if os.path.exists(cmd) else None,
+                  "csrc_sha16": bench.csrc_sha16(),
                   "kernels": {k: v for k, v in out.items() if v}}, indent=1))
