@@ -33,6 +33,7 @@ SYMBOLS = [
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
     "iago_mcts_fresh_leaves", "iago_mcts_descend", "iago_value_rollout_async",
     "iago_value_forward_batch", "iago_mcts_value_ahead_rows", "iago_mcts_value_ahead_store",
+    "iago_mcts_search_persistent",
 ]
 
 
@@ -106,6 +107,24 @@ class MctsValueAhead(C.Structure):
     ]
 
 
+SEARCH_QUEUE_ENTRIES = 4096   # IAGO_SEARCH_QUEUE_ENTRIES
+
+
+class MctsSearchArgs(C.Structure):
+    """Mirror of iago_mcts_search_args (include/iago_hip.h)."""
+    _fields_ = [
+        ("tree", C.c_void_p), ("root_own", C.c_void_p), ("root_opp", C.c_void_p), ("active", C.c_void_p),
+        ("c_puct", C.c_float), ("lmbda", C.c_float), ("n_thr", C.c_int32), ("n_sims", C.c_int32),
+        ("net_workgroups", C.c_int32), ("time_limit_ms", C.c_int32),
+        ("value", C.c_void_p), ("policy", C.c_void_p), ("rollout", C.c_void_p),
+        ("cur_node", C.c_void_p), ("cur_own", C.c_void_p), ("cur_opp", C.c_void_p), ("path", C.c_void_p),
+        ("path_stride", C.c_int32), ("z_log_rows", C.c_int32), ("done", C.c_void_p), ("roll", C.c_void_p),
+        ("leaf_value", C.c_void_p), ("z_log", C.c_void_p), ("z_log_n", C.c_void_p), ("q_slots", C.c_void_p),
+        ("ctl", C.c_void_p), ("rep_v", C.c_void_p), ("rep_p", C.c_void_p), ("totals", C.c_void_p),
+        ("stats", C.c_void_p), ("wg_own", C.c_void_p), ("wg_opp", C.c_void_p),
+    ]
+
+
 class ValueSplitArgs(C.Structure):
     """Mirror of iago_value_split_args (include/iago_hip.h)."""
     _fields_ = [
@@ -130,7 +149,7 @@ NODE_WORDS = 8   # sizeof(iago_mcts_node) / 4: n_visits, q, p, v, first_child, p
 
 
 _lib = None
-ABI_VERSION = 8   # iago_abi_version() of the include/iago_hip.h these bindings mirror
+ABI_VERSION = 9   # iago_abi_version() of the include/iago_hip.h these bindings mirror
 
 
 def lib():
@@ -211,6 +230,7 @@ def lib():
     vap = C.POINTER(MctsValueAhead)
     L.iago_mcts_value_ahead_rows.argtypes = [tp, vap, vp]
     L.iago_mcts_value_ahead_store.argtypes = [tp, vap, vp]
+    L.iago_mcts_search_persistent.argtypes = [C.POINTER(MctsSearchArgs), vp]
     for name in SYMBOLS[3:]:
         getattr(L, name).restype = C.c_int
     _lib = L

@@ -20,302 +20,12 @@
 // bias, softmax: network.py:29-47) is computed from LDS.  Rows come from own / opp through an
 // optional gather list, their number from an optional device word; a workgroup walks the rows
 // with the grid's stride.
-#include "abi_common.hpp"
-
-#include <hip/hip_fp16.h>
+#include "conv_policy_body.hpp"
 
 #include <cstdlib>
 
 namespace {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float float16v __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-
-constexpr int RS = 784;             // bytes of a cell row: 128 ch hi | mid | lo (256 B each) | 16 B (bank skew)
-constexpr int ZB = 1024;            // zero bytes behind the 64 rows: the target of every out-of-board tap
-constexpr int BS = 64 * RS + ZB;    // 51,200
-constexpr int HEAD_FLOATS = 64;     // logits
-constexpr int LDS_BYTES = BS + 1024 + HEAD_FLOATS * 4; // (+1024: the operand prefetch of the last k-step reads past T)
-constexpr float S1 = 1.0f / 2048.0f, S2 = 1.0f / (2048.0f * 2048.0f);
-
-struct PolicyParams {
-    const uint64_t *own, *opp;  // own = side to move (plane 1), opp = plane 0 (game.py:168-174)
-    const int64_t *index;       // optional gather list
-    const int32_t *n_dev;       // optional device-side row count
-    int64_t n;
-    const float *w1, *b1;       // block1 [64][2][3][3], [64]
-    const uint4 *w_hi[7], *w_mid[7], *w_lo[7]; // blocks 2..8: [cin/16][3][3][128][16] f16
-    const float *bias[7];
-    const float *w9, *b10;      // conv9 [128] (1x1, no bias), bias10 [64]
-    float *probs;               // [n][64]
-    uint32_t *overflow;
-    // a launch may run only the layers [layer_lo, layer_hi) of blocks 2..8 (0..7): block1 comes
-    // with layer_lo == 0, the head with layer_hi == 7, a board's LDS image (64 rows of RS bytes)
-    // travels between the launches through `scratch` [n][64 * RS]
-    int layer_lo, layer_hi;
-    uint4 *scratch;
-    // a launch covers the rows [row_lo, row_hi) of the batch; row r parks its image in scratch slot
-    // r - row_lo (the host runs a long batch as chunks of `scratch_rows` rows: bounded scratch)
-    int64_t row_lo, row_hi;
-};
-
-// (conv_trunk_kernel.hip) ds_read_b128 serves lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}
-// in separate LDS cycles; with this lane -> cell map and rows 4 banks apart (RS = 16 mod 256) the
-// 16 lanes of a cycle hit 16 different 4-bank groups for every tap.
-__device__ __forceinline__ int cell_of_lane(int r)
-{
-    return r < 4 ? r : r < 12 ? 16 + (r - 4) : r < 16 ? 4 + (r - 12) : r < 20 ? 24 + (r - 16) : r < 28 ? 8 + (r - 20)
-                                                                                              : 28 + (r - 28);
-}
-
-// a -> (hi, mid, lo) with a == hi + mid 2^-11 + lo 2^-22 exactly (every difference is exact)
-__device__ __forceinline__ void split3(const f2 v, h2 &hi, h2 &mid, h2 &lo)
-{
-    hi = __builtin_convertvector(v, h2);
-    const f2 r1 = (v - __builtin_convertvector(hi, f2)) * 2048.0f;
-    mid = __builtin_convertvector(r1, h2);
-    const f2 r2 = (r1 - __builtin_convertvector(mid, f2)) * 2048.0f;
-    lo = __builtin_convertvector(r2, h2);
-}
-
-extern __shared__ __align__(16) char policy_lds[];
-
-__device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t row_id)
-{
-    char *const T = policy_lds;
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int64_t b = P.index ? P.index[row_id] : row_id;
-
-    // ---- the zero area, then block1 (3x3, 2 -> 64, bias, ReLU; network.py:17-19) in float32
-    if (tid < ZB / 16)
-        *(uint4 *)(T + 64 * RS + tid * 16) = make_uint4(0, 0, 0, 0);
-    bool saturated = false;
-    if (P.layer_lo > 0) {
-        const uint4 *src = P.scratch + (row_id - P.row_lo) * (64 * RS / 16);
-        for (int e = tid; e < 64 * RS / 16; e += 256)
-            *(uint4 *)(T + e * 16) = src[e];
-    } else {
-        const int cell = tid & 63, y = cell >> 3, x = cell & 7;
-        const uint64_t bits0 = P.opp[b], bits1 = P.own[b];
-        float in[18];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                for (int kx = 0; kx < 3; kx++) {
-                    const int yy = y + ky - 1, xx = x + kx - 1;
-                    const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
-                    const int a = (yy * 8 + xx) & 63;
-                    in[c * 9 + ky * 3 + kx] = (ok && (((c ? bits1 : bits0) >> a) & 1ull)) ? 1.0f : 0.0f;
-                }
-#pragma unroll 1
-        for (int g2 = 0; g2 < 2; g2++) {
-            const int grp = __builtin_amdgcn_readfirstlane(g2 * 4 + wv); // channel block * 2 + half: wave-uniform
-            const int co0 = grp * 8;
-            _Float16 p0[8], p1[8], p2[8];
-#pragma unroll
-            for (int k = 0; k < 8; k += 2) {
-                f2 v;
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float *wk = P.w1 + (co0 + k + e) * 18; // [co][ci][ky][kx]
-                    float acc = P.b1[co0 + k + e];
-#pragma unroll
-                    for (int j = 0; j < 18; j++)
-                        acc = fmaf(wk[j], in[j], acc);
-                    saturated |= !(acc <= 65000.0f);
-                    v[e] = fminf(fmaxf(acc, 0.0f), 65000.0f);
-                }
-                h2 a0, a1, a2;
-                split3(v, a0, a1, a2);
-                p0[k] = a0.x, p0[k + 1] = a0.y;
-                p1[k] = a1.x, p1[k + 1] = a1.y;
-                p2[k] = a2.x, p2[k + 1] = a2.y;
-            }
-            char *dst = T + cell * RS + (grp >> 1) * 32 + (grp & 1) * 16;
-            *(uint4 *)dst = *(const uint4 *)p0;
-            *(uint4 *)(dst + 256) = *(const uint4 *)p1;
-            *(uint4 *)(dst + 512) = *(const uint4 *)p2;
-        }
-    }
-    __syncthreads();
-
-    // ---- per-lane addresses of the B operand: cell 32 j + cell_of_lane(r), tap (ky, kx); an
-    // out-of-board tap reads zeros from the slot with the bank offset its cell would have had
-    const int lane_cell = cell_of_lane(r);
-    uint32_t addr[2][9];
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int cell = 32 * j + lane_cell;
-            const int yy = (cell >> 3) + tap / 3 - 1, xx = (cell & 7) + tap % 3 - 1;
-            const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
-            const int lin = (cell + (tap / 3 - 1) * 8 + (tap % 3 - 1)) & 15;
-            addr[j][tap] = (uint32_t)((ok ? (yy * 8 + xx) * RS : 64 * RS + 16 * lin) + h * 16);
-        }
-    uint32_t wrow[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-        wrow[j] = (uint32_t)((32 * j + lane_cell) * RS);
-
-    for (int L = P.layer_lo; L < P.layer_hi; L++) {
-        const int n_chunks = L == 0 ? 4 : 8;
-        // this lane's A operand: output channel 32 wv + r, input channels 8 h .. 8 h + 7 of the
-        // k-step's chunk; a k-step (chunk, tap) is 128 x 32 B further
-        const u32x4 *wh = (const u32x4 *)P.w_hi[L] + (32 * wv + r) * 2 + h;
-        const u32x4 *wm = (const u32x4 *)P.w_mid[L] + (32 * wv + r) * 2 + h;
-        const u32x4 *wl = (const u32x4 *)P.w_lo[L] + (32 * wv + r) * 2 + h;
-        float16v acc0[2], acc1[2], acc2[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int v = 0; v < 16; v++) {
-                acc0[j][v] = 0.0f;
-                acc1[j][v] = 0.0f;
-                acc2[j][v] = 0.0f;
-            }
-        const int n_steps = 9 * n_chunks;
-        u32x4 a_hi[3], a_mid[3], a_lo[3]; // k-steps s, s + 1, s + 2 (ring index = tap % 3)
-        a_hi[0] = wh[0], a_mid[0] = wm[0], a_lo[0] = wl[0];
-        a_hi[1] = wh[256], a_mid[1] = wm[256], a_lo[1] = wl[256];
-        // B operands two tiles ahead of their MFMAs (three register sets); a tile = 6 MFMAs here
-        half8 bh[3], bm[3], bl[3];
-        auto b_addr = [&](int tile18) -> const char * {
-            // tile18 = tap * 2 + j of the running chunk; 18, 19 = the first two tiles of the next chunk
-            const int over = tile18 >= 18 ? 32 : 0, tt = tile18 % 18;
-            return T + addr[tt & 1][tt >> 1] + over;
-        };
-        {
-            const char *p0 = b_addr(0), *p1 = b_addr(1);
-            bh[0] = *(const half8 *)p0, bm[0] = *(const half8 *)(p0 + 256), bl[0] = *(const half8 *)(p0 + 512);
-            bh[1] = *(const half8 *)p1, bm[1] = *(const half8 *)(p1 + 256), bl[1] = *(const half8 *)(p1 + 512);
-        }
-        for (int c = 0; c < n_chunks; c++) {
-#pragma unroll
-            for (int tap = 0; tap < 9; tap++) {
-                const int s = c * 9 + tap;
-                const int s2 = min(s + 2, n_steps - 1); // the last two prefetches repeat the last k-step
-                a_hi[(tap + 2) % 3] = wh[(int64_t)s2 * 256];
-                a_mid[(tap + 2) % 3] = wm[(int64_t)s2 * 256];
-                a_lo[(tap + 2) % 3] = wl[(int64_t)s2 * 256];
-                const half8 ah = __builtin_bit_cast(half8, a_hi[tap % 3]);
-                const half8 am = __builtin_bit_cast(half8, a_mid[tap % 3]);
-                const half8 al = __builtin_bit_cast(half8, a_lo[tap % 3]);
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int tile = tap * 2 + j, cur = tile % 3, nxt = (tile + 2) % 3;
-                    const char *p = b_addr(tile + 2);
-                    bh[nxt] = *(const half8 *)p;
-                    bm[nxt] = *(const half8 *)(p + 256);
-                    bl[nxt] = *(const half8 *)(p + 512);
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cur], acc0[j], 0, 0, 0);
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm[cur], acc1[j], 0, 0, 0);
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh[cur], acc1[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[cur], acc2[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cur], acc2[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bm[cur], acc2[j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            // next chunk of 16 input channels: 32 B further in every row
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int tap = 0; tap < 9; tap++)
-                    addr[j][tap] += 32u;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int tap = 0; tap < 9; tap++)
-                addr[j][tap] -= 32u * (uint32_t)n_chunks;
-
-        // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T.
-        // D row m = 8 q + 4 h + t (v = 4 q + t): channel 32 wv + m of cell 32 j + lane_cell
-        f2 bia[8];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 bq = *(const float4 *)(P.bias[L] + 32 * wv + 8 * q + 4 * h);
-            bia[2 * q] = (f2){bq.x, bq.y};
-            bia[2 * q + 1] = (f2){bq.z, bq.w};
-        }
-        __syncthreads();
-        float vmax = 0.0f;
-        f2 vsum = (f2){0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            char *row = T + wrow[j] + (32 * wv + 4 * h) * 2;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                h2 p0[2], p1[2], p2[2];
-#pragma unroll
-                for (int t2 = 0; t2 < 2; t2++) {
-                    const f2 m0 = (f2){acc0[j][4 * q + 2 * t2], acc0[j][4 * q + 2 * t2 + 1]};
-                    const f2 m1 = (f2){acc1[j][4 * q + 2 * t2], acc1[j][4 * q + 2 * t2 + 1]};
-                    const f2 m2 = (f2){acc2[j][4 * q + 2 * t2], acc2[j][4 * q + 2 * t2 + 1]};
-                    f2 v = (m2 * S2 + m1 * S1) + m0 + bia[2 * q + t2];
-                    vmax = fmaxf(fmaxf(vmax, v.x), v.y);
-                    vsum += v;
-                    v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 65000.0f);
-                    v.y = __builtin_amdgcn_fmed3f(v.y, 0.0f, 65000.0f);
-                    split3(v, p0[t2], p1[t2], p2[t2]);
-                }
-                *(uint2 *)(row + 16 * q) = (uint2){__builtin_bit_cast(uint32_t, p0[0]), __builtin_bit_cast(uint32_t, p0[1])};
-                *(uint2 *)(row + 16 * q + 256) =
-                    (uint2){__builtin_bit_cast(uint32_t, p1[0]), __builtin_bit_cast(uint32_t, p1[1])};
-                *(uint2 *)(row + 16 * q + 512) =
-                    (uint2){__builtin_bit_cast(uint32_t, p2[0]), __builtin_bit_cast(uint32_t, p2[1])};
-            }
-        }
-        // beyond the f16 range, or NaN (the clamp would hide it)
-        saturated |= !(vmax <= 65000.0f) || !(vsum.x + vsum.y == vsum.x + vsum.y);
-        __syncthreads();
-    }
-    if (P.overflow && saturated)
-        *P.overflow = 1u;
-    if (P.layer_hi < 7) { // the next launch goes on from this image
-        uint4 *dst = P.scratch + (row_id - P.row_lo) * (64 * RS / 16);
-        for (int e = tid; e < 64 * RS / 16; e += 256)
-            dst[e] = *(const uint4 *)(T + e * 16);
-        return;
-    }
-
-    // ---- head (network.py:29-47): conv9 (1x1, 128 -> 1, no bias), + bias10 per cell, softmax over
-    // the 64 cells.  One wave: lane = cell, float32 on the exact values hi + mid 2^-11 + lo 2^-22.
-    if (wv == 0) {
-        const char *row = T + lane * RS;
-        float acc = 0.0f;
-#pragma unroll 4
-        for (int c8 = 0; c8 < 16; c8++) {
-            const half8 xh = *(const half8 *)(row + c8 * 16), xm = *(const half8 *)(row + 256 + c8 * 16),
-                        xl = *(const half8 *)(row + 512 + c8 * 16);
-            const float4 wa = *(const float4 *)(P.w9 + c8 * 8), wb = *(const float4 *)(P.w9 + c8 * 8 + 4);
-            const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float xv = ((float)xl[e] * S2 + (float)xm[e] * S1) + (float)xh[e];
-                acc = fmaf(w[e], xv, acc);
-            }
-        }
-        const float logit = acc + P.b10[lane];
-        float mx = logit;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            mx = fmaxf(mx, __shfl_xor(mx, o));
-        const float e = expf(logit - mx);
-        float sum = e;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            sum += __shfl_xor(sum, o);
-        P.probs[row_id * 64 + lane] = e / sum;
-    }
-}
+using namespace iago_policy;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void policy_resident_kernel(PolicyParams P)
 {
@@ -332,36 +42,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 int iago_policy_forward_split3(const iago_policy_split3_args *a, void *stream)
 {
-    if (!a || a->n < 0)
-        return iago_fail(IAGO_ERR_INVALID, "iago_policy_forward_split3: null args or n < 0");
-    if (a->n == 0)
+    if (a && a->n == 0)
         return IAGO_OK;
-    if (!a->own || !a->opp || !a->w1 || !a->b1 || !a->w9 || !a->b10 || !a->probs)
-        return iago_fail(IAGO_ERR_INVALID, "iago_policy_forward_split3: null pointer");
     PolicyParams P;
-    for (int L = 0; L < 7; L++) {
-        if (!a->w_hi[L] || !a->w_mid[L] || !a->w_lo[L] || !a->bias[L] || ((uintptr_t)a->w_hi[L] & 15u) ||
-            ((uintptr_t)a->w_mid[L] & 15u) || ((uintptr_t)a->w_lo[L] & 15u) || ((uintptr_t)a->bias[L] & 15u))
-            return iago_fail(IAGO_ERR_INVALID, "iago_policy_forward_split3: weights and biases of blocks 2..8 must be "
-                                               "non-null and 16-byte aligned");
-        P.w_hi[L] = (const uint4 *)a->w_hi[L];
-        P.w_mid[L] = (const uint4 *)a->w_mid[L];
-        P.w_lo[L] = (const uint4 *)a->w_lo[L];
-        P.bias[L] = a->bias[L];
-    }
-    if ((uintptr_t)a->w9 & 15u)
-        return iago_fail(IAGO_ERR_INVALID, "iago_policy_forward_split3: w9 must be 16-byte aligned");
-    P.own = a->own;
-    P.opp = a->opp;
-    P.index = a->index;
-    P.n_dev = a->n_dev;
-    P.n = a->n;
-    P.w1 = a->w1;
-    P.b1 = a->b1;
-    P.w9 = a->w9;
-    P.b10 = a->b10;
-    P.probs = a->probs;
-    P.overflow = a->overflow;
+    if (const int rc = policy_params_of(a, P))
+        return rc;
     static std::atomic<uint64_t> configured{0};
     if (iago_reserve_lds((const void *)policy_resident_kernel, LDS_BYTES, configured,
                          "iago_policy_forward_split3: cannot reserve 52 KB of LDS"))

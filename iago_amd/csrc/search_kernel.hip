@@ -1,0 +1,618 @@
+// search_kernel.hip -- a whole PV-MCTS search (n_sims playouts of every game, MCTS.get_move's loop,
+// MCTS.py:139-147) as ONE persistent launch in which every game runs on its own clock.
+//
+// Why.  MCTS.playout (MCTS.py:105-133) is sequential inside a game, but the games of a batch are
+// independent.  The lockstep engine (mcts_kernels.hip + conv_trunk_kernel.hip: descent, leaf
+// evaluation, backup as three launches per playout for all games) makes every game wait for the
+// slowest kind of playout -- the 16 % that end on a leaf without a stored value, whose one-board walk
+// through the Value net takes 70 us of a 128 us playout -- and runs the policy net as batches that
+// hold most of the chip while the playouts' kernels want it.  Here the chip is a pool of workgroups
+// (one per CU) of two kinds:
+//   * GAME workgroups (the first n_games / 16 of the grid): each owns 16 games and loops over
+//     descent (8 lanes per game: select, expansion, continued descent, exactly descend_kernel's
+//     arithmetic) -> rollout of the leaves reached (the 16-lanes-per-board body, Philox stream =
+//     stream base + the game's own playout count) -> backup (mix_backup_path_kernel's arithmetic).
+//     A game whose leaf has no stored value sends the leaf's position to the work queue and waits
+//     for the value (its rollout runs meanwhile); a game whose leaf expands (n_visits >= n_thr,
+//     MCTS.py:109) sends the position and waits for the priors -- the policy net runs exactly where
+//     the reference runs it (no look-ahead: no evaluation is wasted); the other 14-15 games of the
+//     workgroup go on.
+//   * NET workgroups (the rest of the grid): each takes the next ticket of the queue, waits for its
+//     entry, walks the board through the Value net (trunk_item<true, 1>) or the SLPolicy net
+//     (policy_item) -- the kernels' own device functions: bit-identical numbers -- and publishes the
+//     result in the game's mailbox.
+// A game's sequence of playouts -- leaves, values, priors, rollouts, backups, expansions -- is exactly
+// the reference's; only the interleaving between games changes: trees are bit-identical to the
+// lockstep engine's (tests/test_search_persistent_gpu.py).
+//
+// Inter-workgroup traffic (cdna_hip_programming.md, guideline 16): every shared word is an 8-byte
+// {tag, 32-bit value} granule written by ONE agent-scope atomic store and polled by agent-scope atomic
+// loads -- the data is the flag, no fence, no cache invalidation that would cost the net workgroups
+// their L2-resident weights.  Queue entry t (ticket t, tag t + 1): 6 granules (kind | game, reply tag,
+// the position's four words); replies: one granule (value) or 64 (priors) tagged with the request's
+// reply tag.  The tree, the cursors and the paths of a game are touched by its own workgroup only.
+// Every wait is a bounded poll: the launch ends by itself when a clock limit passes (abort word).
+#include "mcts_dev.hpp"
+#include "conv_trunk_body.hpp" // (brings rollout_row_body.hpp)
+#include "conv_policy_body.hpp"
+
+namespace {
+using namespace iago;
+using namespace iago_mcts;
+
+typedef unsigned long long u64;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+constexpr uint32_t QCAP = IAGO_SEARCH_QUEUE_ENTRIES; // entries of the request ring (>= 2 x games outstanding at once)
+constexpr int CTL_HEAD = 0, CTL_TAIL = 1, CTL_FINISHED = 2, CTL_ABORT = 3;
+enum { ST_READY = 0, ST_WAIT_PRIOR, ST_PRIOR_READY, ST_ROLL, ST_ROLL_FRESH, ST_WAIT_VALUE, ST_HAVE_VALUE, ST_DONE };
+constexpr uint32_t KIND_VALUE = 0u, KIND_POLICY = 1u;
+
+struct SearchParams {
+    Tree T;
+    const uint64_t *root_own, *root_opp;
+    const uint8_t *active;
+    float c_puct, lmbda;
+    int32_t n_thr, n_sims, n_game_wgs;
+    int32_t *cur_node;
+    uint64_t *cur_own, *cur_opp;
+    int32_t *path;
+    int32_t path_stride;
+    int32_t *done;
+    uint8_t *roll;
+    int8_t *z;
+    float *leaf_value;
+    int8_t *z_log;
+    int32_t *z_log_n;
+    int32_t z_log_rows;
+    u64 *q_slots;
+    uint32_t *ctl;
+    u64 *rep_v, *rep_p;
+    int64_t *totals; // [0] value evaluations, [1] policy evaluations, [2] game-workgroup iterations
+    int32_t *stats;
+    uint64_t *wg_own, *wg_opp;
+    long long clock_limit; // wall_clock64 ticks (100 MHz) after which the launch gives up
+};
+
+__device__ __forceinline__ u64 ld(const u64 *p) { return __hip_atomic_load(p, RLX_AGENT); }
+__device__ __forceinline__ void st(u64 *p, u64 x) { __hip_atomic_store(p, x, RLX_AGENT); }
+
+// one request: 6 granules of entry `t` (one lane)
+__device__ __forceinline__ void send_request(const SearchParams &S, uint32_t kind, int64_t g, uint32_t reply_tag,
+                                             uint64_t own, uint64_t opp)
+{
+    const uint32_t t = __hip_atomic_fetch_add(&S.ctl[CTL_TAIL], 1u, RLX_AGENT);
+    u64 *e = S.q_slots + (u64)(t % QCAP) * 8u;
+    const u64 tag = (u64)(t + 1u) << 32;
+    st(e + 1, tag | reply_tag);
+    st(e + 2, tag | (uint32_t)own);
+    st(e + 3, tag | (uint32_t)(own >> 32));
+    st(e + 4, tag | (uint32_t)opp);
+    st(e + 5, tag | (uint32_t)(opp >> 32));
+    st(e + 0, tag | (kind << 31) | (uint32_t)g);
+    atomicAdd((unsigned long long *)&S.totals[kind], 1ull);
+}
+
+__device__ __forceinline__ bool group8_all(bool x)
+{
+    return group8_add(x ? 0u : 1u) == 0u;
+}
+
+// Node.update_recursive (MCTS.py:51-72) over the recorded path + the leaf mix (MCTS.py:123-125): the
+// arithmetic of mix_backup_path_kernel, 8 lanes per game.
+__device__ __forceinline__ void backup_game(const SearchParams &S, int64_t g, uint32_t r, int leaf, bool fresh, float vg,
+                                            int path_n)
+{
+    const int64_t base = g * (int64_t)S.T.capacity;
+    const float lmbda = S.lmbda;
+    if (fresh && lmbda < 1.0f && r == 0u)
+        S.T.nodes[base + leaf].v = vg; // value_func(leaf), now stored (the value cache)
+    const int8_t zg = lmbda > 0.0f ? S.z[g] : (int8_t)0;
+    const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * vg : 0.0f;
+    const float b = (lmbda > 0.0f) ? (float)((double)lmbda * (double)zg) : 0.0f;
+    const float lv = a + b;
+    if (r == 0u) {
+        S.leaf_value[g] = lv;
+        if (S.z_log && lmbda > 0.0f) {
+            const int k = S.z_log_n[g];
+            S.z_log_n[g] = k + 1;
+            if (k < S.z_log_rows)
+                S.z_log[(int64_t)k * S.T.n_games + g] = zg;
+        }
+    }
+    const int len = path_n < S.path_stride ? path_n : S.path_stride;
+    const int32_t *path = S.path + g * (int64_t)S.path_stride;
+    for (int d = (int)r; d < len; d += 8) {
+        const int node = path[d];
+        uint2 *nq = (uint2 *)&S.T.nodes[base + node];
+        const uint2 old = *nq;
+        const int n = (int)old.x + 1;                // MCTS.py:61
+        const float q = __uint_as_float(old.y);
+        *nq = make_uint2((uint32_t)n, __float_as_uint(q + (lv - q) / (float)n)); // MCTS.py:63
+    }
+}
+
+// The 16 games of a GAME workgroup (threads 0 .. 127: 8 lanes per game; the other two waves join the
+// rollouts and the barriers).
+__device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago_row::HwParams &R, const long long t0)
+{
+    const Tree &T = S.T;
+    const int tid = threadIdx.x;
+    const bool mine = tid < 128;
+    const int64_t g = (int64_t)blockIdx.x * 16 + (tid >> 3);
+    const Lane8 L = make_lane8(threadIdx.x);
+    const uint32_t r = L.l8;
+    const bool exists = mine && g < T.n_games;
+    const int64_t base = exists ? g * (int64_t)T.capacity : 0;
+    const bool need_v = S.lmbda < 1.0f, need_z = S.lmbda > 0.0f;
+    int32_t *const path = S.path + (exists ? g : 0) * (int64_t)S.path_stride;
+
+    int state = (exists && S.active[g] != 0 && S.n_sims > 0) ? ST_READY : ST_DONE;
+    uint32_t epoch = 0u; // reply tag of the game's last request (never 0 once used)
+    int n_done = 0;
+    if (exists && r == 0u) {
+        S.done[g] = 0;
+        S.roll[g] = 0;
+    }
+    // cursor of the descent (kept across iterations while the game waits for priors)
+    int node = 0, fc = -1, k = 0, nv = 0, path_n = 0, leaf = 0;
+    uint32_t vbits = 0;
+    uint64_t own = 0, opp = 0;
+    bool may_expand = false, leaf_fresh = false;
+    float v_reply = 0.0f;
+    int st_levels = 0, st_children = 0;
+    long long iters = 0;
+
+    for (;;) {
+        bool busy = false; // this game did something in this iteration
+        if (mine) {
+            // ---- replies
+            if (state == ST_WAIT_PRIOR) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    ok = ok && (uint32_t)(ld(&S.rep_p[g * 64 + (int)r * 8 + i]) >> 32) == epoch;
+                if (group8_all(ok))
+                    state = ST_PRIOR_READY;
+            } else if (state == ST_WAIT_VALUE) {
+                const u64 x = ld(&S.rep_v[g]);
+                if ((uint32_t)(x >> 32) == epoch) {
+                    v_reply = __uint_as_float((uint32_t)x);
+                    state = ST_HAVE_VALUE;
+                }
+            }
+            // (the 8 lanes of a game load the same word in the same instruction, or agree through group8_all:
+            // one state per game)
+            // ---- backup of the games whose value has arrived (their rollout ran when they descended)
+            if (state == ST_HAVE_VALUE) {
+                backup_game(S, g, r, leaf, true, v_reply, path_n);
+                n_done++;
+                if (r == 0u)
+                    S.done[g] = n_done;
+                state = n_done >= S.n_sims ? ST_DONE : ST_READY;
+                busy = true;
+            }
+            // ---- descent (MCTS.py:105-133): from the root, or on from the leaf whose priors arrived
+            const bool fresh_start = state == ST_READY;
+            bool descending = state == ST_READY || state == ST_PRIOR_READY;
+            bool have_priors = state == ST_PRIOR_READY;
+            bool skip_record = state == ST_PRIOR_READY; // the cursor node is on the path already
+            bool need_prior = false;
+            if (fresh_start) {
+                node = T.root[g];
+                own = S.root_own[g];
+                opp = S.root_opp[g];
+                const uint4 s0 = ((const uint4 *)&T.nodes[base + node])[0], l0 = ((const uint4 *)&T.nodes[base + node])[1];
+                fc = (int)l0.x;
+                k = (int)((l0.z >> 8) & 0xFFu);
+                nv = (int)s0.x;
+                vbits = s0.w;
+                path_n = 0;
+                may_expand = true;
+            }
+            const bool went = descending;
+            busy = busy || went;
+            for (int depth = 0; depth < MAX_DEPTH; depth++) {
+                if (descending && !skip_record) {
+                    if (r == 0u) {
+                        if (path_n < S.path_stride)
+                            path[path_n] = node;
+                        else
+                            T.overflow[g] = 1; // deeper than the path buffer: reported like a full pool
+                    }
+                    path_n++;
+                }
+                skip_record = false;
+                const bool expand = descending && may_expand && fc < 0 && nv >= S.n_thr;
+                if (__builtin_amdgcn_ballot_w64(expand) != 0ull) {
+                    const uint64_t lg = group8_legal(to_lane(own, L), to_lane(opp, L), L);
+                    if (expand) {
+                        const int kn = lg ? __popcll(lg) : 1;
+                        if (lg != 0ull && kn > 1 && !have_priors) {
+                            // Node.expand needs policy_func(state) (MCTS.py:118-120): ask for it and wait here
+                            need_prior = true;
+                            descending = false;
+                        } else {
+                            may_expand = false;
+                            uint32_t fc1 = 0; // first child + 1, 0 = no room
+                            if (r == 0u) {
+                                const int at = T.n_nodes[g];
+                                if (at + kn <= T.capacity) {
+                                    T.n_nodes[g] = at + kn;
+                                    fc1 = (uint32_t)at + 1u;
+                                } else {
+                                    T.overflow[g] = 1;
+                                }
+                            }
+                            fc1 = group8_add(fc1);
+                            if (fc1 != 0u) {
+                                const int nf = (int)fc1 - 1;
+                                if (lg == 0ull || kn == 1) {
+                                    // pass child / single legal move: Node(node, 1), no net (MCTS.py:112-117)
+                                    if (r == 0u)
+                                        init_node(T, base + nf, node, lg ? (int)__builtin_ctzll(lg) : -1, 1.0f + 0.1f);
+                                } else {
+                                    uint32_t row = (uint32_t)(lg >> (8u * r)) & 0xFFu;
+                                    int at = nf + __popcll(lg & ((1ull << (8u * r)) - 1ull));
+                                    while (row) {
+                                        const int a = (int)(8u * r) + __builtin_ctz(row);
+                                        row &= row - 1u;
+                                        const float p = __uint_as_float((uint32_t)ld(&S.rep_p[g * 64 + a]));
+                                        init_node(T, base + at, node, a, p + 0.1f); // MCTS.py:19
+                                        at++;
+                                    }
+                                }
+                                if (r == 0u) {
+                                    T.nodes[base + node].first_child = nf;
+                                    T.nodes[base + node].n_children = (uint8_t)kn;
+                                }
+                                fc = nf;
+                                k = kn;
+                            }
+                        }
+                    }
+                    __threadfence_block(); // the new children are read by the other lanes of the group below
+                }
+                have_priors = false;
+                descending = descending && fc >= 0; // leaf reached (MCTS.py:107)
+                if (__builtin_amdgcn_ballot_w64(descending) == 0ull)
+                    break;
+                const int kk = descending ? k : 0;
+                st_levels += descending ? 1 : 0;
+                st_children += kk;
+                const double sq = sqrt((double)nv); // np.sqrt(parent.n_visits), MCTS.py:49
+                double best_v = -INFINITY;
+                int best_i = 0x7fffffff;
+                uint32_t pl[4] = {0u, 0u, 0u, 0u}; // of the best child: first_child, n_visits, action | n_children << 8, v
+                for (int j0 = (int)r; j0 < kk; j0 += 16) {
+                    const int j1 = j0 + 8;
+                    const bool two = j1 < kk;
+                    const int64_t c0 = base + fc + j0, c1 = two ? base + fc + j1 : c0;
+                    const uint4 s0 = ((const uint4 *)&T.nodes[c0])[0], l0 = ((const uint4 *)&T.nodes[c0])[1];
+                    const uint4 s1 = ((const uint4 *)&T.nodes[c1])[0], l1 = ((const uint4 *)&T.nodes[c1])[1];
+                    const float p0 = __uint_as_float(s0.z), q0 = __uint_as_float(s0.y);
+                    const float p1 = __uint_as_float(s1.z), q1 = __uint_as_float(s1.y);
+                    const int n0 = (int)s0.x, n1 = (int)s1.x;
+                    {
+                        const float cp = S.c_puct * p0;                          // float32, MCTS.py:49
+                        const double u = (double)cp * sq / (0.01 + (double)n0);
+                        const double v = (double)q0 + u;                         // get_value, MCTS.py:75-76
+                        if (v > best_v) { // strict: the first maximum wins (python max, MCTS.py:46)
+                            best_v = v;
+                            best_i = j0;
+                            pl[0] = l0.x, pl[1] = (uint32_t)n0, pl[2] = l0.z & 0xFFFFu, pl[3] = s0.w;
+                        }
+                    }
+                    if (two) {
+                        const float cp = S.c_puct * p1;
+                        const double u = (double)cp * sq / (0.01 + (double)n1);
+                        const double v = (double)q1 + u;
+                        if (v > best_v) {
+                            best_v = v;
+                            best_i = j1;
+                            pl[0] = l1.x, pl[1] = (uint32_t)n1, pl[2] = l1.z & 0xFFFFu, pl[3] = s1.w;
+                        }
+                    }
+                }
+                argmax_step_payload<DPP_XOR1>(best_v, best_i, pl);
+                argmax_step_payload<DPP_XOR2>(best_v, best_i, pl);
+                argmax_step_payload<DPP_HALF_MIRROR>(best_v, best_i, pl);
+                const int child = fc + best_i;
+                const int a = descending ? (int)(int8_t)(pl[2] & 0xFFu) : -1;
+                // GameFunctions.place_stone(state, action, c); c = 3 - c  (MCTS.py:131-132)
+                const uint64_t f = group8_flips(to_lane(own, L), to_lane(opp, L), (uint32_t)a & 63u, L);
+                if (descending) {
+                    uint64_t no = own, np_ = opp;
+                    if (a >= 0) {
+                        const uint64_t bit = 1ull << (a & 63);
+                        no = own | f | bit;
+                        np_ = opp & ~f & ~bit;
+                    }
+                    own = np_;
+                    opp = no;
+                    node = child;
+                    fc = (int)pl[0];
+                    nv = (int)pl[1];
+                    k = (int)(pl[2] >> 8);
+                    vbits = pl[3];
+                }
+            }
+            if (went) {
+                if (need_prior) {
+                    epoch++;
+                    if (r == 0u)
+                        send_request(S, KIND_POLICY, g, epoch, own, opp);
+                    state = ST_WAIT_PRIOR;
+                } else {
+                    if (descending && fc >= 0 && r == 0u)
+                        T.overflow[g] = 1; // path longer than MAX_DEPTH: reported like a full pool
+                    // the leaf of this playout (MCTS.py:123-127): its rollout runs now, its value is the
+                    // stored one or is asked for
+                    leaf = node;
+                    const float c = __uint_as_float(vbits);
+                    leaf_fresh = need_v && c != c;
+                    if (leaf_fresh)
+                        epoch++;
+                    if (r == 0u) {
+                        S.cur_node[g] = node;
+                        S.cur_own[g] = own;
+                        S.cur_opp[g] = opp;
+                        if (leaf_fresh)
+                            send_request(S, KIND_VALUE, g, epoch, own, opp);
+                    }
+                    state = leaf_fresh ? ST_ROLL_FRESH : ST_ROLL;
+                }
+            }
+            if (exists && r == 0u)
+                S.roll[g] = (need_z && (state == ST_ROLL || state == ST_ROLL_FRESH)) ? 1 : 0;
+        }
+        // ---- rollouts of the leaves reached in this iteration (Simulate, mcts_self_play.py:9-134)
+        const int any_roll = __syncthreads_or(mine && need_z && (state == ST_ROLL || state == ST_ROLL_FRESH));
+        if (any_roll) {
+            iago_row::rollout_row_body<false, true>(R, blockIdx.x);
+            __syncthreads();
+        }
+        if (mine) {
+            if (state == ST_ROLL) {
+                backup_game(S, g, r, leaf, false, __uint_as_float(vbits), path_n);
+                n_done++;
+                if (r == 0u)
+                    S.done[g] = n_done;
+                state = n_done >= S.n_sims ? ST_DONE : ST_READY;
+            } else if (state == ST_ROLL_FRESH) {
+                state = ST_WAIT_VALUE;
+            }
+        }
+        iters++;
+        // (the workgroup's own stores to done / the tree are read by its next iteration: same CU)
+        const bool over = wall_clock64() - t0 > S.clock_limit;
+        if (over && tid == 0)
+            __hip_atomic_store(&S.ctl[CTL_ABORT], 1u, RLX_AGENT);
+        const int stop = __syncthreads_or(over || (tid == 0 && __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u));
+        const int all_done = __syncthreads_and(!mine || state == ST_DONE);
+        if (all_done || stop)
+            break;
+        if (!__syncthreads_or(busy))
+            __builtin_amdgcn_s_sleep(32); // every game waits for a reply: poll again in ~1 us
+    }
+    if (exists && r == 0u && S.stats) {
+        S.stats[2 * g] += st_levels;
+        S.stats[2 * g + 1] += st_children;
+    }
+    if (tid == 0) {
+        atomicAdd((unsigned long long *)&S.totals[2], (unsigned long long)iters);
+        __hip_atomic_fetch_add(&S.ctl[CTL_FINISHED], 1u, RLX_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void search_kernel(
+    SearchParams S, iago_row::HwParams R, iago_trunk::TrunkRParams VP, iago_policy::PolicyParams PP)
+{
+    const long long t0 = wall_clock64();
+    if ((int)blockIdx.x < S.n_game_wgs) {
+        game_workgroup(S, R, t0);
+        return;
+    }
+    // ---- NET workgroup: ticket -> entry -> walk -> reply, until every game workgroup has finished.
+    // Two VALUE entries that are in the queue together are walked as a PAIR (trunk_item<true, 2>: the two
+    // boards share the weight stream, which bounds the one-board walk: 46 instead of 70 us of CU time per
+    // board; the same products in the same order per board: bit-identical values).
+    __shared__ __align__(16) uint32_t job[16]; // two entries: kind | game, reply tag, own lo / hi, opp lo / hi; [12] status
+    const int tid = threadIdx.x;
+    const int64_t row0 = 2 * (int64_t)blockIdx.x; // this workgroup's two rows of wg_own / wg_opp / out / probs
+    uint32_t carry = 0;   // a ticket taken for pairing whose entry was not (yet) a VALUE entry to pair with
+    bool have_carry = false;
+
+    // wave 0: wait for entry t (at most max_spins polls; 0 = until it comes or the search is over) -> job[6 * which ..]
+    // returns 0 = entry read, 1 = not there yet, 2 = the search is over / given up
+    auto fetch = [&](uint32_t t, uint32_t max_spins, int which) -> int {
+        const u64 *e = S.q_slots + (u64)(t % QCAP) * 8u;
+        u64 x = 0;
+        int status = 0;
+        for (uint32_t spins = 0;; spins++) {
+            x = (tid < 6) ? ld(e + tid) : 0ull;
+            const bool ok = tid >= 6 || (uint32_t)(x >> 32) == t + 1u;
+            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull)
+                break;
+            if (max_spins && spins + 1u >= max_spins) {
+                status = 1;
+                break;
+            }
+            // nothing queued: leave when every game workgroup is done (no request can come any more) or the
+            // launch has been given up
+            if ((spins & 15u) == 15u) {
+                bool out = false;
+                if (tid == 0)
+                    out = __hip_atomic_load(&S.ctl[CTL_FINISHED], RLX_AGENT) >= (uint32_t)S.n_game_wgs ||
+                          __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u || wall_clock64() - t0 > S.clock_limit;
+                if (__builtin_amdgcn_ballot_w64(out) != 0ull) {
+                    status = 2;
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (status == 0 && tid < 6)
+            job[6 * which + tid] = (uint32_t)x;
+        return status;
+    };
+    auto take = [&]() -> uint32_t {
+        uint32_t t = 0;
+        if (tid == 0)
+            t = __hip_atomic_fetch_add(&S.ctl[CTL_HEAD], 1u, RLX_AGENT);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+
+    for (;;) {
+        if (tid < 64) {
+            const uint32_t t1 = have_carry ? carry : take();
+            have_carry = false;
+            int status = fetch(t1, 0u, 0);
+            uint32_t pair = 0;
+            if (status == 0 && (job[0] >> 31) == KIND_VALUE) {
+                // a second entry waiting?  (tickets handed out so far < entries written so far)
+                uint32_t more = 0;
+                if (tid == 0)
+                    more = (int32_t)(__hip_atomic_load(&S.ctl[CTL_TAIL], RLX_AGENT) -
+                                     __hip_atomic_load(&S.ctl[CTL_HEAD], RLX_AGENT)) > 0 ? 1u : 0u;
+                if (__builtin_amdgcn_readfirstlane(more)) {
+                    const uint32_t t2 = take();
+                    const int s2 = fetch(t2, 8u, 1);
+                    if (s2 == 0 && (job[6] >> 31) == KIND_VALUE) {
+                        pair = 1;
+                    } else {
+                        carry = t2; // not there yet, or a POLICY entry: the next round's entry
+                        have_carry = true;
+                    }
+                }
+            }
+            if (tid == 0) {
+                job[12] = (uint32_t)status;
+                job[13] = pair;
+            }
+        }
+        have_carry = __builtin_amdgcn_readfirstlane((int)have_carry) != 0; // (wave 0's view; the other waves do not use it)
+        __syncthreads();
+        if (job[12] != 0u)
+            return;
+        const uint32_t kind = job[0] >> 31;
+        const bool pair = job[13] != 0u;
+        if (tid < (pair ? 2 : 1)) {
+            S.wg_own[row0 + tid] = ((uint64_t)job[6 * tid + 3] << 32) | job[6 * tid + 2];
+            S.wg_opp[row0 + tid] = ((uint64_t)job[6 * tid + 5] << 32) | job[6 * tid + 4];
+        }
+        __syncthreads(); // (the walks read their rows' positions with plain loads: written by this workgroup)
+        if (kind == KIND_VALUE) {
+            if (pair)
+                iago_trunk::trunk_item<true, 2>(VP, iago_trunk::whole_walk(VP), row0, VP.n);
+            else
+                iago_trunk::trunk_item<true, 1>(VP, iago_trunk::whole_walk(VP), row0, VP.n);
+            __syncthreads();
+            if (tid < (pair ? 2 : 1))
+                st(&S.rep_v[(int64_t)(job[6 * tid] & 0x7FFFFFFFu)],
+                   ((u64)job[6 * tid + 1] << 32) | __float_as_uint(VP.out[row0 + tid]));
+        } else {
+            iago_policy::policy_item(PP, row0);
+            __syncthreads();
+            if (tid < 64)
+                st(&S.rep_p[(int64_t)(job[0] & 0x7FFFFFFFu) * 64 + tid],
+                   ((u64)job[1] << 32) | __float_as_uint(PP.probs[row0 * 64 + tid]));
+        }
+        __syncthreads(); // the next item re-stages the LDS image and job[]
+    }
+}
+
+} // namespace
+
+extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void *stream)
+{
+    if (!a || !a->tree || !a->value || !a->policy || !a->rollout)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: null args");
+    const iago_mcts_tree *tree = a->tree;
+    if (tree->n_games < 1 || tree->capacity < 1 || !tree->nodes || ((uintptr_t)tree->nodes & 31u) || !tree->n_nodes ||
+        !tree->root || !tree->overflow || !tree->has_v)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: bad tree (the value cache `v` is required)");
+    if (tree->n_games > 0x7FFFFFF0ll)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: too many games");
+    if (!a->root_own || !a->root_opp || !a->active || !a->cur_node || !a->cur_own || !a->cur_opp || !a->path ||
+        a->path_stride < 8 || !a->done || !a->roll || !a->leaf_value || !a->q_slots || !a->ctl || !a->rep_v || !a->rep_p ||
+        !a->totals || !a->wg_own || !a->wg_opp || ((uintptr_t)a->q_slots & 63u) || ((uintptr_t)a->rep_p & 7u) ||
+        ((uintptr_t)a->rep_v & 7u) || ((uintptr_t)a->ctl & 15u))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: null or misaligned state array");
+    if (a->n_thr < 1 || a->n_sims < 0 || !(a->lmbda >= 0.0f && a->lmbda <= 1.0f) || a->net_workgroups < 1)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: n_thr >= 1, n_sims >= 0, 0 <= lmbda <= 1, "
+                                           "net_workgroups >= 1 expected");
+    if (a->z_log_rows > 0 && (!a->z_log || !a->z_log_n))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: z_log needs z_log_n");
+    const iago_rollout_args *ro = a->rollout;
+    if (ro->n != tree->n_games || !ro->z || !ro->table || ((uintptr_t)ro->table & 15u) || ro->log_form || ro->trace ||
+        ro->uniforms || ro->throughput_hint != 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: product-form rollout of the n games without "
+                                           "trace / uniforms expected");
+    const int64_t n_game_wgs = (tree->n_games + 15) / 16;
+    const int64_t grid = n_game_wgs + a->net_workgroups;
+    if (a->value->n < 2 * grid || a->policy->n < 2 * grid || a->value->planes || a->value->index || a->value->n_dev ||
+        a->policy->index || a->policy->n_dev || !a->value->own || a->value->own != a->wg_own ||
+        a->value->opp != a->wg_opp || a->policy->own != a->wg_own || a->policy->opp != a->wg_opp)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: the nets read their rows from wg_own / wg_opp "
+                                           "(two rows per workgroup of the grid: n >= 2 x (game + net workgroups)), no gather "
+                                           "list, no device count");
+    iago_trunk::TrunkRParams VP;
+    if (const int rc = iago_trunk::value_params_of(a->value, VP))
+        return rc;
+    VP.count_lo = 0;
+    VP.count_hi = 0x7fffffff;
+    iago_policy::PolicyParams PP;
+    if (const int rc = iago_policy::policy_params_of(a->policy, PP))
+        return rc;
+    SearchParams S;
+    S.T = *tree;
+    S.root_own = a->root_own;
+    S.root_opp = a->root_opp;
+    S.active = a->active;
+    S.c_puct = a->c_puct;
+    S.lmbda = a->lmbda;
+    S.n_thr = a->n_thr;
+    S.n_sims = a->n_sims;
+    S.n_game_wgs = (int32_t)n_game_wgs;
+    S.cur_node = a->cur_node;
+    S.cur_own = a->cur_own;
+    S.cur_opp = a->cur_opp;
+    S.path = a->path;
+    S.path_stride = a->path_stride;
+    S.done = a->done;
+    S.roll = a->roll;
+    S.z = ro->z;
+    S.leaf_value = a->leaf_value;
+    S.z_log = a->z_log_rows > 0 ? a->z_log : nullptr;
+    S.z_log_n = a->z_log_n;
+    S.z_log_rows = a->z_log_rows;
+    S.q_slots = (u64 *)a->q_slots;
+    S.ctl = a->ctl;
+    S.rep_v = (u64 *)a->rep_v;
+    S.rep_p = (u64 *)a->rep_p;
+    S.totals = a->totals;
+    S.stats = a->stats;
+    S.wg_own = a->wg_own;
+    S.wg_opp = a->wg_opp;
+    S.clock_limit = (long long)(a->time_limit_ms > 0 ? a->time_limit_ms : 2000) * 100000ll; // wall_clock64: 100 MHz
+    iago_row::HwParams R = iago_row::hw_params_of(ro);
+    R.own = a->cur_own;
+    R.opp = a->cur_opp;
+    R.mask = a->roll;
+    R.stream_ids = a->done;
+    constexpr int lds_v = iago_trunk::lds_alloc_fused(2), lds_p = iago_policy::LDS_BYTES;
+    constexpr int lds = lds_v > lds_p ? lds_v : lds_p;
+    static std::atomic<uint64_t> configured{0};
+    if (iago_reserve_lds((const void *)search_kernel, lds, configured,
+                         "iago_mcts_search_persistent: cannot reserve the nets' LDS image"))
+        return IAGO_ERR_HIP;
+    // every polled word starts from zero: the control block, the request ring and the reply mailboxes
+    if (hipMemsetAsync(a->ctl, 0, 16, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(a->q_slots, 0, (size_t)QCAP * 64, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(a->rep_v, 0, (size_t)tree->n_games * 8, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(a->rep_p, 0, (size_t)tree->n_games * 512, (hipStream_t)stream) != hipSuccess)
+        return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_persistent: hipMemsetAsync failed");
+    hipLaunchKernelGGL(search_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, S, R, VP, PP);
+    return iago_check_launch("iago_mcts_search_persistent");
+}

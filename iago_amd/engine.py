@@ -148,7 +148,8 @@ class BatchedMCTS(object):
     def __init__(self, n_games, policy_fn, value_fn, rollout_weights, lmbda=0.5, c_puct=1.0,
                  n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False,
                  sync_free=None, lookahead=None, lookahead_slots=None, value_cache=None, lookahead_overlap=None,
-                 z_log_rows=0, async_steps=None, async_parts=None, value_ahead=None):
+                 z_log_rows=0, async_steps=None, async_parts=None, value_ahead=None, persistent=None,
+                 net_workgroups=None):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         self.n_games = n_games
@@ -208,6 +209,25 @@ class BatchedMCTS(object):
         # the playouts' critical path.  Default: K = 4 whenever the sync-free playout with a
         # board-fed policy net applies and n_thr leaves room for it; 0 = the net runs inside the
         # playout that expands (the reference's order of evaluation).  Same trees either way.
+        # Persistent search (iago_mcts_search_persistent in include/iago_hip.h): a whole search is ONE
+        # launch in which every game runs on its own clock -- game workgroups (16 games each: descent,
+        # rollout, backup) and net workgroups that serve a queue of positions with the one-board walks
+        # of the value and the policy net.  The policy net runs exactly where the reference runs it (at
+        # the expansion), so there is no look-ahead in this mode.  Same trees.
+        can_p = (can_cache and getattr(value_fn, "search_args", None) is not None
+                 and getattr(policy_fn, "search_args", None) is not None and getattr(policy_fn, "split3", False)
+                 and rollout_weights is not None and not rollout_weights.log_form and 0.0 <= self.lmbda < 1.0)
+        if persistent is None:
+            persistent = can_p and os.environ.get("IAGO_PERSISTENT", "0") == "1"
+        if persistent and not can_p:
+            raise ValueError("persistent needs the split-f16 value net and the three-piece policy net (modules with "
+                             "search_args), product-form rollout weights and lmbda < 1")
+        self.persistent = bool(persistent)
+        if self.persistent:
+            if not self.value_cache:
+                raise ValueError("persistent needs the value cache")
+            lookahead, async_steps, value_ahead, use_graph = 0, False, False, False
+            self.use_graph = False
         can = (self.sync_free and getattr(policy_fn, "forward_counted_boards", None) is not None)
         if lookahead is None:
             k = int(os.environ.get("IAGO_LOOKAHEAD", "4"))   # (tuning knob: tools/)
@@ -224,7 +244,7 @@ class BatchedMCTS(object):
             j -= 1   # n_thr leaves no room to queue the leaves that much earlier
         self.lookahead_overlap = j
         margin = self.lookahead + max(self.lookahead_overlap - 1, 0)
-        if z_log_rows and not self.lookahead:
+        if z_log_rows and not self.lookahead and not self.persistent:
             raise ValueError("z_log_rows needs the look-ahead playout (rollout_hook serves the other paths)")
         if self.lookahead and not (can and self.n_thr > margin):
             raise ValueError("lookahead needs the sync-free playout, a policy net with "
@@ -333,6 +353,25 @@ class BatchedMCTS(object):
                     self._la_cache_seq[m] = -1
             self.tree.reset_hooks = [reset_lookahead]
         self.value_ahead = bool(getattr(self, "value_ahead", False))
+        if self.persistent:
+            n_gw = (n_games + 15) // 16
+            if net_workgroups is None:
+                net_workgroups = int(os.environ.get("IAGO_PERSISTENT_NET", "0")) or max(1, min(256 - n_gw, 8 * n_games))
+            self.net_workgroups = max(1, int(net_workgroups))
+            grid = n_gw + self.net_workgroups
+            self.PATH_STRIDE = 520
+            i64 = torch.int64
+            self._ps = dict(
+                path=torch.zeros((n_games, self.PATH_STRIDE), dtype=torch.int32, **kw),
+                done=torch.zeros(n_games, dtype=torch.int32, **kw), roll=torch.zeros(n_games, dtype=torch.uint8, **kw),
+                q_slots=torch.zeros(_lib.SEARCH_QUEUE_ENTRIES * 8, dtype=i64, **kw), ctl=torch.zeros(4, dtype=torch.int32, **kw),
+                rep_v=torch.zeros(n_games, dtype=i64, **kw), rep_p=torch.zeros(n_games * 64, dtype=i64, **kw),
+                totals=torch.zeros(3, dtype=i64, **kw), wg_own=torch.zeros(2 * grid, dtype=i64, **kw),
+                wg_opp=torch.zeros(2 * grid, dtype=i64, **kw), wg_v=torch.zeros(2 * grid, dtype=torch.float32, **kw),
+                wg_probs=torch.zeros((2 * grid, 64), dtype=torch.float32, **kw))
+            self.z_log = torch.zeros((z_log_rows, n_games), dtype=torch.int8, **kw) if z_log_rows else None
+            self.z_log_n = torch.zeros(n_games, dtype=torch.int32, **kw) if z_log_rows else None
+            self.time_limit_ms = int(os.environ.get("IAGO_PERSISTENT_LIMIT_MS", "4000"))
         self.tree.reset_hooks = list(getattr(self.tree, "reset_hooks", ())) + [
             lambda mask: setattr(self, "_live_after_compaction", 0)]
         # Game-asynchronous steps (iago_mcts_async in include/iago_hip.h): a game whose leaf has a
@@ -396,6 +435,8 @@ class BatchedMCTS(object):
     # device (sync-free playouts; reading it is a host sync)
     @property
     def n_policy_evals(self):
+        if self.persistent:
+            return int(self._ps["totals"][1].item())
         return self._n_policy_host + int(self._pend_total.item())
 
     @property
@@ -408,6 +449,8 @@ class BatchedMCTS(object):
     @property
     def n_value_inline(self):
         """Evaluations on the playouts' critical path (a leaf visited before it had a value)."""
+        if self.persistent:
+            return int(self._ps["totals"][0].item())
         return int(self._value_total.item()) if self.value_cache else self.n_leaf_evals
 
     @property
@@ -421,6 +464,8 @@ class BatchedMCTS(object):
             raise ValueError("n_policy_evals can only be reset to 0")
         self._n_policy_host = 0
         self._pend_total.zero_()
+        if self.persistent:
+            self._ps["totals"][1].zero_()
 
     def _bucket(self, n):
         """Smallest power-of-two batch >= n (min 16), capped at the pool size."""
@@ -727,7 +772,7 @@ class BatchedMCTS(object):
         """What the captured graph baked in: device pointers and versions of every weight
         (and of the layouts cached from them), the rollout table, the scalar arguments."""
         key = [self.lmbda, self.c_puct, self.n_thr, self.lookahead, self.lookahead_overlap, self.value_cache,
-               self.async_steps, self.value_ahead,
+               self.async_steps, self.value_ahead, self.persistent,
                getattr(self, "fused_descent", False), self.fused_leaf_eval,
                self.stats.data_ptr() if self.stats is not None else 0,
                self.rollout_weights.table.data_ptr() if self.rollout_weights is not None else 0]
@@ -934,6 +979,37 @@ class BatchedMCTS(object):
         self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
         self.n_leaf_evals += n_active * n_sims
 
+    def _search_persistent(self, own, opp, active, n_sims, n_active):
+        """n_sims playouts per active game as ONE launch (iago_mcts_search_persistent)."""
+        if self.rollout_hook is not None:
+            raise ValueError("rollout_hook is not available in the persistent search (z_log_rows records the z)")
+        ps = self._ps
+        sid = self.sim_counter - (1 << 32) if self.sim_counter >= (1 << 31) else self.sim_counter
+        ro = ops.rollout_prepare(self.cur_own, self.cur_opp, self.rollout_weights, seed=self.seed,
+                                 id_base=self.game_id_base, stream_id=sid, out=self._rollout_out)
+        with torch.no_grad():
+            va, keep_v = self.value_fn.search_args(ps["wg_own"], ps["wg_opp"], ps["wg_v"])
+            pa, keep_p = self.policy_fn.search_args(ps["wg_own"], ps["wg_opp"], ps["wg_probs"])
+        a = _lib.MctsSearchArgs()
+        a.tree = C.addressof(self.tree.c)
+        a.root_own, a.root_opp, a.active = own.data_ptr(), opp.data_ptr(), active.data_ptr()
+        a.c_puct, a.lmbda, a.n_thr, a.n_sims = self.c_puct, self.lmbda, self.n_thr, int(n_sims)
+        a.net_workgroups, a.time_limit_ms = self.net_workgroups, self.time_limit_ms
+        a.value, a.policy, a.rollout = C.addressof(va), C.addressof(pa), C.addressof(ro.args)
+        a.cur_node, a.cur_own, a.cur_opp = self.cur_node.data_ptr(), self.cur_own.data_ptr(), self.cur_opp.data_ptr()
+        a.path, a.path_stride = ps["path"].data_ptr(), self.PATH_STRIDE
+        a.done, a.roll, a.leaf_value = ps["done"].data_ptr(), ps["roll"].data_ptr(), self.leaf_value.data_ptr()
+        if self.z_log is not None:
+            a.z_log, a.z_log_n, a.z_log_rows = self.z_log.data_ptr(), self.z_log_n.data_ptr(), self.z_log.shape[0]
+        a.q_slots, a.ctl = ps["q_slots"].data_ptr(), ps["ctl"].data_ptr()
+        a.rep_v, a.rep_p, a.totals = ps["rep_v"].data_ptr(), ps["rep_p"].data_ptr(), ps["totals"].data_ptr()
+        a.stats = self.stats.data_ptr() if self.stats is not None else None
+        a.wg_own, a.wg_opp = ps["wg_own"].data_ptr(), ps["wg_opp"].data_ptr()
+        check(_lib.lib().iago_mcts_search_persistent(C.byref(a), _stream()), "iago_mcts_search_persistent")
+        self._ps_keep = (keep_v, keep_p, ro, va, pa, own, opp, active)   # alive until the next search's launch
+        self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
+        self.n_leaf_evals += n_active * n_sims
+
     def search_counts(self, active):
         """Device tensor int64[2]: games in `active`, nodes of the fullest pool -- what search()
         reads back before it starts (a caller that batches its readbacks passes them in)."""
@@ -967,7 +1043,9 @@ class BatchedMCTS(object):
             self.tree.compact()
             self.n_compactions += 1
             self._live_after_compaction = int(self.tree.n_nodes.max().item())
-        if self.async_steps and self.rollout_hook is None:
+        if self.persistent:
+            self._search_persistent(own, opp, active, n_sims, n_active)
+        elif self.async_steps and self.rollout_hook is None:
             self._search_async(own, opp, active, n_sims, n_active)
         elif self.use_graph:
             self._search_graph(own, opp, active, n_sims, n_active)
@@ -986,8 +1064,9 @@ class BatchedMCTS(object):
             self.raise_errors(self.error_flags().tolist())
 
     def error_flags(self):
-        """Device tensor int64[4]: pools that overflowed, the look-ahead's error word, the
-        saturation flags of the value and the policy net (0 where a net has none)."""
+        """Device tensor int64[5]: pools that overflowed, the look-ahead's error word, the saturation
+        flags of the value and the policy net (0 where a net has none), the persistent search's
+        gave-up word."""
         dev = self.cur_own.device
         zero = torch.zeros((), dtype=torch.int64, device=dev)
         parts = [self.tree.overflow.sum().to(torch.int64),
@@ -995,11 +1074,15 @@ class BatchedMCTS(object):
         for fn in (self.value_fn, self.policy_fn):
             f = getattr(fn, "__dict__", {}).get("_ovf") if hasattr(fn, "check_saturation") else None
             parts.append(f.reshape(-1)[0].to(torch.int64) if f is not None and f.device == dev else zero)
+        parts.append(self._ps["ctl"][3].to(torch.int64) if self.persistent else zero)
         return torch.stack(parts)
 
     def raise_errors(self, flags):
         """The errors of a search from the host copy of error_flags()."""
-        overflow, err, sat_v, sat_p = (int(x) for x in flags)
+        overflow, err, sat_v, sat_p, gave_up = (int(x) for x in flags)
+        if gave_up:
+            raise _lib.IagoError("the persistent search gave up after %d ms (a reply never came: is another job on the "
+                                 "device, or fewer CUs free than workgroups?); the trees are incomplete" % self.time_limit_ms)
         if overflow != 0:
             raise _lib.IagoError("MCTS node pool exhausted (or a search path deeper than 512): "
                                  "raise `capacity` (%d nodes per game)" % self.tree.capacity)
@@ -1146,7 +1229,8 @@ class SelfPlayEngine(object):
             t += 1
             back = torch.cat([m.error_flags(), (mv == -2).any().to(torch.int64).reshape(1),
                               done.all().to(torch.int64).reshape(1), m.search_counts(active)]).tolist()
-            m.raise_errors(back[:4])
+            m.raise_errors(back[:5])
+            back = back[1:]
             if back[4]:
                 # what max() over an empty children dict raises in MCTS.get_move (MCTS.py:147)
                 raise ValueError("a searched root has no children: n_sims is below the "

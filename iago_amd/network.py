@@ -250,6 +250,19 @@ class SLPolicy(nn.Module, _NpzMixin):
             buf = pool[key] = torch.empty((rows, ops.POLICY_SCRATCH_ROW_BYTES), dtype=torch.uint8, device=device)
         return buf
 
+    def search_args(self, own, opp, probs):
+        """iago_policy_split3_args for the persistent search (iago_mcts_search_persistent): this
+        module's three-piece weights, rows read from own / opp, distributions written to probs
+        ((rows, 64) float32).  Returns (args, tensors to keep alive)."""
+        if self.training or not own.is_cuda:
+            raise ValueError("search_args: CUDA, eval mode")
+        from . import _lib
+        a = _lib.PolicySplit3Args.from_buffer_copy(self._split3_template())
+        a.own, a.opp, a.n, a.probs = own.data_ptr(), opp.data_ptr(), own.numel(), probs.data_ptr()
+        a.parts = 1
+        a.overflow = self._overflow_flag(own.device).data_ptr()
+        return a, (self.__dict__["_split3_cache"], own, opp, probs)
+
     def forward_counted_boards(self, own, opp, index, n, n_dev):
         """forward_counted on make_state_var of boards index[0..n) (own = side to move) without
         materialising the planes."""
@@ -416,6 +429,23 @@ class Value(nn.Module, _NpzMixin):
                                        self.fc10.weight, self.fc11.weight,
                                        overflow=self._overflow_flag(own.device), index=index, n_dev=n_dev, out=out,
                                        rollout=rollout)
+
+    def search_args(self, own, opp, out):
+        """iago_value_split_args for the persistent search (iago_mcts_search_persistent): this module's
+        split-f16 weights, rows read from own / opp, values written to out (one slot per workgroup of
+        the launch).  Returns (args, tensors to keep alive while the args are in use)."""
+        if not (self.split_f16 and own.is_cuda and not self.training):
+            raise ValueError("search_args: CUDA, eval mode, split_f16")
+        import ctypes as C
+        from . import _lib, ops
+        layers = [self._split_weights(k) + (getattr(self, "block%d" % k).conv.bias,) for k in range(2, 9)]
+        head = self._head_weights()
+        a = _lib.ValueSplitArgs()
+        a.own, a.opp, a.n, a.out = own.data_ptr(), opp.data_ptr(), own.numel(), out.data_ptr()
+        ops.value_split_weights(a, self.block1.conv.weight, self.block1.conv.bias, layers, head,
+                                self.block9.conv.bias, self.fc10.weight, self.fc11.weight)
+        a.overflow = self._overflow_flag(own.device).data_ptr()
+        return a, (layers, head, own, opp, out)
 
     def forward_boards_batch(self, own, opp, n_dev, out, boards_per_workgroup=2, max_workgroups=192):
         """The net on boards 0 .. *n_dev (device-side count) of own / opp, values to out[i], as a batch

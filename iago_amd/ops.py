@@ -420,6 +420,23 @@ def split_head_weights(w9):
     return hi.contiguous(), lo.contiguous()
 
 
+def value_split_weights(a, w1, b1, layers, head, b9, w10, w11):
+    """The weight half of an iago_value_split_args, checked (value_forward_split, the persistent search)."""
+    if len(layers) != 7 or tuple(w1.shape) != (64, 2, 3, 3) or tuple(w10.shape) != (128, 64) \
+            or tuple(w11.shape) != (1, 128):
+        raise ValueError("value_forward_split: unexpected shapes")
+    a.w1, a.b1 = _dev(w1, torch.float32, "w1").value, _dev(b1, torch.float32, "b1").value
+    for k, (w_hi, w_lo, bias) in enumerate(layers):
+        if w_hi.shape != ((4 if k == 0 else 8), 3, 3, 128, 16):
+            raise ValueError("value_forward_split: layer %d: weight blocks %s" % (k, tuple(w_hi.shape)))
+        a.w_hi[k] = _dev(w_hi, torch.float16, "w_hi").value
+        a.w_lo[k] = _dev(w_lo, torch.float16, "w_lo").value
+        a.bias[k] = _dev(bias, torch.float32, "bias").value
+    a.w9_hi, a.w9_lo = _dev(head[0], torch.float16, "w9_hi").value, _dev(head[1], torch.float16, "w9_lo").value
+    a.b9 = _dev(b9, torch.float32, "b9").value
+    a.w10, a.w11 = _dev(w10, torch.float32, "w10").value, _dev(w11, torch.float32, "w11").value
+
+
 def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None, index=None, n_dev=None,
                         out=None, rollout=None, async_ref=None, batch=None):
     """The whole Value net in one launch (iago_value_forward_split).  x: float32 planes
@@ -441,20 +458,8 @@ def value_forward_split(x, w1, b1, layers, head, w9, b9, w10, w11, overflow=None
             raise ValueError("value_forward_split: planes (n, 2, 8, 8) expected")
         n, dev = x.shape[0], x.device
         a.planes = _dev(x, torch.float32, "planes").value
-    if len(layers) != 7 or tuple(w1.shape) != (64, 2, 3, 3) or tuple(w10.shape) != (128, 64) \
-            or tuple(w11.shape) != (1, 128):
-        raise ValueError("value_forward_split: unexpected shapes")
     a.n = n
-    a.w1, a.b1 = _dev(w1, torch.float32, "w1").value, _dev(b1, torch.float32, "b1").value
-    for k, (w_hi, w_lo, bias) in enumerate(layers):
-        if w_hi.shape != ((4 if k == 0 else 8), 3, 3, 128, 16):
-            raise ValueError("value_forward_split: layer %d: weight blocks %s" % (k, tuple(w_hi.shape)))
-        a.w_hi[k] = _dev(w_hi, torch.float16, "w_hi").value
-        a.w_lo[k] = _dev(w_lo, torch.float16, "w_lo").value
-        a.bias[k] = _dev(bias, torch.float32, "bias").value
-    a.w9_hi, a.w9_lo = _dev(head[0], torch.float16, "w9_hi").value, _dev(head[1], torch.float16, "w9_lo").value
-    a.b9 = _dev(b9, torch.float32, "b9").value
-    a.w10, a.w11 = _dev(w10, torch.float32, "w10").value, _dev(w11, torch.float32, "w11").value
+    value_split_weights(a, w1, b1, layers, head, b9, w10, w11)
     if index is not None:
         if not isinstance(x, tuple) or out is None:
             raise ValueError("value_forward_split: a gather list needs (own, opp) boards and an `out` buffer")

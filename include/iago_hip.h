@@ -731,6 +731,63 @@ IAGO_API int iago_mcts_descend(const iago_mcts_tree *tree, const uint64_t *root_
 IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const iago_rollout_args *rollout,
                                       const iago_mcts_async *async, void *stream);
 
+/*
+ * A whole search -- n_sims playouts of every active game, the loop of MCTS.get_move (MCTS.py:139-147)
+ * around MCTS.playout (MCTS.py:105-133) -- as ONE persistent launch in which every game runs on its
+ * own clock (csrc/search_kernel.hip).  The first ceil(n_games / 16) workgroups each own 16 games and
+ * loop over iago_mcts_descend's descent, iago_rollout's leaf rollout (Philox stream = rollout->stream_id
+ * (+ *stream_id_dev) + the game's own playout count) and iago_mcts_mix_backup's backup for them; a game
+ * whose leaf has no stored value (iago_mcts_fresh_leaves) or expands (n_visits >= n_thr, MCTS.py:109:
+ * MCTS.policy_func exactly where the reference calls it, no look-ahead) queues the position and waits
+ * for the reply while the workgroup's other games go on; the `net_workgroups` other workgroups serve the
+ * queue with iago_value_forward_split's / iago_policy_forward_split3's one-board walks (bit-identical
+ * numbers).  A game's sequence of leaves, values, priors, rollouts and backups is the reference's: the
+ * trees are bit-identical to those of the per-playout launches.
+ *   value / policy: the nets' weights as for iago_value_forward_split / iago_policy_forward_split3 with
+ *     own = wg_own, opp = wg_opp (two rows per workgroup of the grid: a net workgroup walks two boards
+ *     through the value net together when two are queued), n >= 2 x (ceil(n_games / 16) + net_workgroups),
+ *     out / probs sized for n rows, no planes / index / n_dev, parts = 1.
+ *   rollout: table, seed, id_base, stream_id(_dev) and z [n_games] of iago_rollout_args (product form);
+ *     its own / opp are ignored (the leaves' positions cur_own / cur_opp take their place).
+ *   State, caller-owned device memory, no initialisation needed: cur_node / cur_own / cur_opp / done
+ *     [n_games], roll [n_games] uint8, path [n_games][path_stride], leaf_value [n_games], q_slots
+ *     [IAGO_SEARCH_QUEUE_ENTRIES][8] uint64 (64-byte aligned), ctl [4] uint32 (16-byte aligned; after the
+ *     launch ctl[3] != 0: the launch gave up after time_limit_ms), rep_v [n_games] uint64, rep_p
+ *     [n_games][64] uint64, wg_own / wg_opp [2 x grid].  totals [3] int64 ACCUMULATES value evaluations, policy
+ *     evaluations and game-workgroup iterations; stats as for iago_mcts_select; z_log as in
+ *     iago_mcts_lookahead.
+ * At most one workgroup per CU is resident: game workgroups + net_workgroups should not exceed the CUs of
+ * the device (256), and nothing else should occupy the device while the launch runs.
+ */
+#define IAGO_SEARCH_QUEUE_ENTRIES 4096
+typedef struct iago_mcts_search_args {
+    const iago_mcts_tree *tree;
+    const uint64_t *root_own, *root_opp;
+    const uint8_t *active;
+    float c_puct, lmbda;
+    int32_t n_thr, n_sims;
+    int32_t net_workgroups, time_limit_ms;
+    const iago_value_split_args *value;
+    const iago_policy_split3_args *policy;
+    const iago_rollout_args *rollout;
+    int32_t *cur_node;
+    uint64_t *cur_own, *cur_opp;
+    int32_t *path;
+    int32_t path_stride, z_log_rows;
+    int32_t *done;
+    uint8_t *roll;
+    float *leaf_value;
+    int8_t *z_log;
+    int32_t *z_log_n;
+    void *q_slots;
+    uint32_t *ctl;
+    void *rep_v, *rep_p;
+    int64_t *totals;
+    int32_t *stats;
+    uint64_t *wg_own, *wg_opp;
+} iago_mcts_search_args;
+IAGO_API int iago_mcts_search_persistent(const iago_mcts_search_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,115 @@
+"""The persistent search (iago_mcts_search_persistent, include/iago_hip.h; engine.BatchedMCTS(persistent=True)):
+a whole search -- the loop of MCTS.get_move around MCTS.playout (MCTS.py:105-147) -- as ONE launch in
+which every game runs on its own clock, the value and the policy net serving a queue of positions.  What
+must hold: the trees (visit counts, float32 Q and P, child order, pool layout), the values stored in the
+nodes, the rollout results every playout backed up and the number of net evaluations a search NEEDS are
+those of the per-playout launches -- only the interleaving between games differs.  The comparison with
+the oracle's restatement of MCTS.py runs in tests/test_mcts_production_gpu.py (persistent=True there).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import load_json
+from tests.gpu_util import random_positions
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from iago_amd import engine, network, ops
+    assert torch.cuda.is_available()
+    torch.manual_seed(3)
+    policy = network.SLPolicy().cuda().eval()          # random init: broad trees, like bench.py's leg
+    value = network.Value().cuda().eval()
+    g = load_json("simulate.json")
+    return engine, ops, policy, value, ops.RolloutWeights(g["shipped_w"], g["shipped_b"])
+
+
+def _positions(G):
+    own, opp = random_positions(G, seed=78)
+    own[: G // 2] = 0x0000000810000000
+    opp[: G // 2] = 0x0000001008000000
+    return own, opp
+
+
+def _run(nets, G, n_sims, n_sims2, own, opp, idle=(), **kw):
+    engine, ops, policy, value, rw = nets
+    zrows = kw.pop("z_log_rows", n_sims + n_sims2)
+    m = engine.BatchedMCTS(G, policy, value, rw, n_thr=kw.pop("n_thr", 15),
+                           capacity=engine.suggest_capacity(n_sims + n_sims2, 15, moves=2), seed=21, game_id_base=300,
+                           z_log_rows=zrows, **kw)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    active = torch.ones(G, dtype=torch.uint8, device="cuda")
+    for g in idle:
+        active[g] = 0
+    m.search(o, p, active, n_sims)
+    if n_sims2:
+        mv = m.best_move(active)[0].clone()
+        mv = torch.where(mv == -2, torch.full_like(mv, -1), mv)
+        m.update_with_move(mv, active.clone())
+        ops.apply_moves(o, p, mv)
+        m.search(p, o, active, n_sims2)
+    t = m.tree
+    out = {k: getattr(t, k).cpu().numpy().copy() for k in ("n_visits", "q", "p", "first_child", "parent", "action",
+                                                           "n_children", "n_nodes", "root", "v")}
+    # (an unexpanded leaf the look-ahead has queued carries its prior-cache tag <= -2 in first_child: a leaf
+    # either way)
+    out["first_child"] = np.where(out["first_child"] < 0, -1, out["first_child"])
+    if getattr(m, "z_log", None) is not None:
+        out["z_log"], out["z_log_n"] = m.z_log.cpu().numpy().copy(), m.z_log_n.cpu().numpy().copy()
+    out["leaf_value"] = m.leaf_value.cpu().numpy().copy()
+    return m, out
+
+
+@pytest.mark.parametrize("G,n_sims,n_sims2,net", [(16, 40, 0, 3), (20, 100, 45, 8), (96, 100, 45, None), (330, 60, 20, 40)])
+def test_trees_equal_the_per_playout_engine(nets, G, n_sims, n_sims2, net):
+    own, opp = _positions(G)
+    idle = (5,) if G > 16 else ()
+    a, ta = _run(nets, G, n_sims, n_sims2, own, opp, idle, persistent=True, net_workgroups=net)
+    b, tb = _run(nets, G, n_sims, n_sims2, own, opp, idle, persistent=False, use_graph=True)
+    assert a.persistent and not b.persistent and b.lookahead == 4
+    for k in ("n_visits", "q", "p", "first_child", "parent", "action", "n_children", "n_nodes", "root"):
+        assert np.array_equal(ta[k], tb[k]), k
+    # the stored values: the same numbers in the same nodes (NaN = never evaluated, in both)
+    assert np.array_equal(np.isnan(ta["v"]), np.isnan(tb["v"]))
+    assert np.array_equal(ta["v"][~np.isnan(ta["v"])], tb["v"][~np.isnan(tb["v"])])
+    # every playout of every game backed up the same rollout result (same Philox stream per playout)
+    assert np.array_equal(ta["z_log_n"], tb["z_log_n"]) and np.array_equal(ta["z_log"], tb["z_log"])
+    assert a.n_leaf_evals == b.n_leaf_evals
+    # the value net ran once per leaf that needed it -- the per-playout engine's count -- and the policy net
+    # once per expansion with more than one legal move: never more than the look-ahead's batches evaluated
+    assert a.n_value_evals == b.n_value_evals > 0
+    assert 0 < a.n_policy_evals <= b.n_policy_evals
+    for g in idle:
+        assert ta["n_nodes"][g] == 1 and ta["z_log_n"][g] == 0
+    a.value_fn.check_saturation()
+    a.policy_fn.check_saturation()
+
+
+def test_n_thr_one(nets):
+    """n_thr = 1 (SURVEY 8d's second datapoint): every leaf expands at its second visit -- the policy net
+    inside every playout."""
+    G, n_sims = 48, 40
+    own, opp = _positions(G)
+    a, ta = _run(nets, G, n_sims, 0, own, opp, n_thr=1, persistent=True)
+    b, tb = _run(nets, G, n_sims, 0, own, opp, n_thr=1, persistent=False, use_graph=True, z_log_rows=0)
+    assert b.lookahead == 0   # (no visits to run ahead of: the per-playout engine, too, evaluates at the expansion)
+    for k in ("n_visits", "q", "p", "first_child", "parent", "action", "n_children", "n_nodes", "leaf_value"):
+        assert np.array_equal(ta[k], tb[k]), k
+    assert np.all(ta["z_log_n"] == n_sims)
+    # (the per-playout engine counts every expanding leaf, this one the leaves with more than one legal move)
+    assert 0 < a.n_policy_evals <= b.n_policy_evals and a.n_value_evals == b.n_value_evals
+
+
+def test_whole_games(nets):
+    """SelfPlayEngine on the persistent search = on the per-playout launches: moves, visit counts, results."""
+    engine, ops, policy, value, rw = nets
+    res = {}
+    for persistent in (True, False):
+        m = engine.BatchedMCTS(40, policy, value, rw, n_thr=15, capacity=4096, seed=11, use_graph=True, persistent=persistent)
+        r = engine.SelfPlayEngine(m).play(24)
+        res[persistent] = (r.move.cpu().numpy(), r.pi.cpu().numpy(), r.z.cpu().numpy(), r.valid.cpu().numpy())
+    for x, y in zip(res[True], res[False]):
+        assert np.array_equal(x, y)
