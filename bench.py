@@ -136,6 +136,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
         gather_tuples(warm.tuples())   # (RCCL sets up a collective of a new size class on its first use)
     m.n_leaf_evals = m.n_policy_evals = 0
     m._value_total.zero_()
+    if getattr(m, "persistent", False):
+        m._ps["totals"].zero_()
     m.stats.zero_()
     torch.cuda.synchronize()
     if dist is not None:
@@ -168,6 +170,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     out = {"leaf_evals_per_sec": leaf / dt, "leaf_evals": int(leaf), "policy_evals": int(pol),
            "value_evals": int(val), "value_inline": int(m.n_value_inline), "value_ahead": int(m.n_value_ahead),
            "async_steps": int(m.n_steps) if m.async_steps else None,
+           "persistent": ({"net_workgroups": m.net_workgroups, "totals": [int(x) for x in m._ps["totals"].tolist()]}
+                          if getattr(m, "persistent", False) else None),
            "leaf_eval_definition": "one leaf-eval = one playout (MCTS.py:105-133) ending in the leaf "
                                    "evaluation of MCTS.py:123-127: value_func(leaf) + rollout + backup; "
                                    "value_func is a pure function of the position, computed at a leaf's "

@@ -36,6 +36,8 @@
 #include "conv_trunk_body.hpp" // (brings rollout_row_body.hpp)
 #include "conv_policy_body.hpp"
 
+#include <cstdlib>
+
 namespace {
 using namespace iago;
 using namespace iago_mcts;
@@ -68,10 +70,14 @@ struct SearchParams {
     u64 *q_slots;
     uint32_t *ctl;
     u64 *rep_v, *rep_p;
-    int64_t *totals; // [0] value evaluations, [1] policy evaluations, [2] game-workgroup iterations
+    int64_t *totals; // [0] value evaluations, [1] policy evaluations, [2] game-workgroup iterations, [3] pair walks,
+                     // [4] / [5] net workgroups' waiting / walking time (100 MHz ticks), [6] idle game iterations, [7] game time
     int32_t *stats;
     uint64_t *wg_own, *wg_opp;
     long long clock_limit; // wall_clock64 ticks (100 MHz) after which the launch gives up
+    int64_t *trace;        // optional diagnostic [trace_rows][4]: game workgroup 0 samples (ticks, tail, head, finished) per iteration
+    int32_t trace_rows;
+    int32_t pair_backlog;  // entries that must be waiting (beyond the tickets handed out) for a net workgroup to take two
 };
 
 __device__ __forceinline__ u64 ld(const u64 *p) { return __hip_atomic_load(p, RLX_AGENT); }
@@ -161,7 +167,7 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
     bool may_expand = false, leaf_fresh = false;
     float v_reply = 0.0f;
     int st_levels = 0, st_children = 0;
-    long long iters = 0;
+    long long iters = 0, idle_iters = 0;
 
     for (;;) {
         bool busy = false; // this game did something in this iteration
@@ -383,6 +389,12 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                 state = ST_WAIT_VALUE;
             }
         }
+        if (S.trace && blockIdx.x == 0 && tid == 0 && iters < S.trace_rows) {
+            S.trace[4 * iters + 0] = wall_clock64() - t0;
+            S.trace[4 * iters + 1] = __hip_atomic_load(&S.ctl[CTL_TAIL], RLX_AGENT);
+            S.trace[4 * iters + 2] = __hip_atomic_load(&S.ctl[CTL_HEAD], RLX_AGENT);
+            S.trace[4 * iters + 3] = __hip_atomic_load(&S.ctl[CTL_FINISHED], RLX_AGENT);
+        }
         iters++;
         // (the workgroup's own stores to done / the tree are read by its next iteration: same CU)
         const bool over = wall_clock64() - t0 > S.clock_limit;
@@ -392,8 +404,10 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
         const int all_done = __syncthreads_and(!mine || state == ST_DONE);
         if (all_done || stop)
             break;
-        if (!__syncthreads_or(busy))
+        if (!__syncthreads_or(busy)) {
+            idle_iters++;
             __builtin_amdgcn_s_sleep(32); // every game waits for a reply: poll again in ~1 us
+        }
     }
     if (exists && r == 0u && S.stats) {
         S.stats[2 * g] += st_levels;
@@ -401,27 +415,34 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
     }
     if (tid == 0) {
         atomicAdd((unsigned long long *)&S.totals[2], (unsigned long long)iters);
+        atomicAdd((unsigned long long *)&S.totals[6], (unsigned long long)idle_iters);
+        atomicAdd((unsigned long long *)&S.totals[7], (unsigned long long)(wall_clock64() - t0));
         __hip_atomic_fetch_add(&S.ctl[CTL_FINISHED], 1u, RLX_AGENT);
     }
 }
 
+// One grid: the game workgroups first (they are dispatched first, so all of them are resident whatever else
+// holds CUs; a net workgroup never waits for another net workgroup, so one that finds no CU free simply starts
+// late), then the net workgroups.  A game workgroup whose games are done serves the queue like the others.
+// (Measured and dropped: the game workgroups as a launch of their own -- 197 instead of 512 registers, two
+// per CU, 224 net workgroups: no faster (the launch is not bound by the number of net workgroups), and two
+// launches that need each other are only as safe as the guess of how many CUs are free: LABNOTES.md.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void search_kernel(
     SearchParams S, iago_row::HwParams R, iago_trunk::TrunkRParams VP, iago_policy::PolicyParams PP)
 {
     const long long t0 = wall_clock64();
-    if ((int)blockIdx.x < S.n_game_wgs) {
+    if ((int)blockIdx.x < S.n_game_wgs)
         game_workgroup(S, R, t0);
-        return;
-    }
     // ---- NET workgroup: ticket -> entry -> walk -> reply, until every game workgroup has finished.
     // Two VALUE entries that are in the queue together are walked as a PAIR (trunk_item<true, 2>: the two
     // boards share the weight stream, which bounds the one-board walk: 46 instead of 70 us of CU time per
     // board; the same products in the same order per board: bit-identical values).
-    __shared__ __align__(16) uint32_t job[16]; // two entries: kind | game, reply tag, own lo / hi, opp lo / hi; [12] status
+    __shared__ __align__(16) uint32_t job[32]; // up to two entries of 6 words (kind | game, reply tag, own lo / hi, opp lo / hi); [28..]: status, count
     const int tid = threadIdx.x;
-    const int64_t row0 = 2 * (int64_t)blockIdx.x; // this workgroup's two rows of wg_own / wg_opp / out / probs
-    uint32_t carry = 0;   // a ticket taken for pairing whose entry was not (yet) a VALUE entry to pair with
-    bool have_carry = false;
+    const int64_t row0 = 4 * (int64_t)blockIdx.x; // this workgroup's rows of wg_own / wg_opp / out / probs (two in use)
+    // a ticket taken for a pair whose entry was not there yet, or was a POLICY entry: the next round's entry
+    uint32_t carry = 0u;
+    int n_carry = 0;
 
     // wave 0: wait for entry t (at most max_spins polls; 0 = until it comes or the search is over) -> job[6 * which ..]
     // returns 0 = entry read, 1 = not there yet, 2 = the search is over / given up
@@ -462,53 +483,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             t = __hip_atomic_fetch_add(&S.ctl[CTL_HEAD], 1u, RLX_AGENT);
         return __builtin_amdgcn_readfirstlane(t);
     };
+    auto backlog = [&]() -> int {
+        int d = 0;
+        if (tid == 0)
+            d = (int32_t)(__hip_atomic_load(&S.ctl[CTL_TAIL], RLX_AGENT) - __hip_atomic_load(&S.ctl[CTL_HEAD], RLX_AGENT));
+        return __builtin_amdgcn_readfirstlane(d);
+    };
 
+    long long t_wait = 0, t_walk = 0, n_pairs = 0;
     for (;;) {
+        const long long c0 = wall_clock64();
         if (tid < 64) {
-            const uint32_t t1 = have_carry ? carry : take();
-            have_carry = false;
-            int status = fetch(t1, 0u, 0);
-            uint32_t pair = 0;
-            if (status == 0 && (job[0] >> 31) == KIND_VALUE) {
-                // a second entry waiting?  (tickets handed out so far < entries written so far)
-                uint32_t more = 0;
-                if (tid == 0)
-                    more = (int32_t)(__hip_atomic_load(&S.ctl[CTL_TAIL], RLX_AGENT) -
-                                     __hip_atomic_load(&S.ctl[CTL_HEAD], RLX_AGENT)) > 0 ? 1u : 0u;
-                if (__builtin_amdgcn_readfirstlane(more)) {
+            uint32_t t1;
+            if (n_carry > 0) {
+                t1 = carry;
+                n_carry = 0;
+            } else {
+                t1 = take();
+            }
+            const int status = fetch(t1, 0u, 0);
+            int count = status == 0 ? 1 : 0;
+            if (status == 0 && (job[0] >> 31) == KIND_VALUE && n_carry == 0) {
+                // another VALUE entry waiting?  Two boards walk together (trunk_item<true, 2>: they share the weight
+                // stream, the bound of the one-board walk -- 46 instead of 70 us of CU time per board, 92 us for the
+                // pair; the same products in the same order per board: bit-identical values)
+                const int d = backlog();
+                // (four boards per walk were measured too: the third variant's registers spill in this kernel and the
+                // walks lose more than the shared stream gains: LABNOTES.md, round 4)
+                if (d >= S.pair_backlog) {
                     const uint32_t t2 = take();
                     const int s2 = fetch(t2, 8u, 1);
                     if (s2 == 0 && (job[6] >> 31) == KIND_VALUE) {
-                        pair = 1;
+                        count = 2;
                     } else {
                         carry = t2; // not there yet, or a POLICY entry: the next round's entry
-                        have_carry = true;
+                        n_carry = 1;
                     }
                 }
             }
             if (tid == 0) {
-                job[12] = (uint32_t)status;
-                job[13] = pair;
+                job[28] = (uint32_t)status;
+                job[29] = (uint32_t)count;
             }
         }
-        have_carry = __builtin_amdgcn_readfirstlane((int)have_carry) != 0; // (wave 0's view; the other waves do not use it)
         __syncthreads();
-        if (job[12] != 0u)
+        const long long c1 = wall_clock64();
+        t_wait += c1 - c0;
+        if (job[28] != 0u) {
+            if (tid == 0) {
+                atomicAdd((unsigned long long *)&S.totals[3], (unsigned long long)n_pairs);
+                atomicAdd((unsigned long long *)&S.totals[4], (unsigned long long)t_wait);
+                atomicAdd((unsigned long long *)&S.totals[5], (unsigned long long)t_walk);
+            }
             return;
+        }
         const uint32_t kind = job[0] >> 31;
-        const bool pair = job[13] != 0u;
-        if (tid < (pair ? 2 : 1)) {
+        const int count = (int)job[29];
+        n_pairs += count - 1;
+        if (tid < count) {
             S.wg_own[row0 + tid] = ((uint64_t)job[6 * tid + 3] << 32) | job[6 * tid + 2];
             S.wg_opp[row0 + tid] = ((uint64_t)job[6 * tid + 5] << 32) | job[6 * tid + 4];
         }
         __syncthreads(); // (the walks read their rows' positions with plain loads: written by this workgroup)
         if (kind == KIND_VALUE) {
-            if (pair)
-                iago_trunk::trunk_item<true, 2>(VP, iago_trunk::whole_walk(VP), row0, VP.n);
+            if (count == 2)
+                iago_trunk::trunk_item<true, 2>(VP, iago_trunk::whole_walk(VP), row0, row0 + count);
             else
-                iago_trunk::trunk_item<true, 1>(VP, iago_trunk::whole_walk(VP), row0, VP.n);
+                iago_trunk::trunk_item<true, 1>(VP, iago_trunk::whole_walk(VP), row0, row0 + count);
             __syncthreads();
-            if (tid < (pair ? 2 : 1))
+            if (tid < count)
                 st(&S.rep_v[(int64_t)(job[6 * tid] & 0x7FFFFFFFu)],
                    ((u64)job[6 * tid + 1] << 32) | __float_as_uint(VP.out[row0 + tid]));
         } else {
@@ -519,6 +562,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                    ((u64)job[1] << 32) | __float_as_uint(PP.probs[row0 * 64 + tid]));
         }
         __syncthreads(); // the next item re-stages the LDS image and job[]
+        t_walk += wall_clock64() - c1;
     }
 }
 
@@ -551,12 +595,12 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
                                            "trace / uniforms expected");
     const int64_t n_game_wgs = (tree->n_games + 15) / 16;
     const int64_t grid = n_game_wgs + a->net_workgroups;
-    if (a->value->n < 2 * grid || a->policy->n < 2 * grid || a->value->planes || a->value->index || a->value->n_dev ||
+    if (a->value->n < 4 * grid || a->policy->n < 4 * grid || a->value->planes || a->value->index || a->value->n_dev ||
         a->policy->index || a->policy->n_dev || !a->value->own || a->value->own != a->wg_own ||
         a->value->opp != a->wg_opp || a->policy->own != a->wg_own || a->policy->opp != a->wg_opp)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: the nets read their rows from wg_own / wg_opp "
-                                           "(two rows per workgroup of the grid: n >= 2 x (game + net workgroups)), no gather "
-                                           "list, no device count");
+                                           "(four rows per workgroup of the grid: n >= 4 x (game + net workgroups)), no gather list, no "
+                                           "device count");
     iago_trunk::TrunkRParams VP;
     if (const int rc = iago_trunk::value_params_of(a->value, VP))
         return rc;
@@ -596,6 +640,16 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
     S.wg_own = a->wg_own;
     S.wg_opp = a->wg_opp;
     S.clock_limit = (long long)(a->time_limit_ms > 0 ? a->time_limit_ms : 2000) * 100000ll; // wall_clock64: 100 MHz
+    // (tuning knob: a pair shares the weight stream -- 46 instead of 70 us of CU time per board -- but takes 92 us:
+    // worth it only while entries queue up)
+    static const int pair_backlog = [] {
+        const char *e = getenv("IAGO_PERSISTENT_PAIR");
+        const int v = e ? atoi(e) : 1;
+        return v < 1 ? 0x7fffffff : v;
+    }();
+    S.pair_backlog = pair_backlog;
+    S.trace = a->trace_rows > 0 ? a->trace : nullptr;
+    S.trace_rows = a->trace_rows;
     iago_row::HwParams R = iago_row::hw_params_of(ro);
     R.own = a->cur_own;
     R.opp = a->cur_opp;

@@ -366,9 +366,9 @@ class BatchedMCTS(object):
                 done=torch.zeros(n_games, dtype=torch.int32, **kw), roll=torch.zeros(n_games, dtype=torch.uint8, **kw),
                 q_slots=torch.zeros(_lib.SEARCH_QUEUE_ENTRIES * 8, dtype=i64, **kw), ctl=torch.zeros(4, dtype=torch.int32, **kw),
                 rep_v=torch.zeros(n_games, dtype=i64, **kw), rep_p=torch.zeros(n_games * 64, dtype=i64, **kw),
-                totals=torch.zeros(3, dtype=i64, **kw), wg_own=torch.zeros(2 * grid, dtype=i64, **kw),
-                wg_opp=torch.zeros(2 * grid, dtype=i64, **kw), wg_v=torch.zeros(2 * grid, dtype=torch.float32, **kw),
-                wg_probs=torch.zeros((2 * grid, 64), dtype=torch.float32, **kw))
+                totals=torch.zeros(8, dtype=i64, **kw), wg_own=torch.zeros(4 * grid, dtype=i64, **kw),
+                wg_opp=torch.zeros(4 * grid, dtype=i64, **kw), wg_v=torch.zeros(4 * grid, dtype=torch.float32, **kw),
+                wg_probs=torch.zeros((4 * grid, 64), dtype=torch.float32, **kw))
             self.z_log = torch.zeros((z_log_rows, n_games), dtype=torch.int8, **kw) if z_log_rows else None
             self.z_log_n = torch.zeros(n_games, dtype=torch.int32, **kw) if z_log_rows else None
             self.time_limit_ms = int(os.environ.get("IAGO_PERSISTENT_LIMIT_MS", "4000"))
@@ -1005,6 +1005,8 @@ class BatchedMCTS(object):
         a.rep_v, a.rep_p, a.totals = ps["rep_v"].data_ptr(), ps["rep_p"].data_ptr(), ps["totals"].data_ptr()
         a.stats = self.stats.data_ptr() if self.stats is not None else None
         a.wg_own, a.wg_opp = ps["wg_own"].data_ptr(), ps["wg_opp"].data_ptr()
+        if getattr(self, "trace", None) is not None:   # (diagnostic: tools/exp_persistent_trace.py)
+            a.trace, a.trace_rows = self.trace.data_ptr(), self.trace.shape[0]
         check(_lib.lib().iago_mcts_search_persistent(C.byref(a), _stream()), "iago_mcts_search_persistent")
         self._ps_keep = (keep_v, keep_p, ro, va, pa, own, opp, active)   # alive until the next search's launch
         self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF

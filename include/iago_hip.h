@@ -744,8 +744,8 @@ IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const 
  * numbers).  A game's sequence of leaves, values, priors, rollouts and backups is the reference's: the
  * trees are bit-identical to those of the per-playout launches.
  *   value / policy: the nets' weights as for iago_value_forward_split / iago_policy_forward_split3 with
- *     own = wg_own, opp = wg_opp (two rows per workgroup of the grid: a net workgroup walks two boards
- *     through the value net together when two are queued), n >= 2 x (ceil(n_games / 16) + net_workgroups),
+ *     own = wg_own, opp = wg_opp (four rows per workgroup of the grid: a net workgroup walks two boards
+ *     through the value net together when two are queued), n >= 4 x (ceil(n_games / 16) + net_workgroups),
  *     out / probs sized for n rows, no planes / index / n_dev, parts = 1.
  *   rollout: table, seed, id_base, stream_id(_dev) and z [n_games] of iago_rollout_args (product form);
  *     its own / opp are ignored (the leaves' positions cur_own / cur_opp take their place).
@@ -753,8 +753,9 @@ IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const 
  *     [n_games], roll [n_games] uint8, path [n_games][path_stride], leaf_value [n_games], q_slots
  *     [IAGO_SEARCH_QUEUE_ENTRIES][8] uint64 (64-byte aligned), ctl [4] uint32 (16-byte aligned; after the
  *     launch ctl[3] != 0: the launch gave up after time_limit_ms), rep_v [n_games] uint64, rep_p
- *     [n_games][64] uint64, wg_own / wg_opp [2 x grid].  totals [3] int64 ACCUMULATES value evaluations, policy
- *     evaluations and game-workgroup iterations; stats as for iago_mcts_select; z_log as in
+ *     [n_games][64] uint64, wg_own / wg_opp [4 x grid].  totals [8] int64 ACCUMULATES value evaluations, policy
+ *     evaluations, game-workgroup iterations, pair walks, the net workgroups' waiting and walking time (100 MHz
+ *     ticks, summed over the workgroups), idle game-workgroup iterations and the game workgroups' run time; stats as for iago_mcts_select; z_log as in
  *     iago_mcts_lookahead.
  * At most one workgroup per CU is resident: game workgroups + net_workgroups should not exceed the CUs of
  * the device (256), and nothing else should occupy the device while the launch runs.
@@ -785,6 +786,10 @@ typedef struct iago_mcts_search_args {
     int64_t *totals;
     int32_t *stats;
     uint64_t *wg_own, *wg_opp;
+    int64_t *trace;       /* optional diagnostic [trace_rows][4]: game workgroup 0 records (100 MHz ticks since its start,
+                             requests queued so far, tickets handed out so far, game workgroups finished) once per
+                             iteration of its loop */
+    int32_t trace_rows, reserved;
 } iago_mcts_search_args;
 IAGO_API int iago_mcts_search_persistent(const iago_mcts_search_args *args, void *stream);
 

@@ -20,7 +20,7 @@ def one():
     import bench
     out = bench.mcts_leg(games, sims, max(turns, 0), turns < 0, 1, 0, None)
     keep = {k: out.get(k) for k in ("leaf_evals_per_sec", "games_per_sec", "seconds", "policy_evals",
-                                    "value_inline", "value_ahead", "async_steps", "turns_played")}
+                                    "value_inline", "value_ahead", "async_steps", "turns_played", "persistent")}
     keep["leaf_evals_per_sec"] = round(keep["leaf_evals_per_sec"] / 1e6, 3)
     print(os.environ.get("SPEC", ""), json.dumps(keep), flush=True)
 
