@@ -47,7 +47,8 @@ typedef unsigned long long u64;
 
 constexpr uint32_t QCAP = IAGO_SEARCH_QUEUE_ENTRIES; // entries of the request ring (>= 2 x games outstanding at once)
 constexpr int CTL_HEAD = 0, CTL_TAIL = 1, CTL_FINISHED = 2, CTL_ABORT = 3;
-enum { ST_READY = 0, ST_WAIT_PRIOR, ST_PRIOR_READY, ST_ROLL, ST_ROLL_FRESH, ST_WAIT_VALUE, ST_HAVE_VALUE, ST_DONE };
+enum { ST_READY = 0, ST_WAIT_PRIOR, ST_PRIOR_READY, ST_ROLL, ST_ROLL_FRESH, ST_WAIT_VALUE, ST_HAVE_VALUE, ST_DONE, ST_TURN, ST_MOVE };
+constexpr int CTL_NO_CHILDREN = 4; // a searched root had no children (n_sims below n_thr)
 constexpr uint32_t KIND_VALUE = 0u, KIND_POLICY = 1u;
 
 struct SearchParams {
@@ -75,6 +76,17 @@ struct SearchParams {
     int32_t *stats;
     uint64_t *wg_own, *wg_opp;
     long long clock_limit; // wall_clock64 ticks (100 MHz) after which the launch gives up
+    // whole self-play games in the launch (iago_selfplay_persistent): max_turns > 0.  A game then walks through
+    // its turns on its own: legal moves of the mover, a search of n_sims playouts (or a pass), the most visited
+    // move (MCTS.get_move, MCTS.py:147), MCTS.update_with_move (MCTS.py:149-154), the move on the board and the
+    // turn bookkeeping of game.py:117-142,253-255 -- what SelfPlayEngine.play drives per turn for all games
+    int32_t max_turns;
+    uint64_t *game_own, *game_opp;   // [n_games] in: the start positions (own = colour 1, the first mover); out: final
+    int32_t *n_turns;                // [n_games] out: turns the game took (even, or max_turns)
+    uint64_t *rec_own, *rec_opp;     // optional [max_turns][n_games]: the position before every turn (own = mover)
+    uint8_t *rec_valid;              // [max_turns][n_games]: the mover had a move and searched
+    int8_t *rec_move;                // [max_turns][n_games]: the move played, -1 = pass / no turn
+    int32_t *rec_pi;                 // [max_turns][n_games][64]: the root's visit counts by action
     int64_t *trace;        // optional diagnostic [trace_rows][4]: game workgroup 0 samples (ticks, tail, head, finished) per iteration
     int32_t trace_rows;
     int32_t pair_backlog;  // entries that must be waiting (beyond the tickets handed out) for a net workgroup to take two
@@ -97,6 +109,15 @@ __device__ __forceinline__ void send_request(const SearchParams &S, uint32_t kin
     st(e + 5, tag | (uint32_t)(opp >> 32));
     st(e + 0, tag | (kind << 31) | (uint32_t)g);
     atomicAdd((unsigned long long *)&S.totals[kind], 1ull);
+}
+
+template <int CTRL>
+__device__ __forceinline__ void most_visited_step(int &n, int &a)
+{
+    const int on = (int)dpp_u32<CTRL>((uint32_t)n), oa = (int)dpp_u32<CTRL>((uint32_t)a);
+    const bool take = on > n || (on == n && oa < a);
+    n = take ? on : n;
+    a = take ? oa : a;
 }
 
 __device__ __forceinline__ bool group8_all(bool x)
@@ -153,12 +174,24 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
     const bool need_v = S.lmbda < 1.0f, need_z = S.lmbda > 0.0f;
     int32_t *const path = S.path + (exists ? g : 0) * (int64_t)S.path_stride;
 
-    int state = (exists && S.active[g] != 0 && S.n_sims > 0) ? ST_READY : ST_DONE;
+    const bool whole = S.max_turns > 0;
+    int state = (exists && S.active[g] != 0 && S.n_sims > 0) ? (whole ? ST_TURN : ST_READY) : ST_DONE;
     uint32_t epoch = 0u; // reply tag of the game's last request (never 0 once used)
     int n_done = 0;
     if (exists && r == 0u) {
         S.done[g] = 0;
         S.roll[g] = 0;
+    }
+    // whole games: the game's own position (own = side to move), its books (game.py:32,117-142) and its turn
+    uint64_t g_own = 0, g_opp = 0;
+    int turn = 0, stones = 4;
+    bool pass_flg = false, g_over = false;
+    const int search_end = whole ? ST_MOVE : ST_DONE; // where a game goes when its search's last playout is backed up
+    if (whole && exists) {
+        g_own = S.game_own[g];
+        g_opp = S.game_opp[g];
+        if (state == ST_DONE && r == 0u)
+            S.n_turns[g] = 0;
     }
     // cursor of the descent (kept across iterations while the game waits for priors)
     int node = 0, fc = -1, k = 0, nv = 0, path_n = 0, leaf = 0;
@@ -194,9 +227,121 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                 backup_game(S, g, r, leaf, true, v_reply, path_n);
                 n_done++;
                 if (r == 0u)
-                    S.done[g] = n_done;
-                state = n_done >= S.n_sims ? ST_DONE : ST_READY;
+                    S.done[g] = turn * S.n_sims + n_done;
+                state = n_done >= S.n_sims ? search_end : ST_READY;
                 busy = true;
+            }
+            // ---- whole games: the turn's end (the move) and the next turn's start, until the game searches again
+            // or is over (a pass leads straight on to the next turn: at most a few rounds)
+            if (whole) {
+                for (int rep = 0; rep < 6; rep++) {
+                    const bool at_move = state == ST_MOVE, at_turn = state == ST_TURN;
+                    if (__builtin_amdgcn_ballot_w64(at_move || at_turn) == 0ull)
+                        break;
+                    busy = busy || at_move || at_turn;
+                    const uint64_t lg = group8_legal(to_lane(g_own, L), to_lane(g_opp, L), L);
+                    const bool can_move = lg != 0ull && !g_over;
+                    if (at_turn && can_move) {
+                        // the mover searches: MCTS.get_move(state, color) (game.py:112)
+                        n_done = 0;
+                        if (r == 0u)
+                            S.done[g] = turn * S.n_sims; // (the rollouts' Philox stream: stream base + turn x n_sims + playout)
+                        state = ST_READY;
+                    }
+                    const bool moving = at_move || (at_turn && !can_move);
+                    // the root's children are the mover's legal moves in ascending order (Node.expand)
+                    const int root = moving ? T.root[g] : 0;
+                    const int rfc = moving ? T.nodes[base + root].first_child : -1;
+                    int best_n = -1, best_a = 0x7fffffff;
+                    int row_n[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int a = (int)(8u * r) + i;
+                        int n = 0;
+                        if (at_move && rfc >= 0 && ((lg >> a) & 1ull)) {
+                            n = T.nodes[base + rfc + __popcll(lg & ((1ull << a) - 1ull))].n_visits;
+                            if (n > best_n) { // the first maximum wins (MCTS.py:147)
+                                best_n = n;
+                                best_a = a;
+                            }
+                        }
+                        row_n[i] = n;
+                    }
+                    // argmax over the 8 lanes: more visits, then the lower action
+                    most_visited_step<DPP_XOR1>(best_n, best_a);
+                    most_visited_step<DPP_XOR2>(best_n, best_a);
+                    most_visited_step<DPP_HALF_MIRROR>(best_n, best_a);
+                    if (moving) {
+                        int mv = -1;
+                        if (at_move) {
+                            mv = best_n >= 0 ? best_a : -2;
+                            if (mv == -2 && r == 0u) // max() of an empty children dict (MCTS.py:147): n_sims < n_thr
+                                __hip_atomic_store(&S.ctl[CTL_NO_CHILDREN], 1u, RLX_AGENT);
+                        }
+                        if (S.rec_move) {
+                            const int64_t row = (int64_t)turn * T.n_games + g;
+                            if (r == 0u) {
+                                S.rec_own[row] = g_own;
+                                S.rec_opp[row] = g_opp;
+                                S.rec_valid[row] = at_move ? 1 : 0;
+                                S.rec_move[row] = (int8_t)(at_move ? mv : -1);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 8; i++)
+                                S.rec_pi[row * 64 + (int)(8u * r) + i] = row_n[i];
+                        }
+                        // MCTS.update_with_move (MCTS.py:149-154) for the games not over: the child becomes the root,
+                        // or (no such child) a fresh Node(None, 1.0)
+                        if (!g_over && r == 0u) {
+                            int child = -1;
+                            if (rfc >= 0) {
+                                if (mv >= 0 && ((lg >> mv) & 1ull))
+                                    child = rfc + __popcll(lg & ((1ull << mv) - 1ull));
+                                else if (mv == -1 && (int)T.nodes[base + rfc].action == -1)
+                                    child = rfc;
+                            }
+                            if (child >= 0) {
+                                T.root[g] = child;
+                                T.nodes[base + child].parent = -1;
+                            } else {
+                                init_node(T, base, -1, -2, 1.0f + 0.1f);
+                                T.n_nodes[g] = 1;
+                                T.root[g] = 0;
+                            }
+                        }
+                        // the stone, the books, the swap of sides (iago_play_turn; game.py:117-142,253-255)
+                        const bool placed = at_move && mv >= 0;
+                        const uint64_t f = group8_flips(to_lane(g_own, L), to_lane(g_opp, L), (uint32_t)mv & 63u, L);
+                        uint64_t o = g_own, p = g_opp;
+                        if (placed) {
+                            const uint64_t bit = 1ull << (mv & 63);
+                            o = g_own | f | bit;
+                            p = g_opp & ~f & ~bit;
+                        }
+                        const bool was_over = g_over;
+                        stones += at_move ? 1 : 0;
+                        const bool passing = !at_move && !was_over;
+                        if (passing && pass_flg)
+                            stones = 64;                       // a pass after a pass ends the game
+                        if (!was_over)
+                            pass_flg = passing;
+                        if (turn % 2 == 1)                     // `while stone_num < 64` once per pair of turns
+                            g_over = was_over || stones >= 64;
+                        g_own = p;
+                        g_opp = o;
+                        turn++;
+                        if (turn >= S.max_turns || (turn % 2 == 0 && g_over)) {
+                            if (r == 0u) {
+                                S.n_turns[g] = turn;
+                                S.game_own[g] = g_own;         // (colour 1's stones after an even number of turns)
+                                S.game_opp[g] = g_opp;
+                            }
+                            state = ST_DONE;
+                        } else {
+                            state = ST_TURN;
+                        }
+                    }
+                }
             }
             // ---- descent (MCTS.py:105-133): from the root, or on from the leaf whose priors arrived
             const bool fresh_start = state == ST_READY;
@@ -206,8 +351,8 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             bool need_prior = false;
             if (fresh_start) {
                 node = T.root[g];
-                own = S.root_own[g];
-                opp = S.root_opp[g];
+                own = whole ? g_own : S.root_own[g];
+                opp = whole ? g_opp : S.root_opp[g];
                 const uint4 s0 = ((const uint4 *)&T.nodes[base + node])[0], l0 = ((const uint4 *)&T.nodes[base + node])[1];
                 fc = (int)l0.x;
                 k = (int)((l0.z >> 8) & 0xFFu);
@@ -383,8 +528,8 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                 backup_game(S, g, r, leaf, false, __uint_as_float(vbits), path_n);
                 n_done++;
                 if (r == 0u)
-                    S.done[g] = n_done;
-                state = n_done >= S.n_sims ? ST_DONE : ST_READY;
+                    S.done[g] = turn * S.n_sims + n_done;
+                state = n_done >= S.n_sims ? search_end : ST_READY;
             } else if (state == ST_ROLL_FRESH) {
                 state = ST_WAIT_VALUE;
             }
@@ -578,7 +723,7 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: bad tree (the value cache `v` is required)");
     if (tree->n_games > 0x7FFFFFF0ll)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: too many games");
-    if (!a->root_own || !a->root_opp || !a->active || !a->cur_node || !a->cur_own || !a->cur_opp || !a->path ||
+    if (!a->active || !a->cur_node || !a->cur_own || !a->cur_opp || !a->path ||
         a->path_stride < 8 || !a->done || !a->roll || !a->leaf_value || !a->q_slots || !a->ctl || !a->rep_v || !a->rep_p ||
         !a->totals || !a->wg_own || !a->wg_opp || ((uintptr_t)a->q_slots & 63u) || ((uintptr_t)a->rep_p & 7u) ||
         ((uintptr_t)a->rep_v & 7u) || ((uintptr_t)a->ctl & 15u))
@@ -586,6 +731,12 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
     if (a->n_thr < 1 || a->n_sims < 0 || !(a->lmbda >= 0.0f && a->lmbda <= 1.0f) || a->net_workgroups < 1)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: n_thr >= 1, n_sims >= 0, 0 <= lmbda <= 1, "
                                            "net_workgroups >= 1 expected");
+    if (a->max_turns < 0 || (a->max_turns > 0 && (!a->game_own || !a->game_opp || !a->n_turns)) ||
+        (a->max_turns > 0 && a->rec_move && (!a->rec_own || !a->rec_opp || !a->rec_valid || !a->rec_pi)))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: whole games (max_turns > 0) need game_own, game_opp, "
+                                           "n_turns, and all of rec_own / rec_opp / rec_valid / rec_move / rec_pi or none");
+    if (a->max_turns == 0 && (!a->root_own || !a->root_opp))
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: root_own / root_opp expected");
     if (a->z_log_rows > 0 && (!a->z_log || !a->z_log_n))
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: z_log needs z_log_n");
     const iago_rollout_args *ro = a->rollout;
@@ -648,6 +799,15 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
         return v < 1 ? 0x7fffffff : v;
     }();
     S.pair_backlog = pair_backlog;
+    S.max_turns = a->max_turns;
+    S.game_own = a->game_own;
+    S.game_opp = a->game_opp;
+    S.n_turns = a->n_turns;
+    S.rec_own = a->rec_own;
+    S.rec_opp = a->rec_opp;
+    S.rec_valid = a->rec_valid;
+    S.rec_move = a->rec_move;
+    S.rec_pi = a->rec_pi;
     S.trace = a->trace_rows > 0 ? a->trace : nullptr;
     S.trace_rows = a->trace_rows;
     iago_row::HwParams R = iago_row::hw_params_of(ro);
@@ -662,7 +822,7 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
                          "iago_mcts_search_persistent: cannot reserve the nets' LDS image"))
         return IAGO_ERR_HIP;
     // every polled word starts from zero: the control block, the request ring and the reply mailboxes
-    if (hipMemsetAsync(a->ctl, 0, 16, (hipStream_t)stream) != hipSuccess ||
+    if (hipMemsetAsync(a->ctl, 0, 32, (hipStream_t)stream) != hipSuccess ||
         hipMemsetAsync(a->q_slots, 0, (size_t)QCAP * 64, (hipStream_t)stream) != hipSuccess ||
         hipMemsetAsync(a->rep_v, 0, (size_t)tree->n_games * 8, (hipStream_t)stream) != hipSuccess ||
         hipMemsetAsync(a->rep_p, 0, (size_t)tree->n_games * 512, (hipStream_t)stream) != hipSuccess)

@@ -364,7 +364,7 @@ class BatchedMCTS(object):
             self._ps = dict(
                 path=torch.zeros((n_games, self.PATH_STRIDE), dtype=torch.int32, **kw),
                 done=torch.zeros(n_games, dtype=torch.int32, **kw), roll=torch.zeros(n_games, dtype=torch.uint8, **kw),
-                q_slots=torch.zeros(_lib.SEARCH_QUEUE_ENTRIES * 8, dtype=i64, **kw), ctl=torch.zeros(4, dtype=torch.int32, **kw),
+                q_slots=torch.zeros(_lib.SEARCH_QUEUE_ENTRIES * 8, dtype=i64, **kw), ctl=torch.zeros(8, dtype=torch.int32, **kw),
                 rep_v=torch.zeros(n_games, dtype=i64, **kw), rep_p=torch.zeros(n_games * 64, dtype=i64, **kw),
                 totals=torch.zeros(8, dtype=i64, **kw), wg_own=torch.zeros(4 * grid, dtype=i64, **kw),
                 wg_opp=torch.zeros(4 * grid, dtype=i64, **kw), wg_v=torch.zeros(4 * grid, dtype=torch.float32, **kw),
@@ -981,6 +981,13 @@ class BatchedMCTS(object):
 
     def _search_persistent(self, own, opp, active, n_sims, n_active):
         """n_sims playouts per active game as ONE launch (iago_mcts_search_persistent)."""
+        self._launch_persistent(own, opp, active, n_sims)
+        self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
+        self.n_leaf_evals += n_active * n_sims
+
+    def _launch_persistent(self, own, opp, active, n_sims, game=None):
+        """iago_mcts_search_persistent: one search from the roots (own, opp), or -- game = dict(max_turns, own,
+        opp, n_turns, rec_own, rec_opp, rec_valid, rec_move, rec_pi) -- whole self-play games."""
         if self.rollout_hook is not None:
             raise ValueError("rollout_hook is not available in the persistent search (z_log_rows records the z)")
         ps = self._ps
@@ -992,7 +999,9 @@ class BatchedMCTS(object):
             pa, keep_p = self.policy_fn.search_args(ps["wg_own"], ps["wg_opp"], ps["wg_probs"])
         a = _lib.MctsSearchArgs()
         a.tree = C.addressof(self.tree.c)
-        a.root_own, a.root_opp, a.active = own.data_ptr(), opp.data_ptr(), active.data_ptr()
+        if own is not None:
+            a.root_own, a.root_opp = own.data_ptr(), opp.data_ptr()
+        a.active = active.data_ptr()
         a.c_puct, a.lmbda, a.n_thr, a.n_sims = self.c_puct, self.lmbda, self.n_thr, int(n_sims)
         a.net_workgroups, a.time_limit_ms = self.net_workgroups, self.time_limit_ms
         a.value, a.policy, a.rollout = C.addressof(va), C.addressof(pa), C.addressof(ro.args)
@@ -1005,12 +1014,17 @@ class BatchedMCTS(object):
         a.rep_v, a.rep_p, a.totals = ps["rep_v"].data_ptr(), ps["rep_p"].data_ptr(), ps["totals"].data_ptr()
         a.stats = self.stats.data_ptr() if self.stats is not None else None
         a.wg_own, a.wg_opp = ps["wg_own"].data_ptr(), ps["wg_opp"].data_ptr()
+        if game is not None:
+            a.max_turns = int(game["max_turns"])
+            a.time_limit_ms = max(self.time_limit_ms, 60000)   # (a whole game of 400-playout searches takes seconds)
+            a.game_own, a.game_opp, a.n_turns = game["own"].data_ptr(), game["opp"].data_ptr(), game["n_turns"].data_ptr()
+            a.rec_own, a.rec_opp = game["rec_own"].data_ptr(), game["rec_opp"].data_ptr()
+            a.rec_valid, a.rec_move, a.rec_pi = (game["rec_valid"].data_ptr(), game["rec_move"].data_ptr(),
+                                                 game["rec_pi"].data_ptr())
         if getattr(self, "trace", None) is not None:   # (diagnostic: tools/exp_persistent_trace.py)
             a.trace, a.trace_rows = self.trace.data_ptr(), self.trace.shape[0]
         check(_lib.lib().iago_mcts_search_persistent(C.byref(a), _stream()), "iago_mcts_search_persistent")
-        self._ps_keep = (keep_v, keep_p, ro, va, pa, own, opp, active)   # alive until the next search's launch
-        self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
-        self.n_leaf_evals += n_active * n_sims
+        self._ps_keep = (keep_v, keep_p, ro, va, pa, own, opp, active, game)   # alive until the next launch
 
     def search_counts(self, active):
         """Device tensor int64[2]: games in `active`, nodes of the fullest pool -- what search()
@@ -1025,6 +1039,9 @@ class BatchedMCTS(object):
         host sync each) -- the caller reads error_flags() and calls raise_errors()."""
         n_active, used = (int(v) for v in (self.search_counts(active).tolist() if counts is None else counts))
         if n_active == 0:
+            # (the playout counter advances all the same: a game's Philox streams are keyed by ITS turn and
+            # playout, whatever the other games of the batch do at that turn)
+            self.sim_counter = (self.sim_counter + n_sims) & 0xFFFFFFFF
             return
         if self.value_cache:
             # the stored values belong to the weights that computed them
@@ -1186,6 +1203,56 @@ class SelfPlayEngine(object):
         self.B = mcts.n_games
         self.max_turns = max_turns
 
+    def _play_persistent(self, n_sims, own, opp, record):
+        """The whole game of every board in ONE launch (iago_mcts_search_persistent with max_turns > 0): each
+        game walks through its own turns -- search, most visited move, update_with_move, the stone, the books
+        -- with no barrier between the games' turns.  Same moves, visit counts and results as the turn-by-turn
+        loop below (tests/test_search_persistent_gpu.py)."""
+        m, B, T = self.mcts, self.B, self.max_turns
+        dev = own.device
+        g = dict(max_turns=T, own=own, opp=opp, n_turns=torch.zeros(B, dtype=torch.int32, device=dev),
+                 rec_own=torch.zeros((T, B), dtype=torch.int64, device=dev),
+                 rec_opp=torch.zeros((T, B), dtype=torch.int64, device=dev),
+                 rec_valid=torch.zeros((T, B), dtype=torch.uint8, device=dev),
+                 rec_move=torch.full((T, B), -1, dtype=torch.int8, device=dev),
+                 rec_pi=torch.zeros((T, B, 64), dtype=torch.int32, device=dev))
+        active = torch.ones(B, dtype=torch.uint8, device=dev)
+        if m.value_cache:
+            key = tuple((q.data_ptr(), q._version) for q in m.value_fn.parameters())
+            if key != m._value_key:
+                if m._value_key is not None:
+                    m.tree.v.fill_(float("nan"))
+                m._value_key = key
+        m._launch_persistent(None, None, active, n_sims, game=g)
+        back = torch.cat([m.error_flags(), m._ps["ctl"][4].to(torch.int64).reshape(1),
+                          g["n_turns"].max().to(torch.int64).reshape(1),
+                          g["rec_valid"].sum().to(torch.int64).reshape(1)]).tolist()
+        m.raise_errors(back[:5])
+        if back[5]:
+            raise ValueError("a searched root has no children: n_sims is below the expansion threshold n_thr")
+        t = int(back[6])
+        m.sim_counter = (m.sim_counter + t * n_sims) & 0xFFFFFFFF
+        m.n_leaf_evals += int(back[7]) * n_sims
+        res = SelfPlayResult()
+        res.game_id_base = m.game_id_base
+        res.n_turns = t
+        res.mover = [1 if k % 2 == 0 else 2 for k in range(t)]
+        # a game's boards after n_turns[g] swaps of sides; colour 1's stones are `own` after an even number
+        even = (g["n_turns"] % 2 == 0)
+        p1, p2 = torch.where(even, own, opp), torch.where(even, opp, own)
+        res.z = ops.judge(p1, p2)
+        res.final_p1, res.final_p2 = p1, p2
+        if record:
+            turn = torch.arange(t, device=dev).reshape(t, 1)
+            played = turn < g["n_turns"].reshape(1, B)
+            # (the turn-by-turn loop records a finished game's boards, still swapping sides, until the last game
+            # of the batch is over: the same rows here)
+            tw = (turn % 2 == 0)
+            res.own = torch.where(played, g["rec_own"][:t], torch.where(tw, p1.reshape(1, B), p2.reshape(1, B)))
+            res.opp = torch.where(played, g["rec_opp"][:t], torch.where(tw, p2.reshape(1, B), p1.reshape(1, B)))
+            res.valid, res.move, res.pi = g["rec_valid"][:t], g["rec_move"][:t], g["rec_pi"][:t]
+        return res
+
     def play(self, n_sims, handicap=None, record=True):
         m, B = self.mcts, self.B
         dev = m.cur_own.device
@@ -1194,6 +1261,8 @@ class SelfPlayEngine(object):
         if handicap is not None:  # (B,) int64 bit masks of extra colour-2 stones
             opp = opp | handicap
         m.tree.reset()
+        if getattr(m, "persistent", False) and os.environ.get("IAGO_PERSISTENT_GAMES", "1") != "0":
+            return self._play_persistent(n_sims, own, opp, record)
         stone_num = torch.full((B,), 4, dtype=torch.int32, device=dev)  # game.py:32
         pass_flg = torch.zeros(B, dtype=torch.uint8, device=dev)
         done = torch.zeros(B, dtype=torch.uint8, device=dev)

@@ -751,7 +751,7 @@ IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const 
  *     its own / opp are ignored (the leaves' positions cur_own / cur_opp take their place).
  *   State, caller-owned device memory, no initialisation needed: cur_node / cur_own / cur_opp / done
  *     [n_games], roll [n_games] uint8, path [n_games][path_stride], leaf_value [n_games], q_slots
- *     [IAGO_SEARCH_QUEUE_ENTRIES][8] uint64 (64-byte aligned), ctl [4] uint32 (16-byte aligned; after the
+ *     [IAGO_SEARCH_QUEUE_ENTRIES][8] uint64 (64-byte aligned), ctl [8] uint32 (16-byte aligned; after the
  *     launch ctl[3] != 0: the launch gave up after time_limit_ms), rep_v [n_games] uint64, rep_p
  *     [n_games][64] uint64, wg_own / wg_opp [4 x grid].  totals [8] int64 ACCUMULATES value evaluations, policy
  *     evaluations, game-workgroup iterations, pair walks, the net workgroups' waiting and walking time (100 MHz
@@ -786,6 +786,28 @@ typedef struct iago_mcts_search_args {
     int64_t *totals;
     int32_t *stats;
     uint64_t *wg_own, *wg_opp;
+    /* Whole self-play games in the launch: max_turns > 0 (0: one search from root_own / root_opp).  Every game then
+       also walks through its TURNS on its own clock -- the mover's legal moves (game.py:210-235); a search of n_sims
+       playouts and the most visited move (MCTS.get_move, MCTS.py:139-147), or a pass; MCTS.update_with_move
+       (MCTS.py:149-154); the stone and the books of game.py:117-142,253-255 (stone_num, pass_flg, `while
+       stone_num < 64` once per pair of turns: iago_play_turn's arithmetic) -- until it is over or max_turns turns
+       are played: what engine.SelfPlayEngine.play drives turn by turn for all games in lockstep.  Playout p of a
+       game's turn t draws from Philox stream rollout->stream_id + t * n_sims + p.  The trees must be reset and hold
+       a whole game (no compaction in the launch).
+         game_own / game_opp [n_games]: in: the start positions (own = the first mover); out: the final positions
+           as they stand after n_turns swaps of sides;  n_turns [n_games]: out;
+         rec_* (optional, all or none) [max_turns][n_games] (rec_pi: [max_turns][n_games][64] int32): per turn the
+           position before it (own = mover), whether the mover searched, the move (-1: pass / no turn), the root's
+           visit counts by action; rows of turns a game did not play are not written.
+       ctl [8]: ctl[3] != 0: gave up after time_limit_ms; ctl[4] != 0: a searched root had no children
+       (n_sims < n_thr: the reference's max() of an empty dict, MCTS.py:147). */
+    int32_t max_turns, reserved2;
+    uint64_t *game_own, *game_opp;
+    int32_t *n_turns;
+    uint64_t *rec_own, *rec_opp;
+    uint8_t *rec_valid;
+    int8_t *rec_move;
+    int32_t *rec_pi;
     int64_t *trace;       /* optional diagnostic [trace_rows][4]: game workgroup 0 records (100 MHz ticks since its start,
                              requests queued so far, tickets handed out so far, game workgroups finished) once per
                              iteration of its loop */

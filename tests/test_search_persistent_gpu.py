@@ -103,13 +103,35 @@ def test_n_thr_one(nets):
     assert 0 < a.n_policy_evals <= b.n_policy_evals and a.n_value_evals == b.n_value_evals
 
 
-def test_whole_games(nets):
-    """SelfPlayEngine on the persistent search = on the per-playout launches: moves, visit counts, results."""
+@pytest.mark.parametrize("games", ["1", "0"])
+def test_whole_games(nets, games, monkeypatch):
+    """SelfPlayEngine on the persistent search = on the per-playout launches: moves, visit counts, recorded
+    positions, results.  games = "1": the whole game of every board in ONE launch (every game walks through its
+    own turns); "0": one persistent launch per turn."""
     engine, ops, policy, value, rw = nets
+    monkeypatch.setenv("IAGO_PERSISTENT_GAMES", games)
     res = {}
+    hc = torch.zeros(40, dtype=torch.int64, device="cuda")
+    hc[1::2] = 1 << (2 * 8 + 4)          # the handicap stone of src/train_rl.py:43-46 on every other board
     for persistent in (True, False):
-        m = engine.BatchedMCTS(40, policy, value, rw, n_thr=15, capacity=4096, seed=11, use_graph=True, persistent=persistent)
-        r = engine.SelfPlayEngine(m).play(24)
-        res[persistent] = (r.move.cpu().numpy(), r.pi.cpu().numpy(), r.z.cpu().numpy(), r.valid.cpu().numpy())
-    for x, y in zip(res[True], res[False]):
-        assert np.array_equal(x, y)
+        m = engine.BatchedMCTS(40, policy, value, rw, n_thr=15, capacity=4096, seed=11, use_graph=True,
+                               persistent=persistent, z_log_rows=128 * 24)
+        r = engine.SelfPlayEngine(m).play(24, handicap=hc)
+        t = r.tuples()
+        res[persistent] = dict(move=r.move.cpu().numpy(), pi=r.pi.cpu().numpy(), z=r.z.cpu().numpy(),
+                               valid=r.valid.cpu().numpy(), own=r.own.cpu().numpy(), opp=r.opp.cpu().numpy(),
+                               p1=r.final_p1.cpu().numpy(), p2=r.final_p2.cpu().numpy(), n_turns=r.n_turns,
+                               tz=t["z"].cpu().numpy(), tgame=t["game"].cpu().numpy(),
+                               zlog=m.z_log.cpu().numpy(), zn=m.z_log_n.cpu().numpy(), leaf=m.n_leaf_evals,
+                               sim=m.sim_counter)
+    a, b = res[True], res[False]
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["n_turns"] % 2 == 0 and a["valid"].sum() > 40 * 50
+
+
+def test_whole_games_below_n_thr_raise(nets):
+    engine, ops, policy, value, rw = nets
+    m = engine.BatchedMCTS(16, policy, value, rw, n_thr=15, capacity=1024, seed=1, persistent=True)
+    with pytest.raises(ValueError):
+        engine.SelfPlayEngine(m, max_turns=4).play(8)      # MCTS.get_move's max() of an empty dict (MCTS.py:147)
