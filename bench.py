@@ -109,7 +109,8 @@ def cpu_baseline(w, b, budget_s=10.0):
             "board_steps_per_game": steps / games, "one_core_games_per_sec": one_core}
 
 
-def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=False, use_graph=True, n_thr=15):
+def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=False, use_graph=True, n_thr=15,
+             persistent=None):
     """BASELINE configs[2]: PV-MCTS self-play, `n_games` lockstep games per GPU,
     `n_sims` playouts per move, SLPolicy + Value with random-init weights
     (Chainer-default LeCunNormal, seed 0), reference constants lmbda=0.5,
@@ -124,8 +125,14 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     policy = network.SLPolicy().cuda().eval()
     value = network.Value().cuda().eval()
     value.split_f16 = not value_f32
+    # the engine: the persistent search (one launch per whole game, every game on its own clock) wherever it
+    # applies -- the split-f16 value net -- else per-playout launches replayed as hipGraphs (persistent=False: the
+    # comparison figure `mcts_per_playout_launches`)
+    if persistent is None:
+        persistent = not value_f32 and use_graph
     m = engine.BatchedMCTS(n_games, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0,
-                           n_thr=n_thr, seed=7, game_id_base=rank * n_games, use_graph=use_graph,
+                           n_thr=n_thr, seed=7, game_id_base=rank * n_games, use_graph=use_graph and not persistent,
+                           persistent=persistent,
                            capacity=engine.suggest_capacity(n_sims, n_thr, moves=64 if full_games else n_turns + 4))
     eng = engine.SelfPlayEngine(m, max_turns=(128 if full_games else n_turns))
     m.enable_stats()
@@ -178,6 +185,12 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
                                    "first visit and taken from the node afterwards (value_evals = net "
                                    "launches' rows), the rollout runs at every visit; trees bit-identical "
                                    "to evaluating the net at every visit (tests/test_mcts_gpu.py)",
+           "engine": ("persistent search: ONE launch per whole self-play game, game workgroups (16 games each: descent, "
+                      "rollout, backup, moves) + %d net workgroups serving a queue of positions with one-board / two-board "
+                      "walks of the value net and one-board walks of the policy net (at the expansion, as the reference)"
+                      % m.net_workgroups if m.persistent else
+                      "per-playout launches (descent, leaf evaluation, backup) replayed as hipGraphs, policy look-ahead "
+                      "batches on a second stream"),
            "value_cache": bool(m.value_cache), "policy_lookahead": int(m.lookahead),
            "seconds": dt, "turns_played": res.n_turns, "sims_per_move": n_sims,
            "games_per_gpu": n_games, "full_games": bool(full_games),
@@ -541,12 +554,12 @@ def reinforce_leg(n_iters, world, rank, dist, mcts_rounds=1):
         lo, hi = shard_range(games, rank, world)
         value = network.Value().cuda().eval()
         m = engine.BatchedMCTS(hi - lo, tr.model1, value, ops.RolloutWeights(w, b), n_thr=15,
-                               capacity=engine.suggest_capacity(sims, 15), seed=1, game_id_base=lo, use_graph=True)
+                               capacity=engine.suggest_capacity(sims, 15), seed=1, game_id_base=lo, persistent=True)
         sp = engine.SelfPlayEngine(m)
 
         def one():
             tr.model1.eval()
-            res = sp.play(sims)     # (the engine re-captures its graph: the weights changed)
+            res = sp.play(sims)     # (one launch per round: nothing to re-capture when the weights change)
             return tr.step_from_tuples(res.tuples())
 
         one()                       # warm-up round
@@ -951,6 +964,8 @@ def main():
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks as child processes even for --gpus 1 (what --gpus N > 1 does "
                          "when no launcher has set WORLD_SIZE)")
+    ap.add_argument("--mcts-per-playout", action="store_true",
+                    help="PV-MCTS leg: the per-playout launches instead of the persistent search")
     ap.add_argument("--mcts-value-f32", action="store_true",
                     help="PV-MCTS leg: MIOpen float32 convolutions for the Value net instead of the "
                          "split-f16 MFMA kernels")
@@ -1009,13 +1024,19 @@ def main():
     if args.mcts_turns != 0:
         mcts = mcts_leg(args.mcts_games, args.mcts_sims, max(args.mcts_turns, 0),
                         args.mcts_turns < 0, world, rank, dist, value_f32=args.mcts_value_f32,
-                        use_graph=not args.mcts_eager)
+                        use_graph=not args.mcts_eager,
+                        persistent=False if (args.mcts_per_playout or args.mcts_eager) else None)
     if mcts is not None and not args.mcts_value_f32 and args.mcts_turns < 0 and not args.mcts_only:
         # the same leg with MIOpen float32 convolutions for the Value net, on a bounded
         # sample (first 4 turns), for comparison with the split-f16 kernels
         ref = mcts_leg(args.mcts_games, args.mcts_sims, 4, False, world, rank, dist, value_f32=True)
         mcts["value_f32_sample"] = {k: ref[k] for k in ("leaf_evals_per_sec", "leaf_evals", "seconds",
                                                         "turns_played", "value_conv")}
+    if mcts is not None and not args.mcts_value_f32 and args.mcts_turns < 0 and not args.mcts_only and not args.mcts_eager:
+        # the same full games on the per-playout launches (rounds 1-3's engine), for comparison
+        ref = mcts_leg(args.mcts_games, args.mcts_sims, 0, True, world, rank, None, persistent=False)
+        mcts["per_playout_launches"] = {k: ref[k] for k in ("leaf_evals_per_sec", "games_per_sec", "leaf_evals", "policy_evals",
+                                                             "value_evals", "seconds", "turns_played", "engine")}
     nthr1 = None
     if mcts is not None and args.nthr1_turns > 0 and not args.mcts_only and not args.mcts_value_f32:
         # "also report n_thr = 1" (MCTS.py:80,109): every leaf expands at its
@@ -1072,6 +1093,8 @@ def main():
             line["leaf_evals_per_sec"] = mcts["leaf_evals_per_sec"]
             if "games_per_sec" in mcts:
                 line["mcts_games_per_sec"] = mcts["games_per_sec"]
+            if "per_playout_launches" in mcts:
+                line["leaf_evals_per_sec_per_playout_launches"] = mcts["per_playout_launches"]["leaf_evals_per_sec"]
             rl = mcts.get("roofline") or {}
             if "useful_tflops" in rl:
                 line["mcts_useful_tflops"] = rl["useful_tflops"]                # measured in this run

@@ -217,8 +217,15 @@ class BatchedMCTS(object):
         can_p = (can_cache and getattr(value_fn, "search_args", None) is not None
                  and getattr(policy_fn, "search_args", None) is not None and getattr(policy_fn, "split3", False)
                  and rollout_weights is not None and not rollout_weights.log_form and 0.0 <= self.lmbda < 1.0)
-        if persistent is None:
-            persistent = can_p and os.environ.get("IAGO_PERSISTENT", "0") == "1"
+        # Default: ON wherever it applies, unless the caller asks for the per-playout launches (use_graph,
+        # look-ahead / asynchronous-step / value-look-ahead options, a rollout hook comes later); the environment
+        # variable IAGO_PERSISTENT=0 / 1 overrides both (measurements: tools/time_value_ahead.py).
+        env_p = os.environ.get("IAGO_PERSISTENT")
+        if env_p in ("0", "1"):
+            persistent = can_p and env_p == "1"
+        elif persistent is None:
+            persistent = can_p and not (use_graph or async_steps or value_ahead or lookahead is not None
+                                        or lookahead_overlap is not None or sync_free is not None)
         if persistent and not can_p:
             raise ValueError("persistent needs the split-f16 value net and the three-piece policy net (modules with "
                              "search_args), product-form rollout weights and lmbda < 1")

@@ -90,32 +90,39 @@ def _positions(G, golden_rules):
     return own, opp
 
 
-@pytest.mark.parametrize("async_steps,value_ahead", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("async_steps,value_ahead,persistent", [(False, False, True), (False, False, False),
+                                                                (True, False, False), (False, True, False),
+                                                                (True, True, False)])
 @pytest.mark.parametrize("n_sims,n_sims2,G", [(100, 60, 320), (400, 37, 64)])
 def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_sims, n_sims2, G, async_steps,
-                                                     value_ahead):
+                                                     value_ahead, persistent):
     """async_steps=False: lockstep playouts, the default and what bench.py times.  True: the same
     search as game-asynchronous steps (iago_mcts_async: a game with a fresh leaf waits while the value
     net walks its board in 3 pieces beside the other games' steps) -- the same trees, bit for bit.
     value_ahead=True: the children of every expanded node get their values from batches on the side
-    stream (iago_mcts_value_ahead) -- again the same trees."""
+    stream (iago_mcts_value_ahead) -- again the same trees.
+    persistent=True: what bench.py times since round 4 -- the whole search as ONE launch in which every
+    game runs on its own clock (iago_mcts_search_persistent: game workgroups + net workgroups serving a
+    queue of positions; the policy net at the expansion, as the reference) -- the same trees."""
     engine, ops, policy, value, rw = shipped
     own, opp = _positions(G, golden_rules)
     cap = engine.suggest_capacity(n_sims + n_sims2, 15, moves=2)
     m = engine.BatchedMCTS(G, policy, value, rw, lmbda=0.5, c_puct=1.0, n_thr=15, capacity=cap, seed=5,
                            game_id_base=1000, use_graph=True, z_log_rows=max(n_sims, n_sims2),
-                           async_steps=async_steps, value_ahead=value_ahead)
+                           async_steps=async_steps, value_ahead=value_ahead, persistent=persistent)
     assert m.value_ahead == value_ahead and (not value_ahead or m.n_value_ahead == 0)
-    # what bench.py's mcts_leg runs
-    assert m.use_graph and m.sync_free and m.lookahead == 4 and m.lookahead_overlap == 2
-    assert m.value_cache and m.fused_descent and m.fused_leaf_eval and m._la_path is not None
-    assert m.async_steps == async_steps and (not async_steps or m.async_parts == 3)
-    assert policy.split3 and policy.split3_parts == 2 and value.split_f16
+    assert m.persistent == persistent and m.value_cache and policy.split3 and value.split_f16
+    if not persistent:
+        # the per-playout launches at their defaults
+        assert m.use_graph and m.sync_free and m.lookahead == 4 and m.lookahead_overlap == 2
+        assert m.fused_descent and m.fused_leaf_eval and m._la_path is not None
+        assert m.async_steps == async_steps and (not async_steps or m.async_parts == 3)
+        assert policy.split3_parts == 2
     o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
     active = torch.ones(G, dtype=torch.uint8, device="cuda")
     active[5] = 0  # an idle game must stay untouched
     m.search(o, p, active, n_sims)
-    assert m._graph is not None and (n_sims < 32 or m._graph_long is not None)   # replayed, not eager
+    assert persistent or (m._graph is not None and (n_sims < 32 or m._graph_long is not None))   # replayed, not eager
     move = m.best_move(active)[0].cpu().numpy()
     visits = m.visits.cpu().numpy()
     zn = m.z_log_n.cpu().numpy()
@@ -173,18 +180,23 @@ def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_si
     value.check_saturation()
 
 
-@pytest.mark.parametrize("async_steps", [False, True, 2, 4])
+@pytest.mark.parametrize("async_steps", ["persistent", False, True, 2, 4])
 def test_production_self_play_games_vs_oracle(shipped, async_steps):
     """Whole self-play games through SelfPlayEngine at the production defaults (what bench.py's
     PV-MCTS leg times), 20 playouts per move (n_thr = 15 needs > 15): every game's move list and
     result equal the oracle's selfplay_game (game.py:117-142 turn structure) fed the recorded z."""
     engine, ops, policy, value, rw = shipped
     G, n_sims = 8, 24
-    # (True: the default 3 pieces; 2 / 4: the other layer splits and queue rotations of the value net's walk)
+    # ("persistent": whole games in ONE launch, what bench.py times; True: asynchronous steps with the default 3
+    # pieces; 2 / 4: the other layer splits and queue rotations of the value net's walk)
+    persistent = async_steps == "persistent"
+    async_steps = False if persistent else async_steps
     parts = async_steps if async_steps not in (False, True) else None
     m = engine.BatchedMCTS(G, policy, value, rw, n_thr=15, capacity=4096, seed=11, use_graph=True,
-                           z_log_rows=128 * n_sims, async_steps=bool(async_steps), async_parts=parts)
-    assert m.lookahead == 4 and m.value_cache and m.async_steps == bool(async_steps)
+                           z_log_rows=128 * n_sims, async_steps=bool(async_steps), async_parts=parts,
+                           persistent=persistent)
+    assert m.persistent == persistent and m.value_cache
+    assert persistent or (m.lookahead == 4 and m.async_steps == bool(async_steps))
     assert not async_steps or m.async_parts == (parts or 3)
     res = engine.SelfPlayEngine(m).play(n_sims)
     moves = res.move.cpu().numpy()           # (T, G), -1 = pass / finished
@@ -203,8 +215,10 @@ def test_production_self_play_games_vs_oracle(shipped, async_steps):
         assert next(it, None) is None, g     # the oracle consumed exactly the playouts the GPU ran
 
 
+@pytest.mark.parametrize("persistent", [True, False])
 @pytest.mark.parametrize("n_thr,n_sims,n_sims2", [(15, 100, 44), (1, 60, 30)])
-def test_production_search_with_uniform_rollouts_needs_no_replay(shipped, golden_rules, n_thr, n_sims, n_sims2):
+def test_production_search_with_uniform_rollouts_needs_no_replay(shipped, golden_rules, n_thr, n_sims, n_sims2,
+                                                                persistent):
     """The whole playout reproduced by the oracle ITSELF, rollouts included: with the uniform rollout
     policy (arithmetic exact in float32: tests/test_rollout_gpu.py) the oracle plays Simulate from the
     same Philox stream the kernel draws from -- stream id = the search's playout counter -- instead of
@@ -218,8 +232,9 @@ def test_production_search_with_uniform_rollouts_needs_no_replay(shipped, golden
     own, opp = _positions(G, golden_rules)
     cap = engine.suggest_capacity(n_sims + n_sims2, n_thr, moves=2)
     m = engine.BatchedMCTS(G, policy, value, ops.uniform_weights(), lmbda=0.5, c_puct=1.0, n_thr=n_thr, capacity=cap,
-                           seed=seed, game_id_base=base, use_graph=True)
-    assert m.use_graph and m.value_cache and m.fused_leaf_eval and m.lookahead == (4 if n_thr == 15 else 0)
+                           seed=seed, game_id_base=base, use_graph=True, persistent=persistent)
+    assert m.persistent == persistent and m.value_cache
+    assert persistent or (m.use_graph and m.fused_leaf_eval and m.lookahead == (4 if n_thr == 15 else 0))
     o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
     active = torch.ones(G, dtype=torch.uint8, device="cuda")
     m.search(o, p, active, n_sims)
@@ -258,7 +273,8 @@ def test_production_search_with_uniform_rollouts_needs_no_replay(shipped, golden
         _cmp_tree(m.tree.dump(g, max_depth=64), mcts_py.dump_tree(om.root, max_depth=64), "g%d'" % g)
 
 
-def test_production_self_play_uniform_rollouts_no_replay(shipped):
+@pytest.mark.parametrize("persistent", [True, False])
+def test_production_self_play_uniform_rollouts_no_replay(shipped, persistent):
     """Whole PV-MCTS self-play games (SelfPlayEngine at the production defaults) reproduced by the oracle
     with nothing replayed: uniform rollout policy, the oracle plays every leaf rollout itself from the
     Philox stream of that playout -- stream id = (turn of the game) x n_sims + playout, the engine's
@@ -266,8 +282,8 @@ def test_production_self_play_uniform_rollouts_no_replay(shipped):
     engine, ops, policy, value, _ = shipped
     G, n_sims, seed, base = 8, 24, 13, 70
     m = engine.BatchedMCTS(G, policy, value, ops.uniform_weights(), n_thr=15, capacity=4096, seed=seed,
-                           game_id_base=base, use_graph=True)
-    assert m.lookahead == 4 and m.value_cache and m.use_graph
+                           game_id_base=base, use_graph=True, persistent=persistent)
+    assert m.persistent == persistent and m.value_cache and (persistent or (m.lookahead == 4 and m.use_graph))
     res = engine.SelfPlayEngine(m).play(n_sims)
     moves, valid, z = res.move.cpu().numpy(), res.valid.cpu().numpy(), res.z.cpu().numpy()
     f1, f2 = ops.tensor_to_bits(res.final_p1), ops.tensor_to_bits(res.final_p2)
