@@ -108,6 +108,7 @@ class MctsValueAhead(C.Structure):
 
 
 SEARCH_QUEUE_ENTRIES = 4096   # IAGO_SEARCH_QUEUE_ENTRIES
+SEARCH_GAMES_PER_WORKGROUP = 32   # IAGO_SEARCH_GAMES_PER_WORKGROUP
 
 
 class MctsSearchArgs(C.Structure):

@@ -50,6 +50,9 @@ constexpr int CTL_HEAD = 0, CTL_TAIL = 1, CTL_FINISHED = 2, CTL_ABORT = 3;
 enum { ST_READY = 0, ST_WAIT_PRIOR, ST_PRIOR_READY, ST_ROLL, ST_ROLL_FRESH, ST_WAIT_VALUE, ST_HAVE_VALUE, ST_DONE, ST_TURN, ST_MOVE };
 constexpr int CTL_NO_CHILDREN = 4; // a searched root had no children (n_sims below n_thr)
 constexpr uint32_t KIND_VALUE = 0u, KIND_POLICY = 1u;
+// games of a GAME workgroup: 8 lanes per game in the descent and the backup (16 games = two waves, 32 = all four),
+// rollouts in passes of 16 boards (the 16-lanes-per-board body)
+constexpr int GAMES_PER_WG = IAGO_SEARCH_GAMES_PER_WORKGROUP;
 
 struct SearchParams {
     Tree T;
@@ -159,14 +162,14 @@ __device__ __forceinline__ void backup_game(const SearchParams &S, int64_t g, ui
     }
 }
 
-// The 16 games of a GAME workgroup (threads 0 .. 127: 8 lanes per game; the other two waves join the
+// The games of a GAME workgroup (8 lanes per game; with 16 games the other two waves only join the
 // rollouts and the barriers).
 __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago_row::HwParams &R, const long long t0)
 {
     const Tree &T = S.T;
     const int tid = threadIdx.x;
-    const bool mine = tid < 128;
-    const int64_t g = (int64_t)blockIdx.x * 16 + (tid >> 3);
+    const bool mine = tid < 8 * GAMES_PER_WG;
+    const int64_t g = (int64_t)blockIdx.x * GAMES_PER_WG + (tid >> 3);
     const Lane8 L = make_lane8(threadIdx.x);
     const uint32_t r = L.l8;
     const bool exists = mine && g < T.n_games;
@@ -518,10 +521,15 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                 S.roll[g] = (need_z && (state == ST_ROLL || state == ST_ROLL_FRESH)) ? 1 : 0;
         }
         // ---- rollouts of the leaves reached in this iteration (Simulate, mcts_self_play.py:9-134)
-        const int any_roll = __syncthreads_or(mine && need_z && (state == ST_ROLL || state == ST_ROLL_FRESH));
-        if (any_roll) {
-            iago_row::rollout_row_body<false, true>(R, blockIdx.x);
-            __syncthreads();
+        const bool rolls = mine && need_z && (state == ST_ROLL || state == ST_ROLL_FRESH);
+#pragma unroll 1
+        for (int pass = 0; pass < GAMES_PER_WG / 16; pass++) {
+            // (the games of this pass: threads 128 pass .. 128 pass + 127 hold their states)
+            const int any_roll = __syncthreads_or(rolls && (tid >> 7) == pass);
+            if (any_roll) {
+                iago_row::rollout_row_body<false, true>(R, blockIdx.x * (GAMES_PER_WG / 16) + pass);
+                __syncthreads();
+            }
         }
         if (mine) {
             if (state == ST_ROLL) {
@@ -744,7 +752,7 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
         ro->uniforms || ro->throughput_hint != 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: product-form rollout of the n games without "
                                            "trace / uniforms expected");
-    const int64_t n_game_wgs = (tree->n_games + 15) / 16;
+    const int64_t n_game_wgs = (tree->n_games + GAMES_PER_WG - 1) / GAMES_PER_WG;
     const int64_t grid = n_game_wgs + a->net_workgroups;
     if (a->value->n < 4 * grid || a->policy->n < 4 * grid || a->value->planes || a->value->index || a->value->n_dev ||
         a->policy->index || a->policy->n_dev || !a->value->own || a->value->own != a->wg_own ||

@@ -361,7 +361,7 @@ class BatchedMCTS(object):
             self.tree.reset_hooks = [reset_lookahead]
         self.value_ahead = bool(getattr(self, "value_ahead", False))
         if self.persistent:
-            n_gw = (n_games + 15) // 16
+            n_gw = -(-n_games // _lib.SEARCH_GAMES_PER_WORKGROUP)
             if net_workgroups is None:
                 net_workgroups = int(os.environ.get("IAGO_PERSISTENT_NET", "0")) or max(1, min(256 - n_gw, 8 * n_games))
             self.net_workgroups = max(1, int(net_workgroups))

@@ -734,7 +734,7 @@ IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const 
 /*
  * A whole search -- n_sims playouts of every active game, the loop of MCTS.get_move (MCTS.py:139-147)
  * around MCTS.playout (MCTS.py:105-133) -- as ONE persistent launch in which every game runs on its
- * own clock (csrc/search_kernel.hip).  The first ceil(n_games / 16) workgroups each own 16 games and
+ * own clock (csrc/search_kernel.hip).  The first ceil(n_games / IAGO_SEARCH_GAMES_PER_WORKGROUP) workgroups each own that many games and
  * loop over iago_mcts_descend's descent, iago_rollout's leaf rollout (Philox stream = rollout->stream_id
  * (+ *stream_id_dev) + the game's own playout count) and iago_mcts_mix_backup's backup for them; a game
  * whose leaf has no stored value (iago_mcts_fresh_leaves) or expands (n_visits >= n_thr, MCTS.py:109:
@@ -745,7 +745,7 @@ IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const 
  * trees are bit-identical to those of the per-playout launches.
  *   value / policy: the nets' weights as for iago_value_forward_split / iago_policy_forward_split3 with
  *     own = wg_own, opp = wg_opp (four rows per workgroup of the grid: a net workgroup walks two boards
- *     through the value net together when two are queued), n >= 4 x (ceil(n_games / 16) + net_workgroups),
+ *     through the value net together when two are queued), n >= 4 x (game workgroups + net_workgroups),
  *     out / probs sized for n rows, no planes / index / n_dev, parts = 1.
  *   rollout: table, seed, id_base, stream_id(_dev) and z [n_games] of iago_rollout_args (product form);
  *     its own / opp are ignored (the leaves' positions cur_own / cur_opp take their place).
@@ -761,6 +761,7 @@ IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const 
  * the device (256), and nothing else should occupy the device while the launch runs.
  */
 #define IAGO_SEARCH_QUEUE_ENTRIES 4096
+#define IAGO_SEARCH_GAMES_PER_WORKGROUP 32   /* games a game workgroup owns */
 typedef struct iago_mcts_search_args {
     const iago_mcts_tree *tree;
     const uint64_t *root_own, *root_opp;
