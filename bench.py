@@ -203,7 +203,7 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
                            "1e-5 of the float64 outputs on the shipped net, tests/test_nets_shipped.py)"
                            if policy.split3 else
                            "f32: hand-written conv3x3_f32 / policy_head kernels (batches <= 192); MIOpen above"),
-           "roofline": _mcts_roofline(val, pol, dt, world, value_f32, policy.split3),
+           "roofline": _mcts_roofline(val, pol, dt, world, value_f32, policy.split3, bool(m.persistent)),
            "config": "BASELINE configs[2]: PV-MCTS %d sims/move, %d games per GPU, SLPolicy+Value "
                      "random init fp32, lmbda=0.5 c_puct=1 n_thr=%d" % (n_sims, n_games, n_thr),
            "n_thr": n_thr,
@@ -243,7 +243,7 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def net_kernel_profiles():
+def net_kernel_profiles(persistent=False):
     """The two net kernels that ARE on the timed path of the PV-MCTS leg -- value_rollout_kernel
     (the leaf evaluation: one-board Value walks + the rollouts) and policy_resident_kernel (the
     look-ahead batches) -- from the newest committed FULL-GAME eager profile of the leg
@@ -259,16 +259,26 @@ def net_kernel_profiles():
     FLOPs per evaluation / duration, as fraction of the f16 peak and as multiple of the float32
     matrix peak, and the bytes a CU pulls from L2 per evaluation (TCP_TCC_READ_REQ x 128 B)."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mcts_fullgame_pmc_summary.json")))
+    # (the persistent engine: ONE search_kernel launch per whole self-play game -- tools/profile_mcts.sh <tag>
+    # persistent -> profiles/*_mcts_persistent_pmc_summary.json; a launch lasts ~0.5 s, so the rule is a total
+    # profiled duration of >= 0.1 s instead of 100 launches)
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mcts_%s_pmc_summary.json"
+                                          % ("persistent" if persistent else "fullgame"))))
     now = csrc_sha16()
     for path in reversed(paths):
         with open(path) as f:
             prof = json.load(f)
         ks = prof.get("kernels", {})
         out = {}
-        for name in ("value_rollout_kernel", "policy_resident_kernel", "descend_kernel", "mix_backup_path_kernel"):
+        for name in (("search_kernel",) if persistent else
+                     ("value_rollout_kernel", "policy_resident_kernel", "descend_kernel", "mix_backup_path_kernel")):
             k = ks.get(name)
-            if not k or k.get("calls", 0) < MIN_PROFILE_LAUNCHES or k.get("pmc_launches", 0) < MIN_PROFILE_LAUNCHES:
+            if not k:
+                continue
+            if name == "search_kernel":
+                if k.get("calls", 0) * k.get("avg_us", 0.0) < 1e5 or not k.get("pmc_launches"):
+                    continue
+            elif k.get("calls", 0) < MIN_PROFILE_LAUNCHES or k.get("pmc_launches", 0) < MIN_PROFILE_LAUNCHES:
                 continue
             e = {"launches": k["calls"], "rocprof_avg_us": k["avg_us"],
                  "hbm_bytes_per_launch": k.get("hbm_bytes_per_launch")}
@@ -292,7 +302,7 @@ def net_kernel_profiles():
                 gb = k["hbm_bytes_per_launch"] / (k["avg_us"] * 1e-6) / 1e9
                 e.update({"bound": "hbm", "achieved_gb_per_s": gb, "peak": HBM_PEAK_GBS, "frac": gb / HBM_PEAK_GBS})
             out[name] = e
-        if "value_rollout_kernel" in out and "policy_resident_kernel" in out:
+        if ("search_kernel" in out) if persistent else ("value_rollout_kernel" in out and "policy_resident_kernel" in out):
             out["profile"] = os.path.basename(path)
             out["command"] = prof.get("command")
             out["profile_csrc_sha16"] = prof.get("csrc_sha16")
@@ -305,7 +315,7 @@ def net_kernel_profiles():
     return None
 
 
-def _mcts_roofline(leaf, pol, dt, world, value_f32, policy_split3=False):  # leaf = value-net evaluations executed
+def _mcts_roofline(leaf, pol, dt, world, value_f32, policy_split3=False, persistent=False):  # leaf = value-net evaluations executed
     """The convolutions bound this leg.  f32 path: float32 matrix/vector peak 157.3
     TFLOP/s.  Split-f16 path: the Value convolutions of blocks 2..8 (122.68 MFLOP per
     evaluation) execute 3 f16 MFMAs per product sum -- and the SLPolicy ones (same shape) 6 with
@@ -334,7 +344,7 @@ def _mcts_roofline(leaf, pol, dt, world, value_f32, policy_split3=False):  # lea
                     "launches of the search (Value 3.9 MB, SLPolicy 5.8 MB of weights per board into ONE CU) "
                     "are bound by that CU's L2 bandwidth (~70 GB/s: 56 of 69 us, 83 of 113 us), not by the "
                     "matrix pipe (DESIGN.md section 5)",
-            "kernels": net_kernel_profiles()}
+            "kernels": net_kernel_profiles(persistent)}
 
 
 def cpu_workers(kind, budget_s):
@@ -1106,7 +1116,8 @@ def main():
                 # on the kernel sources of this tree
                 line["mcts_kernel_profile"] = ks.get("profile")
                 line["mcts_kernel_profile_current"] = bool(ks.get("current"))
-            for name, key in (("value_rollout_kernel", "mcts_value_kernel"), ("policy_resident_kernel", "mcts_policy_kernel")):
+            for name, key in (("search_kernel", "mcts_search_kernel"), ("value_rollout_kernel", "mcts_value_kernel"),
+                              ("policy_resident_kernel", "mcts_policy_kernel")):
                 if ks.get("current") and name in ks and "frac" in ks[name]:
                     line[key + "_mfma_frac_committed_profile"] = ks[name]["frac"]
                     if "useful_frac_f16_peak" in ks[name]:

@@ -46,7 +46,10 @@ typedef unsigned long long u64;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr uint32_t QCAP = IAGO_SEARCH_QUEUE_ENTRIES; // entries of the request ring (>= 2 x games outstanding at once)
-constexpr int CTL_HEAD = 0, CTL_TAIL = 1, CTL_FINISHED = 2, CTL_ABORT = 3;
+constexpr int CTL_FINISHED = 2, CTL_ABORT = 3;
+// two request rings, one per kind of net work: head (tickets handed out) / tail (entries reserved) of ring q
+__host__ __device__ constexpr int ctl_head(uint32_t q) { return 8 + 2 * (int)q; }
+__host__ __device__ constexpr int ctl_tail(uint32_t q) { return 9 + 2 * (int)q; }
 enum { ST_READY = 0, ST_WAIT_PRIOR, ST_PRIOR_READY, ST_ROLL, ST_ROLL_FRESH, ST_WAIT_VALUE, ST_HAVE_VALUE, ST_DONE, ST_TURN, ST_MOVE };
 constexpr int CTL_NO_CHILDREN = 4; // a searched root had no children (n_sims below n_thr)
 constexpr uint32_t KIND_VALUE = 0u, KIND_POLICY = 1u;
@@ -92,6 +95,7 @@ struct SearchParams {
     int32_t *rec_pi;                 // [max_turns][n_games][64]: the root's visit counts by action
     int64_t *trace;        // optional diagnostic [trace_rows][4]: game workgroup 0 samples (ticks, tail, head, finished) per iteration
     int32_t trace_rows;
+    int32_t policy_xcds;   // XCDs (of 8) whose workgroups serve the POLICY ring first
     int32_t pair_backlog;  // entries that must be waiting (beyond the tickets handed out) for a net workgroup to take two
 };
 
@@ -102,8 +106,8 @@ __device__ __forceinline__ void st(u64 *p, u64 x) { __hip_atomic_store(p, x, RLX
 __device__ __forceinline__ void send_request(const SearchParams &S, uint32_t kind, int64_t g, uint32_t reply_tag,
                                              uint64_t own, uint64_t opp)
 {
-    const uint32_t t = __hip_atomic_fetch_add(&S.ctl[CTL_TAIL], 1u, RLX_AGENT);
-    u64 *e = S.q_slots + (u64)(t % QCAP) * 8u;
+    const uint32_t t = __hip_atomic_fetch_add(&S.ctl[ctl_tail(kind)], 1u, RLX_AGENT);
+    u64 *e = S.q_slots + ((u64)kind * QCAP + t % QCAP) * 8u;
     const u64 tag = (u64)(t + 1u) << 32;
     st(e + 1, tag | reply_tag);
     st(e + 2, tag | (uint32_t)own);
@@ -544,8 +548,8 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
         }
         if (S.trace && blockIdx.x == 0 && tid == 0 && iters < S.trace_rows) {
             S.trace[4 * iters + 0] = wall_clock64() - t0;
-            S.trace[4 * iters + 1] = __hip_atomic_load(&S.ctl[CTL_TAIL], RLX_AGENT);
-            S.trace[4 * iters + 2] = __hip_atomic_load(&S.ctl[CTL_HEAD], RLX_AGENT);
+            S.trace[4 * iters + 1] = __hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT) + __hip_atomic_load(&S.ctl[ctl_tail(1)], RLX_AGENT);
+            S.trace[4 * iters + 2] = __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT) + __hip_atomic_load(&S.ctl[ctl_head(1)], RLX_AGENT);
             S.trace[4 * iters + 3] = __hip_atomic_load(&S.ctl[CTL_FINISHED], RLX_AGENT);
         }
         iters++;
@@ -587,20 +591,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if ((int)blockIdx.x < S.n_game_wgs)
         game_workgroup(S, R, t0);
     // ---- NET workgroup: ticket -> entry -> walk -> reply, until every game workgroup has finished.
-    // Two VALUE entries that are in the queue together are walked as a PAIR (trunk_item<true, 2>: the two
-    // boards share the weight stream, which bounds the one-board walk: 46 instead of 70 us of CU time per
-    // board; the same products in the same order per board: bit-identical values).
+    // The two kinds of net work have a ring each and a HOME on the chip: the workgroups of `policy_xcds` of the 8
+    // XCDs (workgroup i runs on XCD i mod 8) serve the POLICY ring, the others the VALUE ring, so that an XCD's
+    // 4 MB L2 holds ONE net's weights (3.9 / 5.8 MB) instead of thrashing on both; a workgroup whose home ring is
+    // empty serves the other one (no CU idles while work waits).
+    // Two VALUE entries that are in the ring together are walked as a PAIR (trunk_item<true, 2>: the two boards
+    // share the weight stream, which bounds the one-board walk: 46 instead of 70 us of CU time per board; the same
+    // products in the same order per board: bit-identical values).
     __shared__ __align__(16) uint32_t job[32]; // up to two entries of 6 words (kind | game, reply tag, own lo / hi, opp lo / hi); [28..]: status, count
     const int tid = threadIdx.x;
     const int64_t row0 = 4 * (int64_t)blockIdx.x; // this workgroup's rows of wg_own / wg_opp / out / probs (two in use)
-    // a ticket taken for a pair whose entry was not there yet, or was a POLICY entry: the next round's entry
+    const uint32_t home = ((int)(blockIdx.x & 7u) >= 8 - S.policy_xcds) ? KIND_POLICY : KIND_VALUE;
+    // a VALUE ticket taken for a pair whose entry was not there yet: the next round's entry
     uint32_t carry = 0u;
     int n_carry = 0;
 
-    // wave 0: wait for entry t (at most max_spins polls; 0 = until it comes or the search is over) -> job[6 * which ..]
-    // returns 0 = entry read, 1 = not there yet, 2 = the search is over / given up
-    auto fetch = [&](uint32_t t, uint32_t max_spins, int which) -> int {
-        const u64 *e = S.q_slots + (u64)(t % QCAP) * 8u;
+    // wave 0: wait for entry t of ring q (at most max_spins polls; 0 = until it comes or the search is over)
+    // -> job[6 * which ..]; returns 0 = entry read, 1 = not there yet, 2 = the search is over / given up
+    auto fetch = [&](uint32_t q, uint32_t t, uint32_t max_spins, int which) -> int {
+        const u64 *e = S.q_slots + ((u64)q * QCAP + t % QCAP) * 8u;
         u64 x = 0;
         int status = 0;
         for (uint32_t spins = 0;; spins++) {
@@ -612,8 +621,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 status = 1;
                 break;
             }
-            // nothing queued: leave when every game workgroup is done (no request can come any more) or the
-            // launch has been given up
             if ((spins & 15u) == 15u) {
                 bool out = false;
                 if (tid == 0)
@@ -630,16 +637,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             job[6 * which + tid] = (uint32_t)x;
         return status;
     };
-    auto take = [&]() -> uint32_t {
+    auto take = [&](uint32_t q) -> uint32_t {
         uint32_t t = 0;
         if (tid == 0)
-            t = __hip_atomic_fetch_add(&S.ctl[CTL_HEAD], 1u, RLX_AGENT);
+            t = __hip_atomic_fetch_add(&S.ctl[ctl_head(q)], 1u, RLX_AGENT);
         return __builtin_amdgcn_readfirstlane(t);
     };
-    auto backlog = [&]() -> int {
+    auto backlog = [&](uint32_t q) -> int {
         int d = 0;
         if (tid == 0)
-            d = (int32_t)(__hip_atomic_load(&S.ctl[CTL_TAIL], RLX_AGENT) - __hip_atomic_load(&S.ctl[CTL_HEAD], RLX_AGENT));
+            d = (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(q)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(q)], RLX_AGENT));
         return __builtin_amdgcn_readfirstlane(d);
     };
 
@@ -647,32 +654,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (;;) {
         const long long c0 = wall_clock64();
         if (tid < 64) {
-            uint32_t t1;
-            if (n_carry > 0) {
-                t1 = carry;
-                n_carry = 0;
-            } else {
-                t1 = take();
-            }
-            const int status = fetch(t1, 0u, 0);
-            int count = status == 0 ? 1 : 0;
-            if (status == 0 && (job[0] >> 31) == KIND_VALUE && n_carry == 0) {
-                // another VALUE entry waiting?  Two boards walk together (trunk_item<true, 2>: they share the weight
-                // stream, the bound of the one-board walk -- 46 instead of 70 us of CU time per board, 92 us for the
-                // pair; the same products in the same order per board: bit-identical values)
-                const int d = backlog();
-                // (four boards per walk were measured too: the third variant's registers spill in this kernel and the
-                // walks lose more than the shared stream gains: LABNOTES.md, round 4)
-                if (d >= S.pair_backlog) {
-                    const uint32_t t2 = take();
-                    const int s2 = fetch(t2, 8u, 1);
-                    if (s2 == 0 && (job[6] >> 31) == KIND_VALUE) {
-                        count = 2;
-                    } else {
-                        carry = t2; // not there yet, or a POLICY entry: the next round's entry
-                        n_carry = 1;
-                    }
+            int status = 2, count = 0;
+            // an entry waiting in the home ring, else in the other one; nothing anywhere: poll the counters (no
+            // ticket is taken for an entry that is not there, so nobody is committed to a ring that stays empty)
+            for (uint32_t spins = 0;; spins++) {
+                uint32_t q = home;
+                bool have = n_carry > 0;
+                uint32_t t1 = carry;
+                if (have) {
+                    q = KIND_VALUE;
+                    n_carry = 0;
+                } else if (backlog(home) > 0) {
+                    t1 = take(home);
+                    have = true;
+                } else if (backlog(home ^ 1u) > 0) {
+                    q = home ^ 1u;
+                    t1 = take(q);
+                    have = true;
                 }
+                if (have) {
+                    // (a ticket below the tail: its producer is writing the entry right now; one beyond it -- two
+                    // workgroups saw the same entry -- waits for the next entry of that ring)
+                    status = fetch(q, t1, 0u, 0);
+                    count = status == 0 ? 1 : 0;
+                    if (status == 0 && q == KIND_VALUE && backlog(KIND_VALUE) >= S.pair_backlog) {
+                        // (four boards per walk were measured too: the third variant's registers spill in this
+                        // kernel and the walks lose more than the shared stream gains: LABNOTES.md, round 4)
+                        const uint32_t t2 = take(KIND_VALUE);
+                        if (fetch(KIND_VALUE, t2, 8u, 1) == 0) {
+                            count = 2;
+                        } else {
+                            carry = t2; // not there yet: the next round's entry
+                            n_carry = 1;
+                        }
+                    }
+                    break;
+                }
+                bool out = false;
+                if (tid == 0)
+                    out = __hip_atomic_load(&S.ctl[CTL_FINISHED], RLX_AGENT) >= (uint32_t)S.n_game_wgs ||
+                          __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u || wall_clock64() - t0 > S.clock_limit;
+                if (__builtin_amdgcn_ballot_w64(out) != 0ull)
+                    break; // status 2: every game workgroup is done (no request can come any more), or given up
+                __builtin_amdgcn_s_sleep(16);
             }
             if (tid == 0) {
                 job[28] = (uint32_t)status;
@@ -807,6 +831,13 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
         return v < 1 ? 0x7fffffff : v;
     }();
     S.pair_backlog = pair_backlog;
+    // (tuning knob: 27 % of the nets' CU time is the policy net's)
+    static const int policy_xcds = [] {
+        const char *e = getenv("IAGO_PERSISTENT_POLICY_XCDS");
+        const int v = e ? atoi(e) : 2;
+        return v < 0 ? 0 : (v > 7 ? 7 : v);
+    }();
+    S.policy_xcds = policy_xcds;
     S.max_turns = a->max_turns;
     S.game_own = a->game_own;
     S.game_opp = a->game_opp;
@@ -830,8 +861,8 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
                          "iago_mcts_search_persistent: cannot reserve the nets' LDS image"))
         return IAGO_ERR_HIP;
     // every polled word starts from zero: the control block, the request ring and the reply mailboxes
-    if (hipMemsetAsync(a->ctl, 0, 32, (hipStream_t)stream) != hipSuccess ||
-        hipMemsetAsync(a->q_slots, 0, (size_t)QCAP * 64, (hipStream_t)stream) != hipSuccess ||
+    if (hipMemsetAsync(a->ctl, 0, 64, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(a->q_slots, 0, (size_t)2 * QCAP * 64, (hipStream_t)stream) != hipSuccess ||
         hipMemsetAsync(a->rep_v, 0, (size_t)tree->n_games * 8, (hipStream_t)stream) != hipSuccess ||
         hipMemsetAsync(a->rep_p, 0, (size_t)tree->n_games * 512, (hipStream_t)stream) != hipSuccess)
         return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_persistent: hipMemsetAsync failed");

@@ -371,7 +371,7 @@ class BatchedMCTS(object):
             self._ps = dict(
                 path=torch.zeros((n_games, self.PATH_STRIDE), dtype=torch.int32, **kw),
                 done=torch.zeros(n_games, dtype=torch.int32, **kw), roll=torch.zeros(n_games, dtype=torch.uint8, **kw),
-                q_slots=torch.zeros(_lib.SEARCH_QUEUE_ENTRIES * 8, dtype=i64, **kw), ctl=torch.zeros(8, dtype=torch.int32, **kw),
+                q_slots=torch.zeros(2 * _lib.SEARCH_QUEUE_ENTRIES * 8, dtype=i64, **kw), ctl=torch.zeros(16, dtype=torch.int32, **kw),
                 rep_v=torch.zeros(n_games, dtype=i64, **kw), rep_p=torch.zeros(n_games * 64, dtype=i64, **kw),
                 totals=torch.zeros(8, dtype=i64, **kw), wg_own=torch.zeros(4 * grid, dtype=i64, **kw),
                 wg_opp=torch.zeros(4 * grid, dtype=i64, **kw), wg_v=torch.zeros(4 * grid, dtype=torch.float32, **kw),

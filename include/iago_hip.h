@@ -751,7 +751,7 @@ IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const 
  *     its own / opp are ignored (the leaves' positions cur_own / cur_opp take their place).
  *   State, caller-owned device memory, no initialisation needed: cur_node / cur_own / cur_opp / done
  *     [n_games], roll [n_games] uint8, path [n_games][path_stride], leaf_value [n_games], q_slots
- *     [IAGO_SEARCH_QUEUE_ENTRIES][8] uint64 (64-byte aligned), ctl [8] uint32 (16-byte aligned; after the
+ *     [2][IAGO_SEARCH_QUEUE_ENTRIES][8] uint64 (64-byte aligned: one request ring per net), ctl [16] uint32 (16-byte aligned; after the
  *     launch ctl[3] != 0: the launch gave up after time_limit_ms), rep_v [n_games] uint64, rep_p
  *     [n_games][64] uint64, wg_own / wg_opp [4 x grid].  totals [8] int64 ACCUMULATES value evaluations, policy
  *     evaluations, game-workgroup iterations, pair walks, the net workgroups' waiting and walking time (100 MHz
@@ -800,7 +800,7 @@ typedef struct iago_mcts_search_args {
          rec_* (optional, all or none) [max_turns][n_games] (rec_pi: [max_turns][n_games][64] int32): per turn the
            position before it (own = mover), whether the mover searched, the move (-1: pass / no turn), the root's
            visit counts by action; rows of turns a game did not play are not written.
-       ctl [8]: ctl[3] != 0: gave up after time_limit_ms; ctl[4] != 0: a searched root had no children
+       ctl [16]: ctl[3] != 0: gave up after time_limit_ms; ctl[4] != 0: a searched root had no children
        (n_sims < n_thr: the reference's max() of an empty dict, MCTS.py:147). */
     int32_t max_turns, reserved2;
     uint64_t *game_own, *game_opp;

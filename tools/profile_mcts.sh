@@ -9,11 +9,14 @@ set -u
 TAG=${1:-r03}
 MODE=${2:-first4}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-if [ "$MODE" = "full" ]; then TURNS=-1; SUF=_mcts_fullgame; else TURNS=4; SUF=_mcts; fi
+#   tools/profile_mcts.sh <tag> persistent   the persistent engine (what bench.py times since round 4): ONE search_kernel
+#                                      launch per whole self-play game -> profiles/*_mcts_persistent_*
+EAGER="--mcts-eager"
+if [ "$MODE" = "full" ]; then TURNS=-1; SUF=_mcts_fullgame; elif [ "$MODE" = "persistent" ]; then TURNS=-1; SUF=_mcts_persistent; EAGER=""; else TURNS=4; SUF=_mcts; fi
 OUT=$REPO/gpurun_out/prof_${TAG}${SUF}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --large-boards 0 --train-iters 0 --mcts-turns $TURNS --mcts-eager --mcts-only"
+ARGS="--gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --large-boards 0 --train-iters 0 --mcts-turns $TURNS $EAGER --mcts-only"
 echo "python3 bench.py $ARGS" > "$OUT/command.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py $ARGS > "$OUT/trace.log" 2>&1
 # one pass per counter group (MI355X_MICROARCH.md: PMC in runs of their own, no trace domains);
@@ -30,5 +33,5 @@ find "$OUT" -name "*_kernel_trace.csv" -delete
 find "$OUT" -name "*.db" -delete
 python3 $REPO/tools/summarize_mcts_profile.py "$OUT" > "$OUT/summary.json"
 # the counter CSVs of a full game are tens of MB: keep the summary and the stats
-if [ "$MODE" = "full" ]; then find "$OUT" -name "*_counter_collection.csv" -delete; fi
+if [ "$MODE" != "first4" ]; then find "$OUT" -name "*_counter_collection.csv" -delete; fi
 du -sh "$OUT"

@@ -11,7 +11,7 @@ import os
 import sys
 
 src = sys.argv[1]
-KERNELS = ["value_rollout_kernel", "policy_resident_kernel", "mix_backup_path_kernel", "trunk_resident_kernel", "conv3x3_split_trunk_kernel", "descend_kernel", "fresh_leaves_kernel", "select_kernel",
+KERNELS = ["search_kernel", "value_rollout_kernel", "policy_resident_kernel", "mix_backup_path_kernel", "trunk_resident_kernel", "conv3x3_split_trunk_kernel", "descend_kernel", "fresh_leaves_kernel", "select_kernel",
            "mix_backup_lookahead_kernel",
            "expand_cached_kernel", "store_priors_kernel", "mix_backup_kernel", "expand_kernel",
            "pending_kernel", "value_stem_kernel", "value_head_kernel", "conv3x3_f32_counted_kernel", "conv3x3_f32_kernel",
