@@ -1,4 +1,9 @@
-"""Batched PV-MCTS and lockstep self-play on one GPU.
+"""Batched PV-MCTS and self-play on one GPU.
+
+Two engines behind one class, same trees bit for bit: the PERSISTENT search (round 4; the default wherever the
+split-f16 Value net and the three-piece SLPolicy apply) -- a whole search, or a whole batch of self-play games, as
+ONE launch in which every game runs on its own clock (iago_mcts_search_persistent, csrc/search_kernel.hip) -- and
+the per-playout launches described below (use_graph=True and the look-ahead options select them).
 
 Host-side select/expand/backup loop over thousands of games (the reference runs
 one game, one playout at a time: MCTS.py:105-147, game.py:117-142).  Every
@@ -1151,6 +1156,8 @@ class BatchedMCTS(object):
             out["queues"] = sum(t.numel() * t.element_size() for q in self._la_queues for t in q.values())
             if self._la_path is not None:
                 out["paths"] = self._la_path.numel() * 4
+        if self.persistent:
+            out["persistent_search"] = sum(t.numel() * t.element_size() for t in self._ps.values())
         if self.value_ahead:
             out["value_ahead"] = sum(t.numel() * t.element_size() for d in self._va_x + [self._va_rows] for t in d.values())
         pool = getattr(self.policy_fn, "__dict__", {}).get("_split3_scratch_pool", {})
