@@ -157,6 +157,10 @@ class BatchedMCTS(object):
                  net_workgroups=None):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
+        # (what the caller asked for explicitly, before the defaults below fill the options in: any of these selects
+        # the per-playout launches unless `persistent` says otherwise)
+        per_playout_asked = bool(use_graph or async_steps or value_ahead or lookahead is not None
+                                 or lookahead_overlap is not None or sync_free is not None)
         self.n_games = n_games
         self.policy_fn, self.value_fn, self.rollout_weights = policy_fn, value_fn, rollout_weights
         self.lmbda, self.c_puct, self.n_thr = float(lmbda), float(c_puct), int(n_thr)
@@ -219,7 +223,10 @@ class BatchedMCTS(object):
         # rollout, backup) and net workgroups that serve a queue of positions with the one-board walks
         # of the value and the policy net.  The policy net runs exactly where the reference runs it (at
         # the expansion), so there is no look-ahead in this mode.  Same trees.
-        can_p = (can_cache and getattr(value_fn, "search_args", None) is not None
+        # (the launch keeps every game workgroup resident and needs net workgroups beside them: at most half of the
+        # device's 256 CUs for the games, i.e. 4096 games per launch; larger batches take the per-playout launches)
+        can_p = (n_games <= 128 * _lib.SEARCH_GAMES_PER_WORKGROUP
+                 and can_cache and getattr(value_fn, "search_args", None) is not None
                  and getattr(policy_fn, "search_args", None) is not None and getattr(policy_fn, "split3", False)
                  and rollout_weights is not None and not rollout_weights.log_form and 0.0 <= self.lmbda < 1.0)
         # Default: ON wherever it applies, unless the caller asks for the per-playout launches (use_graph,
@@ -229,11 +236,11 @@ class BatchedMCTS(object):
         if env_p in ("0", "1"):
             persistent = can_p and env_p == "1"
         elif persistent is None:
-            persistent = can_p and not (use_graph or async_steps or value_ahead or lookahead is not None
-                                        or lookahead_overlap is not None or sync_free is not None)
+            persistent = can_p and not per_playout_asked
         if persistent and not can_p:
             raise ValueError("persistent needs the split-f16 value net and the three-piece policy net (modules with "
-                             "search_args), product-form rollout weights and lmbda < 1")
+                             "search_args), product-form rollout weights, lmbda < 1 and at most %d games"
+                             % (128 * _lib.SEARCH_GAMES_PER_WORKGROUP))
         self.persistent = bool(persistent)
         if self.persistent:
             if not self.value_cache:

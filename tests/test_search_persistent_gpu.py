@@ -63,7 +63,8 @@ def _run(nets, G, n_sims, n_sims2, own, opp, idle=(), **kw):
     return m, out
 
 
-@pytest.mark.parametrize("G,n_sims,n_sims2,net", [(16, 40, 0, 3), (20, 100, 45, 8), (96, 100, 45, None), (330, 60, 20, 40)])
+@pytest.mark.parametrize("G,n_sims,n_sims2,net", [(1, 60, 30, 2), (16, 40, 0, 3), (20, 100, 45, 8), (96, 100, 45, None),
+                                                  (330, 60, 20, 40)])
 def test_trees_equal_the_per_playout_engine(nets, G, n_sims, n_sims2, net):
     own, opp = _positions(G)
     idle = (5,) if G > 16 else ()
@@ -135,3 +136,15 @@ def test_whole_games_below_n_thr_raise(nets):
     m = engine.BatchedMCTS(16, policy, value, rw, n_thr=15, capacity=1024, seed=1, persistent=True)
     with pytest.raises(ValueError):
         engine.SelfPlayEngine(m, max_turns=4).play(8)      # MCTS.get_move's max() of an empty dict (MCTS.py:147)
+
+
+def test_too_many_games_take_the_per_playout_launches(nets):
+    """More than 4096 games would leave the launch's game workgroups no net workgroup beside them: the default is the
+    per-playout engine there, and asking for the persistent one raises."""
+    engine, ops, policy, value, rw = nets
+    m = engine.BatchedMCTS(4128, policy, value, rw, n_thr=15, capacity=64)
+    assert not m.persistent
+    with pytest.raises(ValueError):
+        engine.BatchedMCTS(4128, policy, value, rw, n_thr=15, capacity=64, persistent=True)
+    m2 = engine.BatchedMCTS(4096, policy, value, rw, n_thr=15, capacity=64)
+    assert m2.persistent and m2.net_workgroups == 128

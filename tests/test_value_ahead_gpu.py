@@ -34,6 +34,7 @@ def nets():
 
 def _search(nets, G, n_sims, own, opp, n_sims2=0, **kw):
     engine, ops, policy, value, rw = nets
+    kw.setdefault("persistent", False)   # (these tests are about the per-playout launches)
     m = engine.BatchedMCTS(G, policy, value, rw, n_thr=15, capacity=engine.suggest_capacity(n_sims + n_sims2, 15, moves=2),
                            seed=21, game_id_base=300, **kw)
     o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
