@@ -126,6 +126,7 @@ class MctsSearchArgs(C.Structure):
         ("max_turns", C.c_int32), ("reserved2", C.c_int32), ("game_own", C.c_void_p), ("game_opp", C.c_void_p),
         ("n_turns", C.c_void_p), ("rec_own", C.c_void_p), ("rec_opp", C.c_void_p), ("rec_valid", C.c_void_p),
         ("rec_move", C.c_void_p), ("rec_pi", C.c_void_p),
+        ("vtable", C.c_void_p), ("vtable_slots", C.c_int64),
         ("trace", C.c_void_p), ("trace_rows", C.c_int32), ("reserved", C.c_int32),
     ]
 

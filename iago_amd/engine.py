@@ -385,9 +385,13 @@ class BatchedMCTS(object):
                 done=torch.zeros(n_games, dtype=torch.int32, **kw), roll=torch.zeros(n_games, dtype=torch.uint8, **kw),
                 q_slots=torch.zeros(2 * _lib.SEARCH_QUEUE_ENTRIES * 8, dtype=i64, **kw), ctl=torch.zeros(16, dtype=torch.int32, **kw),
                 rep_v=torch.zeros(n_games, dtype=i64, **kw), rep_p=torch.zeros(n_games * 64, dtype=i64, **kw),
-                totals=torch.zeros(8, dtype=i64, **kw), wg_own=torch.zeros(4 * grid, dtype=i64, **kw),
+                totals=torch.zeros(16, dtype=i64, **kw), wg_own=torch.zeros(4 * grid, dtype=i64, **kw),
                 wg_opp=torch.zeros(4 * grid, dtype=i64, **kw), wg_v=torch.zeros(4 * grid, dtype=torch.float32, **kw),
                 wg_probs=torch.zeros((4 * grid, 64), dtype=torch.float32, **kw))
+            # position table of the value net (iago_mcts_search_args.vtable): 2^20 entries of 32 bytes, shared by the
+            # games and kept across launches; zeroed when the value net's weights change
+            slots = int(os.environ.get("IAGO_PERSISTENT_TABLE", str(1 << 20)))
+            self._vtable = torch.zeros(4 * slots, dtype=i64, **kw) if slots > 0 else None
             self.z_log = torch.zeros((z_log_rows, n_games), dtype=torch.int8, **kw) if z_log_rows else None
             self.z_log_n = torch.zeros(n_games, dtype=torch.int32, **kw) if z_log_rows else None
             self.time_limit_ms = int(os.environ.get("IAGO_PERSISTENT_LIMIT_MS", "4000"))
@@ -1040,6 +1044,8 @@ class BatchedMCTS(object):
             a.rec_own, a.rec_opp = game["rec_own"].data_ptr(), game["rec_opp"].data_ptr()
             a.rec_valid, a.rec_move, a.rec_pi = (game["rec_valid"].data_ptr(), game["rec_move"].data_ptr(),
                                                  game["rec_pi"].data_ptr())
+        if self._vtable is not None:
+            a.vtable, a.vtable_slots = self._vtable.data_ptr(), self._vtable.numel() // 4
         if getattr(self, "trace", None) is not None:   # (diagnostic: tools/exp_persistent_trace.py)
             a.trace, a.trace_rows = self.trace.data_ptr(), self.trace.shape[0]
         check(_lib.lib().iago_mcts_search_persistent(C.byref(a), _stream()), "iago_mcts_search_persistent")
@@ -1068,6 +1074,8 @@ class BatchedMCTS(object):
             if key != self._value_key:
                 if self._value_key is not None:
                     self.tree.v.fill_(float("nan"))
+                    if getattr(self, "_vtable", None) is not None:
+                        self._vtable.zero_()
                 self._value_key = key
             # (the descent appends to the fresh-leaf list through this count and the backup clears
             # it: a playout aborted between the two must not leave a stale count behind)
@@ -1243,6 +1251,8 @@ class SelfPlayEngine(object):
             if key != m._value_key:
                 if m._value_key is not None:
                     m.tree.v.fill_(float("nan"))
+                    if m._vtable is not None:
+                        m._vtable.zero_()
                 m._value_key = key
         m._launch_persistent(None, None, active, n_sims, game=g)
         back = torch.cat([m.error_flags(), m._ps["ctl"][4].to(torch.int64).reshape(1),

@@ -753,7 +753,7 @@ IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const 
  *     [n_games], roll [n_games] uint8, path [n_games][path_stride], leaf_value [n_games], q_slots
  *     [2][IAGO_SEARCH_QUEUE_ENTRIES][8] uint64 (64-byte aligned: one request ring per net), ctl [16] uint32 (16-byte aligned; after the
  *     launch ctl[3] != 0: the launch gave up after time_limit_ms), rep_v [n_games] uint64, rep_p
- *     [n_games][64] uint64, wg_own / wg_opp [4 x grid].  totals [8] int64 ACCUMULATES value evaluations, policy
+ *     [n_games][64] uint64, wg_own / wg_opp [4 x grid].  totals [16] int64 ACCUMULATES value evaluations, policy
  *     evaluations, game-workgroup iterations, pair walks, the net workgroups' waiting and walking time (100 MHz
  *     ticks, summed over the workgroups), idle game-workgroup iterations and the game workgroups' run time; stats as for iago_mcts_select; z_log as in
  *     iago_mcts_lookahead.
@@ -809,6 +809,12 @@ typedef struct iago_mcts_search_args {
     uint8_t *rec_valid;
     int8_t *rec_move;
     int32_t *rec_pi;
+    void *vtable;          /* optional position table [vtable_slots][4] uint64 (32-byte aligned, vtable_slots a power of two, 0 =
+                              none), zeroed by the caller ONCE and whenever the value net's weights change, kept across
+                              launches: MCTS.value_func (MCTS.py:97-103) is a pure function of the position, so a position any
+                              game has asked for before is answered from the table instead of the queue (same number, same
+                              trees).  totals[8] counts the hits; totals [16] */
+    int64_t vtable_slots;
     int64_t *trace;       /* optional diagnostic [trace_rows][4]: game workgroup 0 records (100 MHz ticks since its start,
                              requests queued so far, tickets handed out so far, game workgroups finished) once per
                              iteration of its loop */
