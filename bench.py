@@ -498,8 +498,9 @@ def mcts_b1_leg(n_sims=200):
     torch.manual_seed(0)
     m = mcts_mod.MCTS(policy_net=network.SLPolicy().cuda().eval(),
                       value_net=network.Value().cuda().eval(),
-                      rollout_weights=ops.RolloutWeights(w, b), n_sims=n_sims, capacity=65536,
-                      use_graph=True)
+                      rollout_weights=ops.RolloutWeights(w, b), n_sims=n_sims, capacity=65536)
+    # (the engine's default: the persistent search -- one launch per get_move; 25.3 k against 20.0 k playouts/s on
+    # the per-playout launches replayed as hipGraphs, tools/_build/b1.py, round 4)
     state = boards.initial_state()
     m._m.warmup()
     m.get_move(state, 1)  # warm-up move (also fills the root)
@@ -510,7 +511,7 @@ def mcts_b1_leg(n_sims=200):
     dt = time.perf_counter() - t0
     m._m.close()
     return {"playouts_per_sec": n_sims / dt, "ms_per_playout": dt / n_sims * 1e3,
-            "sims": n_sims, "move": int(a), "hipgraph": True}
+            "sims": n_sims, "move": int(a), "engine": "persistent search" if m._m.persistent else "per-playout launches"}
 
 
 def miopen_find_db_state():

@@ -23,7 +23,7 @@ torch.manual_seed(0)
 tr = ReinforceTrainer(network.SLPolicy(), pool_dir=None, N=32, seed=0)
 value = network.Value().cuda().eval()
 m = engine.BatchedMCTS(games, tr.model1, value, ops.RolloutWeights(w, b), n_thr=15,
-                       capacity=engine.suggest_capacity(sims, 15), seed=1, use_graph=True)
+                       capacity=engine.suggest_capacity(sims, 15), seed=1)   # default engine: the persistent search
 sp = engine.SelfPlayEngine(m)
 
 
@@ -48,8 +48,7 @@ for i in range(iters):
         print("iteration %d, %.1f s" % (i + 1, time.perf_counter() - t0), file=sys.stderr, flush=True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(json.dumps({"config": "PV-MCTS self-play (%d games per round, %d playouts per move, n_thr 15, lmbda 0.5, look-ahead "
-                            "+ value cache + hipGraph, re-captured after every update) -> tuples (own, opp, move, z) -> "
+print(json.dumps({"config": "PV-MCTS self-play (%d games per round, %d playouts per move, n_thr 15, lmbda 0.5, the engine's default: the persistent search, one launch per round) -> tuples (own, opp, move, z) -> "
                             "REINFORCE update (ChainerAdam alpha 1e-3 + WD 5e-4), 1 x MI355X" % (games, sims),
                   "iterations": iters, "seconds": dt, "iters_per_sec": iters / dt, "games_per_sec": games * iters / dt,
                   "tuples": tuples, "leaf_evals": m.n_leaf_evals - leaf0,
