@@ -1,37 +1,42 @@
-// search_kernel.hip -- a whole PV-MCTS search (n_sims playouts of every game, MCTS.get_move's loop,
-// MCTS.py:139-147) as ONE persistent launch in which every game runs on its own clock.
+// search_kernel.hip -- a whole PV-MCTS search (n_sims playouts of every game: MCTS.get_move's loop,
+// MCTS.py:139-147), or whole self-play games (the turn loop of game.py:117-142,253-255 around it), as
+// ONE persistent launch in which every game runs on its own clock.
 //
 // Why.  MCTS.playout (MCTS.py:105-133) is sequential inside a game, but the games of a batch are
-// independent.  The lockstep engine (mcts_kernels.hip + conv_trunk_kernel.hip: descent, leaf
+// independent.  The per-playout engine (mcts_kernels.hip + conv_trunk_kernel.hip: descent, leaf
 // evaluation, backup as three launches per playout for all games) makes every game wait for the
 // slowest kind of playout -- the 16 % that end on a leaf without a stored value, whose one-board walk
-// through the Value net takes 70 us of a 128 us playout -- and runs the policy net as batches that
-// hold most of the chip while the playouts' kernels want it.  Here the chip is a pool of workgroups
-// (one per CU) of two kinds:
-//   * GAME workgroups (the first n_games / 16 of the grid): each owns 16 games and loops over
-//     descent (8 lanes per game: select, expansion, continued descent, exactly descend_kernel's
-//     arithmetic) -> rollout of the leaves reached (the 16-lanes-per-board body, Philox stream =
-//     stream base + the game's own playout count) -> backup (mix_backup_path_kernel's arithmetic).
-//     A game whose leaf has no stored value sends the leaf's position to the work queue and waits
+// through the Value net takes 70 us of a 128 us playout --, runs the policy net as batches that hold
+// most of the chip while the playouts' kernels want it, and ends every move with a barrier.  Here the
+// chip is a pool of workgroups (one per CU) of two kinds:
+//   * GAME workgroups (the first ceil(n_games / 32) of the grid: dispatched first, so always resident):
+//     each owns 32 games and loops over descent (8 lanes per game: select, expansion, continued
+//     descent, exactly descend_kernel's arithmetic) -> rollout of the leaves reached (the
+//     16-lanes-per-board body in passes of 16 boards, Philox stream = stream base + turn x n_sims + the
+//     game's own playout count) -> backup (mix_backup_path_kernel's arithmetic) and, with whole games,
+//     the game's move between two of its searches (most visited child, update_with_move, the stone,
+//     the books, the recorded tuple).  A game whose leaf has no stored value -- and whose position the
+//     shared position table does not hold -- writes the leaf's position into a request ring and waits
 //     for the value (its rollout runs meanwhile); a game whose leaf expands (n_visits >= n_thr,
-//     MCTS.py:109) sends the position and waits for the priors -- the policy net runs exactly where
-//     the reference runs it (no look-ahead: no evaluation is wasted); the other 14-15 games of the
-//     workgroup go on.
-//   * NET workgroups (the rest of the grid): each takes the next ticket of the queue, waits for its
-//     entry, walks the board through the Value net (trunk_item<true, 1>) or the SLPolicy net
-//     (policy_item) -- the kernels' own device functions: bit-identical numbers -- and publishes the
-//     result in the game's mailbox.
-// A game's sequence of playouts -- leaves, values, priors, rollouts, backups, expansions -- is exactly
-// the reference's; only the interleaving between games changes: trees are bit-identical to the
-// lockstep engine's (tests/test_search_persistent_gpu.py).
+//     MCTS.py:109) does the same and waits for the priors -- the policy net runs exactly where the
+//     reference runs it (no look-ahead: no evaluation is wasted); the workgroup's other games go on.
+//   * NET workgroups (the rest of the grid): each takes a ticket of a ring that has an entry waiting
+//     (its home ring first: one ring per net, the policy ring at home on 2 of the 8 XCDs), reads the
+//     entry, walks the board through the Value net (trunk_item<true, 1>, or <true, 2> for two entries
+//     together) or the SLPolicy net (policy_item) -- the kernels' own device functions: bit-identical
+//     numbers -- and publishes the result in the game's mailbox (and the position table).
+// A game's sequence of playouts -- leaves, values, priors, rollouts, backups, expansions, moves -- is
+// exactly the reference's; only the interleaving between games changes: trees, moves and results are
+// bit-identical to the per-playout engine's (tests/test_search_persistent_gpu.py; the comparisons with
+// the oracle's MCTS.py restatement in tests/test_mcts_production_gpu.py run on this kernel).
 //
-// Inter-workgroup traffic (cdna_hip_programming.md, guideline 16): every shared word is an 8-byte
-// {tag, 32-bit value} granule written by ONE agent-scope atomic store and polled by agent-scope atomic
-// loads -- the data is the flag, no fence, no cache invalidation that would cost the net workgroups
-// their L2-resident weights.  Queue entry t (ticket t, tag t + 1): 6 granules (kind | game, reply tag,
-// the position's four words); replies: one granule (value) or 64 (priors) tagged with the request's
-// reply tag.  The tree, the cursors and the paths of a game are touched by its own workgroup only.
-// Every wait is a bounded poll: the launch ends by itself when a clock limit passes (abort word).
+// Inter-workgroup traffic (cdna_hip_programming.md, guideline 16, form R2): every shared word is an
+// 8-byte {tag, 32-bit value} granule written by ONE agent-scope atomic store and polled by agent-scope
+// atomic loads -- the data is the flag, no fence, no cache invalidation that would cost the net
+// workgroups their L2-resident weights.  Ring entry t (ticket t, tag t + 1): 6 granules (kind | game,
+// reply tag, the position's four words); replies: one granule (value) or 64 (priors) tagged with the
+// request's reply tag.  The tree, the cursors and the paths of a game are touched by its own workgroup
+// only.  Every wait is a bounded poll: the launch ends by itself when a clock limit passes (abort word).
 #include "mcts_dev.hpp"
 #include "conv_trunk_body.hpp" // (brings rollout_row_body.hpp)
 #include "conv_policy_body.hpp"
@@ -45,7 +50,8 @@ using namespace iago_mcts;
 typedef unsigned long long u64;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-constexpr uint32_t QCAP = IAGO_SEARCH_QUEUE_ENTRIES; // entries of the request ring (>= 2 x games outstanding at once)
+constexpr uint32_t QCAP = IAGO_SEARCH_QUEUE_ENTRIES; // entries of a request ring (a game has at most ONE request outstanding:
+                                                     // >= the 4096 games a launch can hold)
 constexpr int CTL_FINISHED = 2, CTL_ABORT = 3;
 // two request rings, one per kind of net work: head (tickets handed out) / tail (entries reserved) of ring q
 __host__ __device__ constexpr int ctl_head(uint32_t q) { return 8 + 2 * (int)q; }
