@@ -150,8 +150,12 @@ __device__ __forceinline__ uint64_t flips_hw(uint64_t o, uint64_t p, uint32_t po
 // instruction, scalar ones and branches included, so the production instance does not even
 // test those pointers.
 // ASYNC: the per-board mask and stream ids of HwParams (prologue only; the turn loop is the same).
-template <bool DIAG, bool ASYNC = false>
-__device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32_t block_id)
+// INDEXED (the persistent search): the 16 boards of the call are boards idx[0..15] (-1 = no board in that row of
+// lanes) instead of boards 16 block_id ..; `table_ready`: the factor table is in LDS already (an earlier call of
+// this workgroup put it there).
+template <bool DIAG, bool ASYNC = false, bool INDEXED = false>
+__device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32_t block_id, const int32_t *idx = nullptr,
+                                                 const bool table_ready = false)
 {
     // T4[orientation][kernel row][plane][row half][5 window bits] -> factors of the 4 cells
     // (in TRUE cell order), 12 KB, gathered from the blob's row tables.  As-is orientation,
@@ -163,6 +167,7 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
     // the table's global loads go out first (3 per thread, all in flight together); lane
     // constants, the board loads and the first Philox blocks are computed under their latency
     f4 stg[N_T4 / HW_BLOCK];
+    if (!(INDEXED && table_ready)) {
 #pragma unroll
     for (uint32_t i = 0; i < (uint32_t)(N_T4 / HW_BLOCK); i++) {
         const uint32_t e = threadIdx.x + i * HW_BLOCK;
@@ -177,6 +182,7 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
             byte = hf ? r5 : (r5 << 3);
         }
         stg[i] = *(const f4 *)(P.blob + OFF_E + (((sky * 2u + pl) * 2u + shf) * 256u + byte) * 4u);
+    }
     }
     const uint32_t lane = threadIdx.x & 63u;
     LaneHw L;
@@ -213,8 +219,13 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
     uint32_t m1f0;
     asm("v_mov_b32 %0, 0x1f0" : "=v"(m1f0));
 
-    const int64_t b = (int64_t)block_id * (HW_BLOCK / 16) + (threadIdx.x >> 4);
+    int64_t b = (int64_t)block_id * (HW_BLOCK / 16) + (threadIdx.x >> 4);
     bool live = b < P.n;
+    if constexpr (INDEXED) {
+        const int32_t at = idx[threadIdx.x >> 4];
+        live = at >= 0;
+        b = live ? at : 0;
+    }
     if constexpr (ASYNC) {
         live = live && P.mask[b] != 0;
         stream_id += live ? (uint32_t)P.stream_ids[b] : 0u;
@@ -240,10 +251,12 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
     };
     if (!(DIAG && P.uniforms))
         draw();
+    if (!(INDEXED && table_ready)) {
 #pragma unroll
-    for (uint32_t i = 0; i < (uint32_t)(N_T4 / HW_BLOCK); i++)
-        t4[threadIdx.x + i * HW_BLOCK] = stg[i];
-    __syncthreads();
+        for (uint32_t i = 0; i < (uint32_t)(N_T4 / HW_BLOCK); i++)
+            t4[threadIdx.x + i * HW_BLOCK] = stg[i];
+        __syncthreads();
+    }
     // A lone wave fetches its instruction stream in 32-byte windows, and an 8-byte instruction
     // that straddles two of them costs extra: the loop's speed moves by +-1 % with its offset
     // in that grid (measured in round 2, offsets 0..7: 25.99 .. 26.57 us).  The loop

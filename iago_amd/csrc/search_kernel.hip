@@ -42,6 +42,7 @@
 #include "conv_policy_body.hpp"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 using namespace iago;
@@ -58,6 +59,8 @@ __host__ __device__ constexpr int ctl_head(uint32_t q) { return 8 + 2 * (int)q; 
 __host__ __device__ constexpr int ctl_tail(uint32_t q) { return 9 + 2 * (int)q; }
 enum { ST_READY = 0, ST_WAIT_PRIOR, ST_PRIOR_READY, ST_ROLL, ST_ROLL_FRESH, ST_WAIT_VALUE, ST_HAVE_VALUE, ST_DONE, ST_TURN, ST_MOVE };
 constexpr int CTL_NO_CHILDREN = 4; // a searched root had no children (n_sims below n_thr)
+// pacing (below): sum over the games in play of their progress (turn x n_sims + playouts of the turn), games in play
+constexpr int CTL_PROGRESS = 5, CTL_PLAYING = 6;
 constexpr uint32_t KIND_VALUE = 0u, KIND_POLICY = 1u;
 // games of a GAME workgroup: 8 lanes per game in the descent and the backup (16 games = two waves, 32 = all four),
 // rollouts in passes of 16 boards (the 16-lanes-per-board body)
@@ -109,6 +112,12 @@ struct SearchParams {
     int32_t trace_rows;
     int32_t policy_xcds;   // XCDs (of 8) whose workgroups serve the POLICY ring first
     int32_t pair_backlog;  // entries that must be waiting (beyond the tickets handed out) for a net workgroup to take two
+    // pacing: a game that is more than `pace_margin` playouts ahead of the mean progress of the games in play starts no
+    // new playout while more than `pace_backlog` requests wait in the rings (< 0: no pacing).  Why: the batch ends with
+    // its slowest game, and a game's speed in the net-bound middle of a batch is set by how many requests it makes (end
+    // time against requests sent: correlation 0.84-0.90, ends spread over +-20 % at 400 playouts per move; LABNOTES.md);
+    // what the leaders do not ask for, the laggards get.  Timing only: a game's own sequence of playouts is untouched
+    int32_t pace_margin, pace_backlog;
 };
 
 __device__ __forceinline__ u64 ld(const u64 *p) { return __hip_atomic_load(p, RLX_AGENT); }
@@ -215,8 +224,7 @@ __device__ __forceinline__ void backup_game(const SearchParams &S, int64_t g, ui
     }
 }
 
-// The games of a GAME workgroup (8 lanes per game; with 16 games the other two waves only join the
-// rollouts and the barriers).
+// The games of a GAME workgroup (8 lanes per game: 32 games = the four waves).
 __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago_row::HwParams &R, const long long t0)
 {
     const Tree &T = S.T;
@@ -257,6 +265,20 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
     float v_reply = 0.0f;
     int st_levels = 0, st_children = 0;
     long long iters = 0, idle_iters = 0;
+    __shared__ int32_t roll_list[GAMES_PER_WG]; // games whose leaf is rolled out in this iteration, packed
+    __shared__ uint32_t roll_wave[BLOCK / 64];
+    bool table_ready = false;                   // the rollout's factor table is in LDS (from the first pass on)
+    // pacing: what this game has added to CTL_PROGRESS / whether CTL_PLAYING counts it; the workgroup's changes of an
+    // iteration are collected in LDS and go out as one atomic each; pace[2]: the progress above which a game holds
+    __shared__ int32_t pace[4];
+    int contrib = 0;
+    bool in_play = state != ST_DONE;
+    if (tid < 4)
+        pace[tid] = tid == 2 ? 0x7fffffff : 0;
+    __syncthreads();
+    if (mine && in_play && r == 0u)
+        atomicAdd(&pace[1], 1);
+    int pace_limit = 0x7fffffff;
 
     for (;;) {
         bool busy = false; // this game did something in this iteration
@@ -282,6 +304,8 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             if (state == ST_HAVE_VALUE) {
                 backup_game(S, g, r, leaf, true, v_reply, path_n);
                 n_done++;
+                if (S.trace && r == 0u)
+                    atomicAdd((unsigned long long *)&S.totals[9], 1ull); // (diagnostic: playouts over time)
                 if (r == 0u)
                     S.done[g] = turn * S.n_sims + n_done;
                 state = n_done >= S.n_sims ? search_end : ST_READY;
@@ -393,6 +417,12 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                                 S.game_opp[g] = g_opp;
                             }
                             state = ST_DONE;
+                            if (S.trace && r == 0u && g < S.trace_rows) { // (diagnostic: the game's end, its requests)
+                                int64_t *row = S.trace + 4 * ((int64_t)S.trace_rows - 1 - g);
+                                row[0] = wall_clock64() - t0;
+                                row[1] = epoch;
+                                row[2] = turn;
+                            }
                         } else {
                             state = ST_TURN;
                         }
@@ -400,8 +430,8 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                 }
             }
             // ---- descent (MCTS.py:105-133): from the root, or on from the leaf whose priors arrived
-            const bool fresh_start = state == ST_READY;
-            bool descending = state == ST_READY || state == ST_PRIOR_READY;
+            const bool fresh_start = state == ST_READY && turn * S.n_sims + n_done <= pace_limit;
+            bool descending = fresh_start || state == ST_PRIOR_READY;
             bool have_priors = state == ST_PRIOR_READY;
             bool skip_record = state == ST_PRIOR_READY; // the cursor node is on the path already
             bool need_prior = false;
@@ -487,6 +517,30 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                 const int kk = descending ? k : 0;
                 st_levels += descending ? 1 : 0;
                 st_children += kk;
+                // Chains of pass nodes.  At the end of a game neither side has a move, and the reference goes on
+                // expanding: a pass child under the pass child, one level deeper every n_thr visits (MCTS.py:109-117) --
+                // the last turns of a game descend through 65 such levels per playout on average (400 playouts per
+                // move; LABNOTES.md).  A node with ONE child leaves nothing to choose (max over one element, MCTS.py:46):
+                // when that is so for every game of the wave that still descends and all those children are passes,
+                // the level is the child's record and the swap of sides
+                if (__builtin_amdgcn_ballot_w64(descending && k != 1) == 0ull) {
+                    const int64_t c = descending ? base + fc : base;
+                    const uint4 s0 = ((const uint4 *)&T.nodes[c])[0], l0 = ((const uint4 *)&T.nodes[c])[1];
+                    const bool pass_child = (int)(int8_t)(l0.z & 0xFFu) < 0;
+                    if (__builtin_amdgcn_ballot_w64(descending && !pass_child) == 0ull) {
+                        if (descending) {
+                            const uint64_t t = own; // GameFunctions.place_stone(state, -1, c) places nothing; c = 3 - c
+                            own = opp;
+                            opp = t;
+                            node = fc;
+                            fc = (int)l0.x;
+                            nv = (int)s0.x;
+                            k = (int)((l0.z >> 8) & 0xFFu);
+                            vbits = s0.w;
+                        }
+                        continue;
+                    }
+                }
                 const double sq = sqrt((double)nv); // np.sqrt(parent.n_visits), MCTS.py:49
                 double best_v = -INFINITY;
                 int best_i = 0x7fffffff;
@@ -588,14 +642,30 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             if (exists && r == 0u)
                 S.roll[g] = (need_z && (state == ST_ROLL || state == ST_ROLL_FRESH)) ? 1 : 0;
         }
-        // ---- rollouts of the leaves reached in this iteration (Simulate, mcts_self_play.py:9-134)
+        // ---- rollouts of the leaves reached in this iteration (Simulate, mcts_self_play.py:9-134): the games that
+        // have one are packed into rows of 16 boards (about half of a workgroup's games reach a leaf in an iteration,
+        // the others wait for a net: one pass of the 16-lanes-per-board body instead of two, most of the time).  A
+        // board's game does not depend on its row: Philox counters are keyed by the game and its playout count
         const bool rolls = mine && need_z && (state == ST_ROLL || state == ST_ROLL_FRESH);
+        {
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(rolls && r == 0u); // bit 8 j: game j of this wave
+            if ((tid & 63) == 0)
+                roll_wave[tid >> 6] = (uint32_t)(((bal & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+            if (tid < GAMES_PER_WG)
+                roll_list[tid] = -1;
+            __syncthreads();
+            uint32_t gm = 0u; // bit j: game j of the workgroup has a rollout
+#pragma unroll
+            for (int w = 0; w < BLOCK / 64; w++)
+                gm |= roll_wave[w] << (8 * w);
+            if (rolls && r == 0u)
+                roll_list[__popc(gm & ((1u << (tid >> 3)) - 1u))] = (int32_t)g;
+            __syncthreads();
+            const int n_roll = __popc(gm);
 #pragma unroll 1
-        for (int pass = 0; pass < GAMES_PER_WG / 16; pass++) {
-            // (the games of this pass: threads 128 pass .. 128 pass + 127 hold their states)
-            const int any_roll = __syncthreads_or(rolls && (tid >> 7) == pass);
-            if (any_roll) {
-                iago_row::rollout_row_body<false, true>(R, blockIdx.x * (GAMES_PER_WG / 16) + pass);
+            for (int at = 0; at < n_roll; at += 16) {
+                iago_row::rollout_row_body<false, true, true>(R, 0u, roll_list + at, table_ready);
+                table_ready = true;
                 __syncthreads();
             }
         }
@@ -603,6 +673,8 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             if (state == ST_ROLL) {
                 backup_game(S, g, r, leaf, leaf_fresh, __uint_as_float(vbits), path_n);
                 n_done++;
+                if (S.trace && r == 0u)
+                    atomicAdd((unsigned long long *)&S.totals[9], 1ull);
                 if (r == 0u)
                     S.done[g] = turn * S.n_sims + n_done;
                 state = n_done >= S.n_sims ? search_end : ST_READY;
@@ -610,19 +682,48 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                 state = ST_WAIT_VALUE;
             }
         }
-        if (S.trace && blockIdx.x == 0 && tid == 0 && iters < S.trace_rows) {
+        if (S.trace && blockIdx.x == 0 && tid == 0 && iters < S.trace_rows - T.n_games) {
             S.trace[4 * iters + 0] = wall_clock64() - t0;
             S.trace[4 * iters + 1] = __hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT) + __hip_atomic_load(&S.ctl[ctl_tail(1)], RLX_AGENT);
             S.trace[4 * iters + 2] = __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT) + __hip_atomic_load(&S.ctl[ctl_head(1)], RLX_AGENT);
-            S.trace[4 * iters + 3] = __hip_atomic_load(&S.ctl[CTL_FINISHED], RLX_AGENT);
+            S.trace[4 * iters + 3] = (int64_t)__hip_atomic_load(&S.ctl[CTL_FINISHED], RLX_AGENT) |
+                                     (__hip_atomic_load(&S.totals[9], RLX_AGENT) << 8);
         }
         iters++;
+        if (mine && r == 0u) {
+            const int prog = state == ST_DONE ? 0 : turn * S.n_sims + n_done;
+            if (prog != contrib)
+                atomicAdd(&pace[0], prog - contrib);
+            if (in_play && state == ST_DONE)
+                atomicAdd(&pace[1], -1);
+        }
+        contrib = state == ST_DONE ? 0 : turn * S.n_sims + n_done;
+        in_play = in_play && state != ST_DONE;
         // (the workgroup's own stores to done / the tree are read by its next iteration: same CU)
         const bool over = wall_clock64() - t0 > S.clock_limit;
         if (over && tid == 0)
             __hip_atomic_store(&S.ctl[CTL_ABORT], 1u, RLX_AGENT);
         const int stop = __syncthreads_or(over || (tid == 0 && __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u));
+        if (tid == 0) {
+            if (pace[0])
+                __hip_atomic_fetch_add(&S.ctl[CTL_PROGRESS], (uint32_t)pace[0], RLX_AGENT);
+            if (pace[1])
+                __hip_atomic_fetch_add(&S.ctl[CTL_PLAYING], (uint32_t)pace[1], RLX_AGENT);
+            pace[0] = 0;
+            pace[1] = 0;
+            int limit = 0x7fffffff;
+            if (S.pace_margin >= 0) {
+                const int32_t waiting =
+                    (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT)) +
+                    (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(1)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(1)], RLX_AGENT));
+                const uint32_t playing = __hip_atomic_load(&S.ctl[CTL_PLAYING], RLX_AGENT);
+                if (waiting > S.pace_backlog && playing != 0u && playing <= (uint32_t)T.n_games)
+                    limit = (int)(__hip_atomic_load(&S.ctl[CTL_PROGRESS], RLX_AGENT) / playing) + S.pace_margin;
+            }
+            pace[2] = limit;
+        }
         const int all_done = __syncthreads_and(!mine || state == ST_DONE);
+        pace_limit = pace[2];
         if (all_done || stop)
             break;
         if (!__syncthreads_or(busy)) {
@@ -906,6 +1007,18 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
         return v < 0 ? 0 : (v > 7 ? 7 : v);
     }();
     S.policy_xcds = policy_xcds;
+    // (tuning knobs of the pacing: "margin" or "margin,backlog"; a negative margin turns it off)
+    static const int pace_margin = [] {
+        const char *e = getenv("IAGO_PERSISTENT_PACE");
+        return e ? atoi(e) : 16;
+    }();
+    static const int pace_backlog = [] {
+        const char *e = getenv("IAGO_PERSISTENT_PACE");
+        const char *c = e ? strchr(e, ',') : nullptr;
+        return c ? atoi(c + 1) : 128;
+    }();
+    S.pace_margin = pace_margin;
+    S.pace_backlog = pace_backlog;
     S.max_turns = a->max_turns;
     S.game_own = a->game_own;
     S.game_opp = a->game_opp;
