@@ -185,10 +185,10 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
                                    "first visit and taken from the node afterwards (value_evals = net "
                                    "launches' rows), the rollout runs at every visit; trees bit-identical "
                                    "to evaluating the net at every visit (tests/test_mcts_gpu.py)",
-           "engine": ("persistent search: ONE launch per whole self-play game, game workgroups (16 games each: descent, "
-                      "rollout, backup, moves) + %d net workgroups serving a queue of positions with one-board / two-board "
-                      "walks of the value net and one-board walks of the policy net (at the expansion, as the reference)"
-                      % m.net_workgroups if m.persistent else
+           "engine": ("persistent search: ONE launch per batch of whole self-play games, game workgroups (%d games each: descent, "
+                      "rollout, backup, moves; leading games paced) + %d net workgroups serving two rings of positions with "
+                      "one-board / two-board walks of the value net and one-board walks of the policy net (at the expansion, "
+                      "as the reference)" % (m.games_per_workgroup, m.net_workgroups) if m.persistent else
                       "per-playout launches (descent, leaf evaluation, backup) replayed as hipGraphs, policy look-ahead "
                       "batches on a second stream"),
            "value_cache": bool(m.value_cache), "policy_lookahead": int(m.lookahead),

@@ -123,11 +123,11 @@ class MctsSearchArgs(C.Structure):
         ("leaf_value", C.c_void_p), ("z_log", C.c_void_p), ("z_log_n", C.c_void_p), ("q_slots", C.c_void_p),
         ("ctl", C.c_void_p), ("rep_v", C.c_void_p), ("rep_p", C.c_void_p), ("totals", C.c_void_p),
         ("stats", C.c_void_p), ("wg_own", C.c_void_p), ("wg_opp", C.c_void_p),
-        ("max_turns", C.c_int32), ("reserved2", C.c_int32), ("game_own", C.c_void_p), ("game_opp", C.c_void_p),
+        ("max_turns", C.c_int32), ("games_per_workgroup", C.c_int32), ("game_own", C.c_void_p), ("game_opp", C.c_void_p),
         ("n_turns", C.c_void_p), ("rec_own", C.c_void_p), ("rec_opp", C.c_void_p), ("rec_valid", C.c_void_p),
         ("rec_move", C.c_void_p), ("rec_pi", C.c_void_p),
         ("vtable", C.c_void_p), ("vtable_slots", C.c_int64),
-        ("trace", C.c_void_p), ("trace_rows", C.c_int32), ("reserved", C.c_int32),
+        ("trace", C.c_void_p), ("trace_rows", C.c_int32), ("pace_margin", C.c_int32),
     ]
 
 

@@ -25,6 +25,12 @@
 //     entry, walks the board through the Value net (trunk_item<true, 1>, or <true, 2> for two entries
 //     together) or the SLPolicy net (policy_item) -- the kernels' own device functions: bit-identical
 //     numbers -- and publishes the result in the game's mailbox (and the position table).
+// Scheduling inside a game workgroup (timing only): the games that reach a leaf in an iteration are packed
+// into rows of 16 boards for the rollout body (about half of the 32 do: one pass instead of two); a game
+// more than `pace_margin` playouts ahead of the batch's mean progress holds while requests queue up (a
+// batch ends with its slowest game, and a game is slow when it asks the nets a lot: what the leaders do
+// not ask for, the laggards get); a level at which every descending game of the wave has ONE child, a
+// pass (the chains the reference grows under a finished game), is followed without scoring.
 // A game's sequence of playouts -- leaves, values, priors, rollouts, backups, expansions, moves -- is
 // exactly the reference's; only the interleaving between games changes: trees, moves and results are
 // bit-identical to the per-playout engine's (tests/test_search_persistent_gpu.py; the comparisons with
@@ -42,7 +48,6 @@
 #include "conv_policy_body.hpp"
 
 #include <cstdlib>
-#include <cstring>
 
 namespace {
 using namespace iago;
@@ -64,14 +69,14 @@ constexpr int CTL_PROGRESS = 5, CTL_PLAYING = 6;
 constexpr uint32_t KIND_VALUE = 0u, KIND_POLICY = 1u;
 // games of a GAME workgroup: 8 lanes per game in the descent and the backup (16 games = two waves, 32 = all four),
 // rollouts in passes of 16 boards (the 16-lanes-per-board body)
-constexpr int GAMES_PER_WG = IAGO_SEARCH_GAMES_PER_WORKGROUP;
+constexpr int GAMES_PER_WG = IAGO_SEARCH_GAMES_PER_WORKGROUP; // at most (the launch's own number: SearchParams::games_per_wg)
 
 struct SearchParams {
     Tree T;
     const uint64_t *root_own, *root_opp;
     const uint8_t *active;
     float c_puct, lmbda;
-    int32_t n_thr, n_sims, n_game_wgs;
+    int32_t n_thr, n_sims, n_game_wgs, games_per_wg;
     int32_t *cur_node;
     uint64_t *cur_own, *cur_opp;
     int32_t *path;
@@ -229,8 +234,8 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
 {
     const Tree &T = S.T;
     const int tid = threadIdx.x;
-    const bool mine = tid < 8 * GAMES_PER_WG;
-    const int64_t g = (int64_t)blockIdx.x * GAMES_PER_WG + (tid >> 3);
+    const bool mine = tid < 8 * S.games_per_wg;
+    const int64_t g = (int64_t)blockIdx.x * S.games_per_wg + (tid >> 3);
     const Lane8 L = make_lane8(threadIdx.x);
     const uint32_t r = L.l8;
     const bool exists = mine && g < T.n_games;
@@ -945,7 +950,10 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
         ro->uniforms || ro->throughput_hint != 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: product-form rollout of the n games without "
                                            "trace / uniforms expected");
-    const int64_t n_game_wgs = (tree->n_games + GAMES_PER_WG - 1) / GAMES_PER_WG;
+    const int gpw = a->games_per_workgroup > 0 ? a->games_per_workgroup : GAMES_PER_WG;
+    if (gpw != 8 && gpw != 16 && gpw != 32)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: games_per_workgroup is 0 (= 32), 8, 16 or 32");
+    const int64_t n_game_wgs = (tree->n_games + gpw - 1) / gpw;
     const int64_t grid = n_game_wgs + a->net_workgroups;
     if (a->value->n < 4 * grid || a->policy->n < 4 * grid || a->value->planes || a->value->index || a->value->n_dev ||
         a->policy->index || a->policy->n_dev || !a->value->own || a->value->own != a->wg_own ||
@@ -971,6 +979,7 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
     S.n_thr = a->n_thr;
     S.n_sims = a->n_sims;
     S.n_game_wgs = (int32_t)n_game_wgs;
+    S.games_per_wg = gpw;
     S.cur_node = a->cur_node;
     S.cur_own = a->cur_own;
     S.cur_opp = a->cur_opp;
@@ -1007,16 +1016,10 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
         return v < 0 ? 0 : (v > 7 ? 7 : v);
     }();
     S.policy_xcds = policy_xcds;
-    // (tuning knobs of the pacing: "margin" or "margin,backlog"; a negative margin turns it off)
-    static const int pace_margin = [] {
-        const char *e = getenv("IAGO_PERSISTENT_PACE");
-        return e ? atoi(e) : 16;
-    }();
-    static const int pace_backlog = [] {
-        const char *e = getenv("IAGO_PERSISTENT_PACE");
-        const char *c = e ? strchr(e, ',') : nullptr;
-        return c ? atoi(c + 1) : 128;
-    }();
+    // (tuning knob of the pacing: requests that must be waiting for a leader to hold)
+    const char *pace_env = getenv("IAGO_PERSISTENT_PACE_BACKLOG"); // (read per launch: the tests vary it)
+    const int pace_backlog = pace_env ? atoi(pace_env) : 128;
+    const int pace_margin = a->pace_margin == 0 ? 16 : (a->pace_margin < 0 ? -1 : a->pace_margin);
     S.pace_margin = pace_margin;
     S.pace_backlog = pace_backlog;
     S.max_turns = a->max_turns;

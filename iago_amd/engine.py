@@ -219,13 +219,17 @@ class BatchedMCTS(object):
         # board-fed policy net applies and n_thr leaves room for it; 0 = the net runs inside the
         # playout that expands (the reference's order of evaluation).  Same trees either way.
         # Persistent search (iago_mcts_search_persistent in include/iago_hip.h): a whole search is ONE
-        # launch in which every game runs on its own clock -- game workgroups (16 games each: descent,
+        # launch in which every game runs on its own clock -- game workgroups (32 games each: descent,
         # rollout, backup) and net workgroups that serve a queue of positions with the one-board walks
         # of the value and the policy net.  The policy net runs exactly where the reference runs it (at
         # the expansion), so there is no look-ahead in this mode.  Same trees.
         # (the launch keeps every game workgroup resident and needs net workgroups beside them: at most half of the
         # device's 256 CUs for the games, i.e. 4096 games per launch; larger batches take the per-playout launches)
-        can_p = (n_games <= 128 * _lib.SEARCH_GAMES_PER_WORKGROUP
+        # (tuning knobs: pacing of the leading games -- playouts a game may be ahead of the mean while requests queue,
+        # 0 = the library's default, < 0 = off; 8 / 16 / 32 games per game workgroup, 32 measured best)
+        self.pace_margin = int(os.environ.get("IAGO_PERSISTENT_PACE", "0"))
+        self.games_per_workgroup = int(os.environ.get("IAGO_PERSISTENT_GPW", "0")) or _lib.SEARCH_GAMES_PER_WORKGROUP
+        can_p = (n_games <= 128 * self.games_per_workgroup
                  and can_cache and getattr(value_fn, "search_args", None) is not None
                  and getattr(policy_fn, "search_args", None) is not None and getattr(policy_fn, "split3", False)
                  and rollout_weights is not None and not rollout_weights.log_form and 0.0 <= self.lmbda < 1.0)
@@ -240,7 +244,7 @@ class BatchedMCTS(object):
         if persistent and not can_p:
             raise ValueError("persistent needs the split-f16 value net and the three-piece policy net (modules with "
                              "search_args), product-form rollout weights, lmbda < 1 and at most %d games"
-                             % (128 * _lib.SEARCH_GAMES_PER_WORKGROUP))
+                             % (128 * self.games_per_workgroup))
         self.persistent = bool(persistent)
         if self.persistent:
             if not self.value_cache:
@@ -373,7 +377,7 @@ class BatchedMCTS(object):
             self.tree.reset_hooks = [reset_lookahead]
         self.value_ahead = bool(getattr(self, "value_ahead", False))
         if self.persistent:
-            n_gw = -(-n_games // _lib.SEARCH_GAMES_PER_WORKGROUP)
+            n_gw = -(-n_games // self.games_per_workgroup)
             if net_workgroups is None:
                 net_workgroups = int(os.environ.get("IAGO_PERSISTENT_NET", "0")) or max(1, min(256 - n_gw, 8 * n_games))
             self.net_workgroups = max(1, int(net_workgroups))
@@ -1027,6 +1031,8 @@ class BatchedMCTS(object):
         a.active = active.data_ptr()
         a.c_puct, a.lmbda, a.n_thr, a.n_sims = self.c_puct, self.lmbda, self.n_thr, int(n_sims)
         a.net_workgroups, a.time_limit_ms = self.net_workgroups, self.time_limit_ms
+        a.games_per_workgroup = self.games_per_workgroup
+        a.pace_margin = self.pace_margin
         a.value, a.policy, a.rollout = C.addressof(va), C.addressof(pa), C.addressof(ro.args)
         a.cur_node, a.cur_own, a.cur_opp = self.cur_node.data_ptr(), self.cur_own.data_ptr(), self.cur_opp.data_ptr()
         a.path, a.path_stride = ps["path"].data_ptr(), self.PATH_STRIDE

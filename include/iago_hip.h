@@ -761,7 +761,7 @@ IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const 
  * the device (256), and nothing else should occupy the device while the launch runs.
  */
 #define IAGO_SEARCH_QUEUE_ENTRIES 4096
-#define IAGO_SEARCH_GAMES_PER_WORKGROUP 32   /* games a game workgroup owns */
+#define IAGO_SEARCH_GAMES_PER_WORKGROUP 32   /* games a game workgroup owns (at most, and by default) */
 typedef struct iago_mcts_search_args {
     const iago_mcts_tree *tree;
     const uint64_t *root_own, *root_opp;
@@ -802,7 +802,9 @@ typedef struct iago_mcts_search_args {
            visit counts by action; rows of turns a game did not play are not written.
        ctl [16]: ctl[3] != 0: gave up after time_limit_ms; ctl[4] != 0: a searched root had no children
        (n_sims < n_thr: the reference's max() of an empty dict, MCTS.py:147). */
-    int32_t max_turns, reserved2;
+    int32_t max_turns;
+    int32_t games_per_workgroup; /* games a game workgroup owns: 0 (= IAGO_SEARCH_GAMES_PER_WORKGROUP), 8, 16 or 32; the first
+                                    ceil(n_games / that) workgroups of the grid are the game workgroups */
     uint64_t *game_own, *game_opp;
     int32_t *n_turns;
     uint64_t *rec_own, *rec_opp;
@@ -815,10 +817,15 @@ typedef struct iago_mcts_search_args {
                               game has asked for before is answered from the table instead of the queue (same number, same
                               trees).  totals[8] counts the hits; totals [16] */
     int64_t vtable_slots;
-    int64_t *trace;       /* optional diagnostic [trace_rows][4]: game workgroup 0 records (100 MHz ticks since its start,
-                             requests queued so far, tickets handed out so far, game workgroups finished) once per
-                             iteration of its loop */
-    int32_t trace_rows, reserved;
+    int64_t *trace;       /* optional diagnostic [trace_rows][4].  Rows 0 .. trace_rows - n_games - 1: game workgroup 0 records
+                             (100 MHz ticks since its start, requests queued so far, tickets handed out so far, game
+                             workgroups finished | playouts of all games so far << 8) once per iteration of its loop; with
+                             max_turns > 0 row trace_rows - 1 - g: (ticks at the end of game g, requests it sent, its turns) */
+    int32_t trace_rows;
+    int32_t pace_margin;  /* pacing of the leading games: a game more than pace_margin playouts ahead of the mean progress of
+                             the games in play starts no new playout while requests queue up (the batch ends with its slowest
+                             game; what the leaders do not ask of the nets, the laggards get).  Timing only -- a game's own
+                             sequence of playouts, hence every tree and move, is unchanged.  0 = default (16), < 0 = off */
 } iago_mcts_search_args;
 IAGO_API int iago_mcts_search_persistent(const iago_mcts_search_args *args, void *stream);
 

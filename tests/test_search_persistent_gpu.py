@@ -133,6 +133,33 @@ def test_whole_games(nets, games, monkeypatch):
     assert a["n_turns"] % 2 == 0 and a["valid"].sum() > 40 * 50
 
 
+@pytest.mark.parametrize("pace,backlog,gpw,net", [("-1", "128", "32", None), ("1", "0", "8", 6), ("16", "4", "16", 24)])
+def test_scheduling_knobs_do_not_change_the_games(nets, pace, backlog, gpw, net, monkeypatch):
+    """Pacing of the leading games (held while requests queue), the games per game workgroup and the number of net
+    workgroups decide WHEN a game's playouts run, never what they are: whole games equal the default schedule's in
+    every move, visit count and rollout result.  (pace 1 / backlog 0: a game one playout ahead of the mean holds
+    whenever anything waits -- the pacing at its most intrusive.)"""
+    engine, ops, policy, value, rw = nets
+    res = []
+    for variant in (False, True):
+        if variant:
+            monkeypatch.setenv("IAGO_PERSISTENT_PACE", pace)
+            monkeypatch.setenv("IAGO_PERSISTENT_PACE_BACKLOG", backlog)
+            monkeypatch.setenv("IAGO_PERSISTENT_GPW", gpw)
+        m = engine.BatchedMCTS(72, policy, value, rw, n_thr=15, capacity=2048, seed=5, persistent=True,
+                               net_workgroups=net if variant else None, z_log_rows=64 * 30)
+        assert m.games_per_workgroup == (int(gpw) if variant else 32)
+        r = engine.SelfPlayEngine(m).play(30)
+        res.append(dict(move=r.move.cpu().numpy(), pi=r.pi.cpu().numpy(), z=r.z.cpu().numpy(), valid=r.valid.cpu().numpy(),
+                        p1=r.final_p1.cpu().numpy(), p2=r.final_p2.cpu().numpy(), n_turns=r.n_turns,
+                        zlog=m.z_log.cpu().numpy(), zn=m.z_log_n.cpu().numpy(), leaf=m.n_leaf_evals,
+                        n_nodes=m.tree.n_nodes.cpu().numpy()))
+        m.close()
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+    assert res[0]["valid"].sum() > 72 * 50
+
+
 def test_whole_games_below_n_thr_raise(nets):
     engine, ops, policy, value, rw = nets
     m = engine.BatchedMCTS(16, policy, value, rw, n_thr=15, capacity=1024, seed=1, persistent=True)
