@@ -167,6 +167,32 @@ def test_whole_games_below_n_thr_raise(nets):
         engine.SelfPlayEngine(m, max_turns=4).play(8)      # MCTS.get_move's max() of an empty dict (MCTS.py:147)
 
 
+def test_clock_limit_ends_the_launch(nets):
+    """Every wait in the launch is a bounded poll under a clock limit (a launch whose net workgroups never become
+    resident must not hang the device): with a limit far below what the search needs the launch ends by itself, the
+    engine reports it, and the device goes on working."""
+    engine, ops, policy, value, rw = nets
+    from iago_amd import _lib
+    own, opp = _positions(512)
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    active = torch.ones(512, dtype=torch.uint8, device="cuda")
+    m = engine.BatchedMCTS(512, policy, value, rw, n_thr=15, capacity=engine.suggest_capacity(400, 15, moves=2), seed=2,
+                           persistent=True)
+    m.time_limit_ms = 1                       # 512 games x 400 playouts take ~15 ms
+    with pytest.raises(_lib.IagoError, match="gave up"):
+        m.search(o, p, active, 400)
+    done = m._ps["done"].cpu().numpy()
+    assert done.min() < 400                   # (it really was cut short)
+    m.close()
+    # the same search with the default limit, on the same device, right after
+    m = engine.BatchedMCTS(512, policy, value, rw, n_thr=15, capacity=engine.suggest_capacity(400, 15, moves=2), seed=2,
+                           persistent=True)
+    m.search(o, p, active, 400)
+    nv = m.tree.n_visits.view(512, -1).cpu().numpy()
+    assert (nv[np.arange(512), m.tree.root.cpu().numpy()] == 400).all()
+    m.close()
+
+
 def test_too_many_games_take_the_per_playout_launches(nets):
     """More than 4096 games would leave the launch's game workgroups no net workgroup beside them: the default is the
     per-playout engine there, and asking for the persistent one raises."""
