@@ -177,6 +177,63 @@ __global__ __launch_bounds__(BLOCK) void sample_moves_kernel(
 }
 
 
+// The same arithmetic with one WAVE per board, for the small batches of the self-play loop (64 games of
+// src/rl_self_play.py step through a turn in lockstep: one thread per board is 192 dependent float64
+// divisions on one lane, 26 us per turn).  Lane k holds cell k; the two float64 sums stay sequential in
+// cell order -- every lane runs them itself over the wave's row in LDS (broadcast reads), so nothing has
+// to be sent back -- and the divisions (one per cell and pass) run side by side: bit for bit the
+// kernel above.
+__global__ __launch_bounds__(BLOCK) void sample_moves_wave_kernel(
+    const float *__restrict__ probs, const uint64_t *__restrict__ legal,
+    const double *__restrict__ uniforms, uint32_t key0, uint32_t key1, uint32_t id_base,
+    uint32_t step, uint32_t stream_id, int8_t *__restrict__ action, int64_t n)
+{
+    __shared__ double row[BLOCK / 64][2][64];
+    const int w = threadIdx.x >> 6, k = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (BLOCK / 64) + w;
+    if (b >= n)
+        return; // (the whole wave: no workgroup barrier below)
+    const uint64_t lg = legal[b];
+    if (lg == 0ull) {
+        if (k == 0)
+            action[b] = -1;
+        return;
+    }
+    double u;
+    if (uniforms) {
+        u = uniforms[b];
+    } else {
+        uint32_t c[4] = {id_base + (uint32_t)b, step >> 2, stream_id, 0u};
+        philox4x32_10(c, key0, key1);
+        u = (double)((float)(c[step & 3u] >> 8) * (1.0f / 16777216.0f));
+    }
+    const double v = ((lg >> k) & 1ull) ? (double)probs[b * 64 + k] : 0.0;
+    row[w][0][k] = v;
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0); the wave's lanes run in lockstep
+    __builtin_amdgcn_wave_barrier();
+    double s = 0.0; // np.sum(prob * valid)
+    for (int j = 0; j < 64; j++)
+        s += row[w][0][j];
+    row[w][1][k] = v / s;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    double acc = 0.0, mine = 0.0; // cumsum(p / s): this lane's element, and cdf[-1]
+    for (int j = 0; j < 64; j++) {
+        acc += row[w][1][j];
+        mine = (j == k) ? acc : mine;
+    }
+    const double last = acc;
+    if (!(s > 0.0) || !(s <= 1.7976931348623157e308) || !(last > 0.0)) {
+        if (k == 0)
+            action[b] = 64;
+        return;
+    }
+    const uint64_t le = __builtin_amdgcn_ballot_w64(mine / last <= u); // searchsorted(cdf, u, side='right')
+    if (k == 0)
+        action[b] = (int8_t)__popcll(le);
+}
+
+
 // Block epilogue: one float4 per thread, 16 threads per (board, channel) plane.
 __global__ __launch_bounds__(BLOCK) void bias_relu_kernel(float4 *__restrict__ x,
                                                           const float *__restrict__ bias,
@@ -329,9 +386,14 @@ int iago_sample_moves(const float *probs, const uint64_t *legal, const double *u
         return iago_fail(IAGO_ERR_INVALID, "iago_sample_moves: null pointer or negative n");
     if (n == 0)
         return IAGO_OK;
-    hipLaunchKernelGGL(sample_moves_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream,
-                       probs, legal, uniforms, (uint32_t)seed, (uint32_t)(seed >> 32), id_base,
-                       step, stream_id, action, n);
+    if (n <= 16384) // (a wave per board up to 64 waves per CU's worth of boards, a lane per board beyond)
+        hipLaunchKernelGGL(sample_moves_wave_kernel, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
+                           (hipStream_t)stream, probs, legal, uniforms, (uint32_t)seed, (uint32_t)(seed >> 32), id_base,
+                           step, stream_id, action, n);
+    else
+        hipLaunchKernelGGL(sample_moves_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream,
+                           probs, legal, uniforms, (uint32_t)seed, (uint32_t)(seed >> 32), id_base,
+                           step, stream_id, action, n);
     return iago_check_launch("iago_sample_moves");
 }
 

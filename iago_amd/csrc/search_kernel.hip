@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             int status = 2, count = 0;
             // an entry waiting in the home ring, else in the other one; nothing anywhere: poll the counters (no
             // ticket is taken for an entry that is not there, so nobody is committed to a ring that stays empty)
-            for (uint32_t spins = 0;; spins++) {
+            for (;;) {
                 uint32_t q = home;
                 bool have = n_carry > 0;
                 uint32_t t1 = carry;

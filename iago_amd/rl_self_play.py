@@ -46,40 +46,57 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
     stone_num = torch.full((B,), 4, dtype=torch.int32, device=device)  # src/rl_self_play.py:20
     pass_flg = torch.zeros(B, dtype=torch.uint8, device=device)
     done = torch.zeros(B, dtype=torch.uint8, device=device)
-    rec_own, rec_opp, rec_act = [], [], []
-    nan_seen = torch.zeros((), dtype=torch.bool, device=device)
+    T = ops.IAGO_MAX_TURNS
+    rec_own = torch.empty((T // 2, B), dtype=torch.int64, device=device)
+    rec_opp = torch.empty((T // 2, B), dtype=torch.int64, device=device)
+    rec_act = torch.empty((T // 2, B), dtype=torch.int8, device=device)
+    a_max = torch.full((B,), -1, dtype=torch.int8, device=device)   # 64 = iago_sample_moves met NaN probabilities
     legal = ops.legal_moves(own, opp)          # of the mover; 0 for a finished game from turn 1 on
     active = (legal != 0).to(torch.uint8)
     legal_next, active_next = torch.empty_like(legal), torch.empty_like(active)
+    # `while stone_num < 64` is tested once per pair of turns (src/rl_self_play.py:28-30).  Reading that flag back
+    # costs the loop a host round trip, and no lockstep batch is over before turn SYNC_FROM in practice: up to there
+    # the flag goes into a device-side log (turns played past the true end change nothing: a finished game has no
+    # legal move, so no action, no stone, no record), and the log gives the turn the batch really ended at
+    SYNC_FROM = 56 if uniforms is None else 0
+    over_log = torch.zeros(T // 2 + 1, dtype=torch.uint8, device=device)
     t = 0
-    while t < ops.IAGO_MAX_TURNS:
+    while t < T:
         color = 1 if t % 2 == 0 else 2
         probs = _move_probs(model1 if color == 1 else model2, own, opp)
         u = next(uniforms) if (uniforms is not None and bool(active.any().item())) else None
         a = ops.sample_moves(probs.to(torch.float32).contiguous(), legal, uniforms=u,
                              seed=seed, id_base=game_id_base, step=t)
-        nan_seen = nan_seen | (a > 63).any()
+        torch.maximum(a_max, a, out=a_max)
         if color == 1:
-            rec_own.append(own.clone())
-            rec_opp.append(opp.clone())
-            rec_act.append(a.clone())
+            torch._foreach_copy_([rec_own[t // 2], rec_opp[t // 2], rec_act[t // 2]], [own, opp, a])
         # the move, stone_num / pass_flg / done (`while stone_num < 64` per pair of turns,
         # src/rl_self_play.py:28-30,130-145), the swap of sides and the next mover's moves
         ops.play_turn(own, opp, a, active, stone_num, pass_flg, done, t % 2 == 1, legal_next, active_next)
         legal, legal_next = legal_next, legal
         active, active_next = active_next, active
         t += 1
-        if t % 2 == 0 and bool(done.all().item()):
-            break
+        if t % 2 == 0:
+            if t >= SYNC_FROM:
+                if bool(done.all().item()):
+                    break
+            else:
+                torch.amin(done, dim=0, out=over_log[t // 2])    # 1 iff every game is over
+    if SYNC_FROM:
+        first = torch.nonzero(over_log[: SYNC_FROM // 2]).reshape(-1)[:1].tolist()   # (one read for the whole batch)
+        if first:
+            t = 2 * first[0]      # the batch was over there already: the later turns were idle (an even number of swaps)
+    nan_seen = a_max > 63
+    rec_own, rec_opp, rec_act = rec_own[: (t + 1) // 2], rec_opp[: (t + 1) // 2], rec_act[: (t + 1) // 2]
     p1, p2 = (own, opp) if t % 2 == 0 else (opp, own)
     for model in (model1, model2):
         if getattr(model, "check_saturation", None) is not None:
             model.check_saturation()   # raises and clears the flag (one readback per model and batch)
-    if bool(nan_seen.item()):
+    if bool(nan_seen.any().item()):
         # iago_sample_moves returns 64 when no cell's CDF exceeds u: NaN probabilities.
         # numpy.random.choice raises here in the reference (src/rl_self_play.py:122)
         raise ValueError("probabilities contain NaN")
-    return dict(own=torch.stack(rec_own), opp=torch.stack(rec_opp), action=torch.stack(rec_act),
+    return dict(own=rec_own, opp=rec_opp, action=rec_act,
                 z=ops.judge(p1, p2), final_p1=p1, final_p2=p2, n_turns=t)
 
 

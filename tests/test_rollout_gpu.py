@@ -252,6 +252,11 @@ def test_sample_moves_bit_exact(ops):
             continue
         want = orc.choice_cdf(orc.masked_probs(probs[i], acts), u[i])
         assert got[i] == want, i
+    # the same rows as a batch beyond 16384 boards take the lane-per-board kernel instead of the wave-per-board one
+    reps = 7
+    big = ops.sample_moves(torch.from_numpy(np.tile(probs, (reps, 1))).cuda(), legal.repeat(reps),
+                           uniforms=torch.from_numpy(np.tile(u, reps)).cuda()).cpu().numpy()
+    assert n * reps > 16384 and np.array_equal(big, np.tile(got, reps))
     # Philox path: the uniform of (seed, id_base + b, step)
     got2 = ops.sample_moves(torch.from_numpy(probs).cuda(), legal, seed=9, id_base=100,
                             step=7).cpu().numpy()
