@@ -10,6 +10,11 @@ import torch
 from . import boards, engine, ops
 
 
+# turn from which play_batch reads the end-of-batch flag back every second turn (before it the flag is logged on the
+# device); 0 = from the first turn on, the reference's loop to the letter (the tests compare the two)
+SYNC_FROM = 56
+
+
 def _move_probs(model, own, opp):
     """model(make_state_var(...)) for every board.  An SLPolicy module is evaluated by its one-launch
     three-piece kernel straight from the boards: one board per workgroup, so a board's distribution
@@ -58,7 +63,7 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
     # costs the loop a host round trip, and no lockstep batch is over before turn SYNC_FROM in practice: up to there
     # the flag goes into a device-side log (turns played past the true end change nothing: a finished game has no
     # legal move, so no action, no stone, no record), and the log gives the turn the batch really ended at
-    SYNC_FROM = 56 if uniforms is None else 0
+    sync_from = SYNC_FROM if uniforms is None else 0
     over_log = torch.zeros(T // 2 + 1, dtype=torch.uint8, device=device)
     t = 0
     while t < T:
@@ -77,13 +82,13 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
         active, active_next = active_next, active
         t += 1
         if t % 2 == 0:
-            if t >= SYNC_FROM:
+            if t >= sync_from:
                 if bool(done.all().item()):
                     break
             else:
                 torch.amin(done, dim=0, out=over_log[t // 2])    # 1 iff every game is over
-    if SYNC_FROM:
-        first = torch.nonzero(over_log[: SYNC_FROM // 2]).reshape(-1)[:1].tolist()   # (one read for the whole batch)
+    if sync_from:
+        first = torch.nonzero(over_log[: sync_from // 2]).reshape(-1)[:1].tolist()   # (one read for the whole batch)
         if first:
             t = 2 * first[0]      # the batch was over there already: the later turns were idle (an even number of swaps)
     nan_seen = a_max > 63

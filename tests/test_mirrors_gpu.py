@@ -95,6 +95,36 @@ def test_rl_game_mirror_replays_reference_games():
         assert orc.state_to_bits(game.state) == (c["q1"], c["q2"])
 
 
+def test_rl_play_batch_short_games_end_where_the_reference_loop_ends(monkeypatch):
+    """play_batch logs the end-of-batch flag on the device for the first 56 turns instead of reading it back every
+    second turn; a batch that is over earlier (here: boards nearly full of colour-2 stones from the start) must come
+    back as if the loop had stopped there: same n_turns, records, results as with the read-back at every pair of turns
+    (`while stone_num < 64`, src/rl_self_play.py:28-30)."""
+    from iago_amd import ops, rl_self_play
+    rs = np.random.RandomState(8)
+    w1, b1 = rs.randn(18).astype(np.float32), (0.5 * rs.randn(64)).astype(np.float32)
+    m1, m2 = _Rollout(w1, b1), _Rollout(w1[::-1].copy(), b1)
+    B = 24
+    start = 0x0000001818000000
+    hc = np.zeros(B, np.uint64)
+    for g in range(B):
+        empty = rs.choice([c for c in range(64) if not (start >> c) & 1], size=2 + g % 7, replace=False)
+        full = (~np.uint64(0)) & ~np.uint64(start)
+        for c in empty:
+            full &= ~(np.uint64(1) << np.uint64(c))
+        hc[g] = full
+    res = []
+    for sync_from in (56, 0):
+        monkeypatch.setattr(rl_self_play, "SYNC_FROM", sync_from)
+        r = rl_self_play.play_batch(m1, m2, B, handicap=ops.bits_to_tensor(hc), seed=5, game_id_base=40)
+        res.append(r)
+    a, b = res
+    assert a["n_turns"] == b["n_turns"] and 2 <= b["n_turns"] < 40
+    for k in ("own", "opp", "action", "z", "final_p1", "final_p2"):
+        assert torch.equal(a[k], b[k]), k
+    assert (a["action"] >= 0).sum().item() > 0
+
+
 def test_rl_play_batch_matches_oracle_games():
     """Batched lockstep games with Philox sampling == the oracle's rl_game driven
     by the same uniforms, game by game."""
