@@ -54,14 +54,31 @@ class ChainerAdam(object):
     def update(self):
         self.t += 1
         a_t = self.alpha * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
+        ps, gs, ms, vs = [], [], [], []
         for n, p in self.model.named_parameters():
             if p.grad is None:
                 continue
-            g = p.grad + self.wd * p
-            m, v = self.state[n]
-            m.add_((g - m) * (1.0 - self.beta1))
-            v.add_((g * g - v) * (1.0 - self.beta2))
-            p.sub_(a_t * m / (v.sqrt() + self.eps))
+            ps.append(p)
+            gs.append(p.grad)
+            ms.append(self.state[n][0])
+            vs.append(self.state[n][1])
+        if not ps:
+            return
+        # the rule above, operation by operation (each product and sum rounded on its own, as numpy rounds them), over
+        # all parameters at once: 14 multi-tensor launches instead of 12 per parameter
+        g = torch._foreach_add(gs, torch._foreach_mul(ps, self.wd))          # g = p.grad + wd * p
+        d = torch._foreach_sub(g, ms)
+        torch._foreach_mul_(d, 1.0 - self.beta1)
+        torch._foreach_add_(ms, d)                                            # m += (g - m) (1 - beta1)
+        gg = torch._foreach_mul(g, g)
+        torch._foreach_sub_(gg, vs)
+        torch._foreach_mul_(gg, 1.0 - self.beta2)
+        torch._foreach_add_(vs, gg)                                           # v += (g g - v) (1 - beta2)
+        den = torch._foreach_sqrt(vs)
+        torch._foreach_add_(den, self.eps)
+        num = torch._foreach_mul(ms, a_t)
+        torch._foreach_div_(num, den)
+        torch._foreach_sub_(ps, num)                                          # p -= a_t m / (sqrt(v) + eps)
 
     def state_dict_npz(self):
         out = {"t": np.asarray(self.t, np.int64), "epoch": np.asarray(0, np.int64)}
