@@ -24,6 +24,8 @@ for path in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
             if "::" + k + "(" in r[0].replace("<", "(") or r[0].startswith(k + "("):
                 out[k]["calls"] = out[k].get("calls", 0) + int(r[1])
                 out[k]["total_ns"] = out[k].get("total_ns", 0) + int(float(r[2]))
+                out[k]["min_us"] = min(out[k].get("min_us", 1e30), float(r[5]) / 1e3)
+                out[k]["max_us"] = max(out[k].get("max_us", 0.0), float(r[6]) / 1e3)
 for k in KERNELS:
     if "calls" in out[k]:
         out[k]["avg_us"] = out[k]["total_ns"] / out[k]["calls"] / 1e3
@@ -57,6 +59,10 @@ for k in KERNELS:
             wgs = d["SQ_WAVES"] / 4.0          # 256-thread workgroups, one per CU
             d["l2_read_gb_per_s_per_workgroup_64B_req"] = d["l2_read_bytes_per_launch_64B_req"] / wgs / d["avg_us"] / 1e3
             d["l2_read_gb_per_s_per_workgroup_128B_req"] = d["l2_read_bytes_per_launch_128B_req"] / wgs / d["avg_us"] / 1e3
+if "calls" in out["search_kernel"]:
+    out["search_kernel"]["note"] = ("one launch = a whole batch of games; the calls are the bench leg's warm-up batch (a few "
+                                    "turns: min_us) and the timed one (max_us): the counters and avg_us are means over both, "
+                                    "so every RATE (counter / time) is the sum over both launches divided by their total time")
 cmd = os.path.join(src, "command.txt")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench  # noqa: E402  (csrc_sha16: the kernel sources this profile was taken on)
