@@ -32,6 +32,7 @@ done
 find "$OUT" -name "*_kernel_trace.csv" -delete
 find "$OUT" -name "*.db" -delete
 python3 $REPO/tools/summarize_mcts_profile.py "$OUT" > "$OUT/summary.json"
-# the counter CSVs of a full game are tens of MB: keep the summary and the stats
-if [ "$MODE" != "first4" ]; then find "$OUT" -name "*_counter_collection.csv" -delete; fi
+# the counter CSVs of a full game on the per-playout launches are tens of MB: keep the summary and the stats
+# (the persistent engine's are two rows per counter: they stay, so that the summary can be rebuilt from the merge-back)
+if [ "$MODE" = "full" ]; then find "$OUT" -name "*_counter_collection.csv" -delete; fi
 du -sh "$OUT"
