@@ -133,7 +133,7 @@ def test_whole_games(nets, games, monkeypatch):
     assert a["n_turns"] % 2 == 0 and a["valid"].sum() > 40 * 50
 
 
-@pytest.mark.parametrize("pace,backlog,gpw,net", [("-1", "128", "32", None), ("1", "0", "8", 6), ("16", "4", "16", 24)])
+@pytest.mark.parametrize("pace,backlog,gpw,net", [("-1", "128", "32", None), ("1", "0", "32", 6), ("16", "4", "16", 24)])
 def test_scheduling_knobs_do_not_change_the_games(nets, pace, backlog, gpw, net, monkeypatch):
     """Pacing of the leading games (held while requests queue), the games per game workgroup and the number of net
     workgroups decide WHEN a game's playouts run, never what they are: whole games equal the default schedule's in
@@ -148,7 +148,7 @@ def test_scheduling_knobs_do_not_change_the_games(nets, pace, backlog, gpw, net,
             monkeypatch.setenv("IAGO_PERSISTENT_GPW", gpw)
         m = engine.BatchedMCTS(72, policy, value, rw, n_thr=15, capacity=2048, seed=5, persistent=True,
                                net_workgroups=net if variant else None, z_log_rows=64 * 30)
-        assert m.games_per_workgroup == (int(gpw) if variant else 32)
+        assert m.games_per_workgroup == (int(gpw) if variant else 8)      # (72 games: 9 game workgroups of 8 by default)
         r = engine.SelfPlayEngine(m).play(30)
         res.append(dict(move=r.move.cpu().numpy(), pi=r.pi.cpu().numpy(), z=r.z.cpu().numpy(), valid=r.valid.cpu().numpy(),
                         p1=r.final_p1.cpu().numpy(), p2=r.final_p2.cpu().numpy(), n_turns=r.n_turns,
