@@ -91,6 +91,24 @@ def test_trees_equal_the_per_playout_engine(nets, G, n_sims, n_sims2, net):
     a.policy_fn.check_saturation()
 
 
+@pytest.mark.parametrize("lmbda,c_puct,n_thr,G,n_sims,n_sims2", [(0.0, 1.0, 15, 40, 80, 30), (0.3, 0.7, 3, 33, 50, 25),
+                                                               (0.9, 2.5, 7, 65, 64, 0), (0.5, 1.0, 15, 9, 14, 16)])
+def test_other_search_parameters(nets, lmbda, c_puct, n_thr, G, n_sims, n_sims2):
+    """MCTS(lmbda, c_puct, n_thr) (MCTS.py:78-82) away from the defaults -- lmbda = 0 (no rollout at all: the leaf's
+    value alone), a small n_thr (expansions all the time), a search shorter than n_thr (no expansion in the first
+    search) -- : the same trees as the per-playout launches."""
+    own, opp = _positions(G)
+    kw = dict(lmbda=lmbda, c_puct=c_puct, n_thr=n_thr, z_log_rows=0)
+    a, ta = _run(nets, G, n_sims, n_sims2, own, opp, persistent=True, **kw)
+    b, tb = _run(nets, G, n_sims, n_sims2, own, opp, persistent=False, use_graph=True, **kw)
+    assert a.persistent and not b.persistent
+    for k in ("n_visits", "q", "p", "first_child", "parent", "action", "n_children", "n_nodes", "root", "leaf_value"):
+        assert np.array_equal(ta[k], tb[k]), k
+    assert np.array_equal(np.isnan(ta["v"]), np.isnan(tb["v"]))
+    assert np.array_equal(ta["v"][~np.isnan(ta["v"])], tb["v"][~np.isnan(tb["v"])])
+    assert a.n_leaf_evals == b.n_leaf_evals == G * (n_sims + n_sims2)
+
+
 def test_n_thr_one(nets):
     """n_thr = 1 (SURVEY 8d's second datapoint): every leaf expands at its second visit -- the policy net
     inside every playout."""
