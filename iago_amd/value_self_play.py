@@ -22,7 +22,7 @@ parser is out of scope); `generate` returns the samples as device tensors.
 import numpy as np
 import torch
 
-from . import boards, engine, ops
+from . import boards, engine, ops, rl_self_play
 
 MAX_TURNS = 2 * ops.IAGO_MAX_TURNS  # every turn either places a stone or is one of <= 2 passes in a row
 
@@ -80,13 +80,15 @@ def generate(model_sl, model_rl, n_games, stop_num=None, seed=0, game_id_base=0,
         movers = (phase_a | phase_c) & has
         action = torch.full((B,), -1, dtype=torch.int8, device=device)
         if bool(movers.any().item()):
-            x = ops.encode_planes(own, opp)
             out = torch.zeros((B, 64), dtype=torch.float32, device=device)
-            with torch.no_grad():
-                for model, mask in ((model_sl, phase_a & has), (model_rl, phase_c & has)):
-                    idx = torch.nonzero(mask).reshape(-1)
-                    if idx.numel():
-                        out[idx] = model(x[idx].contiguous()).reshape(-1, 64).to(torch.float32)
+            # a model that has a mover evaluates the WHOLE batch and its movers' rows are kept: the batch a net sees
+            # has one size from the first turn to the last (a gathered sub-batch changes size every turn, and every new
+            # size sends MIOpen through its solver search: 58 s for 1024 games, measured), and an SLPolicy module goes
+            # through its one-board-per-workgroup kernel, whose rows do not depend on the batch around them
+            for model, mask in ((model_sl, phase_a & has), (model_rl, phase_c & has)):
+                if bool(mask.any().item()):
+                    pm = rl_self_play._move_probs(model, own, opp).reshape(B, 64).to(torch.float32)
+                    out = torch.where(mask.reshape(B, 1), pm, out)
             p = _softmax_like_reference(out)
             # np.random.choice(64, p=softmax(...)): unmasked = every cell "legal"
             a1 = ops.sample_moves(p, every_cell, uniforms=u_next() if it is not None else None,

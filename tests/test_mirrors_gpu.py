@@ -336,3 +336,10 @@ def test_value_self_play_batch_properties():
     assert torch.equal(r["own"], r2["own"]) and torch.equal(r["z"], r2["z"])
     a, b, zz = value_self_play.generate_dataset(sl, rl, 96, batch=64, seed=1)
     assert a.shape == b.shape == zz.shape == (96,)
+    # a net sees ONE batch size from the first turn to the last (a sub-batch gathered per phase changes size every
+    # turn, and every new size sends MIOpen through its solver search: a 1024-game batch took 58 s that way)
+    seen = set()
+    hook = rl.register_forward_pre_hook(lambda mod, args: seen.add(tuple(args[0].shape)))
+    value_self_play.generate(sl, rl, 96, seed=9)
+    hook.remove()
+    assert seen == {(96, 2, 8, 8)}
