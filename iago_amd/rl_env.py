@@ -73,6 +73,11 @@ class GameEnv(object):
             with torch.no_grad():
                 out = torch.as_tensor(model(x)).reshape(64).to(torch.float32).cpu().numpy().copy()
             out -= np.min(out)
+            if not any(out[(q[0] - 1) * 8 + (q[1] - 1)] > 0.0 for q in positions):
+                # the shift gives the net's lowest cell probability 0: when every legal cell sits there the reference
+                # draws again for ever (rl_env.py:167-172, the same net output every time); the mirror says so instead
+                raise RuntimeError("GameEnv.get_position: the shifted net output puts no mass on a legal position "
+                                   "(the reference's retry loop, rl_env.py:167-172, never ends here)")
             idx = int(self.choice(64, p=out / np.sum(out)))
             position = [idx // 8 + 1, idx % 8 + 1]
             if position in positions:

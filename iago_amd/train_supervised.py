@@ -63,8 +63,25 @@ class SupervisedTrainer(object):
     def evaluate(self, own, opp, labels):
         """Test loss (and accuracy for policies), train_policy.py:63-68."""
         self.model.eval()
-        loss, pred = self.loss_fn(self.model, own, opp, labels)
-        out = {"loss": float(loss.item())}
+        n = own.numel()
+        if n <= MINIBATCH:
+            loss, pred = self.loss_fn(self.model, own, opp, labels)
+            out = {"loss": float(loss.item())}
+            if self.kind == "policy":
+                out["accuracy"] = float((pred.argmax(dim=1) == labels.to(torch.int64)).float().mean())
+            return out
+        # a test set beyond one minibatch goes through in minibatches (the reference hands the whole set to the net at
+        # once: activations of 128 x 64 floats per sample and layer, and a convolution shape MIOpen has not seen --
+        # 22 s of solver search for 20,000 samples, measured); the means are the sample-weighted means of the pieces
+        total = torch.zeros((), dtype=torch.float64, device=own.device)
+        hits = torch.zeros((), dtype=torch.float64, device=own.device)
+        for lo in range(0, n, MINIBATCH):
+            sl = slice(lo, min(lo + MINIBATCH, n))
+            loss, pred = self.loss_fn(self.model, own[sl], opp[sl], labels[sl])
+            total += loss.to(torch.float64) * (sl.stop - sl.start)
+            if self.kind == "policy":
+                hits += (pred.argmax(dim=1) == labels[sl].to(torch.int64)).sum()
+        out = {"loss": float((total / n).item())}
         if self.kind == "policy":
-            out["accuracy"] = float((pred.argmax(dim=1) == labels.to(torch.int64)).float().mean())
+            out["accuracy"] = float((hits / n).item())
         return out

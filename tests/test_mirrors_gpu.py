@@ -235,6 +235,25 @@ def test_game_env_mirror():
     assert done and (env.stone_num >= 64 or env.pass_flg)
 
 
+def test_game_env_says_when_the_retry_loop_cannot_end():
+    """rl_env.py:152-172 samples from `out - min(out)` and draws again until the cell is legal: a net whose lowest
+    outputs sit on every legal cell makes the reference draw for ever.  The mirror raises there instead."""
+    from iago_amd import rl_env
+
+    class Opp(torch.nn.Module):
+        def forward(self, x):
+            s = (x[0, 0] + 2 * x[0, 1]).cpu().numpy().astype(np.float32)
+            out = torch.ones(64)
+            for a in orc.legal_actions(s, 2):
+                out[a] = 0.0
+            return (out / out.sum()).reshape(1, 64)
+
+    env = rl_env.GameEnv(None, Opp())
+    env.reset()
+    with pytest.raises(RuntimeError, match="never ends"):
+        env.step(2 * 8 + 3)     # [3, 4]: legal for colour 1; colour 2's reply can not be drawn
+
+
 def test_game_env_replays_golden_episodes():
     """a-14: the 6 recorded reference GameEnv episodes (rl_env.py:26-74,152-172; stand-in
     opponent, the uniforms numpy drew) replayed through the GPU mirror: board, done,

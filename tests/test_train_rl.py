@@ -178,3 +178,8 @@ def test_supervised_trainers_gpu():
     last = tr.evaluate(O, P, L)
     assert last["loss"] < first and 0.0 <= last["accuracy"] <= 1.0
     assert tr.opt.t == 12  # 2 minibatches per epoch
+    # evaluate() walks a test set beyond one minibatch in pieces: the same means as the whole set at once
+    with torch.no_grad():
+        whole, pred = policy_loss(tr.model, O, P, L)
+    assert abs(float(whole) - last["loss"]) < 1e-6
+    assert abs(float((pred.argmax(dim=1) == L).float().mean()) - last["accuracy"]) < 1e-6
