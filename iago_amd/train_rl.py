@@ -245,7 +245,12 @@ class ReinforceTrainer(object):
         self.model1.train()
         for p in self.model1.parameters():
             p.grad = None
-        loss = reinforce_loss(self.model1, own, opp, actions, rewards, pad_to=512)
+        # batch shapes MIOpen gets to see: multiples of a quarter of the batch's power-of-two bucket, at least 512 -- a
+        # set's ~1,920 rows always run as 2,048, a 64-game PV-MCTS round's ~3,840 as 4,096 until it falls below 3,073 (a
+        # new shape costs a 15 s solver search on a fresh box: seen once inside a 1000-round run with multiples of 512)
+        n = int(own.numel())
+        granule = max(512, (1 << max(n - 1, 1).bit_length()) // 4)
+        loss = reinforce_loss(self.model1, own, opp, actions, rewards, pad_to=granule)
         loss.backward()
         self.opt.update()
         idist.broadcast_tensors(list(self.model1.parameters()))  # replicas stay identical
