@@ -33,7 +33,7 @@ SYMBOLS = [
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
     "iago_mcts_fresh_leaves", "iago_mcts_descend", "iago_value_rollout_async",
     "iago_value_forward_batch", "iago_mcts_value_ahead_rows", "iago_mcts_value_ahead_store",
-    "iago_mcts_search_persistent",
+    "iago_mcts_search_persistent", "iago_selfplay_policy",
 ]
 
 
@@ -70,6 +70,16 @@ class PolicySplit3Args(C.Structure):
         ("w_hi", C.c_void_p * 7), ("w_mid", C.c_void_p * 7), ("w_lo", C.c_void_p * 7), ("bias", C.c_void_p * 7),
         ("w9", C.c_void_p), ("b10", C.c_void_p), ("probs", C.c_void_p), ("overflow", C.c_void_p),
         ("parts", C.c_int32), ("scratch_rows", C.c_int32), ("scratch", C.c_void_p),
+    ]
+
+
+class SelfplayPolicyArgs(C.Structure):
+    """Mirror of iago_selfplay_policy_args (include/iago_hip.h)."""
+    _fields_ = [
+        ("model1", C.c_void_p), ("model2", C.c_void_p), ("own", C.c_void_p), ("opp", C.c_void_p), ("n", C.c_int64),
+        ("seed", C.c_uint64), ("id_base", C.c_uint32), ("max_turns", C.c_int32),
+        ("rec_own", C.c_void_p), ("rec_opp", C.c_void_p), ("rec_act", C.c_void_p), ("n_turns", C.c_void_p),
+        ("bad_probs", C.c_void_p),
     ]
 
 
@@ -155,7 +165,7 @@ NODE_WORDS = 8   # sizeof(iago_mcts_node) / 4: n_visits, q, p, v, first_child, p
 
 
 _lib = None
-ABI_VERSION = 9   # iago_abi_version() of the include/iago_hip.h these bindings mirror
+ABI_VERSION = 10   # iago_abi_version() of the include/iago_hip.h these bindings mirror
 
 
 def lib():
@@ -237,6 +247,7 @@ def lib():
     L.iago_mcts_value_ahead_rows.argtypes = [tp, vap, vp]
     L.iago_mcts_value_ahead_store.argtypes = [tp, vap, vp]
     L.iago_mcts_search_persistent.argtypes = [C.POINTER(MctsSearchArgs), vp]
+    L.iago_selfplay_policy.argtypes = [C.POINTER(SelfplayPolicyArgs), vp]
     for name in SYMBOLS[3:]:
         getattr(L, name).restype = C.c_int
     _lib = L

@@ -2,6 +2,7 @@
 // Entry points and the reference interfaces they replace: include/iago_hip.h.
 #include "abi_common.hpp"
 #include "othello_dev.hpp"
+#include "sample_dev.hpp"
 
 using namespace iago;
 
@@ -177,12 +178,9 @@ __global__ __launch_bounds__(BLOCK) void sample_moves_kernel(
 }
 
 
-// The same arithmetic with one WAVE per board, for the small batches of the self-play loop (64 games of
-// src/rl_self_play.py step through a turn in lockstep: one thread per board is 192 dependent float64
-// divisions on one lane, 26 us per turn).  Lane k holds cell k; the two float64 sums stay sequential in
-// cell order -- every lane runs them itself over the wave's row in LDS (broadcast reads), so nothing has
-// to be sent back -- and the divisions (one per cell and pass) run side by side: bit for bit the
-// kernel above.
+// The same arithmetic with one WAVE per board (sample_dev.hpp), for the small batches of the self-play loop (64 games of
+// src/rl_self_play.py step through a turn in lockstep: one thread per board is 192 dependent float64 divisions on
+// one lane, 26 us per turn): bit for bit the kernel above.
 __global__ __launch_bounds__(BLOCK) void sample_moves_wave_kernel(
     const float *__restrict__ probs, const uint64_t *__restrict__ legal,
     const double *__restrict__ uniforms, uint32_t key0, uint32_t key1, uint32_t id_base,
@@ -199,38 +197,10 @@ __global__ __launch_bounds__(BLOCK) void sample_moves_wave_kernel(
             action[b] = -1;
         return;
     }
-    double u;
-    if (uniforms) {
-        u = uniforms[b];
-    } else {
-        uint32_t c[4] = {id_base + (uint32_t)b, step >> 2, stream_id, 0u};
-        philox4x32_10(c, key0, key1);
-        u = (double)((float)(c[step & 3u] >> 8) * (1.0f / 16777216.0f));
-    }
-    const double v = ((lg >> k) & 1ull) ? (double)probs[b * 64 + k] : 0.0;
-    row[w][0][k] = v;
-    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0); the wave's lanes run in lockstep
-    __builtin_amdgcn_wave_barrier();
-    double s = 0.0; // np.sum(prob * valid)
-    for (int j = 0; j < 64; j++)
-        s += row[w][0][j];
-    row[w][1][k] = v / s;
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    double acc = 0.0, mine = 0.0; // cumsum(p / s): this lane's element, and cdf[-1]
-    for (int j = 0; j < 64; j++) {
-        acc += row[w][1][j];
-        mine = (j == k) ? acc : mine;
-    }
-    const double last = acc;
-    if (!(s > 0.0) || !(s <= 1.7976931348623157e308) || !(last > 0.0)) {
-        if (k == 0)
-            action[b] = 64;
-        return;
-    }
-    const uint64_t le = __builtin_amdgcn_ballot_w64(mine / last <= u); // searchsorted(cdf, u, side='right')
+    const double u = uniforms ? uniforms[b] : sample_uniform(key0, key1, id_base + (uint32_t)b, step, stream_id);
+    const int a = sample_wave(probs + b * 64, lg, u, row[w], k);
     if (k == 0)
-        action[b] = (int8_t)__popcll(le);
+        action[b] = (int8_t)a;
 }
 
 

@@ -28,6 +28,39 @@ def _move_probs(model, own, opp):
         return model(ops.encode_planes(own, opp))
 
 
+# the games of play_batch as ONE launch (iago_selfplay_policy: a workgroup per game, the walk's workgroup goes on to the
+# draw, the stone and the next walk) wherever both models are SLPolicy modules on their three-piece kernel and the draws
+# are the Philox ones; False: the launch-per-turn loop everywhere (the tests compare the two)
+ONE_LAUNCH = True
+
+
+def _play_one_launch(model1, model2, own, opp, seed, game_id_base):
+    """iago_selfplay_policy on the start positions own / opp (consumed: the final boards on return)."""
+    import ctypes as C
+    from . import _lib
+    B, dev = own.numel(), own.device
+    T = ops.IAGO_MAX_TURNS
+    rows_own, rows_opp = torch.empty_like(own), torch.empty_like(opp)
+    probs = torch.empty((2, B, 64), dtype=torch.float32, device=dev)
+    a1, keep1 = model1.search_args(rows_own, rows_opp, probs[0])
+    a2, keep2 = model2.search_args(rows_own, rows_opp, probs[1])
+    rec_own = torch.empty((T // 2, B), dtype=torch.int64, device=dev)
+    rec_opp = torch.empty((T // 2, B), dtype=torch.int64, device=dev)
+    rec_act = torch.empty((T // 2, B), dtype=torch.int8, device=dev)
+    n_turns = torch.empty(B, dtype=torch.int32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    a = _lib.SelfplayPolicyArgs()
+    a.model1, a.model2 = C.addressof(a1), C.addressof(a2)
+    a.own, a.opp, a.n = own.data_ptr(), opp.data_ptr(), B
+    a.seed, a.id_base, a.max_turns = int(seed) & 0xFFFFFFFFFFFFFFFF, int(game_id_base) & 0xFFFFFFFF, T
+    a.rec_own, a.rec_opp, a.rec_act = rec_own.data_ptr(), rec_opp.data_ptr(), rec_act.data_ptr()
+    a.n_turns, a.bad_probs = n_turns.data_ptr(), bad.data_ptr()
+    ops.check(_lib.lib().iago_selfplay_policy(C.byref(a), ops._stream()), "iago_selfplay_policy")
+    del keep1, keep2
+    host = torch.cat([n_turns.max().reshape(1), bad]).tolist()     # (the batch's one read-back)
+    return rec_own, rec_opp, rec_act, int(host[0]), bool(host[1])
+
+
 def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, uniforms=None,
                device="cuda"):
     """n_games lockstep games.  handicap: optional (n_games,) int64 bit masks of
@@ -48,6 +81,16 @@ def play_batch(model1, model2, n_games, handicap=None, seed=0, game_id_base=0, u
     opp = torch.full((B,), engine.START_OPP, dtype=torch.int64, device=device)
     if handicap is not None:
         opp = opp | handicap
+    if (ONE_LAUNCH and uniforms is None and B > 0
+            and all(getattr(m, "search_args", None) is not None and getattr(m, "forward_boards_split3", None) is not None
+                    and getattr(m, "split3", False) and not getattr(m, "training", False) for m in (model1, model2))):
+        rec_own, rec_opp, rec_act, t, bad = _play_one_launch(model1, model2, own, opp, seed, game_id_base)
+        for model in (model1, model2):
+            model.check_saturation()
+        if bad:
+            raise ValueError("probabilities contain NaN")      # numpy.random.choice, src/rl_self_play.py:122
+        return dict(own=rec_own[: t // 2], opp=rec_opp[: t // 2], action=rec_act[: t // 2],
+                    z=ops.judge(own, opp), final_p1=own, final_p2=opp, n_turns=t)
     stone_num = torch.full((B,), 4, dtype=torch.int32, device=device)  # src/rl_self_play.py:20
     pass_flg = torch.zeros(B, dtype=torch.uint8, device=device)
     done = torch.zeros(B, dtype=torch.uint8, device=device)

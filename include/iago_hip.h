@@ -829,6 +829,41 @@ typedef struct iago_mcts_search_args {
 } iago_mcts_search_args;
 IAGO_API int iago_mcts_search_persistent(const iago_mcts_search_args *args, void *stream);
 
+/*
+ * Whole policy-vs-policy games -- src/rl_self_play.py:8-149, Game(model1, model2)() for n games -- in ONE launch: a
+ * workgroup plays a game from its first turn to its last (csrc/selfplay_policy_kernel.hip).  Per turn: the mover's
+ * SLPolicy on the board (iago_policy_forward_split3's one-board walk: the same probabilities), the masked draw of
+ * src/rl_self_play.py:111-127 (iago_sample_moves with uniforms = NULL: turn t of game b draws the Philox uniform of
+ * (seed, id_base + b, step t, stream 0)), the stone and the books of iago_play_turn (src/rl_self_play.py:27-31,130-145).
+ * The games are those of the launch-per-turn loop over iago_policy_forward_split3 / iago_sample_moves / iago_play_turn,
+ * record for record.
+ *   model1 (colour 1, moves first) / model2: weights as for iago_policy_forward_split3; both read their rows from the
+ *     SAME own / opp arrays of >= n rows, which the launch writes, and write their distributions to their probs
+ *     (>= n rows each); no index, no n_dev; parts is ignored.  Their overflow words are raised as usual.
+ *   own / opp [n]: in: the start positions (own = colour 1: the standard start, colour 2 possibly with a handicap
+ *     stone, src/train_rl.py:43-46); out: the final positions (own = colour 1).
+ *   rec_own / rec_opp / rec_act [max_turns / 2][n]: the position before each of colour 1's turns (own = colour 1)
+ *     and its move (-1 = no move: a pass, or the game was over) -- rows of turns after a game's end hold its final
+ *     board, as the lockstep loop records them.  n_turns [n]: the even turn at which `while stone_num < 64`
+ *     (src/rl_self_play.py:28) ended the game, max_turns if it never did.
+ *   bad_probs [1]: raised (never cleared) when a draw met NaN / inf / zero-mass probabilities (numpy.random.choice
+ *     raises there, src/rl_self_play.py:122); the game goes on from cell 0 like iago_play_turn after action 64.
+ *   max_turns: even, <= IAGO_MAX_TURNS.
+ */
+typedef struct iago_selfplay_policy_args {
+    const iago_policy_split3_args *model1, *model2;
+    uint64_t *own, *opp;
+    int64_t n;
+    uint64_t seed;
+    uint32_t id_base;
+    int32_t max_turns;
+    uint64_t *rec_own, *rec_opp;
+    int8_t *rec_act;
+    int32_t *n_turns;
+    uint32_t *bad_probs;
+} iago_selfplay_policy_args;
+IAGO_API int iago_selfplay_policy(const iago_selfplay_policy_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

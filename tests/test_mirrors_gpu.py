@@ -125,6 +125,40 @@ def test_rl_play_batch_short_games_end_where_the_reference_loop_ends(monkeypatch
     assert (a["action"] >= 0).sum().item() > 0
 
 
+@pytest.mark.parametrize("short", [False, True])
+def test_rl_play_batch_one_launch_equals_the_turn_loop(short, monkeypatch):
+    """iago_selfplay_policy (whole policy-vs-policy games in one launch, a workgroup per game) plays the games of the
+    launch-per-turn loop (iago_policy_forward_split3, iago_sample_moves, iago_play_turn), record for record -- normal
+    games with the handicap stones of src/train_rl.py:43-46, and boards nearly full from the start (games of a few
+    turns, some over at once: the rows after a game's end, the batch's end)."""
+    from iago_amd import network, ops, rl_self_play
+    torch.manual_seed(5)
+    m1, m2 = network.SLPolicy().cuda().eval(), network.SLPolicy().cuda().eval()
+    rs = np.random.RandomState(3)
+    B = 37
+    if short:
+        start = 0x0000001818000000
+        hc = np.zeros(B, np.uint64)
+        for g in range(B):
+            empty = rs.choice([c for c in range(64) if not (start >> c) & 1], size=1 + g % 9, replace=False)
+            full = (~np.uint64(0)) & ~np.uint64(start)
+            for c in empty:
+                full &= ~(np.uint64(1) << np.uint64(c))
+            hc[g] = full
+    else:
+        cells = [None, (2, 4), (3, 5), (4, 2), (5, 3)]
+        hc = np.array([0 if g % 5 == 0 else 1 << (cells[g % 5][0] * 8 + cells[g % 5][1]) for g in range(B)], np.uint64)
+    res = []
+    for one in (True, False):
+        monkeypatch.setattr(rl_self_play, "ONE_LAUNCH", one)
+        res.append(rl_self_play.play_batch(m1, m2, B, handicap=ops.bits_to_tensor(hc), seed=11, game_id_base=500))
+    a, b = res
+    assert a["n_turns"] == b["n_turns"] and (b["n_turns"] < 40 if short else b["n_turns"] >= 56)
+    for k in ("own", "opp", "action", "z", "final_p1", "final_p2"):
+        assert torch.equal(a[k], b[k]), k
+    assert (a["action"] >= 0).sum().item() > (0 if short else B * 25)
+
+
 def test_rl_play_batch_matches_oracle_games():
     """Batched lockstep games with Philox sampling == the oracle's rl_game driven
     by the same uniforms, game by game."""
