@@ -188,7 +188,8 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
            "engine": ("persistent search: ONE launch per batch of whole self-play games, game workgroups (%d games each: descent, "
                       "rollout, backup, moves; leading games paced) + %d net workgroups serving two rings of positions with "
                       "one-board / two-board walks of the value net and one-board walks of the policy net (at the expansion, "
-                      "as the reference)" % (m.games_per_workgroup, m.net_workgroups) if m.persistent else
+                      "as the reference; while net workgroups idle, the values of an expanding node's children ahead of "
+                      "their first visit: value_ahead)" % (m.games_per_workgroup, m.net_workgroups) if m.persistent else
                       "per-playout launches (descent, leaf evaluation, backup) replayed as hipGraphs, policy look-ahead "
                       "batches on a second stream"),
            "value_cache": bool(m.value_cache), "policy_lookahead": int(m.lookahead),

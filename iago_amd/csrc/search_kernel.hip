@@ -66,6 +66,8 @@ enum { ST_READY = 0, ST_WAIT_PRIOR, ST_PRIOR_READY, ST_ROLL, ST_ROLL_FRESH, ST_W
 constexpr int CTL_NO_CHILDREN = 4; // a searched root had no children (n_sims below n_thr)
 // pacing (below): sum over the games in play of their progress (turn x n_sims + playouts of the turn), games in play
 constexpr int CTL_PROGRESS = 5, CTL_PLAYING = 6;
+constexpr int CTL_IDLE = 14;              // net workgroups that found nothing to do at their last look (they poll)
+constexpr uint32_t NOBODY = 0x7FFFFFFFu;  // "game" of a request nobody waits for (its value goes to the position table only)
 constexpr uint32_t KIND_VALUE = 0u, KIND_POLICY = 1u;
 // games of a GAME workgroup: 8 lanes per game in the descent and the backup (16 games = two waves, 32 = all four),
 // rollouts in passes of 16 boards (the 16-lanes-per-board body)
@@ -123,6 +125,11 @@ struct SearchParams {
     // time against requests sent: correlation 0.84-0.90, ends spread over +-20 % at 400 playouts per move; LABNOTES.md);
     // what the leaders do not ask for, the laggards get.  Timing only: a game's own sequence of playouts is untouched
     int32_t pace_margin, pace_backlog;
+    // values ahead of their first visit, on idle hands only: when a game asks for the priors of a node that expands while
+    // at least `ahead_idle` net workgroups poll and nothing waits in the rings, the node's children (each of them a leaf
+    // without a value at ITS first visit: the first in this very playout, the others a few playouts from now) are walked
+    // through the value net beside the policy walk and put into the position table (< 0: off; needs the table)
+    int32_t ahead_idle;
 };
 
 __device__ __forceinline__ u64 ld(const u64 *p) { return __hip_atomic_load(p, RLX_AGENT); }
@@ -141,7 +148,7 @@ __device__ __forceinline__ void send_request(const SearchParams &S, uint32_t kin
     st(e + 4, tag | (uint32_t)opp);
     st(e + 5, tag | (uint32_t)(opp >> 32));
     st(e + 0, tag | (kind << 31) | (uint32_t)g);
-    atomicAdd((unsigned long long *)&S.totals[kind], 1ull);
+    atomicAdd((unsigned long long *)&S.totals[(uint32_t)g == NOBODY ? 11 : kind], 1ull);
 }
 
 __device__ __forceinline__ uint32_t vtable_slot(const SearchParams &S, uint64_t own, uint64_t opp)
@@ -609,6 +616,25 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                     if (r == 0u)
                         send_request(S, KIND_POLICY, g, epoch, own, opp);
                     state = ST_WAIT_PRIOR;
+                    // The node WILL expand when its priors are back, and its children are leaves without a value at their
+                    // first visits -- the first of them in this very playout.  While net workgroups have nothing to do they
+                    // walk the children's positions beside the policy walk, for the position table (nobody waits for these)
+                    if (pace[3] != 0 && need_v) {
+                        uint64_t rest = group8_legal(to_lane(own, L), to_lane(opp, L), L);
+                        while (rest) {
+                            const uint32_t a2 = (uint32_t)__builtin_ctzll(rest);
+                            rest &= rest - 1ull;
+                            const uint64_t f2 = group8_flips(to_lane(own, L), to_lane(opp, L), a2, L);
+                            const uint64_t bit2 = 1ull << a2;
+                            const uint64_t c_own = opp & ~f2 & ~bit2, c_opp = own | f2 | bit2; // the child: the other side moves
+                            uint32_t known = 0u;
+                            if (r == 0u &&
+                                (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(KIND_VALUE)], RLX_AGENT) -
+                                          __hip_atomic_load(&S.ctl[ctl_head(KIND_VALUE)], RLX_AGENT)) < (int32_t)(QCAP / 2u) &&
+                                !vtable_get(S, c_own, c_opp, known))
+                                send_request(S, KIND_VALUE, (int64_t)NOBODY, 0u, c_own, c_opp);
+                        }
+                    }
                 } else {
                     if (descending && fc >= 0 && r == 0u)
                         T.overflow[g] = 1; // path longer than MAX_DEPTH: reported like a full pool
@@ -717,6 +743,12 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             pace[0] = 0;
             pace[1] = 0;
             int limit = 0x7fffffff;
+            pace[3] = 0;
+            if (S.ahead_idle >= 0 && S.vtable_mask &&
+                __hip_atomic_load(&S.ctl[CTL_IDLE], RLX_AGENT) >= (uint32_t)S.ahead_idle &&
+                (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT)) <= 0 &&
+                (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(1)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(1)], RLX_AGENT)) <= 0)
+                pace[3] = 1;
             if (S.pace_margin >= 0) {
                 const int32_t waiting =
                     (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT)) +
@@ -825,6 +857,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const long long c0 = wall_clock64();
         if (tid < 64) {
             int status = 2, count = 0;
+            bool polling = false;
             // an entry waiting in the home ring, else in the other one; nothing anywhere: poll the counters (no
             // ticket is taken for an entry that is not there, so nobody is committed to a ring that stays empty)
             for (;;) {
@@ -866,8 +899,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                           __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u || wall_clock64() - t0 > S.clock_limit;
                 if (__builtin_amdgcn_ballot_w64(out) != 0ull)
                     break; // status 2: every game workgroup is done (no request can come any more), or given up
+                if (!polling) {
+                    polling = true; // (counted while it polls: values ahead of their visit go to idle hands only)
+                    if (tid == 0)
+                        __hip_atomic_fetch_add(&S.ctl[CTL_IDLE], 1u, RLX_AGENT);
+                }
                 __builtin_amdgcn_s_sleep(16);
             }
+            if (polling && tid == 0)
+                __hip_atomic_fetch_add(&S.ctl[CTL_IDLE], 0xFFFFFFFFu, RLX_AGENT);
             if (tid == 0) {
                 job[28] = (uint32_t)status;
                 job[29] = (uint32_t)count;
@@ -900,7 +940,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __syncthreads();
             if (tid < count) {
                 const uint32_t bits = __float_as_uint(VP.out[row0 + tid]);
-                st(&S.rep_v[(int64_t)(job[6 * tid] & 0x7FFFFFFFu)], ((u64)job[6 * tid + 1] << 32) | bits);
+                if ((job[6 * tid] & 0x7FFFFFFFu) != NOBODY)
+                    st(&S.rep_v[(int64_t)(job[6 * tid] & 0x7FFFFFFFu)], ((u64)job[6 * tid + 1] << 32) | bits);
                 if (S.vtable_mask)
                     vtable_put(S, ((uint64_t)job[6 * tid + 3] << 32) | job[6 * tid + 2],
                                ((uint64_t)job[6 * tid + 5] << 32) | job[6 * tid + 4], bits);
@@ -1022,6 +1063,9 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
     const int pace_margin = a->pace_margin == 0 ? 16 : (a->pace_margin < 0 ? -1 : a->pace_margin);
     S.pace_margin = pace_margin;
     S.pace_backlog = pace_backlog;
+    // (tuning knob: net workgroups that must poll for values to be walked ahead of their visit; -1 = never)
+    const char *ahead_env = getenv("IAGO_PERSISTENT_AHEAD"); // (read per launch: the tests vary it)
+    S.ahead_idle = ahead_env ? atoi(ahead_env) : 4;
     S.max_turns = a->max_turns;
     S.game_own = a->game_own;
     S.game_opp = a->game_opp;

@@ -486,7 +486,11 @@ class BatchedMCTS(object):
 
     @property
     def n_value_ahead(self):
-        """Rows the value look-ahead's batches have evaluated (hits, duplicates and never-visited)."""
+        """Evaluations off the critical path: rows the value look-ahead's batches have evaluated (hits, duplicates and
+        never-visited); with the persistent search the positions idle net workgroups walked for the position table
+        ahead of their first visit (the children of expanding nodes)."""
+        if self.persistent:
+            return int(self._ps["totals"][11].item())
         return int(self._va_total.item()) if self.value_ahead else 0
 
     @n_policy_evals.setter

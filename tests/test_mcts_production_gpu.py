@@ -131,7 +131,7 @@ def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_si
     assert int(m.tree.n_nodes[5].item()) == 1 and int(m.tree.n_visits[5 * cap].item()) == 0
     # the value net ran on a fraction of the leaves only (the cache), the policy a few visits ahead
     assert 0 < m.n_value_evals < 0.6 * m.n_leaf_evals and m.n_policy_evals > 0
-    assert (m.n_value_ahead > 0) == value_ahead
+    assert persistent or (m.n_value_ahead > 0) == value_ahead   # (the persistent search walks values ahead on idle hands)
 
     probe = NetProbe(ops, policy, value)
     checked = [g for g in list(range(0, 12)) + list(range(G // 2 - 2, G // 2 + 6)) if g != 5]

@@ -83,7 +83,7 @@ def test_trees_equal_the_per_playout_engine(nets, G, n_sims, n_sims2, net):
     # once per expansion with more than one legal move: never more than the look-ahead's batches evaluated
     # (fewer where the position table answered: positions another game had asked for)
     hits = int(a._ps["totals"][8].item())
-    assert a.n_value_evals + hits == b.n_value_evals and a.n_value_evals > 0
+    assert a.n_value_inline + hits == b.n_value_evals and a.n_value_evals > 0   # (every fresh leaf: asked for, or in the table)
     assert 0 < a.n_policy_evals <= b.n_policy_evals
     for g in idle:
         assert ta["n_nodes"][g] == 1 and ta["z_log_n"][g] == 0
@@ -109,6 +109,27 @@ def test_other_search_parameters(nets, lmbda, c_puct, n_thr, G, n_sims, n_sims2)
     assert a.n_leaf_evals == b.n_leaf_evals == G * (n_sims + n_sims2)
 
 
+def test_values_ahead_on_idle_net_workgroups(nets, monkeypatch):
+    """While net workgroups poll and nothing waits, the children of a node whose priors a game asks for are walked
+    through the value net for the position table, ahead of their first visits (MCTS.value_func is a pure function of the
+    position, MCTS.py:97-103).  Timing only: the same trees and stored values; and it does take evaluations off the
+    games' critical path (here: 48 games against 256 CUs, the net workgroups poll most of the time)."""
+    G, n_sims, n_sims2 = 48, 120, 40
+    own, opp = _positions(G)
+    monkeypatch.setenv("IAGO_PERSISTENT_AHEAD", "-1")
+    a, ta = _run(nets, G, n_sims, n_sims2, own, opp, persistent=True)
+    monkeypatch.setenv("IAGO_PERSISTENT_AHEAD", "1")
+    b, tb = _run(nets, G, n_sims, n_sims2, own, opp, persistent=True)
+    for k in ("n_visits", "q", "p", "first_child", "parent", "action", "n_children", "n_nodes", "root", "leaf_value", "z_log"):
+        assert np.array_equal(ta[k], tb[k]), k
+    assert np.array_equal(np.isnan(ta["v"]), np.isnan(tb["v"]))
+    assert np.array_equal(ta["v"][~np.isnan(ta["v"])], tb["v"][~np.isnan(tb["v"])])
+    assert a.n_value_ahead == 0 and b.n_value_ahead > 0
+    assert b.n_value_inline < 0.5 * a.n_value_inline          # most first visits find their value in the table
+    hits_a, hits_b = int(a._ps["totals"][8].item()), int(b._ps["totals"][8].item())
+    assert a.n_value_inline + hits_a == b.n_value_inline + hits_b   # the same fresh leaves either way
+
+
 def test_n_thr_one(nets):
     """n_thr = 1 (SURVEY 8d's second datapoint): every leaf expands at its second visit -- the policy net
     inside every playout."""
@@ -121,7 +142,7 @@ def test_n_thr_one(nets):
         assert np.array_equal(ta[k], tb[k]), k
     assert np.all(ta["z_log_n"] == n_sims)
     # (the per-playout engine counts every expanding leaf, this one the leaves with more than one legal move)
-    assert 0 < a.n_policy_evals <= b.n_policy_evals and a.n_value_evals + int(a._ps["totals"][8].item()) == b.n_value_evals
+    assert 0 < a.n_policy_evals <= b.n_policy_evals and a.n_value_inline + int(a._ps["totals"][8].item()) == b.n_value_evals
 
 
 @pytest.mark.parametrize("games", ["1", "0"])
