@@ -383,7 +383,7 @@ class BatchedMCTS(object):
         if self.persistent:
             n_gw = -(-n_games // self.games_per_workgroup)
             if net_workgroups is None:
-                net_workgroups = int(os.environ.get("IAGO_PERSISTENT_NET", "0")) or max(1, min(256 - n_gw, 8 * n_games))
+                net_workgroups = int(os.environ.get("IAGO_PERSISTENT_NET", "0")) or max(1, min(256 - n_gw, max(32, 8 * n_games)))
             self.net_workgroups = max(1, int(net_workgroups))
             grid = n_gw + self.net_workgroups
             self.PATH_STRIDE = 520
