@@ -30,7 +30,10 @@
 // more than `pace_margin` playouts ahead of the batch's mean progress holds while requests queue up (a
 // batch ends with its slowest game, and a game is slow when it asks the nets a lot: what the leaders do
 // not ask for, the laggards get); a level at which every descending game of the wave has ONE child, a
-// pass (the chains the reference grows under a finished game), is followed without scoring.
+// pass (the chains the reference grows under a finished game), is followed without scoring.  And idle net
+// workgroups are put to use: when a game asks for the priors of a node that is about to expand while net
+// workgroups poll and nothing waits in the rings, the node's children are walked through the value net for
+// the position table -- requests nobody waits for; the children's first visits find their values there.
 // A game's sequence of playouts -- leaves, values, priors, rollouts, backups, expansions, moves -- is
 // exactly the reference's; only the interleaving between games changes: trees, moves and results are
 // bit-identical to the per-playout engine's (tests/test_search_persistent_gpu.py; the comparisons with
