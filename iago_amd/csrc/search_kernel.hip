@@ -622,7 +622,7 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                     // The node WILL expand when its priors are back, and its children are leaves without a value at their
                     // first visits -- the first of them in this very playout.  While net workgroups have nothing to do they
                     // walk the children's positions beside the policy walk, for the position table (nobody waits for these)
-                    if (pace[3] != 0 && need_v) {
+                    if (pace[3] > 0 && need_v) {
                         uint64_t rest = group8_legal(to_lane(own, L), to_lane(opp, L), L);
                         while (rest) {
                             const uint32_t a2 = (uint32_t)__builtin_ctzll(rest);
@@ -631,10 +631,10 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                             const uint64_t bit2 = 1ull << a2;
                             const uint64_t c_own = opp & ~f2 & ~bit2, c_opp = own | f2 | bit2; // the child: the other side moves
                             uint32_t known = 0u;
-                            if (r == 0u &&
-                                (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(KIND_VALUE)], RLX_AGENT) -
-                                          __hip_atomic_load(&S.ctl[ctl_head(KIND_VALUE)], RLX_AGENT)) < (int32_t)(QCAP / 2u) &&
-                                !vtable_get(S, c_own, c_opp, known))
+                            // (the ring holds QCAP entries: at most one per game that waits -- <= QCAP / 2 games when this
+                            // is on -- and at most QCAP / 2 of these, handed out as a budget per workgroup and iteration
+                            // while the ring was empty: pace[3])
+                            if (r == 0u && !vtable_get(S, c_own, c_opp, known) && atomicSub(&pace[3], 1) > 0)
                                 send_request(S, KIND_VALUE, (int64_t)NOBODY, 0u, c_own, c_opp);
                         }
                     }
@@ -747,11 +747,11 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             pace[1] = 0;
             int limit = 0x7fffffff;
             pace[3] = 0;
-            if (S.ahead_idle >= 0 && S.vtable_mask &&
+            if (S.ahead_idle >= 0 && S.vtable_mask && T.n_games <= (int64_t)(QCAP / 2u) &&
                 __hip_atomic_load(&S.ctl[CTL_IDLE], RLX_AGENT) >= (uint32_t)S.ahead_idle &&
                 (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT)) <= 0 &&
                 (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(1)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(1)], RLX_AGENT)) <= 0)
-                pace[3] = 1;
+                pace[3] = (int32_t)(QCAP / 2u) / S.n_game_wgs; // this iteration's share of the ring for requests nobody waits for
             if (S.pace_margin >= 0) {
                 const int32_t waiting =
                     (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT)) +
