@@ -130,6 +130,23 @@ def test_values_ahead_on_idle_net_workgroups(nets, monkeypatch):
     assert a.n_value_inline + hits_a == b.n_value_inline + hits_b   # the same fresh leaves either way
 
 
+def test_values_ahead_stay_within_the_ring(nets):
+    """The requests nobody waits for share the value ring with the games' own (at most one per waiting game): they are
+    limited to half the ring per iteration, and batches of more than half the ring's games send none."""
+    engine, ops, policy, value, rw = nets
+    from iago_amd import _lib
+    res = {}
+    for G in (_lib.SEARCH_QUEUE_ENTRIES // 2, _lib.SEARCH_QUEUE_ENTRIES // 2 + 32):
+        own, opp = _positions(G)
+        m = engine.BatchedMCTS(G, policy, value, rw, n_thr=15, capacity=engine.suggest_capacity(20, 15, moves=2), seed=4,
+                               persistent=True)
+        m.search(ops.bits_to_tensor(own), ops.bits_to_tensor(opp), torch.ones(G, dtype=torch.uint8, device="cuda"), 20)
+        res[G] = m.n_value_ahead
+        assert m.n_leaf_evals == 20 * G
+        m.close()
+    assert res[_lib.SEARCH_QUEUE_ENTRIES // 2] > 0 and res[_lib.SEARCH_QUEUE_ENTRIES // 2 + 32] == 0
+
+
 def test_n_thr_one(nets):
     """n_thr = 1 (SURVEY 8d's second datapoint): every leaf expands at its second visit -- the policy net
     inside every playout."""
