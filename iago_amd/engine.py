@@ -228,11 +228,12 @@ class BatchedMCTS(object):
         # (tuning knobs: pacing of the leading games -- playouts a game may be ahead of the mean while requests queue,
         # 0 = the library's default, < 0 = off; 8 / 16 / 32 games per game workgroup)
         self.pace_margin = int(os.environ.get("IAGO_PERSISTENT_PACE", "0"))
-        # (games per game workgroup: about 32 game workgroups measure best at every batch size -- 512 games 11.7 M leaf-evals/s
-        # at 16 per workgroup against 9.7 M at 32, 256 games 6.6 M at 8 against 5.1 M at 32, 1024 games 15.5 M at 32 against
-        # 14.4 M at 16: a workgroup's iteration is as long as its rollout passes of 16 boards)
+        # (games per game workgroup: 32 to 60 game workgroups measure best at every batch size -- 256 games 6.6 M leaf-evals/s
+        # at 8 per workgroup against 5.1 M at 32; 512 / 640 / 768 / 896 games 11.7 / 13.1 / 14.3 / 14.5 M at 16 against 9.7 /
+        # 11.2 / 12.8 / 14.0 M at 32; 1024 games 15.5 M at 32 against 14.4 M at 16: a workgroup's iteration is as long as its
+        # rollout passes of 16 boards, and every game workgroup is a net workgroup less)
         self.games_per_workgroup = int(os.environ.get("IAGO_PERSISTENT_GPW", "0")) or (
-            8 if n_games <= 256 else 16 if n_games <= 512 else _lib.SEARCH_GAMES_PER_WORKGROUP)
+            8 if n_games <= 256 else 16 if n_games <= 960 else _lib.SEARCH_GAMES_PER_WORKGROUP)
         can_p = (n_games <= 128 * self.games_per_workgroup
                  and can_cache and getattr(value_fn, "search_args", None) is not None
                  and getattr(policy_fn, "search_args", None) is not None and getattr(policy_fn, "split3", False)
