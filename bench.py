@@ -4,36 +4,34 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): per GPU, 4096 parallel Othello boards from
-the standard start position are played to the end by the fused HIP rollout
-kernel (16 lanes per board) with the reference's shipped RolloutPolicy weights (82 floats, kept as
-golden data in tests/golden/simulate.json) -- rollout-policy-only self-play.
-One step = ONE launch of 4096 boards = 4096 finished games per GPU; the launches
-of a run are serialized on one stream, so 4096 boards are in flight at any time,
-as the config says.  A round is K = --steps steps; the timed region repeats the
-round R times so that it lasts >= 150 ms whatever K is (R is printed as
-`repeats`; ms_per_step = region / (K R)), which makes `value` independent of
---steps.  With N > 1 every rank plays its own boards (weak scaling, Philox
-streams keyed by a global game id (launch * N + rank) * 4096 + board) and the
-finished (final boards, z, turns) tuples of every round are all-gathered over
-RCCL inside the timed region, on a side stream beside the next round.
+Headline workload (BASELINE.json configs[2], the configuration the north star's metric is quoted on): per
+GPU, 1024 PV-MCTS self-play games of 8x8 Othello, 100 playouts per move, both colours searching, SLPolicy +
+Value nets with random-init weights (Chainer-default LeCunNormal, seed 0), the reference's constants
+lmbda = 0.5, c_puct = 1, n_thr = 15, played from the start position to the end.  ONE STEP = one batch of
+1024 whole games per GPU = ONE launch of the persistent search kernel (csrc/search_kernel.hip) + with N > 1 the
+all-gather of the batch's (s, pi, z) tuples over RCCL.  W untimed warm-up steps of the same kind, then EXACTLY K
+timed steps between barrier + torch.cuda.synchronize() on both sides; the maximum over the ranks; every step
+plays new games and starts from an EMPTY position table (nothing computed outside a step answers a request
+inside it).  `value` = whole-job self-play games/s = N x 1024 x K / timed region; `leaf_evals_per_sec` = playouts/s
+beside it (the metric's second half); `ms_per_step` = timed region / K; `step_ms_min / median / max` = the K
+steps one by one.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the rollout kernel against the
-HBM roof with SURVEY.md section 8(d)'s algorithmic bytes (33 B per board-step):
-bytes of one launch / the launch's duration, measured with HIP event pairs on the
-launch stream around a sample of the timed launches (single tenant: equals the
-rocprofv3 average of tools/profile_rollout.sh, committed under profiles/).
-`cpu_baseline` times the CPU oracle (oracle/, a C port of the reference's Python
-loops) on the host cores over a bounded sample of the same workload, with the
-Python-loop restatement on one core beside it.
-Extra objects, none of them `value`: `overlapped` (the same 4096-board launches
-on 32 HIP streams), `large_batch` (one launch of 1M boards, lane-per-board
-kernel), `mcts` (BASELINE configs[2]: PV-MCTS 100 sims/move, 1024 games, played
-to the end: leaf-evals/s = playouts/s and games/s, with its own 1-core CPU
-baseline; `value_evals` / `policy_evals` = rows the nets really processed -- the
-value of a leaf is computed at its first visit only and the policy runs a few
-visits ahead of the expansion), `reinforce`,
-`mcts_single_game`.
+`roofline` prices the dominant kernel, search_kernel, against the dense f16 MFMA peak (2.5 PFLOP/s,
+MI355X_MICROARCH.md): `achieved` = SURVEY.md 8(d)'s algorithmic FLOPs (122.99 MFLOP per Value evaluation, 122.85
+per SLPolicy evaluation) x the evaluations a launch executed / the launch's duration, measured with HIP event pairs
+on the launch stream around every timed launch; `executed_*` = the f16 MFMA FLOPs issued for them (3 MFMAs per
+product of the Value net, 6 of SLPolicy: float32-grade results on f16 units); `traffic`, `rocprof_kernel_avg_ms`
+and `executed_frac_pmc` come from the committed rocprofv3 profile of this command (tools/profile_mcts.sh ->
+profiles/), quoted only when it was taken on these kernel sources.  `cpu_baseline` times the oracle's restatement
+of MCTS.py (oracle/mcts_py.py, torch-CPU B = 1 nets, C rollout) on the host: P single-threaded processes, and one
+core beside it.
+
+Nested, none of them `value`: `rollout` (BASELINE configs[1], the headline of rounds 1-4: 4096 boards per launch
+played to the end by the fused rollout kernel, with its own HBM / VALU roofline and CPU baselines;
+--rollout-only prints it as the line's headline), `mcts.per_playout_launches` (the same games on the per-playout
+engine), `mcts400` / `mcts_nthr1` (one batch of whole games at 400 playouts per move -- one GPU's share of
+configs[3] -- / with n_thr = 1) and their `*_opening` samples, `reinforce` (configs[4] in miniature, with the
+CPU side beside it), `configs0` (one SL-vs-SL game on the CPU restatement), `mcts_single_game`.
 """
 import argparse
 import ctypes
@@ -110,16 +108,18 @@ def cpu_baseline(w, b, budget_s=10.0):
 
 
 def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=False, use_graph=True, n_thr=15,
-             persistent=None):
-    """BASELINE configs[2]: PV-MCTS self-play, `n_games` lockstep games per GPU,
-    `n_sims` playouts per move, SLPolicy + Value with random-init weights
-    (Chainer-default LeCunNormal, seed 0), reference constants lmbda=0.5,
-    c_puct=1, n_thr=15, both colours search.  One leaf-eval = one playout
-    (value net + rollout at the leaf; the policy net runs on expansions).  The fixed
-    tail of a playout and the next descent replay as one hipGraph launch.
-    By default the games are played to the end (games/s); --mcts-turns N > 0
-    times a bounded sample of the first N turns instead."""
+             persistent=None, steps=1, warmup_steps=0, fresh_table=True):
+    """BASELINE configs[2]: PV-MCTS self-play, `n_games` games per GPU, `n_sims` playouts per move, SLPolicy +
+    Value with random-init weights (Chainer-default LeCunNormal, seed 0), reference constants lmbda=0.5,
+    c_puct=1, n_thr=15, both colours search.  One leaf-eval = one playout (value net + rollout at the leaf; the
+    policy net runs on expansions).  ONE STEP = one batch of `n_games` whole self-play games per GPU (with the
+    persistent search: ONE launch) + with N > 1 the all-gather of its (s, pi, z) tuples; `warmup_steps` untimed
+    steps, then exactly `steps` timed ones between barrier + synchronize on both sides.  Every step plays NEW
+    games (the rollouts' Philox streams go on from the previous step's) and -- fresh_table -- starts from an
+    EMPTY position table: nothing computed outside a step (warm-up, earlier steps) answers a request inside
+    it.  --mcts-turns N > 0 times a bounded sample of the first N turns instead of whole games."""
     from iago_amd import engine, network, ops
+    from iago_amd.dist import all_gather_into, gather_tuples
     w, b = shipped_rollout_weights()
     torch.manual_seed(0)
     policy = network.SLPolicy().cuda().eval()
@@ -127,7 +127,7 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     value.split_f16 = not value_f32
     # the engine: the persistent search (one launch per whole game, every game on its own clock) wherever it
     # applies -- the split-f16 value net -- else per-playout launches replayed as hipGraphs (persistent=False: the
-    # comparison figure `mcts_per_playout_launches`)
+    # comparison figure `per_playout_launches`)
     if persistent is None:
         persistent = not value_f32 and use_graph
     m = engine.BatchedMCTS(n_games, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0,
@@ -137,48 +137,109 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
     eng = engine.SelfPlayEngine(m, max_turns=(128 if full_games else n_turns))
     m.enable_stats()
     m.warmup()                 # MIOpen kernel selection for every batch bucket
-    warm = engine.SelfPlayEngine(m, max_turns=4).play(16, record=True)  # allocator, code objects
-    if dist is not None and full_games:
-        from iago_amd.dist import gather_tuples
-        gather_tuples(warm.tuples())   # (RCCL sets up a collective of a new size class on its first use)
+    gather = dist is not None and full_games
+    if warmup_steps <= 0:
+        warm = engine.SelfPlayEngine(m, max_turns=4).play(16, record=True)  # allocator, code objects
+        if gather:
+            gather_tuples(warm.tuples())   # (RCCL sets up a collective of a new size class on its first use)
+    for _ in range(max(warmup_steps, 0)):      # untimed warm-up STEPS: whole batches like the timed ones
+        warm = eng.play(n_sims, record=True)
+        if gather:
+            gather_tuples(warm.tuples())
     m.n_leaf_evals = m.n_policy_evals = 0
     m._value_total.zero_()
-    if getattr(m, "persistent", False):
+    is_p = bool(getattr(m, "persistent", False))
+    if is_p:
         m._ps["totals"].zero_()
+        m.launch_events = []
     m.stats.zero_()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = eng.play(n_sims, record=True)
-    gathered = None
-    t_play = None
-    if dist is not None and full_games:
-        from iago_amd.dist import gather_tuples
-        torch.cuda.synchronize()
-        t_play = time.perf_counter() - t0
-        gathered = gather_tuples(res.tuples())
+    step_s, play_s, gather_s = [], [], []
+    res = gathered = None
+    n_tuples = 0
+    for _ in range(steps):
+        ts = time.perf_counter()
+        if is_p and fresh_table and m._vtable is not None:
+            m._vtable.zero_()   # (32 MB memset on the launch's stream, inside the timed region)
+        res = eng.play(n_sims, record=True)    # (ends with the read-back of the launch's flags: the games are done)
+        tp = time.perf_counter()
+        if gather:
+            gathered = gather_tuples(res.tuples())
+            n_tuples = int(gathered["z"].numel())
+            torch.cuda.synchronize()
+        te = time.perf_counter()
+        step_s.append(te - ts)
+        play_s.append(tp - ts)
+        gather_s.append(te - tp)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in m.launch_events] if is_p else []
+    if is_p:
+        m.launch_events = None
     stats = torch.tensor([dt, m.n_leaf_evals, m.n_policy_evals, m.n_value_evals], dtype=torch.float64,
                          device="cuda")
+    diag = None
     if dist is not None:
         tm = stats[:1].clone()
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats)
         stats[0] = tm[0]
+        # the N > 1 run says what it did (the driver's 8-rank run cannot be debugged): the ranks the process group
+        # really has, every rank's time inside its own games, the time of the gathers, and whether the ranks
+        # played different games (a checksum of every rank's recorded moves and final boards)
+        mv = res.move.to(torch.int64).reshape(-1)
+        chk = ((mv + 2) * (torch.arange(mv.numel(), device=mv.device, dtype=torch.int64) % 1000003 + 1)).sum() \
+            + (res.final_p1 ^ (res.final_p2 * 31)).sum()
+        mine = torch.stack([chk.to(torch.int64).reshape(()),
+                            torch.tensor(int(sum(play_s) * 1e6), dtype=torch.int64, device="cuda"),
+                            torch.tensor(int(sum(gather_s) * 1e6), dtype=torch.int64, device="cuda"),
+                            torch.tensor(int(rank), dtype=torch.int64, device="cuda")])
+        every = torch.empty(world * 4, dtype=torch.int64, device="cuda")
+        all_gather_into(every, mine)
+        every = every.reshape(world, 4).cpu()
+        sums, plays, gathers, ranks = (every[:, i].tolist() for i in range(4))
+        plays, gathers = [x * 1e-6 for x in plays], [x * 1e-6 for x in gathers]
+        diag = {"ranks_seen": int(dist.get_world_size()), "ranks_reporting": sorted(int(r) for r in ranks),
+                "rank_play_seconds_min": min(plays), "rank_play_seconds_max": max(plays),
+                "gather_ms_per_step_max": max(gathers) / max(steps, 1) * 1e3,
+                "ranks_played_different_games": len(set(sums)) == world,
+                "backend": dist.get_backend()}
     dt, leaf, pol, val = (float(x) for x in stats.tolist())
+    totals = [int(x) for x in m._ps["totals"].tolist()] if is_p else None
     # Value / SLPolicy FLOPs per evaluation, for the evaluations EXECUTED (with the
     # value cache the net runs on a leaf's first visit only; the policy look-ahead also evaluates
     # leaves that never expand)
-    flops = val * 122_994_944 + pol * 122_847_232
+    flops = val * VALUE_FLOP + pol * POLICY_FLOP
+    ss = sorted(step_s)
     out = {"leaf_evals_per_sec": leaf / dt, "leaf_evals": int(leaf), "policy_evals": int(pol),
            "value_evals": int(val), "value_inline": int(m.n_value_inline), "value_ahead": int(m.n_value_ahead),
+           "steps": steps, "warmup_steps": max(warmup_steps, 0),
+           "step_seconds": step_s, "step_ms_min": ss[0] * 1e3, "step_ms_median": ss[len(ss) // 2] * 1e3,
+           "step_ms_max": ss[-1] * 1e3,
            "async_steps": int(m.n_steps) if m.async_steps else None,
-           "persistent": ({"net_workgroups": m.net_workgroups, "totals": [int(x) for x in m._ps["totals"].tolist()]}
-                          if getattr(m, "persistent", False) else None),
+           "persistent": ({"net_workgroups": getattr(m, "net_workgroups_launched", m.net_workgroups),
+                           "game_workgroups": -(-n_games // m.games_per_workgroup),
+                           "resident_workgroups_of_the_device": m.resident_workgroups,
+                           "totals": totals,
+                           "totals_legend": "[0] value evaluations on a game's critical path, [1] policy evaluations, [2] "
+                                            "game-workgroup iterations, [3] pair walks, [4] / [5] net workgroups' waiting / "
+                                            "walking time (100 MHz ticks, summed), [6] idle game-workgroup iterations, [7] game "
+                                            "workgroups' run time, [8] position-table hits, [11] values walked ahead of "
+                                            "their first visit, [12] hits on a value the asking game itself put there",
+                           "position_table": {"fresh_per_step": bool(fresh_table), "hits": totals[8],
+                                              "hits_same_game": totals[12], "hits_cross_game": totals[8] - totals[12],
+                                              "note": "cross-game hits exist because all games of a batch start from "
+                                                      "ONE position with ONE net: value_func (MCTS.py:97-103) is a pure "
+                                                      "function of the position"},
+                           "kernel_ms": kernel_ms}
+                          if is_p else None),
            "leaf_eval_definition": "one leaf-eval = one playout (MCTS.py:105-133) ending in the leaf "
                                    "evaluation of MCTS.py:123-127: value_func(leaf) + rollout + backup; "
                                    "value_func is a pure function of the position, computed at a leaf's "
@@ -189,12 +250,14 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
                       "rollout, backup, moves; leading games paced) + %d net workgroups serving two rings of positions with "
                       "one-board / two-board walks of the value net and one-board walks of the policy net (at the expansion, "
                       "as the reference; while net workgroups idle, the values of an expanding node's children ahead of "
-                      "their first visit: value_ahead)" % (m.games_per_workgroup, m.net_workgroups) if m.persistent else
+                      "their first visit: value_ahead)" % (m.games_per_workgroup, getattr(m, "net_workgroups_launched", m.net_workgroups))
+                      if m.persistent else
                       "per-playout launches (descent, leaf evaluation, backup) replayed as hipGraphs, policy look-ahead "
                       "batches on a second stream"),
            "value_cache": bool(m.value_cache), "policy_lookahead": int(m.lookahead),
            "seconds": dt, "turns_played": res.n_turns, "sims_per_move": n_sims,
            "games_per_gpu": n_games, "full_games": bool(full_games),
+           "batches_replayed_turn_by_turn": int(getattr(eng, "n_replayed", 0)),
            "net_tflops_fp32": flops / dt / 1e12,   # float32-equivalent FLOP/s of both nets, executed evaluations
            "value_conv": ("f32 (MIOpen)" if value_f32 else
                           "split-f16 MFMA: f16 hi/lo operands, 3 MFMAs per product sum, f32 accumulation; "
@@ -211,11 +274,37 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
            "tree_pool_bytes_per_gpu": m.tree.bytes(), "tree_traffic_rank0": m.tree_bytes(),
            "tree_nodes_used_max": int(m.tree.n_nodes.max().item()),
            "tree_capacity": m.tree.capacity}
+    if diag is not None:
+        out["ranks"] = diag
     if full_games:
-        out["games_per_sec"] = world * n_games / dt
+        out["games_per_sec"] = world * n_games * steps / dt
         if gathered is not None:
-            out["gathered_tuples"] = int(gathered["z"].numel())
-            out["play_seconds_rank0"] = t_play   # the rest of `seconds`: packing + all-gather of the tuples + barrier
+            out["gathered_tuples"] = n_tuples
+            out["play_seconds_rank0"] = sum(play_s)   # the rest of `seconds`: packing + all-gather of the tuples + barrier
+    if is_p and kernel_ms:
+        # the dominant kernel of the leg, per launch, on THIS rank's GPU: HIP event pairs around the launches on
+        # their stream (the pair also spans the four small memsets that zero the rings before the kernel)
+        n_l = len(kernel_ms)
+        k_s = sum(kernel_ms) * 1e-3
+        val_r, pol_r = totals[0] + totals[11], totals[1]
+        useful = (val_r * VALUE_FLOP + pol_r * POLICY_FLOP) / k_s / 1e12
+        executed = (val_r * VALUE_MFMA_PER_BOARD + pol_r * POLICY_MFMA_PER_BOARD) * MFMA_FLOP_32x32x16 / k_s / 1e12
+        out["kernel_roofline"] = {
+            "bound": "mfma", "achieved": useful, "peak": F16_PEAK_TF, "unit": "TFLOP/s", "frac": useful / F16_PEAK_TF,
+            "kernel": "search_kernel (persistent search: one launch = one batch of whole games)",
+            "launches": n_l, "kernel_ms": k_s / n_l * 1e3, "kernel_ms_min": min(kernel_ms), "kernel_ms_max": max(kernel_ms),
+            "algorithmic_flops_per_launch": (val_r * VALUE_FLOP + pol_r * POLICY_FLOP) / n_l,
+            "units_per_launch": {"value_evaluations": val_r / n_l, "policy_evaluations": pol_r / n_l,
+                                 "leaf_evals": m.n_leaf_evals / n_l},
+            "flops_per_unit": {"value_evaluation": VALUE_FLOP, "policy_evaluation": POLICY_FLOP},
+            "executed_tflops": executed, "executed_frac": executed / F16_PEAK_TF,
+            "executed_definition": "f16 MFMA FLOPs issued: 3 MFMAs per product of the Value net, 6 per product of "
+                                   "SLPolicy (float32-grade results on f16 matrix units) x 32,768 FLOP per "
+                                   "v_mfma_f32_32x32x16_f16, counted from the evaluations this run executed",
+            "achieved_definition": "ALGORITHMIC FLOPs (SURVEY.md 8(d): 122.99 MFLOP per Value evaluation, 122.85 "
+                                   "per SLPolicy evaluation) of the evaluations executed / the launches' duration",
+            "useful_x_f32_matrix_peak": useful / F32_MATRIX_PEAK_TF,
+        }
     out["device_memory_bytes"] = m.memory_bytes()
     m.close()   # the captured graphs go now, not whenever the garbage collector finds the engine
     return out
@@ -402,30 +491,17 @@ def cpu_worker_main(kind, budget_s, start_at, seed):
         def unit():
             return 1, py_loops.simulate(s0, 1, policy, rs)[1]
     elif kind == "mcts":
-        from iago_amd import network
-        from oracle import mcts_py
-        from oracle import oracle as orc
-        torch.manual_seed(0)
-        policy_net, value_net = network.SLPolicy().eval(), network.Value().eval()
-        counter = [seed << 24]
-
-        def pol(x):
-            with torch.no_grad():
-                return policy_net(torch.from_numpy(x)).numpy().reshape(64)
-
-        def val(x):
-            with torch.no_grad():
-                return value_net(torch.from_numpy(x)).numpy().reshape(1)[0]
-
-        def roll(state, color):
-            counter[0] += 1
-            return orc.simulate(state, color, w, b, seed=3, game_id=counter[0])[0]
-
-        m = mcts_py.MCTS(pol, val, roll, lmbda=0.5, c_puct=1, n_thr=15)
+        m = _cpu_mcts(w, b, seed)
 
         def unit():   # 20 playouts of the worker's own game tree from the start position
+            from oracle import oracle as orc
             m.get_move(orc.initial_state(), 1, 20)
             return 20, 0
+    elif kind == "sl_game":
+        play = _cpu_sl_game(seed)
+
+        def unit():   # one SLPolicy-vs-SLPolicy game (src/rl_self_play.py:27-31)
+            return 1, play()
     else:
         raise SystemExit("unknown --cpu-worker kind %r" % kind)
     unit()                                  # warm-up
@@ -440,53 +516,165 @@ def cpu_worker_main(kind, budget_s, start_at, seed):
     print(json.dumps({"count": count, "steps": steps, "seconds": time.perf_counter() - t0, "late_s": late}), flush=True)
 
 
-def mcts_cpu_baseline(n_sims=600):
-    """The reference's own algorithm for the PV-MCTS leg on ONE host core: the
-    oracle's restatement of MCTS.playout (oracle/mcts_py.py) with float32
-    torch-CPU SLPolicy / Value (B = 1 calls, one thread, like the reference's
+def _cpu_mcts(w, b, seed):
+    """The reference's own algorithm for the PV-MCTS leg on ONE host core: the oracle's restatement of MCTS.playout
+    (oracle/mcts_py.py) with float32 torch-CPU SLPolicy / Value (B = 1 calls, one thread, like the reference's
     Chainer calls) and the C oracle's rollout; same constants as the GPU leg."""
     from iago_amd import network
     from oracle import mcts_py
     from oracle import oracle as orc
-    w, b = shipped_rollout_weights()
     torch.manual_seed(0)
+    policy_net, value_net = network.SLPolicy().eval(), network.Value().eval()
+    counter = [seed << 24]
+
+    def pol(x):
+        with torch.no_grad():
+            return policy_net(torch.from_numpy(x)).numpy().reshape(64)
+
+    def val(x):
+        with torch.no_grad():
+            return value_net(torch.from_numpy(x)).numpy().reshape(1)[0]
+
+    def roll(state, color):
+        counter[0] += 1
+        return orc.simulate(state, color, w, b, seed=3, game_id=counter[0])[0]
+
+    return mcts_py.MCTS(pol, val, roll, lmbda=0.5, c_puct=1, n_thr=15)
+
+
+def _cpu_sl_game(seed):
+    """BASELINE configs[0]: one SLPolicy-vs-SLPolicy game (src/rl_self_play.py:27-31,111-145) as the reference runs
+    it -- the oracle's restatement (oracle/mcts_py.rl_game) with a float32 torch-CPU SLPolicy called on ONE board
+    per move (random init, seed 0), one thread, numpy draws.  Returns a callable that plays one game and returns
+    the moves colour 1 made."""
+    from iago_amd import network
+    from oracle import mcts_py
+    torch.manual_seed(0)
+    net = network.SLPolicy().eval()
+    rs = np.random.RandomState(seed)
+
+    def pol(x):
+        with torch.no_grad():
+            return net(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))).numpy().reshape(64)
+
+    def uniforms():
+        while True:
+            yield float(rs.random_sample())
+
+    def play():
+        states, actions, z, final = mcts_py.rl_game(pol, pol, uniforms())
+        return len(actions)
+
+    return play
+
+
+def _all_cores(kind, budget_s, unit, what):
+    pw = cpu_workers(kind, budget_s)
+    if "error" in pw:
+        return pw
+    return {"value": pw["count"] / pw["seconds"], "unit": unit, "cores": pw["processes"], "kind": "port",
+            "sample": "%d independent single-threaded worker processes (%s), %d in a common %.1f s window"
+                      % (pw["processes"], what, pw["count"], pw["seconds"])}
+
+
+def mcts_cpu_baseline(n_sims=600, leaf_evals_per_game=None):
+    """cpu_baseline of the headline: the MCTS restatement on ONE core (n_sims playouts of one game from the start
+    position) and on P = host_cores() independent processes; `leaf_evals_per_game` (from the GPU run: playouts one
+    finished self-play game took) converts leaf-evals/s into the headline's unit, games/s."""
+    from oracle import oracle as orc
+    w, b = shipped_rollout_weights()
     nthreads = torch.get_num_threads()
     torch.set_num_threads(1)
     try:
-        policy, value = network.SLPolicy().eval(), network.Value().eval()
-        counter = [0]
-
-        def pol(x):
-            with torch.no_grad():
-                return policy(torch.from_numpy(x)).numpy().reshape(64)
-
-        def val(x):
-            with torch.no_grad():
-                return value(torch.from_numpy(x)).numpy().reshape(1)[0]
-
-        def roll(state, color):
-            counter[0] += 1
-            return orc.simulate(state, color, w, b, seed=3, game_id=counter[0])[0]
-
-        m = mcts_py.MCTS(pol, val, roll, lmbda=0.5, c_puct=1, n_thr=15)
+        m = _cpu_mcts(w, b, 0)
         m.get_move(orc.initial_state(), 1, 5)  # warm-up
         t0 = time.perf_counter()
         m.get_move(orc.initial_state(), 1, n_sims)
         dt = time.perf_counter() - t0
     finally:
         torch.set_num_threads(nthreads)
-    out = {"value": n_sims / dt, "unit": "leaf-evals/s", "cores": 1, "kind": "port",
+    one = {"value": n_sims / dt, "unit": "leaf-evals/s", "cores": 1, "kind": "port",
            "sample": "%d playouts of one game from the start position, oracle/mcts_py.py + "
                      "torch-CPU fp32 nets (1 thread) + C rollout, %.1f s" % (n_sims, dt)}
-    pw = cpu_workers("mcts", 6.0)
-    if "error" in pw:
-        out["all_cores"] = pw
+    out = _all_cores("mcts", 8.0, "leaf-evals/s", "one game tree each, the same restatement")
+    if "error" in out:
+        out = dict(one, all_cores=out)
     else:
-        out["all_cores"] = {"value": pw["count"] / pw["seconds"], "unit": "leaf-evals/s", "cores": pw["processes"],
-                            "kind": "port",
-                            "sample": "%d independent single-threaded worker processes (one game tree each, the "
-                                      "same restatement), %d playouts in a common %.1f s window"
-                                      % (pw["processes"], pw["count"], pw["seconds"])}
+        out["one_core"] = one
+    if leaf_evals_per_game:
+        out["leaf_evals_per_game"] = leaf_evals_per_game
+        out["games_per_sec"] = out["value"] / leaf_evals_per_game
+        if "one_core" in out:
+            out["one_core"]["games_per_sec"] = one["value"] / leaf_evals_per_game
+    # SURVEY.md section 6 / BASELINE.md section 2: the reference's OWN board code (rl_env.py imported under stub
+    # chainer modules) measured in the survey container, for scale -- the restatements here are ~3x faster
+    out["reference_loops_games_per_sec_per_core"] = 73.9
+    out["reference_loops_note"] = ("uniform-random playouts, board logic only, rl_env.py itself on 1 core of the survey "
+                                   "container (BASELINE.md section 2); oracle/py_loops.py, timed in `rollout.cpu_baseline`, "
+                                   "runs the same loops ~3x faster (no numpy scalar boxing in the inner loop)")
+    return out
+
+
+def sl_game_cpu_baseline(budget_s=4.0):
+    """BASELINE configs[0] (plumbing, no GPU) and the CPU side of configs[4]'s self-play: SLPolicy-vs-SLPolicy games
+    on the CPU restatement, 1 core and P processes."""
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        play = _cpu_sl_game(0)
+        play()
+        games = moves = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            moves += play()
+            games += 1
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthreads)
+    out = {"value": games / dt, "unit": "games/s", "cores": 1, "kind": "port",
+           "seconds_per_game": dt / games, "colour1_moves_per_game": moves / games,
+           "sample": "%d SLPolicy-vs-SLPolicy games, oracle/mcts_py.rl_game + torch-CPU fp32 SLPolicy on one board per "
+                     "move (1 thread), %.1f s" % (games, dt)}
+    out["all_cores"] = _all_cores("sl_game", budget_s, "games/s", "the same restatement")
+    return out
+
+
+def reinforce_cpu_baseline(sl):
+    """CPU side of BASELINE configs[4]: one REINFORCE set = 64 SL-vs-SL games (src/train_rl.py:41-51; rate from
+    sl_game_cpu_baseline) + one update (src/train_rl.py:55-66: planes of the recorded states, double-softmax
+    cross-entropy x z, mean, Adam) on torch-CPU float32 with all host threads, on a synthetic set of the recorded
+    size (64 games x ~30 colour-1 moves)."""
+    from iago_amd import network
+    import torch.nn.functional as F
+    n = int(round(64 * sl.get("colour1_moves_per_game", 30.0)))
+    torch.manual_seed(0)
+    net = network.SLPolicy().train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
+    x = (torch.rand(n, 2, 8, 8) < 0.3).float()
+    y = torch.randint(0, 64, (n,))
+    z = torch.randint(0, 2, (n,)).float() * 2 - 1
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        pred = net(x)
+        loss = (F.cross_entropy(pred, y, reduction="none") * z).mean()   # (pred is a softmax output already: the quirk)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    upd = min(times)
+    ac = sl.get("all_cores", {})
+    gps_all = ac.get("value")
+    out = {"unit": "sets/s", "kind": "port", "update_seconds": upd, "update_threads": torch.get_num_threads(),
+           "update_rows": n,
+           "one_core_games": {"value": 1.0 / (64.0 / sl["value"] + upd), "cores": 1,
+                              "note": "64 games on one core + the update"},
+           "sample": "64 x the measured seconds per SL-vs-SL game + one torch-CPU update of %d rows (best of 3)" % n}
+    if gps_all:
+        out["value"] = 1.0 / (64.0 / gps_all + upd)
+        out["cores"] = ac.get("cores")
+    else:
+        out["value"], out["cores"] = out["one_core_games"]["value"], 1
     return out
 
 
@@ -513,6 +701,17 @@ def mcts_b1_leg(n_sims=200):
     m._m.close()
     return {"playouts_per_sec": n_sims / dt, "ms_per_playout": dt / n_sims * 1e3,
             "sims": n_sims, "move": int(a), "engine": "persistent search" if m._m.persistent else "per-playout launches"}
+
+
+def miopen_find_db_state():
+    """MIOpen's user find-db decides which backward-convolution solvers the REINFORCE update runs on:
+    on a fresh box (no tuned entries) the immediate-mode fallback solvers take ~40 ms per update, once
+    any process has run a find (torch.backends.cudnn.benchmark = True: ~110 s of tuning, not done here)
+    ~10 ms (LABNOTES.md, round 3).  'warm' = the user db holds find records for this GPU."""
+    import glob
+    home = os.environ.get("MIOPEN_USER_DB_PATH") or os.path.join(os.path.expanduser("~"), ".config", "miopen")
+    files = [f for f in glob.glob(os.path.join(home, "**", "*.ufdb.txt"), recursive=True) if os.path.getsize(f) > 0]
+    return "warm" if files else "cold"
 
 
 def miopen_find_db_state():
@@ -960,45 +1159,51 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps.  Default run: whole-game PV-MCTS batches (default 5); with --rollout-only: "
+                         "4096-board rollout launches (default 2000)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps of the same kind (default 1 / 100)")
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
+    ap.add_argument("--rollout-steps", type=int, default=2000, help="steps of the nested configs[1] leg (`rollout`)")
+    ap.add_argument("--rollout-warmup", type=int, default=100)
     ap.add_argument("--repeats", type=int, default=0,
-                    help="rounds of --steps steps in the timed region (0 = as many as make it >= 150 ms)")
+                    help="rollout leg: rounds of its steps in the timed region (0 = as many as make it >= 150 ms)")
     ap.add_argument("--streams", type=int, default=32,
                     help="HIP streams of the `overlapped` datapoint")
     ap.add_argument("--rollout-only", action="store_true",
-                    help="only the headline leg (what tools/profile_rollout.sh profiles)")
+                    help="only the configs[1] leg, printed as the line's headline (what tools/profile_rollout.sh profiles)")
     ap.add_argument("--mcts-only", action="store_true",
-                    help="skip the extra datapoints of the rollout leg and the single-game leg (what "
-                         "tools/profile_mcts.sh profiles)")
+                    help="only the headline leg (what tools/profile_mcts.sh profiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollout-leg", action="store_true", help="skip the nested configs[1] leg")
     ap.add_argument("--large-boards", type=int, default=1 << 20,
-                    help="extra occupancy datapoint: boards in one launch (0 = skip)")
+                    help="extra occupancy datapoint of the rollout leg: boards in one launch (0 = skip)")
     ap.add_argument("--train-iters", type=int, default=3,
                     help="REINFORCE iterations of the training leg (0 = skip)")
     ap.add_argument("--mcts-games", type=int, default=1024)
     ap.add_argument("--mcts-sims", type=int, default=100)
     ap.add_argument("--mcts-turns", type=int, default=-1,
-                    help="PV-MCTS leg: -1 = play the games to the end (default), N > 0 = a bounded "
-                         "sample of the first N turns, 0 = skip the leg")
+                    help="headline leg: -1 = play the games to the end (default), N > 0 = a bounded "
+                         "sample of the first N turns (rehearsals)")
+    ap.add_argument("--keep-table", action="store_true",
+                    help="headline leg: keep the position table across the steps (default: every step starts from an "
+                         "empty table)")
     ap.add_argument("--mcts-eager", action="store_true",
-                    help="PV-MCTS leg: plain launches instead of hipGraph replay (rocprofv3 does not "
-                         "attribute kernels launched from a graph)")
+                    help="PV-MCTS legs on the per-playout launches, eagerly (rocprofv3 does not attribute kernels "
+                         "launched from a graph)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks as child processes even for --gpus 1 (what --gpus N > 1 does "
                          "when no launcher has set WORLD_SIZE)")
     ap.add_argument("--mcts-per-playout", action="store_true",
-                    help="PV-MCTS leg: the per-playout launches instead of the persistent search")
+                    help="headline leg on the per-playout launches instead of the persistent search")
     ap.add_argument("--mcts-value-f32", action="store_true",
-                    help="PV-MCTS leg: MIOpen float32 convolutions for the Value net instead of the "
+                    help="headline leg: MIOpen float32 convolutions for the Value net instead of the "
                          "split-f16 MFMA kernels")
-    ap.add_argument("--mcts400-turns", type=int, default=4,
-                    help="PV-MCTS at 400 playouts per move (one GPU's share of BASELINE configs[3]): turns of the "
-                         "bounded sample, 0 = skip")
-    ap.add_argument("--nthr1-turns", type=int, default=8,
-                    help="PV-MCTS with n_thr = 1 (SURVEY.md 8d: the policy net inside every playout): turns of "
-                         "the bounded sample, 0 = skip")
+    ap.add_argument("--mcts400-turns", type=int, default=-1,
+                    help="PV-MCTS at 400 playouts per move (one GPU's share of BASELINE configs[3]): -1 = one batch of "
+                         "whole games (default), N > 0 = only the opening sample of N turns, 0 = skip")
+    ap.add_argument("--nthr1-turns", type=int, default=-1,
+                    help="PV-MCTS with n_thr = 1 (SURVEY.md 8d: the policy net inside every playout): as --mcts400-turns")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-budget", type=float, default=4.0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-start", type=float, default=0.0, help=argparse.SUPPRESS)
@@ -1007,8 +1212,14 @@ def main():
     if args.cpu_worker:   # a CPU-baseline worker process (cpu_workers): never touches the GPU
         cpu_worker_main(args.cpu_worker, args.cpu_worker_budget, args.cpu_worker_start, args.cpu_worker_seed)
         return
+    if args.steps is None:
+        args.steps = 2000 if args.rollout_only else 5
+    if args.warmup is None:
+        args.warmup = 100 if args.rollout_only else 1
+    if args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--steps >= 1 and --warmup >= 0 expected")
     if args.rollout_only:
-        args.mcts_turns, args.train_iters, args.no_cpu_baseline, args.nthr1_turns, args.mcts400_turns = 0, 0, True, 0, 0
+        args.rollout_steps, args.rollout_warmup = args.steps, args.warmup
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher
@@ -1041,110 +1252,187 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    B, K, W = args.boards, args.steps, args.warmup
-    head, (w, b) = rollout_leg(args, world, rank, dist)
+    def log(msg):   # progress on stderr: a long run shows where it is
+        if rank == 0:
+            print("[bench %6.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
-    mcts = None
-    if args.mcts_turns != 0:
-        mcts = mcts_leg(args.mcts_games, args.mcts_sims, max(args.mcts_turns, 0),
-                        args.mcts_turns < 0, world, rank, dist, value_f32=args.mcts_value_f32,
-                        use_graph=not args.mcts_eager,
-                        persistent=False if (args.mcts_per_playout or args.mcts_eager) else None)
-    if mcts is not None and not args.mcts_value_f32 and args.mcts_turns < 0 and not args.mcts_only:
-        # the same leg with MIOpen float32 convolutions for the Value net, on a bounded
-        # sample (first 4 turns), for comparison with the split-f16 kernels
-        ref = mcts_leg(args.mcts_games, args.mcts_sims, 4, False, world, rank, dist, value_f32=True)
-        mcts["value_f32_sample"] = {k: ref[k] for k in ("leaf_evals_per_sec", "leaf_evals", "seconds",
-                                                        "turns_played", "value_conv")}
-    if mcts is not None and not args.mcts_value_f32 and args.mcts_turns < 0 and not args.mcts_only and not args.mcts_eager:
-        # the same full games on the per-playout launches (rounds 1-3's engine), for comparison
+    K, W = args.steps, args.warmup
+    w, b = shipped_rollout_weights()
+    line = None
+
+    # ---- the nested configs[1] leg (the headline of rounds 1-4, and of --rollout-only)
+    roll = None
+    if args.rollout_only or not (args.no_rollout_leg or args.mcts_only):
+        import copy
+        ra = copy.copy(args)
+        ra.steps, ra.warmup = args.rollout_steps, args.rollout_warmup
+        log("configs[1]: %d-board rollout launches" % args.boards)
+        roll, _ = rollout_leg(ra, world, rank, dist)
+        roll["steps"], roll["warmup"] = ra.steps, ra.warmup
+        roll["config"] = {"workload": "BASELINE configs[1]: %d parallel Othello boards per GPU in ONE launch "
+                                      "per step, launches serialized on one stream, rollout-policy-only "
+                                      "playouts from the start position to the end, shipped "
+                                      "RolloutPolicy weights" % args.boards,
+                          "boards_per_gpu": args.boards, "boards_per_launch": args.boards,
+                          "games_per_step": world * args.boards, "launches_in_flight": 1,
+                          "tuple_allgather": roll["exchange"] if dist is not None else "none"}
+    if args.rollout_only:
+        if rank == 0:
+            line = {"metric": "self-play games/sec", "value": roll["value"], "unit": "games/s",
+                    "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": roll["ms_per_step"],
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "u64 bitboards + f32 policy", "data": "synthetic", "config": roll["config"],
+                    "repeats": roll["repeats"], "timed_region_s": roll["timed_region_s"],
+                    "board_steps_per_sec": roll["board_steps_per_sec"],
+                    "board_steps_per_game": roll["board_steps_per_game"], "roofline": roll["roofline"],
+                    "note": "--rollout-only: the nested `rollout` leg of the default run (BASELINE configs[1]) as the headline"}
+            for key in ("overlapped", "large_batch"):
+                if key in roll:
+                    line[key] = roll[key]
+            if not args.no_cpu_baseline and world == 1:
+                line["cpu_baseline"] = cpu_baseline(w, b)
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- the headline: BASELINE configs[2], K whole-game batches under the clock
+    full = args.mcts_turns < 0
+    log("configs[2]: %d warm-up + %d timed batches of %d games x %d playouts per move%s"
+        % (W, K, args.mcts_games, args.mcts_sims, "" if full else " (first %d turns)" % args.mcts_turns))
+    mcts = mcts_leg(args.mcts_games, args.mcts_sims, max(args.mcts_turns, 0), full, world, rank, dist,
+                    value_f32=args.mcts_value_f32, use_graph=not args.mcts_eager,
+                    persistent=False if (args.mcts_per_playout or args.mcts_eager) else None,
+                    steps=K, warmup_steps=W, fresh_table=not args.keep_table)
+    log("configs[2]: %.3f s per batch, %.2f M leaf-evals/s" % (mcts["seconds"] / K, mcts["leaf_evals_per_sec"] / 1e6))
+    extras = not args.mcts_only and not args.mcts_value_f32
+    if extras and full and not args.mcts_eager:
+        # the same games on the per-playout launches (rounds 1-3's engine), one batch, for comparison
+        log("configs[2] on the per-playout launches (one batch)")
         ref = mcts_leg(args.mcts_games, args.mcts_sims, 0, True, world, rank, None, persistent=False)
         mcts["per_playout_launches"] = {k: ref[k] for k in ("leaf_evals_per_sec", "games_per_sec", "leaf_evals", "policy_evals",
                                                              "value_evals", "seconds", "turns_played", "engine")}
-    nthr1 = None
-    if mcts is not None and args.nthr1_turns > 0 and not args.mcts_only and not args.mcts_value_f32:
-        # "also report n_thr = 1" (MCTS.py:80,109): every leaf expands at its
-        # second visit, so the look-ahead cannot apply (no visits to run ahead of) and the policy net
-        # sits inside every playout: select, pending, policy_resident_kernel x 2 on the expanding
-        # leaves, expand, continued select, fresh_leaves, value_rollout_kernel, mix_backup -- one
-        # hipGraph replay per playout.  Bounded sample: the first turns of the same 1024 games
-        r1 = mcts_leg(args.mcts_games, args.mcts_sims, args.nthr1_turns, False, world, rank, dist, n_thr=1,
-                      use_graph=not args.mcts_eager)
-        nthr1 = {k: r1[k] for k in ("leaf_evals_per_sec", "leaf_evals", "policy_evals", "value_evals", "seconds",
-                                    "turns_played", "sims_per_move", "games_per_gpu", "n_thr", "policy_lookahead",
-                                    "value_cache", "tree_nodes_used_max", "tree_capacity", "config")}
-        nthr1["sample"] = ("the first %d turns of the games (bounded sample: the value net's position table answers more "
-                           "requests there than over a whole game), policy net inside every playout" % args.nthr1_turns)
-        nthr1["default_n_thr15_leaf_evals_per_sec"] = mcts["leaf_evals_per_sec"]
-    m400 = None
-    if mcts is not None and args.mcts400_turns > 0 and not args.mcts_only and not args.mcts_value_f32:
-        # BASELINE configs[3] at one GPU's share: the reference's 10 s budget per move (MCTS.py:80,139-147) as
-        # 400 playouts, `--mcts-games` games per GPU; bounded sample of the first turns (a full game at 400
-        # playouts is ~4 s: tools/time_value_ahead.py with SIMS=400), with the tuple gather when N > 1
-        r4 = mcts_leg(args.mcts_games, 400, args.mcts400_turns, False, world, rank, dist, use_graph=not args.mcts_eager)
-        m400 = {k: r4[k] for k in ("leaf_evals_per_sec", "leaf_evals", "policy_evals", "value_evals", "seconds",
-                                   "turns_played", "sims_per_move", "games_per_gpu", "tree_nodes_used_max",
-                                   "tree_capacity", "config")}
-        m400["config"] = m400["config"].replace("configs[2]", "configs[3] (one GPU's share)")
-        m400["sample"] = ("the first %d turns of the games (bounded sample; the games start from ONE position, so these turns "
-                          "repeat each other's positions and the value net's position table answers more requests than over a "
-                          "whole game: value_evals are the evaluations executed)" % args.mcts400_turns)
-    train = reinforce_leg(args.train_iters, world, rank, dist) if args.train_iters > 0 else None
-    b1 = mcts_b1_leg() if (mcts is not None and rank == 0 and not args.mcts_only) else None
+
+    def variant(name, sims, n_thr, turns_arg, what):
+        """A variant of the headline leg: one batch of WHOLE games (turns_arg < 0) and the sample of its opening
+        turns that rounds 3-4 reported (`*_opening`: from ONE start position the first turns repeat each other's
+        positions, so the position table answers more requests there than over a whole game)."""
+        outs = {}
+        keys = ("leaf_evals_per_sec", "games_per_sec", "leaf_evals", "policy_evals", "value_evals", "seconds", "turns_played",
+                "sims_per_move", "games_per_gpu", "n_thr", "policy_lookahead", "value_cache", "tree_nodes_used_max",
+                "tree_capacity", "config", "batches_replayed_turn_by_turn")
+        if turns_arg < 0:
+            log("%s: one batch of whole games" % name)
+            r = mcts_leg(args.mcts_games, sims, 0, True, world, rank, dist, n_thr=n_thr, use_graph=not args.mcts_eager,
+                         persistent=False if args.mcts_eager else None, steps=1, warmup_steps=0)
+            outs[name] = {k: r[k] for k in keys if k in r}
+            outs[name]["config"] = outs[name]["config"].replace("configs[2]", what)
+            outs[name]["sample"] = "one batch of whole games (games_per_sec), a fresh position table"
+        n_open = 4 if sims >= 400 else 8
+        if turns_arg != 0:
+            n_open = n_open if turns_arg < 0 else turns_arg
+            r = mcts_leg(args.mcts_games, sims, n_open, False, world, rank, dist, n_thr=n_thr, use_graph=not args.mcts_eager,
+                         persistent=False if args.mcts_eager else None, steps=1, warmup_steps=0)
+            o = {k: r[k] for k in keys if k in r}
+            o["config"] = o["config"].replace("configs[2]", what)
+            o["sample"] = ("the first %d turns of the games only (NOT a game rate: the openings of games from one start position "
+                           "repeat each other's positions)" % n_open)
+            outs[name + "_opening"] = o
+        return outs
+
+    more = {}
+    if extras and args.mcts400_turns != 0:
+        # BASELINE configs[3] at one GPU's share: the reference's 10 s budget per move (MCTS.py:80,139-147) as 400 playouts
+        more.update(variant("mcts400", 400, 15, args.mcts400_turns, "configs[3] (one GPU's share)"))
+    if extras and args.nthr1_turns != 0:
+        # SURVEY.md 8(d) config 3: "also report n_thr = 1" (MCTS.py:80,109): every leaf expands at its second visit --
+        # the policy net inside every playout
+        more.update(variant("mcts_nthr1", args.mcts_sims, 1, args.nthr1_turns, "configs[2] with n_thr = 1"))
+    train = None
+    if args.train_iters > 0 and not args.mcts_only:
+        log("configs[4] in miniature: REINFORCE sets")
+        train = reinforce_leg(args.train_iters, world, rank, dist)
+    b1 = None
+    if rank == 0 and not args.mcts_only:
+        log("one game (serving mode)")
+        b1 = mcts_b1_leg()
 
     if rank == 0:
+        kr = mcts.get("kernel_roofline")
+        prof = (mcts.get("roofline") or {}).get("kernels") or {}
+        sk = prof.get("search_kernel") or {}
+        if kr is not None:
+            roof = dict(kr)
+            # HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE KiB, MI355X_MICROARCH.md) and rocprofv3's average
+            # duration come from the committed profile of this command -- quoted only when it was taken on these
+            # kernel sources
+            roof["traffic"] = sk.get("hbm_bytes_per_launch") if prof.get("current") else None
+            roof["profile"] = prof.get("profile")
+            roof["profile_current"] = bool(prof.get("current"))
+            roof["rocprof_kernel_avg_ms"] = (sk.get("rocprof_avg_us") or 0.0) / 1e3 or None
+            if prof.get("current") and sk.get("frac") is not None:
+                roof["executed_frac_pmc"] = sk["frac"]     # SQ_INSTS_MFMA x 32,768 / duration / peak, committed profile
+        else:
+            r0 = mcts["roofline"]
+            roof = {"bound": r0["bound"], "achieved": r0.get("useful_tflops", r0["achieved"]), "peak": r0["peak"],
+                    "unit": r0["unit"], "frac": r0.get("useful_frac_f16_peak", r0["frac"]), "traffic": None,
+                    "kernel": "per-playout launches: loop level (no single dominant launch is timed here)",
+                    "executed_tflops": r0["achieved"], "executed_frac": r0["frac"]}
+        games_step = world * args.mcts_games
         line = {
-            "metric": "self-play games/sec", "value": head["value"], "unit": "games/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"],
+            "metric": "self-play games/sec", "value": games_step * K / mcts["seconds"], "unit": "games/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": mcts["seconds"] / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 bitboards + f32 policy", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d parallel Othello boards per GPU in ONE launch "
-                                   "per step, launches serialized on one stream, rollout-policy-only "
-                                   "playouts from the start position to the end, shipped "
-                                   "RolloutPolicy weights" % B,
-                       "boards_per_gpu": B, "boards_per_launch": B, "games_per_step": world * B,
-                       "launches_in_flight": 1,
-                       "tuple_allgather": head["exchange"] if dist is not None else "none"},
-            "repeats": head["repeats"], "timed_region_s": head["timed_region_s"],
-            "board_steps_per_sec": head["board_steps_per_sec"],
-            "board_steps_per_game": head["board_steps_per_game"],
-            "roofline": head["roofline"],
+            "dtype": "f16 MFMA operands (float32 split in 2 / 3 pieces), f32 accumulate; u64 bitboards; f32 / f64 tree statistics",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: PV-MCTS self-play, %d games per GPU x %d playouts per move, %s, SLPolicy + "
+                                   "Value random init (seed 0), lmbda=0.5 c_puct=1 n_thr=15, both colours search; one step = one "
+                                   "batch of games%s" % (args.mcts_games, args.mcts_sims,
+                                                         "whole games" if full else "FIRST %d TURNS ONLY (rehearsal)" % args.mcts_turns,
+                                                         " = ONE launch of the persistent search" if mcts["persistent"] else ""),
+                       "games_per_gpu": args.mcts_games, "sims_per_move": args.mcts_sims, "games_per_step": games_step,
+                       "full_games": full, "n_thr": 15, "lmbda": 0.5, "c_puct": 1.0,
+                       "position_table": "empty at the start of every step" if not args.keep_table else "kept across the steps",
+                       "tuple_allgather": ("%s all-gather of every batch's (s, pi, z) tuples inside its step"
+                                           % mcts["ranks"]["backend"].replace("nccl", "rccl")) if "ranks" in mcts else "none"},
+            "step_ms_min": mcts["step_ms_min"], "step_ms_median": mcts["step_ms_median"], "step_ms_max": mcts["step_ms_max"],
+            "timed_region_s": mcts["seconds"],
+            "leaf_evals_per_sec": mcts["leaf_evals_per_sec"], "mcts_games_per_sec": mcts.get("games_per_sec"),
+            "leaf_evals_per_step": mcts["leaf_evals"] / K,
+            "roofline": roof,
         }
-        for key in ("overlapped", "large_batch"):
-            if key in head:
-                line[key] = head[key]
-        if mcts is not None:
-            # the north star's second metric as top-level scalars (the driver's `parsed` keeps scalars
-            # only): PV-MCTS configs[2], split-f16 Value + three-piece SLPolicy, whole job over all ranks
-            line["leaf_evals_per_sec"] = mcts["leaf_evals_per_sec"]
-            if "games_per_sec" in mcts:
-                line["mcts_games_per_sec"] = mcts["games_per_sec"]
-            if "per_playout_launches" in mcts:
-                line["leaf_evals_per_sec_per_playout_launches"] = mcts["per_playout_launches"]["leaf_evals_per_sec"]
-            rl = mcts.get("roofline") or {}
-            if "useful_tflops" in rl:
-                line["mcts_useful_tflops"] = rl["useful_tflops"]                # measured in this run
-                line["mcts_useful_frac_f16_peak"] = rl["useful_frac_f16_peak"]
-                line["mcts_executed_frac_f16_peak"] = rl["frac"]
-            ks = rl.get("kernels") or {}
-            if ks:
-                # per-kernel fractions come from a COMMITTED profile (named here), and only from one taken
-                # on the kernel sources of this tree
-                line["mcts_kernel_profile"] = ks.get("profile")
-                line["mcts_kernel_profile_current"] = bool(ks.get("current"))
-            for name, key in (("search_kernel", "mcts_search_kernel"), ("value_rollout_kernel", "mcts_value_kernel"),
-                              ("policy_resident_kernel", "mcts_policy_kernel")):
-                if ks.get("current") and name in ks and "frac" in ks[name]:
-                    line[key + "_mfma_frac_committed_profile"] = ks[name]["frac"]
-                    if "useful_frac_f16_peak" in ks[name]:
-                        line[key + "_useful_frac_committed_profile"] = ks[name]["useful_frac_f16_peak"]
-            line["mcts"] = mcts
-        if m400 is not None:
-            line["mcts400"] = m400
-            line["leaf_evals_per_sec_400"] = m400["leaf_evals_per_sec"]
-        if nthr1 is not None:
-            line["mcts_nthr1"] = nthr1
-            line["leaf_evals_per_sec_nthr1"] = nthr1["leaf_evals_per_sec"]
+        if mcts["persistent"]:
+            line["table_hits"] = mcts["persistent"]["position_table"]
+        if "ranks" in mcts:
+            line.update({"ranks_seen": mcts["ranks"]["ranks_seen"],
+                         "rank_play_seconds_min": mcts["ranks"]["rank_play_seconds_min"],
+                         "rank_play_seconds_max": mcts["ranks"]["rank_play_seconds_max"],
+                         "gather_ms": mcts["ranks"]["gather_ms_per_step_max"],
+                         "ranks_played_different_games": mcts["ranks"]["ranks_played_different_games"]})
+        if "per_playout_launches" in mcts:
+            line["leaf_evals_per_sec_per_playout_launches"] = mcts["per_playout_launches"]["leaf_evals_per_sec"]
+        rl = mcts.get("roofline") or {}
+        if "useful_tflops" in rl:     # loop level (whole timed region, all ranks): measured in this run
+            line["mcts_useful_tflops"] = rl["useful_tflops"]
+            line["mcts_useful_frac_f16_peak"] = rl["useful_frac_f16_peak"]
+            line["mcts_executed_frac_f16_peak"] = rl["frac"]
+        line["mcts"] = mcts
+        for k, v in more.items():
+            line[k] = v
+        if "mcts400" in more:
+            line["leaf_evals_per_sec_400"] = more["mcts400"]["leaf_evals_per_sec"]
+            line["games_per_sec_400"] = more["mcts400"].get("games_per_sec")
+        elif "mcts400_opening" in more:
+            line["leaf_evals_per_sec_400_opening"] = more["mcts400_opening"]["leaf_evals_per_sec"]
+        if "mcts_nthr1" in more:
+            line["leaf_evals_per_sec_nthr1"] = more["mcts_nthr1"]["leaf_evals_per_sec"]
+        elif "mcts_nthr1_opening" in more:
+            line["leaf_evals_per_sec_nthr1_opening"] = more["mcts_nthr1_opening"]["leaf_evals_per_sec"]
+        if roll is not None:
+            line["rollout"] = roll
+            line["rollout_games_per_sec"] = roll["value"]
         if train is not None:
             line["reinforce"] = train
             line["reinforce_iters_per_sec"] = train["iters_per_sec"]
@@ -1156,16 +1444,27 @@ def main():
         if b1 is not None:
             line["mcts_single_game"] = b1
         if not args.no_cpu_baseline and world == 1:  # the CPU baselines are N = 1 figures
-            line["cpu_baseline"] = cpu_baseline(w, b)
-            line["cpu_baseline"]["python_loops_one_core"] = python_loop_baseline(w, b)
-            if mcts is not None:
-                mcts["cpu_baseline"] = mcts_cpu_baseline()
+            log("CPU baselines")
+            per_game = mcts["leaf_evals"] / (games_step * K) if full else None
+            line["cpu_baseline"] = mcts_cpu_baseline(leaf_evals_per_game=per_game)
+            if roll is not None:
+                roll["cpu_baseline"] = cpu_baseline(w, b)
+                roll["cpu_baseline"]["python_loops_one_core"] = python_loop_baseline(w, b)
+            if not args.mcts_only:
+                sl = sl_game_cpu_baseline()
+                line["configs0"] = dict(sl, config="BASELINE configs[0]: one SLPolicy-vs-SLPolicy game, CPU only (plumbing; "
+                                                   "src/rl_self_play.py:27-31 semantics, self_play.py itself is broken)")
+                if train is not None:
+                    train["cpu_baseline"] = reinforce_cpu_baseline(sl)
+        log("done")
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
+
+T_START = time.perf_counter()
 
 if __name__ == "__main__":
     main()

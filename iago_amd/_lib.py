@@ -33,7 +33,7 @@ SYMBOLS = [
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
     "iago_mcts_fresh_leaves", "iago_mcts_descend", "iago_value_rollout_async",
     "iago_value_forward_batch", "iago_mcts_value_ahead_rows", "iago_mcts_value_ahead_store",
-    "iago_mcts_search_persistent", "iago_selfplay_policy",
+    "iago_mcts_search_persistent", "iago_mcts_search_capacity", "iago_selfplay_policy",
 ]
 
 
@@ -138,6 +138,7 @@ class MctsSearchArgs(C.Structure):
         ("rec_move", C.c_void_p), ("rec_pi", C.c_void_p),
         ("vtable", C.c_void_p), ("vtable_slots", C.c_int64),
         ("trace", C.c_void_p), ("trace_rows", C.c_int32), ("pace_margin", C.c_int32),
+        ("max_cus", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -165,7 +166,7 @@ NODE_WORDS = 8   # sizeof(iago_mcts_node) / 4: n_visits, q, p, v, first_child, p
 
 
 _lib = None
-ABI_VERSION = 10   # iago_abi_version() of the include/iago_hip.h these bindings mirror
+ABI_VERSION = 11   # iago_abi_version() of the include/iago_hip.h these bindings mirror
 
 
 def lib():
@@ -247,6 +248,7 @@ def lib():
     L.iago_mcts_value_ahead_rows.argtypes = [tp, vap, vp]
     L.iago_mcts_value_ahead_store.argtypes = [tp, vap, vp]
     L.iago_mcts_search_persistent.argtypes = [C.POINTER(MctsSearchArgs), vp]
+    L.iago_mcts_search_capacity.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.iago_selfplay_policy.argtypes = [C.POINTER(SelfplayPolicyArgs), vp]
     for name in SYMBOLS[3:]:
         getattr(L, name).restype = C.c_int

@@ -69,6 +69,7 @@ enum { ST_READY = 0, ST_WAIT_PRIOR, ST_PRIOR_READY, ST_ROLL, ST_ROLL_FRESH, ST_W
 constexpr int CTL_NO_CHILDREN = 4; // a searched root had no children (n_sims below n_thr)
 // pacing (below): sum over the games in play of their progress (turn x n_sims + playouts of the turn), games in play
 constexpr int CTL_PROGRESS = 5, CTL_PLAYING = 6;
+constexpr int CTL_NET_WGS = 7;            // net workgroups of this launch (written by the launch: the grid follows the device)
 constexpr int CTL_IDLE = 14;              // net workgroups that found nothing to do at their last look (they poll)
 constexpr uint32_t NOBODY = 0x7FFFFFFFu;  // "game" of a request nobody waits for (its value goes to the position table only)
 constexpr uint32_t KIND_VALUE = 0u, KIND_POLICY = 1u;
@@ -165,18 +166,21 @@ __device__ __forceinline__ uint32_t vtable_slot(const SearchParams &S, uint64_t 
 
 // value of the position if the table holds it (one lane); the five loads are in flight together, the entry counts only
 // if its sequence word is even and did not move
-__device__ __forceinline__ bool vtable_get(const SearchParams &S, uint64_t own, uint64_t opp, uint32_t &bits)
+__device__ __forceinline__ bool vtable_get(const SearchParams &S, uint64_t own, uint64_t opp, uint32_t &bits, uint32_t &writer)
 {
     const u64 *e = S.vtable + (u64)vtable_slot(S, own, opp) * 4u;
     const u64 s1 = ld(e), o = ld(e + 1), p = ld(e + 2), v = ld(e + 3);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (compiler order only: the words are agent-scope atomics)
     const u64 s2 = ld(e);
     bits = (uint32_t)v;
+    writer = (uint32_t)(s1 >> 32);
     return s1 != 0ull && (s1 & 1ull) == 0ull && s1 == s2 && o == own && p == opp && (v >> 32) == (s1 & 0xFFFFFFFFull);
 }
 
-// (one lane) the value the net has just computed for the position; a slot somebody else is writing is left alone
-__device__ __forceinline__ void vtable_put(const SearchParams &S, uint64_t own, uint64_t opp, uint32_t bits)
+// (one lane) the value the net has just computed for the position; a slot somebody else is writing is left alone.
+// Sequence word: low half = the sequence number (odd while the entry is being written, never 0 once used), high half =
+// the game whose request put the value there (diagnostic: hits by the same game / by another game, totals[12])
+__device__ __forceinline__ void vtable_put(const SearchParams &S, uint64_t own, uint64_t opp, uint32_t bits, uint32_t writer)
 {
     u64 *e = S.vtable + (u64)vtable_slot(S, own, opp) * 4u;
     u64 s = ld(e);
@@ -184,11 +188,13 @@ __device__ __forceinline__ void vtable_put(const SearchParams &S, uint64_t own, 
         return;
     if (!__hip_atomic_compare_exchange_strong(e, &s, s + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         return;
+    uint32_t seq = (uint32_t)s + 2u;
+    seq = seq ? seq : 2u;
     st(e + 1, own);
     st(e + 2, opp);
-    st(e + 3, ((s + 2ull) << 32) | bits);   // (the value word carries the sequence number it belongs to)
+    st(e + 3, ((u64)seq << 32) | bits);   // (the value word carries the sequence number it belongs to)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    st(e, s + 2ull);
+    st(e, ((u64)writer << 32) | seq);
 }
 
 template <int CTRL>
@@ -630,12 +636,12 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                             const uint64_t f2 = group8_flips(to_lane(own, L), to_lane(opp, L), a2, L);
                             const uint64_t bit2 = 1ull << a2;
                             const uint64_t c_own = opp & ~f2 & ~bit2, c_opp = own | f2 | bit2; // the child: the other side moves
-                            uint32_t known = 0u;
+                            uint32_t known = 0u, by = 0u;
                             // (the ring holds QCAP entries: at most one per game that waits -- <= QCAP / 2 games when this
                             // is on -- and at most QCAP / 2 of these, handed out as a budget per workgroup and iteration
                             // while the ring was empty: pace[3])
-                            if (r == 0u && !vtable_get(S, c_own, c_opp, known) && atomicSub(&pace[3], 1) > 0)
-                                send_request(S, KIND_VALUE, (int64_t)NOBODY, 0u, c_own, c_opp);
+                            if (r == 0u && !vtable_get(S, c_own, c_opp, known, by) && atomicSub(&pace[3], 1) > 0)
+                                send_request(S, KIND_VALUE, (int64_t)NOBODY, (uint32_t)g, c_own, c_opp); // (reply tag: the sender)
                         }
                     }
                 } else {
@@ -649,10 +655,12 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                     bool ask = leaf_fresh;
                     if (S.vtable_mask) {
                         // has any game of any launch asked for this position before?
-                        uint32_t hit = 0u, bits = 0u;
-                        if (leaf_fresh && r == 0u && vtable_get(S, own, opp, bits)) {
+                        uint32_t hit = 0u, bits = 0u, by = 0u;
+                        if (leaf_fresh && r == 0u && vtable_get(S, own, opp, bits, by)) {
                             hit = 1u;
                             atomicAdd((unsigned long long *)&S.totals[8], 1ull);
+                            if (by == (uint32_t)g) // (asked for -- or walked ahead -- by this very game)
+                                atomicAdd((unsigned long long *)&S.totals[12], 1ull);
                         }
                         hit = group8_add(hit);
                         bits = group8_add(r == 0u ? bits : 0u);
@@ -793,6 +801,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     SearchParams S, iago_row::HwParams R, iago_trunk::TrunkRParams VP, iago_policy::PolicyParams PP)
 {
     const long long t0 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) // (what the launch was given: the host sized the grid from the device)
+        __hip_atomic_store(&S.ctl[CTL_NET_WGS], (uint32_t)gridDim.x - (uint32_t)S.n_game_wgs, RLX_AGENT);
     if ((int)blockIdx.x < S.n_game_wgs)
         game_workgroup(S, R, t0);
     // ---- NET workgroup: ticket -> entry -> walk -> reply, until every game workgroup has finished.
@@ -807,13 +817,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x;
     const int64_t row0 = 4 * (int64_t)blockIdx.x; // this workgroup's rows of wg_own / wg_opp / out / probs (two in use)
     const uint32_t home = ((int)(blockIdx.x & 7u) >= 8 - S.policy_xcds) ? KIND_POLICY : KIND_VALUE;
-    // a VALUE ticket taken for a pair whose entry was not there yet: the next round's entry
-    uint32_t carry = 0u;
-    int n_carry = 0;
-
-    // wave 0: wait for entry t of ring q (at most max_spins polls; 0 = until it comes or the search is over)
-    // -> job[6 * which ..]; returns 0 = entry read, 1 = not there yet, 2 = the search is over / given up
-    auto fetch = [&](uint32_t q, uint32_t t, uint32_t max_spins, int which) -> int {
+    // wave 0: wait for entry t of ring q (a ticket is only ever handed out for an entry that has been reserved: its
+    // producer is writing it right now) -> job[6 * which ..]; returns 0 = entry read, 2 = the search is over / given up
+    auto fetch = [&](uint32_t q, uint32_t t, int which) -> int {
         const u64 *e = S.q_slots + ((u64)q * QCAP + t % QCAP) * 8u;
         u64 x = 0;
         int status = 0;
@@ -822,31 +828,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const bool ok = tid >= 6 || (uint32_t)(x >> 32) == t + 1u;
             if (__builtin_amdgcn_ballot_w64(ok) == ~0ull)
                 break;
-            if (max_spins && spins + 1u >= max_spins) {
-                status = 1;
-                break;
-            }
             if ((spins & 15u) == 15u) {
                 bool out = false;
                 if (tid == 0)
-                    out = __hip_atomic_load(&S.ctl[CTL_FINISHED], RLX_AGENT) >= (uint32_t)S.n_game_wgs ||
-                          __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u || wall_clock64() - t0 > S.clock_limit;
+                    out = __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u || wall_clock64() - t0 > S.clock_limit;
                 if (__builtin_amdgcn_ballot_w64(out) != 0ull) {
                     status = 2;
                     break;
                 }
             }
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(4);
         }
         if (status == 0 && tid < 6)
             job[6 * which + tid] = (uint32_t)x;
         return status;
     };
-    auto take = [&](uint32_t q) -> uint32_t {
-        uint32_t t = 0;
-        if (tid == 0)
-            t = __hip_atomic_fetch_add(&S.ctl[ctl_head(q)], 1u, RLX_AGENT);
-        return __builtin_amdgcn_readfirstlane(t);
+    // wave 0: a ticket of ring q if an entry waits there -- head moves by compare-and-swap and never passes the tail,
+    // so a workgroup is never committed to an entry that does not exist (it stays free for the other ring), and
+    // tail - head is exactly the number of entries nobody has taken
+    auto claim = [&](uint32_t q, uint32_t &ticket) -> bool {
+        uint32_t got = 0u, t = 0u;
+        if (tid == 0) {
+            uint32_t h = __hip_atomic_load(&S.ctl[ctl_head(q)], RLX_AGENT);
+            for (;;) {
+                const uint32_t tl = __hip_atomic_load(&S.ctl[ctl_tail(q)], RLX_AGENT);
+                if ((int32_t)(tl - h) <= 0)
+                    break;
+                if (__hip_atomic_compare_exchange_strong(&S.ctl[ctl_head(q)], &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT)) {
+                    got = 1u;
+                    t = h;
+                    break;
+                }
+            }
+        }
+        ticket = __builtin_amdgcn_readfirstlane(t);
+        return __builtin_amdgcn_readfirstlane(got) != 0u;
     };
     auto backlog = [&](uint32_t q) -> int {
         int d = 0;
@@ -861,38 +878,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (tid < 64) {
             int status = 2, count = 0;
             bool polling = false;
-            // an entry waiting in the home ring, else in the other one; nothing anywhere: poll the counters (no
-            // ticket is taken for an entry that is not there, so nobody is committed to a ring that stays empty)
+            // an entry waiting in the home ring, else in the other one; nothing anywhere: poll the counters
             for (;;) {
-                uint32_t q = home;
-                bool have = n_carry > 0;
-                uint32_t t1 = carry;
-                if (have) {
-                    q = KIND_VALUE;
-                    n_carry = 0;
-                } else if (backlog(home) > 0) {
-                    t1 = take(home);
-                    have = true;
-                } else if (backlog(home ^ 1u) > 0) {
+                uint32_t q = home, t1 = 0u;
+                bool have = claim(home, t1);
+                if (!have) {
                     q = home ^ 1u;
-                    t1 = take(q);
-                    have = true;
+                    have = claim(q, t1);
                 }
                 if (have) {
-                    // (a ticket below the tail: its producer is writing the entry right now; one beyond it -- two
-                    // workgroups saw the same entry -- waits for the next entry of that ring)
-                    status = fetch(q, t1, 0u, 0);
+                    status = fetch(q, t1, 0);
                     count = status == 0 ? 1 : 0;
                     if (status == 0 && q == KIND_VALUE && backlog(KIND_VALUE) >= S.pair_backlog) {
                         // (four boards per walk were measured too: the third variant's registers spill in this
                         // kernel and the walks lose more than the shared stream gains: LABNOTES.md, round 4)
-                        const uint32_t t2 = take(KIND_VALUE);
-                        if (fetch(KIND_VALUE, t2, 8u, 1) == 0) {
+                        uint32_t t2 = 0u;
+                        if (claim(KIND_VALUE, t2) && fetch(KIND_VALUE, t2, 1) == 0)
                             count = 2;
-                        } else {
-                            carry = t2; // not there yet: the next round's entry
-                            n_carry = 1;
-                        }
                     }
                     break;
                 }
@@ -945,9 +947,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const uint32_t bits = __float_as_uint(VP.out[row0 + tid]);
                 if ((job[6 * tid] & 0x7FFFFFFFu) != NOBODY)
                     st(&S.rep_v[(int64_t)(job[6 * tid] & 0x7FFFFFFFu)], ((u64)job[6 * tid + 1] << 32) | bits);
-                if (S.vtable_mask)
+                if (S.vtable_mask) {
+                    const uint32_t asked = job[6 * tid] & 0x7FFFFFFFu;
                     vtable_put(S, ((uint64_t)job[6 * tid + 3] << 32) | job[6 * tid + 2],
-                               ((uint64_t)job[6 * tid + 5] << 32) | job[6 * tid + 4], bits);
+                               ((uint64_t)job[6 * tid + 5] << 32) | job[6 * tid + 4], bits,
+                               asked != NOBODY ? asked : job[6 * tid + 1]);
+                }
             }
         } else {
             iago_policy::policy_item(PP, row0);
@@ -962,6 +967,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 } // namespace
+
+namespace {
+constexpr int search_lds()
+{
+    constexpr int lds_v = iago_trunk::lds_alloc_fused(2), lds_p = iago_policy::LDS_BYTES;
+    return lds_v > lds_p ? lds_v : lds_p;
+}
+} // namespace
+
+extern "C" int iago_mcts_search_capacity(int32_t *cus, int32_t *workgroups_per_cu)
+{
+    if (!cus || !workgroups_per_cu)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_capacity: null pointer");
+    static std::atomic<uint64_t> configured{0};
+    if (iago_reserve_lds((const void *)search_kernel, search_lds(), configured,
+                         "iago_mcts_search_capacity: cannot reserve the nets' LDS image"))
+        return IAGO_ERR_HIP;
+    // (asked of the runtime once per device: every launch comes through here)
+    static std::atomic<int32_t> known[64]; // cus << 8 | workgroups per CU, 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_capacity: hipGetDevice failed");
+    int32_t k = known[dev & 63].load(std::memory_order_acquire);
+    if (k == 0) {
+        int n_cu = 0, per = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void *)search_kernel, 256, (size_t)search_lds()) != hipSuccess)
+            return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_capacity: the device does not answer");
+        if (n_cu < 1 || per < 1 || per > 255)
+            return iago_fail(IAGO_ERR_CAPACITY, "iago_mcts_search_capacity: the search kernel does not fit a CU of this device");
+        k = (int32_t)(n_cu << 8 | per);
+        known[dev & 63].store(k, std::memory_order_release);
+    }
+    *cus = k >> 8;
+    *workgroups_per_cu = k & 255;
+    return IAGO_OK;
+}
 
 extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void *stream)
 {
@@ -998,7 +1040,21 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
     if (gpw != 8 && gpw != 16 && gpw != 32)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: games_per_workgroup is 0 (= 32), 8, 16 or 32");
     const int64_t n_game_wgs = (tree->n_games + gpw - 1) / gpw;
-    const int64_t grid = n_game_wgs + a->net_workgroups;
+    // The grid follows the device: every game workgroup must be resident together with at least one net workgroup (a
+    // game waits for replies only net workgroups give), and a net workgroup beyond what fits would only start when
+    // another one ends -- at the end of the launch.  Resident workgroups = CUs the launch may count on (max_cus, else
+    // the device's) x workgroups of this kernel per CU (its registers and LDS allow one).
+    int32_t cus = 0, per_cu = 0;
+    if (const int rc = iago_mcts_search_capacity(&cus, &per_cu))
+        return rc;
+    if (a->max_cus < 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: max_cus < 0");
+    const int64_t resident = (int64_t)(a->max_cus > 0 && a->max_cus < cus ? a->max_cus : cus) * per_cu;
+    if (n_game_wgs + 1 > resident)
+        return iago_fail(IAGO_ERR_CAPACITY, "iago_mcts_search_persistent: the game workgroups and one net workgroup do not "
+                                            "fit the device together (fewer games per launch, or the per-playout launches)");
+    const int64_t net_wgs = a->net_workgroups < resident - n_game_wgs ? a->net_workgroups : resident - n_game_wgs;
+    const int64_t grid = n_game_wgs + net_wgs;
     if (a->value->n < 4 * grid || a->policy->n < 4 * grid || a->value->planes || a->value->index || a->value->n_dev ||
         a->policy->index || a->policy->n_dev || !a->value->own || a->value->own != a->wg_own ||
         a->value->opp != a->wg_opp || a->policy->own != a->wg_own || a->policy->opp != a->wg_opp)
@@ -1094,12 +1150,7 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
     R.opp = a->cur_opp;
     R.mask = a->roll;
     R.stream_ids = a->done;
-    constexpr int lds_v = iago_trunk::lds_alloc_fused(2), lds_p = iago_policy::LDS_BYTES;
-    constexpr int lds = lds_v > lds_p ? lds_v : lds_p;
-    static std::atomic<uint64_t> configured{0};
-    if (iago_reserve_lds((const void *)search_kernel, lds, configured,
-                         "iago_mcts_search_persistent: cannot reserve the nets' LDS image"))
-        return IAGO_ERR_HIP;
+    constexpr int lds = search_lds(); // (reserved for the kernel by iago_mcts_search_capacity above)
     // every polled word starts from zero: the control block, the request ring and the reply mailboxes
     if (hipMemsetAsync(a->ctl, 0, 64, (hipStream_t)stream) != hipSuccess ||
         hipMemsetAsync(a->q_slots, 0, (size_t)2 * QCAP * 64, (hipStream_t)stream) != hipSuccess ||

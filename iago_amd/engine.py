@@ -38,9 +38,12 @@ _stream = ops._stream   # the current HIP stream as a void*
 def suggest_capacity(n_sims, n_thr=15, moves=64, branching=12):
     """Nodes per game that a whole self-play game needs without ever compacting the pools:
     every expansion adds ~`branching` children, a search adds at most
-    n_sims / n_thr + 1 expansions.  (BatchedMCTS.search compacts a pool that is half full --
-    TreePool.compact -- so a smaller capacity only costs compaction passes, as long as one
-    search's live tree fits in half of it.)"""
+    n_sims / n_thr + 1 expansions.  The turn-by-turn loop (BatchedMCTS.search) compacts a pool that is
+    half full -- TreePool.compact -- so there a smaller capacity only costs compaction passes, as long as
+    one search's live tree fits in half of it.  The one-launch whole-game path of the persistent search
+    never compacts: SelfPlayEngine.play takes it only for a pool of at least half this size (the nodes a
+    game really leaves behind: 1,718 at 100 playouts per move) and replays the batch through the turn
+    loop if a pool fills up all the same."""
     per_move = (n_sims // max(n_thr, 1) + 1) * branching
     cap = 1024
     while cap < per_move * moves:
@@ -154,7 +157,7 @@ class BatchedMCTS(object):
                  n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False,
                  sync_free=None, lookahead=None, lookahead_slots=None, value_cache=None, lookahead_overlap=None,
                  z_log_rows=0, async_steps=None, async_parts=None, value_ahead=None, persistent=None,
-                 net_workgroups=None):
+                 net_workgroups=None, max_cus=None):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         # (what the caller asked for explicitly, before the defaults below fill the options in: any of these selects
@@ -234,7 +237,14 @@ class BatchedMCTS(object):
         # rollout passes of 16 boards, and every game workgroup is a net workgroup less)
         self.games_per_workgroup = int(os.environ.get("IAGO_PERSISTENT_GPW", "0")) or (
             8 if n_games <= 256 else 16 if n_games <= 960 else _lib.SEARCH_GAMES_PER_WORKGROUP)
-        can_p = (n_games <= 128 * self.games_per_workgroup
+        # The launch's grid follows the device (iago_mcts_search_capacity: CUs x workgroups of the search kernel per CU,
+        # all of them resident from the start); max_cus / IAGO_PERSISTENT_CUS: the CUs the launch may count on when fewer
+        # are free for it -- a CU-masked stream, a device shared with another job.  The games take at most half of them
+        # (4096 games per launch on a whole MI355X); larger batches take the per-playout launches.
+        self.max_cus = int(max_cus if max_cus is not None else os.environ.get("IAGO_PERSISTENT_CUS", "0"))
+        self.resident_workgroups = self._search_capacity()
+        n_gw = -(-n_games // self.games_per_workgroup)
+        can_p = (self.resident_workgroups > 0 and 2 * n_gw <= self.resident_workgroups
                  and can_cache and getattr(value_fn, "search_args", None) is not None
                  and getattr(policy_fn, "search_args", None) is not None and getattr(policy_fn, "split3", False)
                  and rollout_weights is not None and not rollout_weights.log_form and 0.0 <= self.lmbda < 1.0)
@@ -248,8 +258,9 @@ class BatchedMCTS(object):
             persistent = can_p and not per_playout_asked
         if persistent and not can_p:
             raise ValueError("persistent needs the split-f16 value net and the three-piece policy net (modules with "
-                             "search_args), product-form rollout weights, lmbda < 1 and at most %d games"
-                             % (128 * self.games_per_workgroup))
+                             "search_args), product-form rollout weights, lmbda < 1 and at most %d games (the games' "
+                             "workgroups may take half of the %d workgroups this device keeps resident)"
+                             % (self.resident_workgroups // 2 * self.games_per_workgroup, self.resident_workgroups))
         self.persistent = bool(persistent)
         if self.persistent:
             if not self.value_cache:
@@ -382,10 +393,10 @@ class BatchedMCTS(object):
             self.tree.reset_hooks = [reset_lookahead]
         self.value_ahead = bool(getattr(self, "value_ahead", False))
         if self.persistent:
-            n_gw = -(-n_games // self.games_per_workgroup)
             if net_workgroups is None:
-                net_workgroups = int(os.environ.get("IAGO_PERSISTENT_NET", "0")) or max(1, min(256 - n_gw, max(32, 8 * n_games)))
-            self.net_workgroups = max(1, int(net_workgroups))
+                net_workgroups = int(os.environ.get("IAGO_PERSISTENT_NET", "0")) or max(32, 8 * n_games)
+            # (an upper bound: the launch itself takes no more than fit beside the game workgroups)
+            self.net_workgroups = max(1, min(int(net_workgroups), self.resident_workgroups - n_gw))
             grid = n_gw + self.net_workgroups
             self.PATH_STRIDE = 520
             i64 = torch.int64
@@ -463,12 +474,20 @@ class BatchedMCTS(object):
         self._rollout_out = ops.RolloutResult()
         self._rollout_out.z = self.z
 
+    def _search_capacity(self):
+        """Workgroups of the persistent search this device keeps resident (0: the kernel cannot run here)."""
+        cus, per = C.c_int32(0), C.c_int32(0)
+        if _lib.lib().iago_mcts_search_capacity(C.byref(cus), C.byref(per)) != 0:
+            return 0
+        n = cus.value if self.max_cus <= 0 else min(self.max_cus, cus.value)
+        return n * per.value
+
     # policy evaluations so far: counted on the host (host-counted playouts) and on the
     # device (sync-free playouts; reading it is a host sync)
     @property
     def n_policy_evals(self):
-        if self.persistent:
-            return int(self._ps["totals"][1].item())
+        if self.persistent:   # (+ the per-playout launches a rollout hook sends the searches through)
+            return int(self._ps["totals"][1].item()) + self._n_policy_host + int(self._pend_total.item())
         return self._n_policy_host + int(self._pend_total.item())
 
     @property
@@ -482,7 +501,7 @@ class BatchedMCTS(object):
     def n_value_inline(self):
         """Evaluations on the playouts' critical path (a leaf visited before it had a value)."""
         if self.persistent:
-            return int(self._ps["totals"][0].item())
+            return int(self._ps["totals"][0].item()) + int(self._value_total.item())
         return int(self._value_total.item()) if self.value_cache else self.n_leaf_evals
 
     @property
@@ -1042,6 +1061,7 @@ class BatchedMCTS(object):
         a.net_workgroups, a.time_limit_ms = self.net_workgroups, self.time_limit_ms
         a.games_per_workgroup = self.games_per_workgroup
         a.pace_margin = self.pace_margin
+        a.max_cus = self.max_cus
         a.value, a.policy, a.rollout = C.addressof(va), C.addressof(pa), C.addressof(ro.args)
         a.cur_node, a.cur_own, a.cur_opp = self.cur_node.data_ptr(), self.cur_own.data_ptr(), self.cur_opp.data_ptr()
         a.path, a.path_stride = ps["path"].data_ptr(), self.PATH_STRIDE
@@ -1063,7 +1083,14 @@ class BatchedMCTS(object):
             a.vtable, a.vtable_slots = self._vtable.data_ptr(), self._vtable.numel() // 4
         if getattr(self, "trace", None) is not None:   # (diagnostic: tools/exp_persistent_trace.py)
             a.trace, a.trace_rows = self.trace.data_ptr(), self.trace.shape[0]
+        ev = getattr(self, "launch_events", None)   # (bench.py: HIP event pairs around the launches, on their stream)
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         check(_lib.lib().iago_mcts_search_persistent(C.byref(a), _stream()), "iago_mcts_search_persistent")
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         self._ps_keep = (keep_v, keep_p, ro, va, pa, own, opp, active, game)   # alive until the next launch
 
     def search_counts(self, active):
@@ -1104,7 +1131,7 @@ class BatchedMCTS(object):
             self.tree.compact()
             self.n_compactions += 1
             self._live_after_compaction = int(self.tree.n_nodes.max().item())
-        if self.persistent:
+        if self.persistent and self.rollout_hook is None:
             self._search_persistent(own, opp, active, n_sims, n_active)
         elif self.async_steps and self.rollout_hook is None:
             self._search_async(own, opp, active, n_sims, n_active)
@@ -1188,6 +1215,8 @@ class BatchedMCTS(object):
                 out["paths"] = self._la_path.numel() * 4
         if self.persistent:
             out["persistent_search"] = sum(t.numel() * t.element_size() for t in self._ps.values())
+            if self._vtable is not None:
+                out["position_table"] = self._vtable.numel() * 8
         if self.value_ahead:
             out["value_ahead"] = sum(t.numel() * t.element_size() for d in self._va_x + [self._va_rows] for t in d.values())
         pool = getattr(self.policy_fn, "__dict__", {}).get("_split3_scratch_pool", {})
@@ -1269,10 +1298,19 @@ class SelfPlayEngine(object):
                     if m._vtable is not None:
                         m._vtable.zero_()
                 m._value_key = key
+        # (what the launch accumulates into, in case a pool fills up and the batch is replayed turn by turn)
+        keep = [(t, t.clone()) for t in (m._ps["totals"], m.z_log_n, m.stats) if t is not None]
         m._launch_persistent(None, None, active, n_sims, game=g)
         back = torch.cat([m.error_flags(), m._ps["ctl"][4].to(torch.int64).reshape(1),
                           g["n_turns"].max().to(torch.int64).reshape(1),
-                          g["rec_valid"].sum().to(torch.int64).reshape(1)]).tolist()
+                          g["rec_valid"].sum().to(torch.int64).reshape(1),
+                          m._ps["ctl"][7].to(torch.int64).reshape(1)]).tolist()
+        m.net_workgroups_launched = int(back[8])
+        if back[0] and not back[4]:
+            # a pool filled up (the launch cannot compact): nothing of this attempt counts
+            for t, was in keep:
+                t.copy_(was)
+            return None
         m.raise_errors(back[:5])
         if back[5]:
             raise ValueError("a searched root has no children: n_sims is below the expansion threshold n_thr")
@@ -1288,6 +1326,7 @@ class SelfPlayEngine(object):
         p1, p2 = torch.where(even, own, opp), torch.where(even, opp, own)
         res.z = ops.judge(p1, p2)
         res.final_p1, res.final_p2 = p1, p2
+        res.game_turns = g["n_turns"]    # (B,) the turn at which each game ended (the batch's last: n_turns)
         if record:
             turn = torch.arange(t, device=dev).reshape(t, 1)
             played = turn < g["n_turns"].reshape(1, B)
@@ -1307,8 +1346,17 @@ class SelfPlayEngine(object):
         if handicap is not None:  # (B,) int64 bit masks of extra colour-2 stones
             opp = opp | handicap
         m.tree.reset()
-        if getattr(m, "persistent", False) and os.environ.get("IAGO_PERSISTENT_GAMES", "1") != "0":
-            return self._play_persistent(n_sims, own, opp, record)
+        # The one-launch whole-game path wherever the persistent search applies and the pools can hold a whole game
+        # without compaction; else -- and when a pool fills up all the same -- the turn-by-turn loop below, whose
+        # searches (one persistent launch per turn) compact a pool that is half full.  Same games either way.
+        if (getattr(m, "persistent", False) and m.rollout_hook is None
+                and os.environ.get("IAGO_PERSISTENT_GAMES", "1") != "0"
+                and 2 * m.tree.capacity >= suggest_capacity(n_sims, m.n_thr, moves=min(self.max_turns, 64))):
+            res = self._play_persistent(n_sims, own.clone(), opp.clone(), record)
+            if res is not None:
+                return res
+            self.n_replayed = getattr(self, "n_replayed", 0) + 1   # batches replayed through the turn loop
+            m.tree.reset()
         stone_num = torch.full((B,), 4, dtype=torch.int32, device=dev)  # game.py:32
         pass_flg = torch.zeros(B, dtype=torch.uint8, device=dev)
         done = torch.zeros(B, dtype=torch.uint8, device=dev)
@@ -1360,6 +1408,7 @@ class SelfPlayEngine(object):
         res.z = ops.judge(p1, p2)
         res.final_p1, res.final_p2 = p1, p2
         res.n_turns = t
+        res.game_turns = None   # (per-game end turns: the one-launch path records them)
         if record:
             for name in ("own", "opp", "pi", "valid", "move"):
                 setattr(res, name, getattr(res, name)[:t])

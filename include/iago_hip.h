@@ -757,8 +757,9 @@ IAGO_API int iago_value_rollout_async(const iago_value_split_args *value, const 
  *     evaluations, game-workgroup iterations, pair walks, the net workgroups' waiting and walking time (100 MHz
  *     ticks, summed over the workgroups), idle game-workgroup iterations and the game workgroups' run time; stats as for iago_mcts_select; z_log as in
  *     iago_mcts_lookahead.
- * At most one workgroup per CU is resident: game workgroups + net_workgroups should not exceed the CUs of
- * the device (256), and nothing else should occupy the device while the launch runs.
+ * At most one workgroup per CU is resident; the grid is sized from the device (iago_mcts_search_capacity below,
+ * max_cus), so net_workgroups is an upper bound.  Nothing else should occupy the device while the launch runs: a game
+ * workgroup that finds no CU free for its net workgroups gives up after time_limit_ms.
  */
 #define IAGO_SEARCH_QUEUE_ENTRIES 4096
 #define IAGO_SEARCH_GAMES_PER_WORKGROUP 32   /* games a game workgroup owns (at most, and by default) */
@@ -815,7 +816,9 @@ typedef struct iago_mcts_search_args {
                               none), zeroed by the caller ONCE and whenever the value net's weights change, kept across
                               launches: MCTS.value_func (MCTS.py:97-103) is a pure function of the position, so a position any
                               game has asked for before is answered from the table instead of the queue (same number, same
-                              trees).  totals[8] counts the hits; totals [16] */
+                              trees).  An entry's sequence word carries the game whose request put the value there in its
+                              high half.  totals[8] counts the hits, totals[12] those of them on a value the asking game
+                              itself had put there (or had walked ahead); totals [16] */
     int64_t vtable_slots;
     int64_t *trace;       /* optional diagnostic [trace_rows][4].  Rows 0 .. trace_rows - n_games - 1: game workgroup 0 records
                              (100 MHz ticks since its start, requests queued so far, tickets handed out so far, game
@@ -826,8 +829,20 @@ typedef struct iago_mcts_search_args {
                              the games in play starts no new playout while requests queue up (the batch ends with its slowest
                              game; what the leaders do not ask of the nets, the laggards get).  Timing only -- a game's own
                              sequence of playouts, hence every tree and move, is unchanged.  0 = default (16), < 0 = off */
+    int32_t max_cus;      /* CUs the launch may count on when fewer than the device's are free for it (a CU-masked stream, a
+                             device shared with another job); 0 = all CUs of the device */
+    int32_t reserved;
 } iago_mcts_search_args;
 IAGO_API int iago_mcts_search_persistent(const iago_mcts_search_args *args, void *stream);
+/*
+ * What the persistent launch can count on: the CUs of the current device and the workgroups of the search kernel that
+ * fit one CU (its registers and LDS allow one).  iago_mcts_search_persistent sizes its grid from these: all game
+ * workgroups + min(net_workgroups, CUs x workgroups per CU - game workgroups) net workgroups -- every workgroup of the
+ * launch is resident from the start -- and returns IAGO_ERR_CAPACITY when the game workgroups and ONE net workgroup do
+ * not fit (the launch could never finish: games wait for replies only net workgroups give).  ctl[7] after a launch: the
+ * net workgroups it ran with.
+ */
+IAGO_API int iago_mcts_search_capacity(int32_t *cus, int32_t *workgroups_per_cu);
 
 /*
  * Whole policy-vs-policy games -- src/rl_self_play.py:8-149, Game(model1, model2)() for n games -- in ONE launch: a

@@ -32,7 +32,7 @@ def test_library_exports_every_symbol(so):
     L = _lib.lib()
     for name in header_symbols():
         assert hasattr(L, name), name
-    assert L.iago_abi_version() == _lib.ABI_VERSION == 10
+    assert L.iago_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_gfx950_code_object(so):

@@ -26,17 +26,21 @@ def _rollout_weights(ops):
     return ops.RolloutWeights(np.asarray(g["shipped_w"], np.float32), np.asarray(g["shipped_b"], np.float32))
 
 
-def test_config3_share_1024_games_400_sims():
-    """One GPU's share of configs[3]: 1024 lockstep games x 400 playouts from the start
-    position (hipGraph replay, as bench.py runs it), pool sized by suggest_capacity(400).
-    Size-independent properties of MCTS.py:105-133 on the device trees."""
+@pytest.mark.parametrize("persistent", [True, False])
+def test_config3_share_1024_games_400_sims(persistent):
+    """One GPU's share of configs[3]: 1024 games x 400 playouts from the start position, pool sized by
+    suggest_capacity(400), on the persistent search (the engine bench.py's mcts400 leg times: ONE launch) and on
+    the per-playout launches (hipGraph replay, policy look-ahead).  Size-independent properties of
+    MCTS.py:105-133 on the device trees.  (The same share against the ORACLE on the persistent search:
+    tests/test_bench_batch_gpu.py::test_config3_share_on_the_persistent_search.)"""
     from iago_amd import engine, network, ops
     torch.manual_seed(0)
     policy, value = network.SLPolicy().cuda().eval(), network.Value().cuda().eval()
     G, n_sims, n_thr = 1024, 400, 15
     cap = engine.suggest_capacity(n_sims, n_thr)
     m = engine.BatchedMCTS(G, policy, value, _rollout_weights(ops), lmbda=0.5, c_puct=1.0, n_thr=n_thr,
-                           capacity=cap, seed=3, use_graph=True)
+                           capacity=cap, seed=3, use_graph=not persistent, persistent=persistent)
+    assert m.persistent == persistent
     own = torch.full((G,), engine.START_OWN, dtype=torch.int64, device="cuda")
     opp = torch.full((G,), engine.START_OPP, dtype=torch.int64, device="cuda")
     act = torch.ones(G, dtype=torch.uint8, device="cuda")
@@ -54,8 +58,13 @@ def test_config3_share_1024_games_400_sims():
     # every expansion had the policy evaluated exactly once (single-move / pass expansions too:
     # the batch evaluates every queued leaf); with the policy look-ahead the leaves that are
     # queued but not yet expanded (first_child <= -2) have been evaluated as well
-    assert m.lookahead == 4
-    assert m.n_policy_evals == int(expanded.sum()) + int((live & (fc <= -2)).sum())
+    if persistent:
+        # the policy net exactly where the reference runs it: at the expansion of a node with a choice (MCTS.py:118-120)
+        assert m.lookahead == 0
+        assert m.n_policy_evals == int((expanded & (nc > 1)).sum())
+    else:
+        assert m.lookahead == 4
+        assert m.n_policy_evals == int(expanded.sum()) + int((live & (fc <= -2)).sum())
     for g in range(0, G, 37):
         for i in np.nonzero(expanded[g])[0]:
             kids = slice(fc[g, i], fc[g, i] + nc[g, i])

@@ -135,31 +135,42 @@ def test_bench_starts_its_own_ranks():
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """bench.py --gpus 2 started the way the driver starts it (no launcher: it spawns its ranks),
     every leg, with both ranks on the one GPU of the box over gloo (IAGO_BENCH_BACKEND / _DEVICE:
-    RCCL refuses two ranks on one device): the N > 1 code of the bench -- global game ids per rank,
-    the side-stream all-gather of the round buffers and its "ranks played different games" check, the
-    max-over-ranks timing, the PV-MCTS leg's sharded engines and tuple gather, the sharded REINFORCE
-    leg -- runs and prints ONE line with whole-job values."""
+    RCCL refuses two ranks on one device): the N > 1 code of the bench -- the headline's sharded engines
+    (global game ids per rank), the all-gather of every batch's tuples inside its step, the max-over-ranks
+    timing, the self-diagnosis keys (ranks seen, per-rank play time, "ranks played different games"), the
+    nested rollout leg's side-stream gathers, the sharded REINFORCE leg -- runs and prints ONE line with
+    whole-job values."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(IAGO_BENCH_BACKEND="gloo", IAGO_BENCH_DEVICE="0")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-                          "--mcts-games", "128", "--mcts-turns", "6", "--nthr1-turns", "0", "--mcts400-turns", "2", "--train-iters", "2"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--rollout-steps", "20", "--rollout-warmup", "5", "--large-boards", "0",
+                          "--mcts-games", "128", "--nthr1-turns", "0", "--mcts400-turns", "2", "--train-iters", "2"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
-    assert line["config"]["games_per_step"] == 2 * 4096 and "gloo all-gather" in line["config"]["tuple_allgather"]
-    assert abs(line["value"] - 2 * 4096 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
-    assert line["mcts"]["leaf_evals"] == 2 * 128 * 100 * line["mcts"]["turns_played"]   # both ranks' playouts
-    assert line["leaf_evals_per_sec"] == line["mcts"]["leaf_evals_per_sec"] > 0
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2 and line["warmup"] == 1
+    assert line["config"]["games_per_step"] == 2 * 128 and line["config"]["full_games"] is True
+    assert "gloo all-gather" in line["config"]["tuple_allgather"]
+    assert abs(line["value"] - 2 * 128 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    assert line["value"] == line["mcts_games_per_sec"]
+    m = line["mcts"]
+    assert m["steps"] == 2 and len(m["step_seconds"]) == 2 and m["gathered_tuples"] > 2 * 128 * 50
+    assert line["leaf_evals_per_sec"] == m["leaf_evals_per_sec"] > 0
+    assert line["ranks_seen"] == 2 and line["ranks_played_different_games"] is True
+    assert m["ranks"]["ranks_reporting"] == [0, 1]
+    assert 0 < line["rank_play_seconds_min"] <= line["rank_play_seconds_max"] and line["gather_ms"] > 0
+    r = line["rollout"]
+    assert r["config"]["games_per_step"] == 2 * 4096 and "gloo all-gather" in r["config"]["tuple_allgather"]
+    assert abs(r["value"] - 2 * 4096 * 1e3 / r["ms_per_step"]) < 1e-6 * r["value"]
     assert line["reinforce"]["iters"] == 2 and "cpu_baseline" not in line   # CPU baselines are N = 1 figures
-    assert line["mcts400"]["leaf_evals"] == 2 * 128 * 400 * 2 and line["leaf_evals_per_sec_400"] > 0
+    assert line["mcts400_opening"]["leaf_evals"] == 2 * 128 * 400 * 2 and line["leaf_evals_per_sec_400_opening"] > 0
     assert line["reinforce"]["mcts_fed"]["rounds"] == 1 and line["reinforce_miopen_find_db"] in ("cold", "warm")
 
 
-FIVE = ["--gpus", "5", "--steps", "20", "--warmup", "5", "--boards", "4096", "--mcts-games", "32", "--mcts-turns", "4",
-       "--nthr1-turns", "0", "--mcts400-turns", "0", "--train-iters", "1", "--large-boards", "0"]
+FIVE = ["--gpus", "5", "--steps", "2", "--warmup", "1", "--boards", "4096", "--rollout-steps", "20", "--rollout-warmup", "5",
+        "--mcts-games", "32", "--nthr1-turns", "0", "--mcts400-turns", "0", "--train-iters", "1", "--large-boards", "0"]
 
 
 def _rehearsal_env():
@@ -180,9 +191,12 @@ def test_bench_five_ranks_rehearsal_on_one_gpu():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 5 and line["scaling"] == "weak"
-    assert line["config"]["games_per_step"] == 5 * 4096 and "gloo all-gather" in line["config"]["tuple_allgather"]
-    assert abs(line["value"] - 5 * 4096 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
-    assert line["mcts"]["leaf_evals"] == 5 * 32 * 100 * line["mcts"]["turns_played"] and line["mcts"]["turns_played"] == 4
+    assert line["config"]["games_per_step"] == 5 * 32 and "gloo all-gather" in line["config"]["tuple_allgather"]
+    assert abs(line["value"] - 5 * 32 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    assert line["ranks_seen"] == 5 and line["ranks_played_different_games"] is True
+    assert line["mcts"]["ranks"]["ranks_reporting"] == [0, 1, 2, 3, 4]
+    assert line["mcts"]["gathered_tuples"] > 5 * 32 * 50         # every rank's rows of the last batch
+    assert line["rollout"]["config"]["games_per_step"] == 5 * 4096
     assert line["reinforce"]["iters"] == 1 and line["reinforce"]["mcts_fed"]["rounds"] == 1
     assert line["reinforce"]["mcts_fed"]["tuples_per_round"] > 64 * 40      # all 64 games of the round, gathered
     assert "cpu_baseline" not in line
@@ -195,7 +209,7 @@ def test_bench_launcher_propagates_a_killed_rank():
     import time
     # (a run long enough to be in full swing when the rank is killed: whole games, a long training leg)
     long_run = [x for x in FIVE]
-    long_run[long_run.index("--mcts-turns") + 1] = "-1"
+    long_run[long_run.index("--steps") + 1] = "40"
     long_run[long_run.index("--mcts-games") + 1] = "256"
     long_run[long_run.index("--train-iters") + 1] = "400"
     p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + long_run, cwd=ROOT, stdout=subprocess.PIPE,

@@ -259,3 +259,106 @@ def test_too_many_games_take_the_per_playout_launches(nets):
         engine.BatchedMCTS(4128, policy, value, rw, n_thr=15, capacity=64, persistent=True)
     m2 = engine.BatchedMCTS(4096, policy, value, rw, n_thr=15, capacity=64)
     assert m2.persistent and m2.net_workgroups == 128
+
+
+def _cu_masked_stream(n_cus):
+    """A HIP stream whose kernels may only use `n_cus` of the device's CUs (hipExtStreamCreateWithCUMask), as a
+    torch stream.  The mask enables every (256 / n_cus)-th CU so that the CUs come from all XCDs."""
+    import ctypes as C
+    import os
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    total = torch.cuda.get_device_properties(0).multi_processor_count
+    step = total // n_cus
+    words = (C.c_uint32 * ((total + 31) // 32))()
+    for cu in range(0, total, step):
+        words[cu // 32] |= 1 << (cu % 32)
+    stream = C.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(stream), C.c_uint32(len(words)), words)
+    assert rc == 0 and stream.value
+    return hip, stream, torch.cuda.ExternalStream(stream.value)
+
+
+def test_grid_follows_the_device(nets):
+    """The launch sizes its grid from the device (iago_mcts_search_capacity: CUs x workgroups of the kernel per CU) and
+    from max_cus, the CUs it may count on: on a stream masked to 64 of the CUs a search told so (max_cus=64) runs with
+    64 - game workgroups net workgroups, builds the same trees as on the whole device and does not run into the
+    clock limit; a launch whose game workgroups + one net workgroup do not fit is refused (IAGO_ERR_CAPACITY), and
+    the engine's default there is the per-playout engine."""
+    engine, ops, policy, value, rw = nets
+    from iago_amd import _lib
+    import ctypes as C
+    cus, per = C.c_int32(0), C.c_int32(0)
+    assert _lib.lib().iago_mcts_search_capacity(C.byref(cus), C.byref(per)) == 0
+    props = torch.cuda.get_device_properties(0)
+    assert cus.value == props.multi_processor_count and per.value == 1     # 512 registers, 70 KB of LDS: one per CU
+    G, n_sims, n_sims2 = 96, 100, 45
+    own, opp = _positions(G)
+    m0, whole = _run(nets, G, n_sims, n_sims2, own, opp, persistent=True)
+    assert m0.resident_workgroups == cus.value and m0.net_workgroups == cus.value - 12
+    assert int(m0._ps["ctl"][7].item()) == m0.net_workgroups               # what the launch really ran with
+    hip, raw, masked = _cu_masked_stream(64)
+    try:
+        with torch.cuda.stream(masked):
+            m1, part = _run(nets, G, n_sims, n_sims2, own, opp, persistent=True, max_cus=64)
+            masked.synchronize()
+        assert m1.resident_workgroups == 64 and m1.net_workgroups == 64 - 12
+        assert int(m1._ps["ctl"][7].item()) == 52 and int(m1._ps["ctl"][3].item()) == 0   # no clock-limit abort
+        for k in whole:
+            assert np.array_equal(whole[k], part[k], equal_nan=True), k
+        # told nothing, the launch asks for the whole device's net workgroups; those the masked stream has no CU for
+        # start when the others end -- at the end of the launch: same trees, no abort
+        with torch.cuda.stream(masked):
+            m2, blind = _run(nets, G, n_sims, n_sims2, own, opp, persistent=True)
+            masked.synchronize()
+        assert int(m2._ps["ctl"][3].item()) == 0
+        for k in whole:
+            assert np.array_equal(whole[k], blind[k], equal_nan=True), k
+    finally:
+        torch.cuda.synchronize()
+        hip.hipStreamDestroy(raw)
+    # 12 game workgroups + 1 net workgroup need 13 CUs: refused by the library, never launched
+    m3 = engine.BatchedMCTS(G, policy, value, rw, n_thr=15, capacity=1024, seed=21, persistent=True, max_cus=24)
+    m3.max_cus = 12
+    o, p = ops.bits_to_tensor(own), ops.bits_to_tensor(opp)
+    with pytest.raises(_lib.IagoError, match="do not fit"):
+        m3.search(o, p, torch.ones(G, dtype=torch.uint8, device="cuda"), 20)
+    # ... and the engine does not choose the persistent search where the games would take more than half the CUs
+    m4 = engine.BatchedMCTS(G, policy, value, rw, n_thr=15, capacity=1024, max_cus=16)
+    assert not m4.persistent
+    with pytest.raises(ValueError):
+        engine.BatchedMCTS(G, policy, value, rw, n_thr=15, capacity=1024, persistent=True, max_cus=16)
+
+
+def test_whole_games_fall_back_to_the_turn_loop_when_a_pool_is_small(nets, monkeypatch):
+    """The one-launch whole-game path cannot compact its pools: SelfPlayEngine.play takes it only for
+    pools that can hold a whole game, replays the batch through the turn loop (whose searches compact) when a pool
+    fills up all the same -- and the games are the same either way."""
+    engine, ops, policy, value, rw = nets
+    G, n_sims = 16, 60
+    big = engine.BatchedMCTS(G, policy, value, rw, n_thr=15, capacity=engine.suggest_capacity(n_sims, 15), seed=9,
+                             persistent=True)
+    e0 = engine.SelfPlayEngine(big)
+    want = e0.play(n_sims)
+    assert getattr(e0, "n_replayed", 0) == 0 and want.game_turns is not None
+    used = int(big.tree.n_nodes.max().item())
+    assert used > 300
+
+    def check(cap, replays):
+        small = engine.BatchedMCTS(G, policy, value, rw, n_thr=15, capacity=cap, seed=9, persistent=True)
+        e1 = engine.SelfPlayEngine(small)
+        got = e1.play(n_sims)
+        assert getattr(e1, "n_replayed", 0) == replays and got.game_turns is None
+        assert got.n_turns == want.n_turns and small.n_leaf_evals == big.n_leaf_evals
+        for k in ("own", "opp", "valid", "move", "pi", "z"):
+            assert torch.equal(getattr(got, k), getattr(want, k)), (cap, k)
+        assert small.n_compactions > 0
+        assert small.n_value_evals >= big.n_value_inline      # (nothing of a failed attempt is counted twice)
+        small.close()
+
+    # a pool below half of suggest_capacity: the turn loop from the start
+    check(256, 0)
+    # a pool that passes play()'s test (made lenient here) but cannot hold what these games leave behind: the launch
+    # reports the full pool and the batch is replayed turn by turn, from the same Philox streams
+    monkeypatch.setattr(engine, "suggest_capacity", lambda *a, **k: 64)
+    check(256, 1)
+    big.close()
