@@ -817,9 +817,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x;
     const int64_t row0 = 4 * (int64_t)blockIdx.x; // this workgroup's rows of wg_own / wg_opp / out / probs (two in use)
     const uint32_t home = ((int)(blockIdx.x & 7u) >= 8 - S.policy_xcds) ? KIND_POLICY : KIND_VALUE;
-    // wave 0: wait for entry t of ring q (a ticket is only ever handed out for an entry that has been reserved: its
-    // producer is writing it right now) -> job[6 * which ..]; returns 0 = entry read, 2 = the search is over / given up
-    auto fetch = [&](uint32_t q, uint32_t t, int which) -> int {
+    // Tickets are handed out by fetch-and-add whenever the ring shows an entry waiting: several workgroups that saw the
+    // same entry all take one, and the later ones wait in fetch() for the ring's next entries.  (Measured and dropped,
+    // round 5: head moved by compare-and-swap bounded by the tail, so that nobody is committed to an entry that does not
+    // exist -- a retry loop took the 1024-game batch from 0.39 to 3.6 s, one attempt per look to 1.76 s: the losers keep
+    // polling and retrying on ONE word from all XCDs, same-address atomics serialise, and every claim queues behind them.)
+    // a VALUE ticket taken for a pair whose entry was not there yet: the next round's entry
+    uint32_t carry = 0u;
+    int n_carry = 0;
+
+    // wave 0: wait for entry t of ring q (at most max_spins polls; 0 = until it comes or the search is over)
+    // -> job[6 * which ..]; returns 0 = entry read, 1 = not there yet, 2 = the search is over / given up
+    auto fetch = [&](uint32_t q, uint32_t t, uint32_t max_spins, int which) -> int {
         const u64 *e = S.q_slots + ((u64)q * QCAP + t % QCAP) * 8u;
         u64 x = 0;
         int status = 0;
@@ -828,42 +837,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const bool ok = tid >= 6 || (uint32_t)(x >> 32) == t + 1u;
             if (__builtin_amdgcn_ballot_w64(ok) == ~0ull)
                 break;
+            if (max_spins && spins + 1u >= max_spins) {
+                status = 1;
+                break;
+            }
             if ((spins & 15u) == 15u) {
                 bool out = false;
                 if (tid == 0)
-                    out = __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u || wall_clock64() - t0 > S.clock_limit;
+                    out = __hip_atomic_load(&S.ctl[CTL_FINISHED], RLX_AGENT) >= (uint32_t)S.n_game_wgs ||
+                          __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u || wall_clock64() - t0 > S.clock_limit;
                 if (__builtin_amdgcn_ballot_w64(out) != 0ull) {
                     status = 2;
                     break;
                 }
             }
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(8);
         }
         if (status == 0 && tid < 6)
             job[6 * which + tid] = (uint32_t)x;
         return status;
     };
-    // wave 0: a ticket of ring q if an entry waits there -- head moves by compare-and-swap and never passes the tail,
-    // so a workgroup is never committed to an entry that does not exist (it stays free for the other ring), and
-    // tail - head is exactly the number of entries nobody has taken
-    auto claim = [&](uint32_t q, uint32_t &ticket) -> bool {
-        uint32_t got = 0u, t = 0u;
-        if (tid == 0) {
-            uint32_t h = __hip_atomic_load(&S.ctl[ctl_head(q)], RLX_AGENT);
-            for (;;) {
-                const uint32_t tl = __hip_atomic_load(&S.ctl[ctl_tail(q)], RLX_AGENT);
-                if ((int32_t)(tl - h) <= 0)
-                    break;
-                if (__hip_atomic_compare_exchange_strong(&S.ctl[ctl_head(q)], &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT)) {
-                    got = 1u;
-                    t = h;
-                    break;
-                }
-            }
-        }
-        ticket = __builtin_amdgcn_readfirstlane(t);
-        return __builtin_amdgcn_readfirstlane(got) != 0u;
+    auto take = [&](uint32_t q) -> uint32_t {
+        uint32_t t = 0;
+        if (tid == 0)
+            t = __hip_atomic_fetch_add(&S.ctl[ctl_head(q)], 1u, RLX_AGENT);
+        return __builtin_amdgcn_readfirstlane(t);
     };
     auto backlog = [&](uint32_t q) -> int {
         int d = 0;
@@ -878,23 +876,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (tid < 64) {
             int status = 2, count = 0;
             bool polling = false;
-            // an entry waiting in the home ring, else in the other one; nothing anywhere: poll the counters
+            // an entry waiting in the home ring, else in the other one; nothing anywhere: poll the counters (no
+            // ticket is taken for an entry that is not there, so nobody is committed to a ring that stays empty)
             for (;;) {
-                uint32_t q = home, t1 = 0u;
-                bool have = claim(home, t1);
-                if (!have) {
+                uint32_t q = home;
+                bool have = n_carry > 0;
+                uint32_t t1 = carry;
+                if (have) {
+                    q = KIND_VALUE;
+                    n_carry = 0;
+                } else if (backlog(home) > 0) {
+                    t1 = take(home);
+                    have = true;
+                } else if (backlog(home ^ 1u) > 0) {
                     q = home ^ 1u;
-                    have = claim(q, t1);
+                    t1 = take(q);
+                    have = true;
                 }
                 if (have) {
-                    status = fetch(q, t1, 0);
+                    // (a ticket below the tail: its producer is writing the entry right now; one beyond it -- two
+                    // workgroups saw the same entry -- waits for the next entry of that ring)
+                    status = fetch(q, t1, 0u, 0);
                     count = status == 0 ? 1 : 0;
                     if (status == 0 && q == KIND_VALUE && backlog(KIND_VALUE) >= S.pair_backlog) {
                         // (four boards per walk were measured too: the third variant's registers spill in this
                         // kernel and the walks lose more than the shared stream gains: LABNOTES.md, round 4)
-                        uint32_t t2 = 0u;
-                        if (claim(KIND_VALUE, t2) && fetch(KIND_VALUE, t2, 1) == 0)
+                        const uint32_t t2 = take(KIND_VALUE);
+                        if (fetch(KIND_VALUE, t2, 8u, 1) == 0) {
                             count = 2;
+                        } else {
+                            carry = t2; // not there yet: the next round's entry
+                            n_carry = 1;
+                        }
                     }
                     break;
                 }

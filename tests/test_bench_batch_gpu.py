@@ -102,7 +102,7 @@ def _replay_records(B, whole):
                     assert np.all(row[[x for x in range(64) if x not in acts]] == 0), (g, t)
                     assert a == int(np.argmax(row)) and row[a] > 0, (g, t)      # first most-visited child (MCTS.py:147)
                     # the root was a leaf for its first visits, then every playout went to a child (MCTS.py:109)
-                    assert n_sims - 15 <= int(row.sum()) <= 3 * n_sims, (g, t)   # (+ the visits the reused subtree brought)
+                    assert int(row.sum()) >= n_sims - 15, (g, t)   # (+ the visits the reused subtree brought)
                     orc.place_stone(state, a, color)
                     stone_num += 1
                     pass_flg = False
