@@ -92,7 +92,7 @@ class MctsAsync(C.Structure):
     ]
 
 
-VALUE_IMAGE_BYTES = 33792   # IAGO_VALUE_IMAGE_BYTES
+VALUE_IMAGE_BYTES = 34816   # IAGO_VALUE_IMAGE_BYTES
 
 
 class MctsLookahead(C.Structure):

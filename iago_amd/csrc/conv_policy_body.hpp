@@ -16,13 +16,16 @@ namespace iago_policy {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x32_f16, accumulator in place (conv_trunk_body.hpp: IAGO_MFMA16)
+#define IAGO_POLICY_MFMA16(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-constexpr int RS = 784;             // bytes of a cell row: 128 ch hi | mid | lo (256 B each) | 16 B (bank skew)
-constexpr int ZB = 1024;            // zero bytes behind the 64 rows: the target of every out-of-board tap
-constexpr int BS = 64 * RS + ZB;    // 51,200
+constexpr int RS = 800;             // bytes of a cell row: 128 ch hi | mid | lo (256 B each) | 32 B (bank skew: rows 2 x 16 B apart mod 256)
+constexpr int ZB = 1280;            // zero bytes behind the 64 rows: the target of every out-of-board tap
+constexpr int BS = 64 * RS + ZB;    // 52,480
 constexpr int HEAD_FLOATS = 64;     // logits
 constexpr int LDS_BYTES = BS + 1024 + HEAD_FLOATS * 4; // (+1024: the operand prefetch of the last k-step reads past T)
 constexpr float S1 = 1.0f / 2048.0f, S2 = 1.0f / (2048.0f * 2048.0f);
@@ -48,15 +51,6 @@ struct PolicyParams {
     int64_t row_lo, row_hi;
 };
 
-// (conv_trunk_kernel.hip) ds_read_b128 serves lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}
-// in separate LDS cycles; with this lane -> cell map and rows 4 banks apart (RS = 16 mod 256) the
-// 16 lanes of a cycle hit 16 different 4-bank groups for every tap.
-__device__ __forceinline__ int cell_of_lane(int r)
-{
-    return r < 4 ? r : r < 12 ? 16 + (r - 4) : r < 16 ? 4 + (r - 12) : r < 20 ? 24 + (r - 16) : r < 28 ? 8 + (r - 20)
-                                                                                              : 28 + (r - 28);
-}
-
 // a -> (hi, mid, lo) with a == hi + mid 2^-11 + lo 2^-22 exactly (every difference is exact)
 __device__ __forceinline__ void split3(const f2 v, h2 &hi, h2 &mid, h2 &lo)
 {
@@ -72,7 +66,7 @@ extern __shared__ __align__(16) char policy_lds[];
 __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t row_id)
 {
     char *const T = policy_lds;
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int64_t b = P.index ? P.index[row_id] : row_id;
 
     // ---- the zero area, then block1 (3x3, 2 -> 64, bias, ReLU; network.py:17-19) in float32
@@ -130,132 +124,161 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
     }
     __syncthreads();
 
-    // ---- per-lane addresses of the B operand: cell 32 j + cell_of_lane(r), tap (ky, kx); an
-    // out-of-board tap reads zeros from the slot with the bank offset its cell would have had
-    const int lane_cell = cell_of_lane(r);
-    uint32_t addr[2][9];
+    // ---- per-lane addresses of the B operand.  The K loop runs on v_mfma_f32_16x16x32_f16 (conv_trunk_body.hpp says
+    // why): lane = (column c16 = lane & 15, k quarter kq = lane >> 4); a k-step covers 32 input channels = two
+    // 16-channel chunks at one tap, a B tile is 16 cells (quarter q of the board) x 32 channels: this lane reads cell
+    // 16 q + c16, 16 bytes at + 16 kq of the chunk pair, tap (ky, kx); an out-of-board tap reads zeros from the slot with
+    // the bank offset its row would have had (rows are 2 x 16 B apart mod 256 B)
+    const int c16 = lane & 15, kq = lane >> 4;
+    uint32_t addr[4][9];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            const int cell = 32 * j + lane_cell;
+            const int cell = 16 * q + c16;
             const int yy = (cell >> 3) + tap / 3 - 1, xx = (cell & 7) + tap % 3 - 1;
             const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
-            const int lin = (cell + (tap / 3 - 1) * 8 + (tap % 3 - 1)) & 15;
-            addr[j][tap] = (uint32_t)((ok ? (yy * 8 + xx) * RS : 64 * RS + 16 * lin) + h * 16);
+            const int lin = (cell + (tap / 3 - 1) * 8 + (tap % 3 - 1)) & 7;
+            addr[q][tap] = (uint32_t)((ok ? (yy * 8 + xx) * RS : 64 * RS + 32 * lin) + kq * 16);
         }
-    uint32_t wrow[2];
+    uint32_t wrow[4];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-        wrow[j] = (uint32_t)((32 * j + lane_cell) * RS);
+    for (int q = 0; q < 4; q++)
+        wrow[q] = (uint32_t)((16 * q + c16) * RS);
 
     for (int L = P.layer_lo; L < P.layer_hi; L++) {
-        const int n_chunks = L == 0 ? 4 : 8;
-        // this lane's A operand: output channel 32 wv + r, input channels 8 h .. 8 h + 7 of the
-        // k-step's chunk; a k-step (chunk, tap) is 128 x 32 B further
-        const u32x4 *wh = (const u32x4 *)P.w_hi[L] + (32 * wv + r) * 2 + h;
-        const u32x4 *wm = (const u32x4 *)P.w_mid[L] + (32 * wv + r) * 2 + h;
-        const u32x4 *wl = (const u32x4 *)P.w_lo[L] + (32 * wv + r) * 2 + h;
-        float16v acc0[2], acc1[2], acc2[2];
+        const int n_pairs = L == 0 ? 2 : 4; // chunk pairs of 32 input channels
+        // this lane's A operands: output channels 32 wv + c16 (M tile 0) and + 16 (M tile 1), input channels
+        // 8 (kq & 1) .. + 7 of chunk 2 cp + (kq >> 1); a chunk is 9 x 128 x 32 B, a tap 128 x 32 B further
+        const int a_off = (32 * wv + c16) * 2 + (kq & 1) + (kq >> 1) * (9 * 256);
+        const u32x4 *wh = (const u32x4 *)P.w_hi[L] + a_off;
+        const u32x4 *wm = (const u32x4 *)P.w_mid[L] + a_off;
+        const u32x4 *wl = (const u32x4 *)P.w_lo[L] + a_off;
+        float4v acc0[2][4], acc1[2][4], acc2[2][4];
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int m = 0; m < 2; m++)
 #pragma unroll
-            for (int v = 0; v < 16; v++) {
-                acc0[j][v] = 0.0f;
-                acc1[j][v] = 0.0f;
-                acc2[j][v] = 0.0f;
-            }
-        const int n_steps = 9 * n_chunks;
-        u32x4 a_hi[3], a_mid[3], a_lo[3]; // k-steps s, s + 1, s + 2 (ring index = tap % 3)
-        a_hi[0] = wh[0], a_mid[0] = wm[0], a_lo[0] = wl[0];
-        a_hi[1] = wh[256], a_mid[1] = wm[256], a_lo[1] = wl[256];
-        // B operands two tiles ahead of their MFMAs (three register sets); a tile = 6 MFMAs here
+            for (int n = 0; n < 4; n++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    acc0[m][n][v] = 0.0f;
+                    acc1[m][n][v] = 0.0f;
+                    acc2[m][n][v] = 0.0f;
+                }
+        u32x4 a_hi[3][2], a_mid[3][2], a_lo[3][2]; // k-steps s, s + 1, s + 2 (ring index = tap % 3) x the two M tiles
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            a_hi[i][0] = wh[i * 256], a_hi[i][1] = wh[i * 256 + 32];
+            a_mid[i][0] = wm[i * 256], a_mid[i][1] = wm[i * 256 + 32];
+            a_lo[i][0] = wl[i * 256], a_lo[i][1] = wl[i * 256 + 32];
+        }
+        // B operands two tiles ahead of their MFMAs (three register sets); a tile = 12 MFMAs here
         half8 bh[3], bm[3], bl[3];
-        auto b_addr = [&](int tile18) -> const char * {
-            // tile18 = tap * 2 + j of the running chunk; 18, 19 = the first two tiles of the next chunk
-            const int over = tile18 >= 18 ? 32 : 0, tt = tile18 % 18;
-            return T + addr[tt & 1][tt >> 1] + over;
+        auto b_addr = [&](int tile) -> const char * {
+            // tile = tap * 4 + q of the running chunk pair; 36, 37 = the first two tiles of the next pair
+            const int over = tile >= 36 ? 64 : 0, tt = tile % 36;
+            return T + addr[tt & 3][tt >> 2] + over;
         };
         {
             const char *p0 = b_addr(0), *p1 = b_addr(1);
             bh[0] = *(const half8 *)p0, bm[0] = *(const half8 *)(p0 + 256), bl[0] = *(const half8 *)(p0 + 512);
             bh[1] = *(const half8 *)p1, bm[1] = *(const half8 *)(p1 + 256), bl[1] = *(const half8 *)(p1 + 512);
         }
-        for (int c = 0; c < n_chunks; c++) {
+        for (int cp = 0; cp < n_pairs; cp++) {
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
-                const int s = c * 9 + tap;
-                const int s2 = min(s + 2, n_steps - 1); // the last two prefetches repeat the last k-step
-                a_hi[(tap + 2) % 3] = wh[(int64_t)s2 * 256];
-                a_mid[(tap + 2) % 3] = wm[(int64_t)s2 * 256];
-                a_lo[(tap + 2) % 3] = wl[(int64_t)s2 * 256];
-                const half8 ah = __builtin_bit_cast(half8, a_hi[tap % 3]);
-                const half8 am = __builtin_bit_cast(half8, a_mid[tap % 3]);
-                const half8 al = __builtin_bit_cast(half8, a_lo[tap % 3]);
+                // k-step s + 2 (the last two prefetches repeat the last k-step): weights at (18 cp + tap) x 256
+                int cp2 = cp, tp2 = tap + 2;
+                if (tp2 >= 9) {
+                    tp2 -= 9;
+                    cp2 += 1;
+                }
+                if (cp2 >= n_pairs) {
+                    cp2 = n_pairs - 1;
+                    tp2 = 8;
+                }
+                const int64_t w2 = (int64_t)(18 * cp2 + tp2) * 256;
+                a_hi[(tap + 2) % 3][0] = wh[w2], a_hi[(tap + 2) % 3][1] = wh[w2 + 32];
+                a_mid[(tap + 2) % 3][0] = wm[w2], a_mid[(tap + 2) % 3][1] = wm[w2 + 32];
+                a_lo[(tap + 2) % 3][0] = wl[w2], a_lo[(tap + 2) % 3][1] = wl[w2 + 32];
+                half8 ah[2], am[2], al[2];
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int tile = tap * 2 + j, cur = tile % 3, nxt = (tile + 2) % 3;
+                for (int m = 0; m < 2; m++) {
+                    ah[m] = __builtin_bit_cast(half8, a_hi[tap % 3][m]);
+                    am[m] = __builtin_bit_cast(half8, a_mid[tap % 3][m]);
+                    al[m] = __builtin_bit_cast(half8, a_lo[tap % 3][m]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int tile = tap * 4 + q, cur = tile % 3, nxt = (tile + 2) % 3;
                     const char *p = b_addr(tile + 2);
                     bh[nxt] = *(const half8 *)p;
                     bm[nxt] = *(const half8 *)(p + 256);
                     bl[nxt] = *(const half8 *)(p + 512);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cur], acc0[j], 0, 0, 0);
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm[cur], acc1[j], 0, 0, 0);
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh[cur], acc1[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[cur], acc2[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cur], acc2[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bm[cur], acc2[j], 0, 0, 0);
+                    IAGO_POLICY_MFMA16(acc0[0][q], ah[0], bh[cur]);
+                    IAGO_POLICY_MFMA16(acc0[1][q], ah[1], bh[cur]);
+                    IAGO_POLICY_MFMA16(acc1[0][q], ah[0], bm[cur]);
+                    IAGO_POLICY_MFMA16(acc1[1][q], ah[1], bm[cur]);
+                    IAGO_POLICY_MFMA16(acc2[0][q], ah[0], bl[cur]);
+                    IAGO_POLICY_MFMA16(acc2[1][q], ah[1], bl[cur]);
+                    IAGO_POLICY_MFMA16(acc1[0][q], am[0], bh[cur]);
+                    IAGO_POLICY_MFMA16(acc1[1][q], am[1], bh[cur]);
+                    IAGO_POLICY_MFMA16(acc2[0][q], al[0], bh[cur]);
+                    IAGO_POLICY_MFMA16(acc2[1][q], al[1], bh[cur]);
+                    IAGO_POLICY_MFMA16(acc2[0][q], am[0], bm[cur]);
+                    IAGO_POLICY_MFMA16(acc2[1][q], am[1], bm[cur]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // next chunk of 16 input channels: 32 B further in every row
+            // next chunk pair of 32 input channels: 64 B further in every row
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int q = 0; q < 4; q++)
 #pragma unroll
                 for (int tap = 0; tap < 9; tap++)
-                    addr[j][tap] += 32u;
+                    addr[q][tap] += 64u;
         }
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int q = 0; q < 4; q++)
 #pragma unroll
             for (int tap = 0; tap < 9; tap++)
-                addr[j][tap] -= 32u * (uint32_t)n_chunks;
+                addr[q][tap] -= 64u * (uint32_t)n_pairs;
 
         // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T.
-        // D row m = 8 q + 4 h + t (v = 4 q + t): channel 32 wv + m of cell 32 j + lane_cell
-        f2 bia[8];
+        // D row 4 kq + v of M tile m, column c16: channel 32 wv + 16 m + 4 kq + v of cell 16 q + c16
+        f2 bia[2][2];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 bq = *(const float4 *)(P.bias[L] + 32 * wv + 8 * q + 4 * h);
-            bia[2 * q] = (f2){bq.x, bq.y};
-            bia[2 * q + 1] = (f2){bq.z, bq.w};
+        for (int m = 0; m < 2; m++) {
+            const float4 bq = *(const float4 *)(P.bias[L] + 32 * wv + 16 * m + 4 * kq);
+            bia[m][0] = (f2){bq.x, bq.y};
+            bia[m][1] = (f2){bq.z, bq.w};
         }
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); // (inline-asm MFMAs: their results land 4 passes after issue)
         __syncthreads();
         float vmax = 0.0f;
         f2 vsum = (f2){0.0f, 0.0f};
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            char *row = T + wrow[j] + (32 * wv + 4 * h) * 2;
+        for (int q = 0; q < 4; q++) {
+            char *row = T + wrow[q] + (32 * wv + 4 * kq) * 2;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int m = 0; m < 2; m++) {
                 h2 p0[2], p1[2], p2[2];
 #pragma unroll
                 for (int t2 = 0; t2 < 2; t2++) {
-                    const f2 m0 = (f2){acc0[j][4 * q + 2 * t2], acc0[j][4 * q + 2 * t2 + 1]};
-                    const f2 m1 = (f2){acc1[j][4 * q + 2 * t2], acc1[j][4 * q + 2 * t2 + 1]};
-                    const f2 m2 = (f2){acc2[j][4 * q + 2 * t2], acc2[j][4 * q + 2 * t2 + 1]};
-                    f2 v = (m2 * S2 + m1 * S1) + m0 + bia[2 * q + t2];
+                    const f2 m0 = (f2){acc0[m][q][2 * t2], acc0[m][q][2 * t2 + 1]};
+                    const f2 m1 = (f2){acc1[m][q][2 * t2], acc1[m][q][2 * t2 + 1]};
+                    const f2 m2 = (f2){acc2[m][q][2 * t2], acc2[m][q][2 * t2 + 1]};
+                    f2 v = (m2 * S2 + m1 * S1) + m0 + bia[m][t2];
                     vmax = fmaxf(fmaxf(vmax, v.x), v.y);
                     vsum += v;
                     v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 65000.0f);
                     v.y = __builtin_amdgcn_fmed3f(v.y, 0.0f, 65000.0f);
                     split3(v, p0[t2], p1[t2], p2[t2]);
                 }
-                *(uint2 *)(row + 16 * q) = (uint2){__builtin_bit_cast(uint32_t, p0[0]), __builtin_bit_cast(uint32_t, p0[1])};
-                *(uint2 *)(row + 16 * q + 256) =
+                *(uint2 *)(row + 32 * m) = (uint2){__builtin_bit_cast(uint32_t, p0[0]), __builtin_bit_cast(uint32_t, p0[1])};
+                *(uint2 *)(row + 32 * m + 256) =
                     (uint2){__builtin_bit_cast(uint32_t, p1[0]), __builtin_bit_cast(uint32_t, p1[1])};
-                *(uint2 *)(row + 16 * q + 512) =
+                *(uint2 *)(row + 32 * m + 512) =
                     (uint2){__builtin_bit_cast(uint32_t, p2[0]), __builtin_bit_cast(uint32_t, p2[1])};
             }
         }

@@ -14,7 +14,7 @@
 // with its own summation order, at 16 / 6 = 2.7x the float32 MFMA rate.
 //
 // Structure: conv_trunk_kernel.hip's LDS-resident walk with ONE board per workgroup: the
-// activations of the board (64 cell rows of 128 channels x 3 pieces = 784 B + zero area, 51 KB)
+// activations of the board (64 cell rows of 128 channels x 3 pieces = 800 B + zero area, 52 KB)
 // stay in LDS from block1 to the head, the weights go from L2 straight into the A-operand
 // registers (each wave its quarter of the output channels), the head (1x1 convolution, per-cell
 // bias, softmax: network.py:29-47) is computed from LDS.  Rows come from own / opp through an
@@ -64,7 +64,7 @@ int iago_policy_forward_split3(const iago_policy_split3_args *a, void *stream)
     const int parts = a->parts < 1 ? 1 : (a->parts > 7 ? 7 : a->parts);
     if (parts > 1 && (!a->scratch || ((uintptr_t)a->scratch & 15u)))
         return iago_fail(IAGO_ERR_INVALID, "iago_policy_forward_split3: parts > 1 needs a 16-byte aligned scratch "
-                                           "buffer of n x 50,176 bytes");
+                                           "buffer of n x 51,200 bytes");
     P.scratch = (uint4 *)a->scratch;
     // scratch_rows > 0: the scratch holds that many rows; a longer batch runs as chunks of
     // scratch_rows rows, each chunk its `parts` launches (launches of one stream run in order, so

@@ -15,16 +15,23 @@ namespace iago_trunk {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-constexpr int RS = 528;            // bytes of a cell row: 128 ch hi | 128 ch lo | 16 B (bank skew)
-constexpr int ZB = 768;            // zero bytes behind a board's 64 rows: the target of every out-of-board tap
+constexpr int RS = 544;            // bytes of a cell row: 128 ch hi | 128 ch lo | 32 B (bank skew: rows 2 x 16 B apart mod 256)
+constexpr int ZB = 1024;           // zero bytes behind a board's 64 rows: the target of every out-of-board tap
 constexpr int BS = 64 * RS + ZB;   // bytes of a board
 // boards per workgroup TB = 4 (138,240 B of LDS) or 2 (small batches: half the latency per workgroup)
 constexpr int lds_alloc(int tb) { return tb * BS + 1024; } // the operand prefetch of the last k-step reads up to 48 B past T
 constexpr int MAX_LAYERS = 8;
+
+// v_mfma_f32_16x16x32_f16 with the accumulator in place (AGPRs).  Why this shape: on random data the chip holds a
+// higher clock under the 16x16x32 form than under 32x32x16 at equal FLOPs per cycle (MI355X_MICROARCH.md, DVFS item 7;
+// tools/exp_mfma_shape2.hip).  Why inline asm: through the builtin hipcc gives a float4 accumulator a destination that
+// is not its source C and moves the accumulators around every MFMA (7 v_accvgpr_* per MFMA: LABNOTES.md, round 5).
+#define IAGO_MFMA16(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 
 struct TrunkRParams {
     const uint4 *x_hi, *x_lo;   // input of layer 0  [n][cin0/16][64][16] f16
@@ -85,8 +92,7 @@ extern __shared__ __align__(16) char trunk_lds[];
 template <bool FUSED, int TB>
 __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W, const int64_t b0, const int64_t n_rows)
 {
-    constexpr int NT = 2 * TB;      // 32-cell tiles of a wave: TB boards x 2 halves
-    constexpr int NPAIR = (TB + 1) / 2; // board pairs (address sets)
+    constexpr int NN = 4 * TB;      // 16-cell B tiles of a k-step: TB boards x 4 quarters
     char *const T = trunk_lds;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
 
@@ -194,65 +200,64 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
     }
     __syncthreads();
 
-    // ---- per-lane addresses of the B operand: cell 32 j + cell_of_lane(r), tap (ky, kx);
-    // boards 0/1 through `lo_pair`, boards 2/3 through `hi_pair` (+ an immediate BS for the
-    // odd board); the hi / lo halves of a row are 256 B apart (immediate)
-    const int lane_cell = cell_of_lane(r);
-    uint32_t addr[NPAIR][2][9]; // [board pair][j][tap]
+    // ---- per-lane addresses of the B operand.  The K loop runs on v_mfma_f32_16x16x32_f16: lane = (column c16 =
+    // lane & 15, k quarter kq = lane >> 4); a k-step covers 32 input channels = two 16-channel chunks at one tap,
+    // a B tile is 16 cells (quarter q of a board) x 32 channels: this lane reads cell 16 q + c16, channels 8 kq ..
+    // 8 kq + 7 of the chunk pair (16 bytes at + 16 kq), tap (ky, kx).  Boards 0 / 1 through addr (+ an immediate BS
+    // for the odd board), boards 2 / 3 by adding 2 BS; the hi / lo halves of a row are 256 B apart (immediate)
+    const int c16 = lane & 15, kq = lane >> 4;
+    uint32_t addr[4][9]; // [quarter][tap]
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            const int cell = 32 * j + lane_cell;
+            const int cell = 16 * q + c16;
             const int yy = (cell >> 3) + tap / 3 - 1, xx = (cell & 7) + tap % 3 - 1;
             const bool ok = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
-            // an out-of-board tap reads zeros from the slot with the bank offset its cell would
-            // have had (16 B per cell index mod 16): the 16 lanes of an LDS cycle keep 16
-            // different 4-bank groups whether or not some of them are redirected
-            const int lin = (cell + (tap / 3 - 1) * 8 + (tap % 3 - 1)) & 15;
-            const uint32_t a = (uint32_t)((ok ? (yy * 8 + xx) * RS : 64 * RS + 16 * lin) + h * 16);
-#pragma unroll
-            for (int pr = 0; pr < NPAIR; pr++)
-                addr[pr][j][tap] = a + (uint32_t)(pr * 2 * BS);
+            // an out-of-board tap reads zeros from the slot with the bank offset its row would have had (rows are
+            // 2 x 16 B apart mod 256 B: 32 B per row index mod 8): the 16 lanes of an LDS cycle keep 16 different
+            // 4-bank groups whether or not some of them are redirected
+            const int lin = (cell + (tap / 3 - 1) * 8 + (tap % 3 - 1)) & 7;
+            addr[q][tap] = (uint32_t)((ok ? (yy * 8 + xx) * RS : 64 * RS + 32 * lin) + kq * 16);
         }
-    // rows this lane writes in the epilogue (its cells), same pairing
-    uint32_t wrow[NPAIR][2];
+    // rows this lane writes in the epilogue (its cell of every quarter)
+    uint32_t wrow[4];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int pr = 0; pr < NPAIR; pr++)
-            wrow[pr][j] = (uint32_t)((32 * j + lane_cell) * RS + pr * 2 * BS);
+    for (int q = 0; q < 4; q++)
+        wrow[q] = (uint32_t)((16 * q + c16) * RS);
 
     const int L_lo = PIECES ? W.layer_lo : 0, L_hi = PIECES ? W.layer_hi : P.n_layers;
     for (int L = L_lo; L < L_hi; L++) {
-        const int n_chunks = L == 0 ? (P.cin0 >> 4) : 8;
-        // this lane's A operand: output channel 32 wv + r, input channels 8 h .. 8 h + 7 of
-        // the k-step's chunk; a k-step (chunk, tap) is 128 x 32 B further
-        const u32x4 *wh = (const u32x4 *)P.w_hi[L] + (32 * wv + r) * 2 + h;
-        const u32x4 *wl = (const u32x4 *)P.w_lo[L] + (32 * wv + r) * 2 + h;
-        float16v acc_main[NT], acc_cross[NT];
+        const int n_pairs = L == 0 ? (P.cin0 >> 5) : 4; // chunk pairs: 32 input channels each
+        // this lane's A operands: output channels 32 wv + c16 (M tile 0) and + 16 (M tile 1), input channels
+        // 8 (kq & 1) .. + 7 of chunk 2 cp + (kq >> 1); a chunk is 9 x 128 x 32 B, a tap 128 x 32 B further
+        const u32x4 *wh = (const u32x4 *)P.w_hi[L] + (32 * wv + c16) * 2 + (kq & 1) + (kq >> 1) * (9 * 256);
+        const u32x4 *wl = (const u32x4 *)P.w_lo[L] + (32 * wv + c16) * 2 + (kq & 1) + (kq >> 1) * (9 * 256);
+        float4v acc_main[2][NN], acc_cross[2][NN];
 #pragma unroll
-        for (int j8 = 0; j8 < NT; j8++)
+        for (int m = 0; m < 2; m++)
 #pragma unroll
-            for (int v = 0; v < 16; v++) {
-                acc_main[j8][v] = 0.0f;
-                acc_cross[j8][v] = 0.0f;
-            }
+            for (int n = 0; n < NN; n++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    acc_main[m][n][v] = 0.0f;
+                    acc_cross[m][n][v] = 0.0f;
+                }
 
-        const int n_steps = 9 * n_chunks;
-        u32x4 a_hi[3], a_lo[3]; // k-steps s, s + 1, s + 2 (ring index = tap % 3)
-        a_hi[0] = wh[0];
-        a_lo[0] = wl[0];
-        a_hi[1] = wh[256];
-        a_lo[1] = wl[256];
-        // B operands TWO tiles ahead of the MFMAs that use them (three register sets): an LDS
-        // read issued now has six MFMAs (192 cycles) to arrive; one tile ahead left every
-        // group of three waiting (measured: 72 us of a 1024-board forward, tools/exp_trunk_variants.sh)
+        // k-steps of 32 input channels: s = 9 cp + tap, 9 n_pairs of them
+        u32x4 a_hi[3][2], a_lo[3][2]; // k-steps s, s + 1, s + 2 (ring index = tap % 3) x the two M tiles
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            a_hi[i][0] = wh[i * 256], a_hi[i][1] = wh[i * 256 + 32];
+            a_lo[i][0] = wl[i * 256], a_lo[i][1] = wl[i * 256 + 32];
+        }
+        // B operands TWO tiles ahead of the MFMAs that use them (three register sets): an LDS read issued now
+        // has twelve MFMAs (192 cycles) to arrive
         half8 bh[3], bl[3];
-        auto b_addr = [&](int tile72) -> const char * {
-            // tile72 = tap * NT + j8 of the running chunk; 9 NT, 9 NT + 1 = the first two tiles of the next chunk
-            const int over = tile72 >= 9 * NT ? 32 : 0, tt = tile72 % (9 * NT), tp = tt / NT, jj = tt % NT;
-            return T + addr[jj >> 2][jj & 1][tp] + ((jj >> 1) & 1) * BS + over;
+        auto b_addr = [&](int tile) -> const char * {
+            // tile = tap * NN + n of the running chunk pair; 9 NN, 9 NN + 1 = the first two tiles of the next pair
+            const int over = tile >= 9 * NN ? 64 : 0, tt = tile % (9 * NN), tp = tt / NN, n = tt % NN;
+            return T + addr[n & 3][tp] + (n >> 2) * BS + over;
         };
         {
             const char *p0 = b_addr(0), *p1 = b_addr(1);
@@ -261,56 +266,67 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
             bh[1] = *(const half8 *)p1;
             bl[1] = *(const half8 *)(p1 + 256);
         }
-        for (int c = 0; c < n_chunks; c++) {
+        for (int cp = 0; cp < n_pairs; cp++) {
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
-                const int s = c * 9 + tap;
-                const int s2 = min(s + 2, n_steps - 1); // the last two prefetches repeat the last k-step
-                a_hi[(tap + 2) % 3] = wh[(int64_t)s2 * 256];
-                a_lo[(tap + 2) % 3] = wl[(int64_t)s2 * 256];
-                const half8 ah = __builtin_bit_cast(half8, a_hi[tap % 3]);
-                const half8 al = __builtin_bit_cast(half8, a_lo[tap % 3]);
+                // k-step s + 2 (the last two prefetches repeat the last k-step): weights at (18 cp + tap) x 256
+                int cp2 = cp, tp2 = tap + 2;
+                if (tp2 >= 9) {
+                    tp2 -= 9;
+                    cp2 += 1;
+                }
+                if (cp2 >= n_pairs) {
+                    cp2 = n_pairs - 1;
+                    tp2 = 8;
+                }
+                const int64_t w2 = (int64_t)(18 * cp2 + tp2) * 256;
+                a_hi[(tap + 2) % 3][0] = wh[w2], a_hi[(tap + 2) % 3][1] = wh[w2 + 32];
+                a_lo[(tap + 2) % 3][0] = wl[w2], a_lo[(tap + 2) % 3][1] = wl[w2 + 32];
+                const half8 ah0 = __builtin_bit_cast(half8, a_hi[tap % 3][0]), ah1 = __builtin_bit_cast(half8, a_hi[tap % 3][1]);
+                const half8 al0 = __builtin_bit_cast(half8, a_lo[tap % 3][0]), al1 = __builtin_bit_cast(half8, a_lo[tap % 3][1]);
 #pragma unroll
-                for (int j8 = 0; j8 < NT; j8++) {
-                    const int tile = tap * NT + j8, cur = tile % 3, nxt = (tile + 2) % 3;
-                    // (past the last chunk: harmless reads 32 B further in the same rows)
+                for (int n = 0; n < NN; n++) {
+                    const int tile = tap * NN + n, cur = tile % 3, nxt = (tile + 2) % 3;
+                    // (past the last chunk pair: harmless reads 64 B further in the same rows)
                     const char *p = b_addr(tile + 2);
                     bh[nxt] = *(const half8 *)p;
                     bl[nxt] = *(const half8 *)(p + 256);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc_main[j8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cur], acc_main[j8], 0, 0, 0);
-                    acc_cross[j8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[cur], acc_cross[j8], 0, 0, 0);
-                    acc_cross[j8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cur], acc_cross[j8], 0, 0, 0);
+                    IAGO_MFMA16(acc_main[0][n], ah0, bh[cur]);
+                    IAGO_MFMA16(acc_main[1][n], ah1, bh[cur]);
+                    IAGO_MFMA16(acc_cross[0][n], ah0, bl[cur]);
+                    IAGO_MFMA16(acc_cross[1][n], ah1, bl[cur]);
+                    IAGO_MFMA16(acc_cross[0][n], al0, bh[cur]);
+                    IAGO_MFMA16(acc_cross[1][n], al1, bh[cur]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // next chunk of 16 input channels: 32 B further in every row (the zero rows are
-            // 528 B of zeros: their addresses move along)
+            // next chunk pair of 32 input channels: 64 B further in every row (the zero rows are RS bytes of
+            // zeros and more: their addresses move along)
 #pragma unroll
-            for (int pr = 0; pr < NPAIR; pr++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int tap = 0; tap < 9; tap++)
-                        addr[pr][j][tap] += 32u;
-        }
-#pragma unroll
-        for (int pr = 0; pr < NPAIR; pr++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int q = 0; q < 4; q++)
 #pragma unroll
                 for (int tap = 0; tap < 9; tap++)
-                    addr[pr][j][tap] -= 32u * (uint32_t)n_chunks;
+                    addr[q][tap] += 64u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++)
+                addr[q][tap] -= 64u * (uint32_t)n_pairs;
 
         // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T
-        // bias of the 16 channels this lane finishes: 32 wv + 8 q + 4 h + t
-        f2 bia[8];
+        // bias of the 8 channels this lane finishes: 32 wv + 16 m + 4 kq + v
+        f2 bia[2][2];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 bq = *(const float4 *)(P.bias[L] + 32 * wv + 8 * q + 4 * h);
-            bia[2 * q] = (f2){bq.x, bq.y};
-            bia[2 * q + 1] = (f2){bq.z, bq.w};
+        for (int m = 0; m < 2; m++) {
+            const float4 bq = *(const float4 *)(P.bias[L] + 32 * wv + 16 * m + 4 * kq);
+            bia[m][0] = (f2){bq.x, bq.y};
+            bia[m][1] = (f2){bq.z, bq.w};
         }
+        // (the MFMAs above are inline asm: the compiler does not know that their results land 4 passes after issue;
+        // the barrier alone is hundreds of cycles, the s_nop makes the read-after-MFMA distance explicit)
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
         __syncthreads();
         // One wave per SIMD pays 4 cycles per instruction: packed float32 math, v_med3 for the
         // clamp, v_cvt_pk_f16_f32; the range check is a running maximum and a running sum (a
@@ -318,17 +334,17 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
         float vmax = 0.0f;
         f2 vsum = (f2){0.0f, 0.0f};
 #pragma unroll
-        for (int j8 = 0; j8 < NT; j8++) {
-            const int bb = j8 >> 1, j = j8 & 1;
-            char *row = T + wrow[bb >> 1][j] + (bb & 1) * BS + (32 * wv + 4 * h) * 2;
+        for (int n = 0; n < NN; n++) {
+            // D row 4 kq + v of M tile m, column c16: channel 32 wv + 16 m + 4 kq + v of cell 16 (n & 3) + c16, board n >> 2
+            char *row = T + wrow[n & 3] + (n >> 2) * BS + (32 * wv + 4 * kq) * 2;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int m = 0; m < 2; m++) {
                 h2 hi[2], lo[2];
 #pragma unroll
                 for (int t2 = 0; t2 < 2; t2++) {
-                    const f2 m = (f2){acc_main[j8][4 * q + 2 * t2], acc_main[j8][4 * q + 2 * t2 + 1]};
-                    const f2 c = (f2){acc_cross[j8][4 * q + 2 * t2], acc_cross[j8][4 * q + 2 * t2 + 1]};
-                    f2 v = c * (1.0f / 2048.0f) + m + bia[2 * q + t2];
+                    const f2 mm = (f2){acc_main[m][n][2 * t2], acc_main[m][n][2 * t2 + 1]};
+                    const f2 c = (f2){acc_cross[m][n][2 * t2], acc_cross[m][n][2 * t2 + 1]};
+                    f2 v = c * (1.0f / 2048.0f) + mm + bia[m][t2];
                     vmax = fmaxf(fmaxf(vmax, v.x), v.y);
                     vsum += v;
                     v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 65000.0f);
@@ -336,8 +352,8 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                     hi[t2] = __builtin_convertvector(v, h2);
                     lo[t2] = __builtin_convertvector((v - __builtin_convertvector(hi[t2], f2)) * 2048.0f, h2);
                 }
-                *(uint2 *)(row + 16 * q) = (uint2){__builtin_bit_cast(uint32_t, hi[0]), __builtin_bit_cast(uint32_t, hi[1])};
-                *(uint2 *)(row + 16 * q + 256) =
+                *(uint2 *)(row + 32 * m) = (uint2){__builtin_bit_cast(uint32_t, hi[0]), __builtin_bit_cast(uint32_t, hi[1])};
+                *(uint2 *)(row + 32 * m + 256) =
                     (uint2){__builtin_bit_cast(uint32_t, lo[0]), __builtin_bit_cast(uint32_t, lo[1])};
             }
         }
@@ -373,6 +389,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
         for (int c = 0; c < 16; c++)
             w10row[c] = ((const float4 *)(P.w10 + (tid & 127) * 64))[c];
         const float w11j = P.w11[tid & 127];
+        const int lane_cell = cell_of_lane(r); // (this block's 32x32x16 lane map: output row r, k half h)
         if (wv < TB) { // wave wv takes board wv
             const u32x4 *w9h = (const u32x4 *)P.w9_hi + r * 2 + h;
             const u32x4 *w9l = (const u32x4 *)P.w9_lo + r * 2 + h;
@@ -391,7 +408,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
 #pragma unroll
                 for (int jt = 0; jt < 2; jt++) {
                     const int jj = 2 * wv + jt; // wave-uniform: board jj >> 1, cell half jj & 1
-                    const char *p = T + addr[0][jt][4] + (uint32_t)((jj >> 2) * 2 * BS + ((jj >> 1) & 1) * BS + c * 32);
+                    const char *p = T + (jj >> 1) * BS + (32 * (jj & 1) + lane_cell) * RS + h * 16 + c * 32; // centre tap
                     const half8 bh9 = *(const half8 *)p, bl9 = *(const half8 *)(p + 256);
                     hm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh9, hm[jt], 0, 0, 0);
                     hc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl9, hc[jt], 0, 0, 0);

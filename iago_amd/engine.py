@@ -1202,7 +1202,7 @@ class BatchedMCTS(object):
         """Device memory this engine holds, by part: the tree pools (32-byte node records;
         twice that once compact() has allocated its second pool), the look-ahead's
         prior cache ([game][slot][64] float32) and queues, the recorded paths, and the policy
-        net's scratch for its multi-launch forward (network.SLPolicy.SPLIT3_SCRATCH_ROWS x 50,176 B
+        net's scratch for its multi-launch forward (network.SLPolicy.SPLIT3_SCRATCH_ROWS x 51,200 B
         = 205 MB per stream that calls it -- the search uses up to three: eager, capture, side
         stream -- bounded whatever n_games is; longer batches run in chunks)."""
         out = {"tree": self.tree.bytes()}

@@ -222,7 +222,7 @@ class SLPolicy(nn.Module, _NpzMixin):
                                                       n_dev=n_dev, overflow=overflow, parts=self.split3_parts,
                                                       scratch=scratch)
 
-    # rows of a multi-launch forward's scratch buffer: 4096 x 50,176 B = 205 MB per stream that
+    # rows of a multi-launch forward's scratch buffer: 4096 x 51,200 B = 205 MB per stream that
     # calls the net, whatever the batch (a longer batch runs as chunks of this many rows)
     SPLIT3_SCRATCH_ROWS = 4096
 

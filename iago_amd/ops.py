@@ -314,7 +314,7 @@ def split_weights3_many(weights):
     return out
 
 
-POLICY_SCRATCH_ROW_BYTES = 50176   # a board's LDS image in iago_policy_forward_split3 (64 rows of 784 B)
+POLICY_SCRATCH_ROW_BYTES = 51200   # a board's LDS image in iago_policy_forward_split3 (64 rows of 800 B)
 
 
 def policy_split3_prepare(w1, b1, layers, w9, b10):

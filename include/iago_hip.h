@@ -323,7 +323,7 @@ typedef struct iago_policy_split3_args {
     int32_t scratch_rows;   /* parts > 1: rows the scratch holds; 0 = n.  A batch of more rows runs as chunks of
                                scratch_rows rows (each chunk its `parts` launches), so the scratch stays bounded
                                whatever n is */
-    void *scratch;          /* parts > 1: [scratch_rows or n][50,176] bytes, a board's activations between the
+    void *scratch;          /* parts > 1: [scratch_rows or n][51,200] bytes, a board's activations between the
                                launches */
 } iago_policy_split3_args;
 IAGO_API int iago_policy_forward_split3(const iago_policy_split3_args *args, void *stream);
@@ -597,7 +597,7 @@ IAGO_API int iago_mcts_compact(const iago_mcts_tree *tree, const iago_mcts_tree 
  * (one word, any value), n_sims (one word: playouts per game of this search), scratch
  * [parts][n_games][IAGO_VALUE_IMAGE_BYTES].
  */
-#define IAGO_VALUE_IMAGE_BYTES 33792   /* a board's activations between two pieces: 64 cells x 528 B */
+#define IAGO_VALUE_IMAGE_BYTES 34816   /* a board's activations between two pieces: 64 cells x 544 B */
 #define IAGO_ASYNC_MAX_PARTS 4
 typedef struct iago_mcts_async {
     int32_t parts;           /* pieces of the value net = steps a fresh leaf waits: 2..IAGO_ASYNC_MAX_PARTS */

@@ -84,13 +84,91 @@ def phase_stamps(s):
     return s
 
 
+STAMP_DEFS = """
+// ---- diagnostic build only (tools/build_search_variants.py: search_walkstamps.so)
+__device__ unsigned long long iago_walk_stamps[192];
+__device__ __forceinline__ void iago_stamp(unsigned long long *st, int i)
+{
+    if (threadIdx.x == 0)
+        st[i] = __builtin_amdgcn_s_memrealtime();
+}
+"""
+
+WALK_END = """
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+            unsigned long long *g = iago_trunk::iago_walk_stamps + KINDBASE;
+            WST[23] = __builtin_amdgcn_s_memrealtime();
+            for (int i = 0; i < 23; i++)
+                atomicAdd(&g[i], WST[i + 1] - WST[i]);
+            atomicAdd(&g[30], c1 - WST[30]);
+            atomicAdd(&g[29], WST[23] - WST[0]);
+            atomicAdd(&g[31], 1ull);
+        }
+"""
+
+
+def walk_stamps(src):
+    """The net workgroups' walks by phase, under load: 100 MHz clock stamps of thread 0 at the entry of a walk, after
+    block1, per layer after the K loop / after the barrier that follows it / after the epilogue's barrier, and at the
+    end of the head; summed per kind of walk (value pair, value single, policy) in iago_walk_stamps [kind][32]: slots
+    0..22 the phases, 29 the whole walks, 30 their shader-clock cycles (s_memtime), 31 the walks counted.  Patched
+    COPIES of the two walk headers go beside the variant's source."""
+    nop = 'asm volatile("s_nop 15\\n\\ts_nop 7" ::: "memory");'
+    sat = "        saturated |= !(vmax <= 65000.0f) || !(vsum.x + vsum.y == vsum.x + vsum.y);\n        __syncthreads();\n    }\n"
+    t = open(os.path.join(CSRC, "conv_trunk_body.hpp")).read()
+    t = patch(t, "namespace iago_trunk {\n", "namespace iago_trunk {\n" + STAMP_DEFS)
+    t = patch(t, "    char *const T = trunk_lds;\n", "    char *const T = trunk_lds;\n    __shared__ unsigned long long wst[32];\n"
+              "    iago_stamp(wst, 0);\n    if (threadIdx.x == 0) wst[30] = __builtin_amdgcn_s_memtime();\n")
+    t = patch(t, "    __syncthreads();\n\n    // ---- per-lane addresses of the B operand.", "    __syncthreads();\n    iago_stamp(wst, 1);\n\n    // ---- per-lane addresses of the B operand.")
+    t = patch(t, "        // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T\n",
+              "        iago_stamp(wst, 2 + 3 * L);\n        // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T\n")
+    t = patch(t, "        " + nop + "\n        __syncthreads();\n", "        " + nop + "\n        __syncthreads();\n        iago_stamp(wst, 3 + 3 * L);\n")
+    t = patch(t, sat, sat.replace("        __syncthreads();\n    }\n", "        __syncthreads();\n        iago_stamp(wst, 4 + 3 * L);\n    }\n"))
+    t = patch(t, "            P.out[W.index ? W.index[row] : row] = v;\n        }\n        return;",
+              "            P.out[W.index ? W.index[row] : row] = v;\n        }\n" +
+              WALK_END.replace("KINDBASE", "(TB == 2 ? 0 : 32)").replace("WST", "wst") + "        return;")
+    open(os.path.join(OUT, "conv_trunk_body_stamped.hpp"), "w").write(t)
+    q = open(os.path.join(CSRC, "conv_policy_body.hpp")).read()
+    q = patch(q, "    char *const T = policy_lds;\n", "    char *const T = policy_lds;\n    __shared__ unsigned long long pst[32];\n"
+              "    iago_trunk::iago_stamp(pst, 0);\n    if (threadIdx.x == 0) pst[30] = __builtin_amdgcn_s_memtime();\n")
+    q = patch(q, "    __syncthreads();\n\n    // ---- per-lane addresses of the B operand.", "    __syncthreads();\n    iago_trunk::iago_stamp(pst, 1);\n\n    // ---- per-lane addresses of the B operand.")
+    q = patch(q, "        // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T.\n",
+              "        iago_trunk::iago_stamp(pst, 2 + 3 * L);\n        // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T.\n")
+    q = patch(q, nop, nop + "\n        __syncthreads();\n        iago_trunk::iago_stamp(pst, 3 + 3 * L);\n        if (false)")
+    q = patch(q, sat, sat.replace("        __syncthreads();\n    }\n", "        __syncthreads();\n        iago_trunk::iago_stamp(pst, 4 + 3 * L);\n    }\n"))
+    q = patch(q, "        P.probs[row_id * 64 + lane] = e / sum;\n    }\n}",
+              "        P.probs[row_id * 64 + lane] = e / sum;\n    }\n" + WALK_END.replace("KINDBASE", "64").replace("WST", "pst") + "}")
+    open(os.path.join(OUT, "conv_policy_body_stamped.hpp"), "w").write(q)
+    s = patch(src, '#include "conv_trunk_body.hpp" // (brings rollout_row_body.hpp)', '#include "conv_trunk_body_stamped.hpp"')
+    s = patch(s, '#include "conv_policy_body.hpp"', '#include "conv_policy_body_stamped.hpp"')
+    s += """
+extern "C" __attribute__((visibility("default"))) int iago_debug_walk_stamps(unsigned long long *host, int clear)
+{
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(iago_trunk::iago_walk_stamps), 192 * 8) != hipSuccess)
+        return -1;
+    if (clear) {
+        static unsigned long long zeros[192];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(iago_trunk::iago_walk_stamps), zeros, 192 * 8) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+"""
+    return s
+
+
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT, exist_ok=True)
     src = open(os.path.join(CSRC, "search_kernel.hip")).read()
     objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "iago_amd", "_obj", "*.o"))) if "search_kernel" not in o]
     assert objs, "build the product first: python -m iago_amd.build"
-    for name, fn in (("search_log", request_log), ("search_phases", phase_stamps)):
+    only = sys.argv[1:]
+    for name, fn in (("search_log", request_log), ("search_phases", phase_stamps), ("search_walkstamps", walk_stamps)):
+        if only and name not in only:
+            continue
         path = os.path.join(OUT, name + ".hip")
         open(path, "w").write(fn(src))
         obj = os.path.join(OUT, name + ".o")
