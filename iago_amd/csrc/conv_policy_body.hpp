@@ -27,7 +27,8 @@ constexpr int RS = 800;             // bytes of a cell row: 128 ch hi | mid | lo
 constexpr int ZB = 1280;            // zero bytes behind the 64 rows: the target of every out-of-board tap
 constexpr int BS = 64 * RS + ZB;    // 52,480
 constexpr int HEAD_FLOATS = 64;     // logits
-constexpr int LDS_BYTES = BS + 1024 + HEAD_FLOATS * 4; // (+1024: the operand prefetch of the last k-step reads past T)
+constexpr int W1_LDS = (64 * 18 + 64) * 4;  // block1's weights and biases, staged per walk
+constexpr int LDS_BYTES = BS + 1024 + HEAD_FLOATS * 4 + W1_LDS; // (+1024: the operand prefetch of the last k-step reads past T)
 constexpr float S1 = 1.0f / 2048.0f, S2 = 1.0f / (2048.0f * 2048.0f);
 
 struct PolicyParams {
@@ -63,7 +64,10 @@ __device__ __forceinline__ void split3(const f2 v, h2 &hi, h2 &mid, h2 &lo)
 
 extern __shared__ __align__(16) char policy_lds[];
 
-__device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t row_id)
+// pos / res / w1s: the persistent search's hand-offs through LDS (conv_trunk_body.hpp, Piece): the position (word 2 / 3 =
+// own lo / hi, 4 / 5 = opp lo / hi), the distribution [64] instead of P.probs, block1's weights staged already
+__device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t row_id, const uint32_t *pos = nullptr,
+                                            float *res = nullptr, const float *w1_staged = nullptr)
 {
     char *const T = policy_lds;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -79,7 +83,8 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
             *(uint4 *)(T + e * 16) = src[e];
     } else {
         const int cell = tid & 63, y = cell >> 3, x = cell & 7;
-        const uint64_t bits0 = P.opp[b], bits1 = P.own[b];
+        const uint64_t bits0 = pos ? (((uint64_t)pos[5] << 32) | pos[4]) : P.opp[b];
+        const uint64_t bits1 = pos ? (((uint64_t)pos[3] << 32) | pos[2]) : P.own[b];
         float in[18];
 #pragma unroll
         for (int c = 0; c < 2; c++)
@@ -92,6 +97,18 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
                     const int a = (yy * 8 + xx) & 63;
                     in[c * 9 + ky * 3 + kx] = (ok && (((c ? bits1 : bits0) >> a) & 1ull)) ? 1.0f : 0.0f;
                 }
+        // block1's weights and biases (4.9 KB) through LDS: one round trip to L2 for the workgroup, then broadcast reads
+        // (conv_trunk_body.hpp says what the channel-by-channel loads from global memory cost)
+        const float *w1s = w1_staged; // [64][18] weights, [64] biases
+        if (!w1s) {
+            float *const st = (float *)(T + BS + 1024 + HEAD_FLOATS * 4);
+            for (int e = tid; e < 64 * 18 / 4; e += 256)
+                ((float4 *)st)[e] = ((const float4 *)P.w1)[e];
+            if (tid < 16)
+                ((float4 *)(st + 64 * 18))[tid] = ((const float4 *)P.b1)[tid];
+            __syncthreads();
+            w1s = st;
+        }
 #pragma unroll 1
         for (int g2 = 0; g2 < 2; g2++) {
             const int grp = __builtin_amdgcn_readfirstlane(g2 * 4 + wv); // channel block * 2 + half: wave-uniform
@@ -102,8 +119,8 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
                 f2 v;
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    const float *wk = P.w1 + (co0 + k + e) * 18; // [co][ci][ky][kx]
-                    float acc = P.b1[co0 + k + e];
+                    const float *wk = w1s + (co0 + k + e) * 18; // [co][ci][ky][kx]
+                    float acc = w1s[64 * 18 + co0 + k + e];
 #pragma unroll
                     for (int j = 0; j < 18; j++)
                         acc = fmaf(wk[j], in[j], acc);
@@ -150,10 +167,12 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
         const int n_pairs = L == 0 ? 2 : 4; // chunk pairs of 32 input channels
         // this lane's A operands: output channels 32 wv + c16 (M tile 0) and + 16 (M tile 1), input channels
         // 8 (kq & 1) .. + 7 of chunk 2 cp + (kq >> 1); a chunk is 9 x 128 x 32 B, a tap 128 x 32 B further
-        const int a_off = (32 * wv + c16) * 2 + (kq & 1) + (kq >> 1) * (9 * 256);
-        const u32x4 *wh = (const u32x4 *)P.w_hi[L] + a_off;
-        const u32x4 *wm = (const u32x4 *)P.w_mid[L] + a_off;
-        const u32x4 *wl = (const u32x4 *)P.w_lo[L] + a_off;
+        // (a wave-uniform base -- the layer's weights + the k-step's offset: scalar registers -- + this lane's byte offset)
+        const char *const wh = (const char *)P.w_hi[L], *const wm = (const char *)P.w_mid[L], *const wl = (const char *)P.w_lo[L];
+        const uint32_t a_lane = (uint32_t)(((32 * wv + c16) * 2 + (kq & 1) + (kq >> 1) * (9 * 256)) * 16);
+        auto a_load = [&](const char *base, uint32_t step_bytes, int m) -> u32x4 {
+            return *(const u32x4 *)(base + step_bytes + a_lane + (uint32_t)m * 512u);
+        };
         float4v acc0[2][4], acc1[2][4], acc2[2][4];
 #pragma unroll
         for (int m = 0; m < 2; m++)
@@ -167,12 +186,16 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
                 }
         u32x4 a_hi[3][2], a_mid[3][2], a_lo[3][2]; // k-steps s, s + 1, s + 2 (ring index = tap % 3) x the two M tiles
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            a_hi[i][0] = wh[i * 256], a_hi[i][1] = wh[i * 256 + 32];
-            a_mid[i][0] = wm[i * 256], a_mid[i][1] = wm[i * 256 + 32];
-            a_lo[i][0] = wl[i * 256], a_lo[i][1] = wl[i * 256 + 32];
-        }
-        // B operands two tiles ahead of their MFMAs (three register sets); a tile = 12 MFMAs here
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                a_hi[i][m] = a_load(wh, (uint32_t)i * 4096u, m);
+                a_mid[i][m] = a_load(wm, (uint32_t)i * 4096u, m);
+                a_lo[i][m] = a_load(wl, (uint32_t)i * 4096u, m);
+            }
+        // B operands two tiles ahead of their MFMAs (three register sets); a tile = 12 MFMAs here.  The three reads of
+        // a tile go out one per MFMA gap (an MFMA of this shape leaves 8 of its 16 cycles to other instructions), and
+        // the MFMAs that add into one accumulator stand at least four apart (conv_trunk_body.hpp)
         half8 bh[3], bm[3], bl[3];
         auto b_addr = [&](int tile) -> const char * {
             // tile = tap * 4 + q of the running chunk pair; 36, 37 = the first two tiles of the next pair
@@ -197,10 +220,7 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
                     cp2 = n_pairs - 1;
                     tp2 = 8;
                 }
-                const int64_t w2 = (int64_t)(18 * cp2 + tp2) * 256;
-                a_hi[(tap + 2) % 3][0] = wh[w2], a_hi[(tap + 2) % 3][1] = wh[w2 + 32];
-                a_mid[(tap + 2) % 3][0] = wm[w2], a_mid[(tap + 2) % 3][1] = wm[w2 + 32];
-                a_lo[(tap + 2) % 3][0] = wl[w2], a_lo[(tap + 2) % 3][1] = wl[w2 + 32];
+                const uint32_t w2 = (uint32_t)(18 * cp2 + tp2) * 4096u; // (its six loads go out in the tiles below)
                 half8 ah[2], am[2], al[2];
 #pragma unroll
                 for (int m = 0; m < 2; m++) {
@@ -212,20 +232,39 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
                 for (int q = 0; q < 4; q++) {
                     const int tile = tap * 4 + q, cur = tile % 3, nxt = (tile + 2) % 3;
                     const char *p = b_addr(tile + 2);
+                    // (per accumulator the same order of additions as before: acc1 = ah bm + am bh, acc2 = ah bl + al bh + am bm)
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_POLICY_MFMA16(acc2[0][q], ah[0], bl[cur]);
                     bh[nxt] = *(const half8 *)p;
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_POLICY_MFMA16(acc2[1][q], ah[1], bl[cur]);
                     bm[nxt] = *(const half8 *)(p + 256);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_POLICY_MFMA16(acc1[0][q], ah[0], bm[cur]);
                     bl[nxt] = *(const half8 *)(p + 512);
                     __builtin_amdgcn_sched_barrier(0);
-                    IAGO_POLICY_MFMA16(acc0[0][q], ah[0], bh[cur]);
-                    IAGO_POLICY_MFMA16(acc0[1][q], ah[1], bh[cur]);
-                    IAGO_POLICY_MFMA16(acc1[0][q], ah[0], bm[cur]);
                     IAGO_POLICY_MFMA16(acc1[1][q], ah[1], bm[cur]);
-                    IAGO_POLICY_MFMA16(acc2[0][q], ah[0], bl[cur]);
-                    IAGO_POLICY_MFMA16(acc2[1][q], ah[1], bl[cur]);
-                    IAGO_POLICY_MFMA16(acc1[0][q], am[0], bh[cur]);
-                    IAGO_POLICY_MFMA16(acc1[1][q], am[1], bh[cur]);
+                    // the A operands of k-step s + 2: one 16-byte load per gap, six over the step's first three tiles
+                    if (q == 0)
+                        a_hi[(tap + 2) % 3][0] = a_load(wh, w2, 0);
+                    else if (q == 1)
+                        a_mid[(tap + 2) % 3][0] = a_load(wm, w2, 0);
+                    else if (q == 2)
+                        a_lo[(tap + 2) % 3][0] = a_load(wl, w2, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_POLICY_MFMA16(acc0[0][q], ah[0], bh[cur]);
+                    if (q == 0)
+                        a_hi[(tap + 2) % 3][1] = a_load(wh, w2, 1);
+                    else if (q == 1)
+                        a_mid[(tap + 2) % 3][1] = a_load(wm, w2, 1);
+                    else if (q == 2)
+                        a_lo[(tap + 2) % 3][1] = a_load(wl, w2, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_POLICY_MFMA16(acc0[1][q], ah[1], bh[cur]);
                     IAGO_POLICY_MFMA16(acc2[0][q], al[0], bh[cur]);
                     IAGO_POLICY_MFMA16(acc2[1][q], al[1], bh[cur]);
+                    IAGO_POLICY_MFMA16(acc1[0][q], am[0], bh[cur]);
+                    IAGO_POLICY_MFMA16(acc1[1][q], am[1], bh[cur]);
                     IAGO_POLICY_MFMA16(acc2[0][q], am[0], bm[cur]);
                     IAGO_POLICY_MFMA16(acc2[1][q], am[1], bm[cur]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -322,7 +361,10 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
             sum += __shfl_xor(sum, o);
-        P.probs[row_id * 64 + lane] = e / sum;
+        if (res)
+            res[lane] = e / sum;
+        else
+            P.probs[row_id * 64 + lane] = e / sum;
     }
 }
 
@@ -343,8 +385,8 @@ inline int policy_params_of(const iago_policy_split3_args *a, PolicyParams &P)
         P.w_lo[L] = (const uint4 *)a->w_lo[L];
         P.bias[L] = a->bias[L];
     }
-    if ((uintptr_t)a->w9 & 15u)
-        return iago_fail(IAGO_ERR_INVALID, "iago_policy_forward_split3: w9 must be 16-byte aligned");
+    if (((uintptr_t)a->w9 & 15u) || ((uintptr_t)a->w1 & 15u) || ((uintptr_t)a->b1 & 15u))
+        return iago_fail(IAGO_ERR_INVALID, "iago_policy_forward_split3: w1, b1, w9 must be 16-byte aligned");
     P.own = a->own;
     P.opp = a->opp;
     P.index = a->index;

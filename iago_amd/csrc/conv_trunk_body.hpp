@@ -67,14 +67,20 @@ struct Piece {
     const int32_t *n_dev;
     char *scratch;
     int layer_lo, layer_hi;
+    // the persistent search's hand-offs inside the workgroup, through LDS instead of global memory (a store to global
+    // memory read back by the same workgroup is a round trip to L2: ~2 us under load, twice per walk):
+    const uint32_t *pos; // optional, LDS: the boards' positions, six words per board (word 2 / 3 = own lo / hi, 4 / 5 = opp lo / hi)
+    float *res;          // optional, LDS: the walk's values [TB] instead of P.out
+    const float *w1s;    // optional, LDS: block1's weights [64][18] and biases [64] staged there already
 };
 __device__ __forceinline__ Piece whole_walk(const TrunkRParams &P)
 {
-    return Piece{P.index, P.n_dev, P.scratch, P.layer_lo, P.layer_hi};
+    return Piece{P.index, P.n_dev, P.scratch, P.layer_lo, P.layer_hi, nullptr, nullptr, nullptr};
 }
 
 constexpr int head_lds(int tb) { return (9 * 64 * tb + 64 * tb + 128 * tb) * 4; } // tap maps, block9 output, fc terms
-constexpr int lds_alloc_fused(int tb) { return lds_alloc(tb) + head_lds(tb); }
+constexpr int W1_LDS = (64 * 18 + 64) * 4;   // block1's weights and biases, staged per walk
+constexpr int lds_alloc_fused(int tb) { return lds_alloc(tb) + head_lds(tb) + W1_LDS; }
 
 // ds_read_b128 serves lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (and the same + 32)
 // in separate LDS cycles: the first group holds cells 0-15 of a 32-cell block, the second
@@ -131,7 +137,15 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
             const int64_t row = min(b0 + board, n_rows - 1);
             const int64_t b = W.index ? W.index[row] : row;
             const float *pl = P.planes + b * 128;
-            const uint64_t bits0 = P.planes ? 0ull : P.opp[b], bits1 = P.planes ? 0ull : P.own[b];
+            uint64_t bits0, bits1;
+            if (W.pos) {
+                const uint32_t *w = W.pos + 6 * board;
+                bits1 = ((uint64_t)w[3] << 32) | w[2];
+                bits0 = ((uint64_t)w[5] << 32) | w[4];
+            } else {
+                bits0 = P.planes ? 0ull : P.opp[b];
+                bits1 = P.planes ? 0ull : P.own[b];
+            }
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
@@ -149,8 +163,20 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                         in[board][c * 9 + ky * 3 + kx] = v;
                     }
         }
-        // the weights of an output channel are wave-uniform (scalar loads): each is fetched
-        // once and used for the 4 boards
+        // block1's weights and biases (4.9 KB) through LDS: ONE round trip to L2 for the workgroup, then broadcast reads
+        // per output channel (fetched from global memory channel by channel they were sixteen dependent round trips per
+        // wave: 5.2 us of a pair's walk under load, LABNOTES.md round 5)
+        const float *w1s = W.w1s; // [64][18] weights, [64] biases
+        if (!w1s) {
+            float *const st = (float *)(T + lds_alloc(TB) + head_lds(TB));
+            for (int e = tid; e < 64 * 18 / 4; e += 256)
+                ((float4 *)st)[e] = ((const float4 *)P.w1)[e];
+            if (tid < 16)
+                ((float4 *)(st + 64 * 18))[tid] = ((const float4 *)P.b1)[tid];
+            __syncthreads();
+            w1s = st;
+        }
+        // the weights of an output channel are wave-uniform: each is fetched once and used for the boards
 #pragma unroll 1
         for (int g2 = 0; g2 < 2; g2++) {
             const int grp = __builtin_amdgcn_readfirstlane(g2 * 4 + wv); // channel block * 2 + half
@@ -158,8 +184,8 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
             _Float16 h8[TB][8], l8[TB][8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const float *wk = P.w1 + (co0 + k) * 18; // [co][ci][ky][kx]
-                const float bk = P.b1[co0 + k];
+                const float *wk = w1s + (co0 + k) * 18; // [co][ci][ky][kx]
+                const float bk = w1s[64 * 18 + co0 + k];
                 float wreg[18];
 #pragma unroll
                 for (int j = 0; j < 18; j++)
@@ -230,9 +256,13 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
     for (int L = L_lo; L < L_hi; L++) {
         const int n_pairs = L == 0 ? (P.cin0 >> 5) : 4; // chunk pairs: 32 input channels each
         // this lane's A operands: output channels 32 wv + c16 (M tile 0) and + 16 (M tile 1), input channels
-        // 8 (kq & 1) .. + 7 of chunk 2 cp + (kq >> 1); a chunk is 9 x 128 x 32 B, a tap 128 x 32 B further
-        const u32x4 *wh = (const u32x4 *)P.w_hi[L] + (32 * wv + c16) * 2 + (kq & 1) + (kq >> 1) * (9 * 256);
-        const u32x4 *wl = (const u32x4 *)P.w_lo[L] + (32 * wv + c16) * 2 + (kq & 1) + (kq >> 1) * (9 * 256);
+        // 8 (kq & 1) .. + 7 of chunk 2 cp + (kq >> 1); a chunk is 9 x 128 x 32 B, a tap 128 x 32 B further.  Addressed as
+        // a wave-uniform base (the layer's weights + the k-step's offset: scalar registers) + this lane's byte offset
+        const char *const wh = (const char *)P.w_hi[L], *const wl = (const char *)P.w_lo[L];
+        const uint32_t a_lane = (uint32_t)(((32 * wv + c16) * 2 + (kq & 1) + (kq >> 1) * (9 * 256)) * 16);
+        auto a_load = [&](const char *base, uint32_t step_bytes, int m) -> u32x4 {
+            return *(const u32x4 *)(base + step_bytes + a_lane + (uint32_t)m * 512u);
+        };
         float4v acc_main[2][NN], acc_cross[2][NN];
 #pragma unroll
         for (int m = 0; m < 2; m++)
@@ -247,24 +277,29 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
         // k-steps of 32 input channels: s = 9 cp + tap, 9 n_pairs of them
         u32x4 a_hi[3][2], a_lo[3][2]; // k-steps s, s + 1, s + 2 (ring index = tap % 3) x the two M tiles
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            a_hi[i][0] = wh[i * 256], a_hi[i][1] = wh[i * 256 + 32];
-            a_lo[i][0] = wl[i * 256], a_lo[i][1] = wl[i * 256 + 32];
-        }
-        // B operands TWO tiles ahead of the MFMAs that use them (three register sets): an LDS read issued now
-        // has twelve MFMAs (192 cycles) to arrive
-        half8 bh[3], bl[3];
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                a_hi[i][m] = a_load(wh, (uint32_t)i * 4096u, m);
+                a_lo[i][m] = a_load(wl, (uint32_t)i * 4096u, m);
+            }
+        // B operands THREE tiles ahead of the MFMAs that use them (four register sets): an LDS read issued now has
+        // eighteen MFMAs (288 cycles) to arrive.  A v_mfma_f32_16x16x32_f16 leaves 8 of its 16 cycles to the wave's
+        // other instructions: the two reads of a tile go out one per MFMA gap, and the two MFMAs that add into the
+        // same accumulator stand four apart (measured with tools/exp_walk_stamps.py on the stamped build: with the
+        // reads bunched between two tiles and one MFMA between the dependent pair the K loops of a pair took 99.6 us
+        // against 75.9 us of MFMA issue; LABNOTES.md, round 5)
+        half8 bh[4], bl[4];
         auto b_addr = [&](int tile) -> const char * {
-            // tile = tap * NN + n of the running chunk pair; 9 NN, 9 NN + 1 = the first two tiles of the next pair
+            // tile = tap * NN + n of the running chunk pair; 9 NN .. 9 NN + 2 = the first three tiles of the next pair
             const int over = tile >= 9 * NN ? 64 : 0, tt = tile % (9 * NN), tp = tt / NN, n = tt % NN;
             return T + addr[n & 3][tp] + (n >> 2) * BS + over;
         };
-        {
-            const char *p0 = b_addr(0), *p1 = b_addr(1);
-            bh[0] = *(const half8 *)p0;
-            bl[0] = *(const half8 *)(p0 + 256);
-            bh[1] = *(const half8 *)p1;
-            bl[1] = *(const half8 *)(p1 + 256);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const char *p0 = b_addr(i);
+            bh[i] = *(const half8 *)p0;
+            bl[i] = *(const half8 *)(p0 + 256);
         }
         for (int cp = 0; cp < n_pairs; cp++) {
 #pragma unroll
@@ -279,23 +314,33 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                     cp2 = n_pairs - 1;
                     tp2 = 8;
                 }
-                const int64_t w2 = (int64_t)(18 * cp2 + tp2) * 256;
-                a_hi[(tap + 2) % 3][0] = wh[w2], a_hi[(tap + 2) % 3][1] = wh[w2 + 32];
-                a_lo[(tap + 2) % 3][0] = wl[w2], a_lo[(tap + 2) % 3][1] = wl[w2 + 32];
+                const uint32_t w2 = (uint32_t)(18 * cp2 + tp2) * 4096u; // (its four loads go out one per tile below)
                 const half8 ah0 = __builtin_bit_cast(half8, a_hi[tap % 3][0]), ah1 = __builtin_bit_cast(half8, a_hi[tap % 3][1]);
                 const half8 al0 = __builtin_bit_cast(half8, a_lo[tap % 3][0]), al1 = __builtin_bit_cast(half8, a_lo[tap % 3][1]);
 #pragma unroll
                 for (int n = 0; n < NN; n++) {
-                    const int tile = tap * NN + n, cur = tile % 3, nxt = (tile + 2) % 3;
+                    const int tile = tap * NN + n, cur = tile % 4, nxt = (tile + 3) % 4;
                     // (past the last chunk pair: harmless reads 64 B further in the same rows)
-                    const char *p = b_addr(tile + 2);
+                    const char *p = b_addr(tile + 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_MFMA16(acc_cross[0][n], ah0, bl[cur]);
                     bh[nxt] = *(const half8 *)p;
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_MFMA16(acc_cross[1][n], ah1, bl[cur]);
                     bl[nxt] = *(const half8 *)(p + 256);
                     __builtin_amdgcn_sched_barrier(0);
                     IAGO_MFMA16(acc_main[0][n], ah0, bh[cur]);
+                    // the A operands of k-step s + 2: one 16-byte load in this gap of each of the step's first four tiles
+                    if (n == 0)
+                        a_hi[(tap + 2) % 3][0] = a_load(wh, w2, 0);
+                    else if (n == 1)
+                        a_hi[(tap + 2) % 3][1] = a_load(wh, w2, 1);
+                    else if (n == 2)
+                        a_lo[(tap + 2) % 3][0] = a_load(wl, w2, 0);
+                    else if (n == 3)
+                        a_lo[(tap + 2) % 3][1] = a_load(wl, w2, 1);
+                    __builtin_amdgcn_sched_barrier(0);
                     IAGO_MFMA16(acc_main[1][n], ah1, bh[cur]);
-                    IAGO_MFMA16(acc_cross[0][n], ah0, bl[cur]);
-                    IAGO_MFMA16(acc_cross[1][n], ah1, bl[cur]);
                     IAGO_MFMA16(acc_cross[0][n], al0, bh[cur]);
                     IAGO_MFMA16(acc_cross[1][n], al1, bh[cur]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -401,10 +446,18 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                     hm[jt][v] = 0.0f;
                     hc[jt][v] = 0.0f;
                 }
+            // (all sixteen 16-byte loads in flight together: one L2 round trip instead of eight dependent ones -- the
+            // head of a pair took 8.4 us under load with a load, a wait and three MFMAs per chunk: LABNOTES.md, round 5)
+            u32x4 w9a[8], w9b[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const half8 ah = __builtin_bit_cast(half8, w9h[c * 64]);
-                const half8 al = __builtin_bit_cast(half8, w9l[c * 64]);
+                w9a[c] = w9h[c * 64];
+                w9b[c] = w9l[c * 64];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const half8 ah = __builtin_bit_cast(half8, w9a[c]);
+                const half8 al = __builtin_bit_cast(half8, w9b[c]);
 #pragma unroll
                 for (int jt = 0; jt < 2; jt++) {
                     const int jj = 2 * wv + jt; // wave-uniform: board jj >> 1, cell half jj & 1
@@ -480,7 +533,10 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                 v += hv[j4].w;
             }
             const int64_t row = b0 + tid;
-            P.out[W.index ? W.index[row] : row] = v;
+            if (W.res)
+                W.res[tid] = v;
+            else
+                P.out[W.index ? W.index[row] : row] = v;
         }
         return;
     }
@@ -536,8 +592,9 @@ inline int value_params_of(const iago_value_split_args *a, TrunkRParams &P)
     P.w_hi[7] = P.w_hi[6];
     P.w_lo[7] = P.w_lo[6];
     P.bias[7] = P.bias[6];
-    if (((uintptr_t)a->w9_hi & 15u) || ((uintptr_t)a->w9_lo & 15u) || ((uintptr_t)a->w10 & 15u))
-        return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: w9_hi, w9_lo, w10 must be 16-byte aligned");
+    if (((uintptr_t)a->w9_hi & 15u) || ((uintptr_t)a->w9_lo & 15u) || ((uintptr_t)a->w10 & 15u) || ((uintptr_t)a->w1 & 15u) ||
+        ((uintptr_t)a->b1 & 15u))
+        return iago_fail(IAGO_ERR_INVALID, "iago_value_forward_split: w1, b1, w9_hi, w9_lo, w10 must be 16-byte aligned");
     P.x_hi = P.x_lo = nullptr;
     P.y_hi = P.y_lo = nullptr;
     P.n = a->n;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int part = Y.parts - 1 - (int)(x / ASYNC_NV); // the oldest queue's workgroups are dispatched first
     const int64_t bid = x % ASYNC_NV;
     const uint32_t row = (*Y.step + (uint32_t)(Y.parts - part)) % (uint32_t)Y.parts; // == (step - part) mod parts
-    Piece W;
+    Piece W = whole_walk(P);
     W.index = Y.fq_index + (int64_t)row * P.n;
     W.n_dev = Y.fq_count + row;
     W.scratch = Y.scratch + (int64_t)row * P.n * IMG;

@@ -77,6 +77,12 @@ constexpr uint32_t KIND_VALUE = 0u, KIND_POLICY = 1u;
 // rollouts in passes of 16 boards (the 16-lanes-per-board body)
 constexpr int GAMES_PER_WG = IAGO_SEARCH_GAMES_PER_WORKGROUP; // at most (the launch's own number: SearchParams::games_per_wg)
 
+// dynamic LDS of the kernel: the walks' images (the larger of a value pair's and a policy board's, with their heads), then
+// block1's weights of both nets
+constexpr int SEARCH_IMG_V = iago_trunk::lds_alloc(2) + iago_trunk::head_lds(2);
+constexpr int SEARCH_IMG_P = iago_policy::BS + 1024 + iago_policy::HEAD_FLOATS * 4;
+constexpr int SEARCH_IMG_TOP = SEARCH_IMG_V > SEARCH_IMG_P ? SEARCH_IMG_V : SEARCH_IMG_P;
+
 struct SearchParams {
     Tree T;
     const uint64_t *root_own, *root_opp;
@@ -177,24 +183,32 @@ __device__ __forceinline__ bool vtable_get(const SearchParams &S, uint64_t own, 
     return s1 != 0ull && (s1 & 1ull) == 0ull && s1 == s2 && o == own && p == opp && (v >> 32) == (s1 & 0xFFFFFFFFull);
 }
 
-// (one lane) the value the net has just computed for the position; a slot somebody else is writing is left alone.
+// (one lane) the value the net has just computed for the position, in two steps.  vtable_put_begin takes the slot with
+// ONE atomic (fetch-or of the sequence word's low bit: odd = being written; a slot somebody else is writing is left
+// alone) and stores the position and the value; vtable_put_end -- called by the same lane before its next request, a
+// walk later -- publishes the new even sequence word once those stores have landed.  (As one routine -- load, compare-and-
+// swap, stores, wait, store -- it was three dependent round trips to L2 behind every value walk: LABNOTES.md, round 5.)
 // Sequence word: low half = the sequence number (odd while the entry is being written, never 0 once used), high half =
 // the game whose request put the value there (diagnostic: hits by the same game / by another game, totals[12])
-__device__ __forceinline__ void vtable_put(const SearchParams &S, uint64_t own, uint64_t opp, uint32_t bits, uint32_t writer)
+__device__ __forceinline__ u64 *vtable_put_begin(const SearchParams &S, uint64_t own, uint64_t opp, uint32_t bits, uint32_t writer,
+                                                 u64 &publish)
 {
     u64 *e = S.vtable + (u64)vtable_slot(S, own, opp) * 4u;
-    u64 s = ld(e);
+    const u64 s = __hip_atomic_fetch_or(e, 1ull, RLX_AGENT);
     if (s & 1ull)
-        return;
-    if (!__hip_atomic_compare_exchange_strong(e, &s, s + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        return;
+        return nullptr;
     uint32_t seq = (uint32_t)s + 2u;
     seq = seq ? seq : 2u;
     st(e + 1, own);
     st(e + 2, opp);
     st(e + 3, ((u64)seq << 32) | bits);   // (the value word carries the sequence number it belongs to)
+    publish = ((u64)writer << 32) | seq;
+    return e;
+}
+__device__ __forceinline__ void vtable_put_end(u64 *e, u64 publish)
+{
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    st(e, ((u64)writer << 32) | seq);
+    st(e, publish);
 }
 
 template <int CTRL>
@@ -870,9 +884,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return __builtin_amdgcn_readfirstlane(d);
     };
 
+    // block1's weights and biases of both nets, staged ONCE per workgroup at the top of the dynamic LDS (above the
+    // walks' images: conv_trunk_body.hpp, Piece::w1s)
+    float *const w1_val = (float *)(iago_trunk::trunk_lds + SEARCH_IMG_TOP), *const w1_pol = w1_val + (64 * 18 + 64);
+    __shared__ float res_v[2], res_p[64];
+    for (int e = tid; e < 64 * 18 / 4; e += 256) {
+        ((float4 *)w1_val)[e] = ((const float4 *)VP.w1)[e];
+        ((float4 *)w1_pol)[e] = ((const float4 *)PP.w1)[e];
+    }
+    if (tid < 16) {
+        ((float4 *)(w1_val + 64 * 18))[tid] = ((const float4 *)VP.b1)[tid];
+        ((float4 *)(w1_pol + 64 * 18))[tid] = ((const float4 *)PP.b1)[tid];
+    }
+    __syncthreads();
+    u64 *put_e = nullptr; // (lanes 0 / 1: the position-table entry whose sequence word is still to be published)
+    u64 put_word = 0;
     long long t_wait = 0, t_walk = 0, n_pairs = 0;
     for (;;) {
         const long long c0 = wall_clock64();
+        if (put_e) {
+            vtable_put_end(put_e, put_word);
+            put_e = nullptr;
+        }
         if (tid < 64) {
             int status = 2, count = 0;
             bool polling = false;
@@ -945,34 +978,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const uint32_t kind = job[0] >> 31;
         const int count = (int)job[29];
         n_pairs += count - 1;
-        if (tid < count) {
-            S.wg_own[row0 + tid] = ((uint64_t)job[6 * tid + 3] << 32) | job[6 * tid + 2];
-            S.wg_opp[row0 + tid] = ((uint64_t)job[6 * tid + 5] << 32) | job[6 * tid + 4];
-        }
-        __syncthreads(); // (the walks read their rows' positions with plain loads: written by this workgroup)
+        // (positions, values and priors go between the request's words and the walks through LDS: a store to global
+        // memory read back by this very workgroup was a round trip to L2, ~2 us under load, twice per walk)
         if (kind == KIND_VALUE) {
+            iago_trunk::Piece W = iago_trunk::whole_walk(VP);
+            W.pos = job;
+            W.res = res_v;
+            W.w1s = w1_val;
             if (count == 2)
-                iago_trunk::trunk_item<true, 2>(VP, iago_trunk::whole_walk(VP), row0, row0 + count);
+                iago_trunk::trunk_item<true, 2>(VP, W, row0, row0 + count);
             else
-                iago_trunk::trunk_item<true, 1>(VP, iago_trunk::whole_walk(VP), row0, row0 + count);
+                iago_trunk::trunk_item<true, 1>(VP, W, row0, row0 + count);
             __syncthreads();
             if (tid < count) {
-                const uint32_t bits = __float_as_uint(VP.out[row0 + tid]);
+                const uint32_t bits = __float_as_uint(res_v[tid]);
                 if ((job[6 * tid] & 0x7FFFFFFFu) != NOBODY)
                     st(&S.rep_v[(int64_t)(job[6 * tid] & 0x7FFFFFFFu)], ((u64)job[6 * tid + 1] << 32) | bits);
                 if (S.vtable_mask) {
                     const uint32_t asked = job[6 * tid] & 0x7FFFFFFFu;
-                    vtable_put(S, ((uint64_t)job[6 * tid + 3] << 32) | job[6 * tid + 2],
-                               ((uint64_t)job[6 * tid + 5] << 32) | job[6 * tid + 4], bits,
-                               asked != NOBODY ? asked : job[6 * tid + 1]);
+                    put_e = vtable_put_begin(S, ((uint64_t)job[6 * tid + 3] << 32) | job[6 * tid + 2],
+                                             ((uint64_t)job[6 * tid + 5] << 32) | job[6 * tid + 4], bits,
+                                             asked != NOBODY ? asked : job[6 * tid + 1], put_word);
                 }
             }
         } else {
-            iago_policy::policy_item(PP, row0);
+            iago_policy::policy_item(PP, row0, job, res_p, w1_pol);
             __syncthreads();
             if (tid < 64)
-                st(&S.rep_p[(int64_t)(job[0] & 0x7FFFFFFFu) * 64 + tid],
-                   ((u64)job[1] << 32) | __float_as_uint(PP.probs[row0 * 64 + tid]));
+                st(&S.rep_p[(int64_t)(job[0] & 0x7FFFFFFFu) * 64 + tid], ((u64)job[1] << 32) | __float_as_uint(res_p[tid]));
         }
         __syncthreads(); // the next item re-stages the LDS image and job[]
         t_walk += wall_clock64() - c1;
@@ -982,11 +1015,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 } // namespace
 
 namespace {
-constexpr int search_lds()
-{
-    constexpr int lds_v = iago_trunk::lds_alloc_fused(2), lds_p = iago_policy::LDS_BYTES;
-    return lds_v > lds_p ? lds_v : lds_p;
-}
+constexpr int search_lds() { return SEARCH_IMG_TOP + iago_trunk::W1_LDS + iago_policy::W1_LDS; }
 } // namespace
 
 extern "C" int iago_mcts_search_capacity(int32_t *cus, int32_t *workgroups_per_cu)

@@ -306,7 +306,8 @@ IAGO_API int iago_policy_head(const float *x, const float *w9, const float *b10,
  *   index[b] when a gather list is given; n_dev: optional device-side row count.
  *   w_hi / w_mid / w_lo[k]: block 2+k as three f16 tensors [cin/16][3][3][128][16]
  *   (hi = f16(w), mid = f16((w - hi) 2^11), lo = f16(((w - hi) 2^11 - mid) 2^11)); w1 [64][2][3][3],
- *   b1 [64], bias[k] [128], w9 [128], b10 [64]; probs [n][64].  overflow: see iago_conv3x3_split.
+ *   b1 [64], bias[k] [128], w9 [128], b10 [64] (w1, b1, w9 and every weight piece 16-byte aligned); probs [n][64].
+ *   overflow: see iago_conv3x3_split.
  */
 typedef struct iago_policy_split3_args {
     const uint64_t *own, *opp;
@@ -365,7 +366,7 @@ typedef struct iago_value_split_args {
     const float *planes;
     const uint64_t *own, *opp;
     int64_t n;
-    const float *w1, *b1;
+    const float *w1, *b1;            /* 16-byte aligned */
     const void *w_hi[7], *w_lo[7];
     const float *bias[7];
     const void *w9_hi, *w9_lo;

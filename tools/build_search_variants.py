@@ -129,6 +129,18 @@ def walk_stamps(src):
     t = patch(t, "            P.out[W.index ? W.index[row] : row] = v;\n        }\n        return;",
               "            P.out[W.index ? W.index[row] : row] = v;\n        }\n" +
               WALK_END.replace("KINDBASE", "(TB == 2 ? 0 : 32)").replace("WST", "wst") + "        return;")
+    # finer stamps (raw, wst[24..]): inside block1 after the staging barrier; inside the head after its MFMAs and after
+    # each of its three barriers -> slots 23..27 (head: MFMAs, barrier 1, tap sums + barrier 2, fc10 + barrier 3, the
+    # final sum + store) and 28 (block1: entry -> weights staged)
+    t = patch(t, "        // the weights of an output channel are wave-uniform: each is fetched once",
+              "        iago_stamp(wst, 24);\n        // the weights of an output channel are wave-uniform: each is fetched once")
+    t = patch(t, "        __syncthreads();\n        if (tid < NC) {", "        iago_stamp(wst, 25);\n        __syncthreads();\n        iago_stamp(wst, 26);\n        if (tid < NC) {")
+    t = patch(t, "        __syncthreads();\n        if ((tid >> 7) * 2 < TB) {", "        __syncthreads();\n        iago_stamp(wst, 27);\n        if ((tid >> 7) * 2 < TB) {")
+    t = patch(t, "        __syncthreads();\n        if (tid < TB && b0 + tid < n_rows) {", "        __syncthreads();\n        iago_stamp(wst, 28);\n        if (tid < TB && b0 + tid < n_rows) {")
+    t = patch(t, "            atomicAdd(&g[31], 1ull);\n", "            atomicAdd(&g[31], 1ull);\n"
+              "            atomicAdd(&g[23], wst[25] - wst[22]);\n            atomicAdd(&g[24], wst[26] - wst[25]);\n"
+              "            atomicAdd(&g[25], wst[27] - wst[26]);\n            atomicAdd(&g[26], wst[28] - wst[27]);\n"
+              "            atomicAdd(&g[27], wst[23] - wst[28]);\n            atomicAdd(&g[28], wst[24] - wst[0]);\n")
     open(os.path.join(OUT, "conv_trunk_body_stamped.hpp"), "w").write(t)
     q = open(os.path.join(CSRC, "conv_policy_body.hpp")).read()
     q = patch(q, "    char *const T = policy_lds;\n", "    char *const T = policy_lds;\n    __shared__ unsigned long long pst[32];\n"
@@ -159,6 +171,53 @@ extern "C" __attribute__((visibility("default"))) int iago_debug_walk_stamps(uns
     return s
 
 
+def walk_stamps_no_a(src):
+    """TIMING ONLY (wrong numbers): the stamped build with the weight loads of the K loops removed -- the A operands of
+    every k-step are those of the first two.  What is left of the K loops' time is MFMA issue + LDS reads."""
+    s = walk_stamps(src)
+    for name in ("conv_trunk_body_stamped.hpp", "conv_policy_body_stamped.hpp"):
+        path = os.path.join(OUT, name)
+        t = open(path).read()
+        for piece in ("hi", "mid", "lo"):
+            w = {"hi": "wh", "mid": "wm", "lo": "wl"}[piece]
+            old = "                a_%s[(tap + 2) %% 3][0] = %s[w2], a_%s[(tap + 2) %% 3][1] = %s[w2 + 32];\n" % (piece, w, piece, w)
+            if piece == "mid" and "trunk" in name:
+                continue
+            t = patch(t, old, "                a_%s[(tap + 2) %% 3][0] = a_%s[tap %% 3][1], a_%s[(tap + 2) %% 3][1] = a_%s[tap %% 3][0];\n"
+                      % (piece, piece, piece, piece))
+        open(path.replace("_stamped", "_stamped_noa"), "w").write(t)
+    s = s.replace("conv_trunk_body_stamped.hpp", "conv_trunk_body_stamped_noa.hpp").replace(
+        "conv_policy_body_stamped.hpp", "conv_policy_body_stamped_noa.hpp")
+    return s
+
+
+def walk_stamps_no_b(src):
+    """TIMING ONLY (wrong numbers): the stamped build with the LDS reads of the K loops removed (every tile multiplies
+    the first two tiles' operands)."""
+    s = walk_stamps(src)
+    for name in ("conv_trunk_body_stamped.hpp", "conv_policy_body_stamped.hpp"):
+        path = os.path.join(OUT, name)
+        t = open(path).read()
+        if "trunk" in name:
+            t = patch(t, """                    bh[nxt] = *(const half8 *)p;
+                    bl[nxt] = *(const half8 *)(p + 256);
+                    __builtin_amdgcn_sched_barrier(0);""", """                    bh[nxt] = bl[cur];
+                    bl[nxt] = bh[cur];
+                    (void)p;
+                    __builtin_amdgcn_sched_barrier(0);""")
+        else:
+            t = patch(t, """                    bh[nxt] = *(const half8 *)p;
+                    bm[nxt] = *(const half8 *)(p + 256);
+                    bl[nxt] = *(const half8 *)(p + 512);""", """                    bh[nxt] = bl[cur];
+                    bm[nxt] = bh[cur];
+                    bl[nxt] = bm[cur];
+                    (void)p;""")
+        open(path.replace("_stamped", "_stamped_nob"), "w").write(t)
+    s = s.replace("conv_trunk_body_stamped.hpp", "conv_trunk_body_stamped_nob.hpp").replace(
+        "conv_policy_body_stamped.hpp", "conv_policy_body_stamped_nob.hpp")
+    return s
+
+
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT, exist_ok=True)
@@ -166,7 +225,8 @@ def main():
     objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "iago_amd", "_obj", "*.o"))) if "search_kernel" not in o]
     assert objs, "build the product first: python -m iago_amd.build"
     only = sys.argv[1:]
-    for name, fn in (("search_log", request_log), ("search_phases", phase_stamps), ("search_walkstamps", walk_stamps)):
+    for name, fn in (("search_log", request_log), ("search_phases", phase_stamps), ("search_walkstamps", walk_stamps),
+                     ("search_walkstamps_noa", walk_stamps_no_a), ("search_walkstamps_nob", walk_stamps_no_b)):
         if only and name not in only:
             continue
         path = os.path.join(OUT, name + ".hip")

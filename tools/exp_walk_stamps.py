@@ -29,10 +29,13 @@ def main():
     buf = (C.c_ulonglong * 192)()
     # warm-up batch inside mcts_leg (warmup_steps=1), then clear before the timed ones: cleared here by reading after
     # the run and subtracting nothing -- the warm-up walks are in the sums too (same workload)
-    out = bench.mcts_leg(games, sims, 0, True, 1, 0, None, steps=2, warmup_steps=1)
+    try:
+        out = bench.mcts_leg(games, sims, 0, True, 1, 0, None, steps=2, warmup_steps=1)
+        res = {"leaf_evals_per_sec": out["leaf_evals_per_sec"], "seconds_per_batch": out["seconds"] / 2}
+    except Exception as e:      # (the timing-only builds compute wrong numbers: a saturation flag may end the leg)
+        res = {"error": str(e)[:200]}
     assert L.iago_debug_walk_stamps(buf, 1) == 0
     st = list(buf)
-    res = {"leaf_evals_per_sec": out["leaf_evals_per_sec"], "seconds_per_batch": out["seconds"] / 2}
     for name, base, mfma_cycles in (("value_pair", 0, 234 * 48 * 16), ("value_single", 32, 234 * 24 * 16), ("policy", 64, 234 * 48 * 16)):
         n = st[base + 31]
         if not n:
@@ -48,6 +51,10 @@ def main():
                      "k_loop_by_layer_us": [round(x, 2) for x in k], "barrier_by_layer_us": [round(x, 2) for x in bar],
                      "epilogue_by_layer_us": [round(x, 2) for x in epi],
                      "mfma_issue_us_at_that_clock": mfma_cycles / clock}
+        if base < 64:   # (the value walks carry finer stamps)
+            res[name]["head_parts_us"] = dict(zip(("mfma", "barrier1", "tap_sums_barrier2", "fc10_barrier3", "sum_store"),
+                                                  [round(st[base + 23 + i] / n / 100.0, 2) for i in range(5)]))
+            res[name]["block1_until_weights_staged_us"] = round(st[base + 28] / n / 100.0, 2)
     print(json.dumps(res, indent=1))
 
 
