@@ -66,8 +66,12 @@ extern __shared__ __align__(16) char policy_lds[];
 
 // pos / res / w1s: the persistent search's hand-offs through LDS (conv_trunk_body.hpp, Piece): the position (word 2 / 3 =
 // own lo / hi, 4 / 5 = opp lo / hi), the distribution [64] instead of P.probs, block1's weights staged already
+// head_w (LDS): conv9's weights [128] and bias10 [64] staged there already
+// SRCH: the persistent search's form (all four given; a compile-time choice: conv_trunk_body.hpp, trunk_item)
+template <bool SRCH = false>
 __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t row_id, const uint32_t *pos = nullptr,
-                                            float *res = nullptr, const float *w1_staged = nullptr)
+                                            float *res = nullptr, const float *w1_staged = nullptr,
+                                            const float *head_w = nullptr)
 {
     char *const T = policy_lds;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -83,8 +87,8 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
             *(uint4 *)(T + e * 16) = src[e];
     } else {
         const int cell = tid & 63, y = cell >> 3, x = cell & 7;
-        const uint64_t bits0 = pos ? (((uint64_t)pos[5] << 32) | pos[4]) : P.opp[b];
-        const uint64_t bits1 = pos ? (((uint64_t)pos[3] << 32) | pos[2]) : P.own[b];
+        const uint64_t bits0 = SRCH ? (((uint64_t)pos[5] << 32) | pos[4]) : P.opp[b];
+        const uint64_t bits1 = SRCH ? (((uint64_t)pos[3] << 32) | pos[2]) : P.own[b];
         float in[18];
 #pragma unroll
         for (int c = 0; c < 2; c++)
@@ -100,7 +104,7 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
         // block1's weights and biases (4.9 KB) through LDS: one round trip to L2 for the workgroup, then broadcast reads
         // (conv_trunk_body.hpp says what the channel-by-channel loads from global memory cost)
         const float *w1s = w1_staged; // [64][18] weights, [64] biases
-        if (!w1s) {
+        if constexpr (!SRCH) {
             float *const st = (float *)(T + BS + 1024 + HEAD_FLOATS * 4);
             for (int e = tid; e < 64 * 18 / 4; e += 256)
                 ((float4 *)st)[e] = ((const float4 *)P.w1)[e];
@@ -343,7 +347,8 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
         for (int c8 = 0; c8 < 16; c8++) {
             const half8 xh = *(const half8 *)(row + c8 * 16), xm = *(const half8 *)(row + 256 + c8 * 16),
                         xl = *(const half8 *)(row + 512 + c8 * 16);
-            const float4 wa = *(const float4 *)(P.w9 + c8 * 8), wb = *(const float4 *)(P.w9 + c8 * 8 + 4);
+            const float *w9 = SRCH ? head_w : P.w9;
+            const float4 wa = *(const float4 *)(w9 + c8 * 8), wb = *(const float4 *)(w9 + c8 * 8 + 4);
             const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
             for (int e = 0; e < 8; e++) {
@@ -351,7 +356,7 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
                 acc = fmaf(w[e], xv, acc);
             }
         }
-        const float logit = acc + P.b10[lane];
+        const float logit = acc + (SRCH ? head_w[128 + lane] : P.b10[lane]);
         float mx = logit;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
@@ -361,7 +366,7 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
             sum += __shfl_xor(sum, o);
-        if (res)
+        if constexpr (SRCH)
             res[lane] = e / sum;
         else
             P.probs[row_id * 64 + lane] = e / sum;

@@ -72,10 +72,15 @@ struct Piece {
     const uint32_t *pos; // optional, LDS: the boards' positions, six words per board (word 2 / 3 = own lo / hi, 4 / 5 = opp lo / hi)
     float *res;          // optional, LDS: the walk's values [TB] instead of P.out
     const float *w1s;    // optional, LDS: block1's weights [64][18] and biases [64] staged there already
+    const char *head_w;  // optional, LDS: the head's weights staged there already (HEAD_W_* below)
 };
+// the head's weights as the persistent search keeps them in LDS: w9_hi | w9_lo (as in global memory) | w10 transposed
+// ([16 float4 columns][128 rows]: a thread's row at stride 16 B between threads) | w11 [128] | b9
+constexpr int HEAD_W_W9LO = 8192, HEAD_W_W10 = 16384, HEAD_W_W11 = 16384 + 32768, HEAD_W_B9 = HEAD_W_W11 + 512,
+              HEAD_W_LDS = HEAD_W_B9 + 16;
 __device__ __forceinline__ Piece whole_walk(const TrunkRParams &P)
 {
-    return Piece{P.index, P.n_dev, P.scratch, P.layer_lo, P.layer_hi, nullptr, nullptr, nullptr};
+    return Piece{P.index, P.n_dev, P.scratch, P.layer_lo, P.layer_hi, nullptr, nullptr, nullptr, nullptr};
 }
 
 constexpr int head_lds(int tb) { return (9 * 64 * tb + 64 * tb + 128 * tb) * 4; } // tap maps, block9 output, fc terms
@@ -95,7 +100,9 @@ __device__ __forceinline__ int cell_of_lane(int r)
 extern __shared__ __align__(16) char trunk_lds[];
 
 // The work of one workgroup on the TB boards (rows) b0 .. b0 + TB - 1 of n_rows.
-template <bool FUSED, int TB>
+// SRCH: the persistent search's form -- W.pos, W.res, W.w1s and W.head_w are all given (decided at compile time: as
+// run-time choices both forms' registers were live in the head and the kernel spilled 103 of them)
+template <bool FUSED, int TB, bool SRCH = false>
 __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W, const int64_t b0, const int64_t n_rows)
 {
     constexpr int NN = 4 * TB;      // 16-cell B tiles of a k-step: TB boards x 4 quarters
@@ -138,7 +145,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
             const int64_t b = W.index ? W.index[row] : row;
             const float *pl = P.planes + b * 128;
             uint64_t bits0, bits1;
-            if (W.pos) {
+            if constexpr (SRCH) {
                 const uint32_t *w = W.pos + 6 * board;
                 bits1 = ((uint64_t)w[3] << 32) | w[2];
                 bits0 = ((uint64_t)w[5] << 32) | w[4];
@@ -167,7 +174,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
         // per output channel (fetched from global memory channel by channel they were sixteen dependent round trips per
         // wave: 5.2 us of a pair's walk under load, LABNOTES.md round 5)
         const float *w1s = W.w1s; // [64][18] weights, [64] biases
-        if (!w1s) {
+        if constexpr (!SRCH) {
             float *const st = (float *)(T + lds_alloc(TB) + head_lds(TB));
             for (int e = tid; e < 64 * 18 / 4; e += 256)
                 ((float4 *)st)[e] = ((const float4 *)P.w1)[e];
@@ -429,11 +436,16 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
         float *const h9s = Dm + 9 * NC;                  // [TB][64]
         float *const hid = h9s + NC;                     // [TB][128]
         // this thread's fc10 row (tid & 127), fetched under the MFMAs below
+        // (from LDS where the persistent search keeps the head's weights: fetched from global memory per walk they were
+        // 96 KB through the CU's L2 port and, streamed past by the trunks' weights, mostly L2 misses -- 6.6 us of a
+        // pair's walk under load: LABNOTES.md, round 5)
         float4 w10row[16];
 #pragma unroll
         for (int c = 0; c < 16; c++)
-            w10row[c] = ((const float4 *)(P.w10 + (tid & 127) * 64))[c];
-        const float w11j = P.w11[tid & 127];
+            w10row[c] = SRCH ? ((const float4 *)(W.head_w + HEAD_W_W10))[c * 128 + (tid & 127)]
+                             : ((const float4 *)(P.w10 + (tid & 127) * 64))[c];
+        const float w11j = SRCH ? ((const float *)(W.head_w + HEAD_W_W11))[tid & 127] : P.w11[tid & 127];
+        const float b9 = SRCH ? *(const float *)(W.head_w + HEAD_W_B9) : P.b9[0];
         const int lane_cell = cell_of_lane(r); // (this block's 32x32x16 lane map: output row r, k half h)
         if (wv < TB) { // wave wv takes board wv
             const u32x4 *w9h = (const u32x4 *)P.w9_hi + r * 2 + h;
@@ -451,8 +463,8 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
             u32x4 w9a[8], w9b[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                w9a[c] = w9h[c * 64];
-                w9b[c] = w9l[c * 64];
+                w9a[c] = SRCH ? ((const u32x4 *)W.head_w)[c * 64 + r * 2 + h] : w9h[c * 64];
+                w9b[c] = SRCH ? ((const u32x4 *)(W.head_w + HEAD_W_W9LO))[c * 64 + r * 2 + h] : w9l[c * 64];
             }
 #pragma unroll
             for (int c = 0; c < 8; c++) {
@@ -490,7 +502,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                 if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8)
                     s9 += Dm[tap * NC + (tid & ~63) + yy * 8 + xx];
             }
-            h9s[tid] = fmaxf(s9 + P.b9[0], 0.0f);
+            h9s[tid] = fmaxf(s9 + b9, 0.0f);
         }
         __syncthreads();
         if ((tid >> 7) * 2 < TB) {
@@ -533,7 +545,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                 v += hv[j4].w;
             }
             const int64_t row = b0 + tid;
-            if (W.res)
+            if constexpr (SRCH)
                 W.res[tid] = v;
             else
                 P.out[W.index ? W.index[row] : row] = v;

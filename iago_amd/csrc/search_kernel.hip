@@ -896,6 +896,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ((float4 *)(w1_val + 64 * 18))[tid] = ((const float4 *)VP.b1)[tid];
         ((float4 *)(w1_pol + 64 * 18))[tid] = ((const float4 *)PP.b1)[tid];
     }
+    // ... and the heads' weights (the value net's 48.5 KB: block9 as MFMA operand, fc10 transposed so that a thread's row is
+    // read at 16 B between threads, fc11, block9's bias; the policy net's conv9 and bias10): read once per walk from
+    // global memory they are evicted from L2 by the trunks' weight streams in between
+    char *const head_v = (char *)(w1_pol + (64 * 18 + 64));
+    float *const head_p = (float *)(head_v + iago_trunk::HEAD_W_LDS);
+    for (int e = tid; e < 512; e += 256) {
+        ((uint4 *)head_v)[e] = VP.w9_hi[e];
+        ((uint4 *)(head_v + iago_trunk::HEAD_W_W9LO))[e] = VP.w9_lo[e];
+    }
+    for (int e = tid; e < 128 * 16; e += 256) // fc10 [128][64]: row j = e / 16, float4 column c = e % 16
+        ((float4 *)(head_v + iago_trunk::HEAD_W_W10))[(e & 15) * 128 + (e >> 4)] = ((const float4 *)VP.w10)[e];
+    if (tid < 128)
+        ((float *)(head_v + iago_trunk::HEAD_W_W11))[tid] = VP.w11[tid];
+    if (tid == 0)
+        *(float *)(head_v + iago_trunk::HEAD_W_B9) = VP.b9[0];
+    if (tid < 128)
+        head_p[tid] = PP.w9[tid];
+    if (tid < 64)
+        head_p[128 + tid] = PP.b10[tid];
     __syncthreads();
     u64 *put_e = nullptr; // (lanes 0 / 1: the position-table entry whose sequence word is still to be published)
     u64 put_word = 0;
@@ -985,10 +1004,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             W.pos = job;
             W.res = res_v;
             W.w1s = w1_val;
+            W.head_w = head_v;
             if (count == 2)
-                iago_trunk::trunk_item<true, 2>(VP, W, row0, row0 + count);
+                iago_trunk::trunk_item<true, 2, true>(VP, W, row0, row0 + count);
             else
-                iago_trunk::trunk_item<true, 1>(VP, W, row0, row0 + count);
+                iago_trunk::trunk_item<true, 1, true>(VP, W, row0, row0 + count);
             __syncthreads();
             if (tid < count) {
                 const uint32_t bits = __float_as_uint(res_v[tid]);
@@ -1002,7 +1022,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
         } else {
-            iago_policy::policy_item(PP, row0, job, res_p, w1_pol);
+            iago_policy::policy_item<true>(PP, row0, job, res_p, w1_pol, head_p);
             __syncthreads();
             if (tid < 64)
                 st(&S.rep_p[(int64_t)(job[0] & 0x7FFFFFFFu) * 64 + tid], ((u64)job[1] << 32) | __float_as_uint(res_p[tid]));
@@ -1015,7 +1035,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 } // namespace
 
 namespace {
-constexpr int search_lds() { return SEARCH_IMG_TOP + iago_trunk::W1_LDS + iago_policy::W1_LDS; }
+constexpr int search_lds() { return SEARCH_IMG_TOP + iago_trunk::W1_LDS + iago_policy::W1_LDS + iago_trunk::HEAD_W_LDS + 192 * 4; }
 } // namespace
 
 extern "C" int iago_mcts_search_capacity(int32_t *cus, int32_t *workgroups_per_cu)
