@@ -177,7 +177,9 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
         auto a_load = [&](const char *base, uint32_t step_bytes, int m) -> u32x4 {
             return *(const u32x4 *)(base + step_bytes + a_lane + (uint32_t)m * 512u);
         };
-        float4v acc0[2][4], acc1[2][4], acc2[2][4];
+        // (acc0: the hi x hi products, in two halves by tap parity -- two chains of 18 additions instead of one of 36: the
+        // accumulator's rounding is what the net's 1e-5 bound on the move distribution is spent on)
+        float4v acc0[2][4], acc0b[2][4], acc1[2][4], acc2[2][4];
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -185,6 +187,7 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     acc0[m][n][v] = 0.0f;
+                    acc0b[m][n][v] = 0.0f;
                     acc1[m][n][v] = 0.0f;
                     acc2[m][n][v] = 0.0f;
                 }
@@ -256,7 +259,10 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
                     else if (q == 2)
                         a_lo[(tap + 2) % 3][0] = a_load(wl, w2, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    IAGO_POLICY_MFMA16(acc0[0][q], ah[0], bh[cur]);
+                    if (tap & 1)
+                        IAGO_POLICY_MFMA16(acc0b[0][q], ah[0], bh[cur]);
+                    else
+                        IAGO_POLICY_MFMA16(acc0[0][q], ah[0], bh[cur]);
                     if (q == 0)
                         a_hi[(tap + 2) % 3][1] = a_load(wh, w2, 1);
                     else if (q == 1)
@@ -264,7 +270,10 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
                     else if (q == 2)
                         a_lo[(tap + 2) % 3][1] = a_load(wl, w2, 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    IAGO_POLICY_MFMA16(acc0[1][q], ah[1], bh[cur]);
+                    if (tap & 1)
+                        IAGO_POLICY_MFMA16(acc0b[1][q], ah[1], bh[cur]);
+                    else
+                        IAGO_POLICY_MFMA16(acc0[1][q], ah[1], bh[cur]);
                     IAGO_POLICY_MFMA16(acc2[0][q], al[0], bh[cur]);
                     IAGO_POLICY_MFMA16(acc2[1][q], al[1], bh[cur]);
                     IAGO_POLICY_MFMA16(acc1[0][q], am[0], bh[cur]);
@@ -308,7 +317,7 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
                 h2 p0[2], p1[2], p2[2];
 #pragma unroll
                 for (int t2 = 0; t2 < 2; t2++) {
-                    const f2 m0 = (f2){acc0[m][q][2 * t2], acc0[m][q][2 * t2 + 1]};
+                    const f2 m0 = (f2){acc0[m][q][2 * t2], acc0[m][q][2 * t2 + 1]} + (f2){acc0b[m][q][2 * t2], acc0b[m][q][2 * t2 + 1]};
                     const f2 m1 = (f2){acc1[m][q][2 * t2], acc1[m][q][2 * t2 + 1]};
                     const f2 m2 = (f2){acc2[m][q][2 * t2], acc2[m][q][2 * t2 + 1]};
                     f2 v = (m2 * S2 + m1 * S1) + m0 + bia[m][t2];

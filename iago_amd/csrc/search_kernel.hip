@@ -1099,7 +1099,7 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: product-form rollout of the n games without "
                                            "trace / uniforms expected");
     const int gpw = a->games_per_workgroup > 0 ? a->games_per_workgroup : GAMES_PER_WG;
-    if (gpw != 8 && gpw != 16 && gpw != 32)
+    if (gpw != 8 && gpw != 16 && gpw != 24 && gpw != 32)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: games_per_workgroup is 0 (= 32), 8, 16 or 32");
     const int64_t n_game_wgs = (tree->n_games + gpw - 1) / gpw;
     // The grid follows the device: every game workgroup must be resident together with at least one net workgroup (a

@@ -309,20 +309,35 @@ def test_value_and_rollout_in_one_launch(count):
 
 
 def test_trunk_kernel_equals_layer_by_layer():
-    """iago_conv3x3_split_trunk (several layers, one launch) must reproduce the per-layer
-    launches bit for bit, for a ragged batch and a 64-channel first layer."""
+    """iago_conv3x3_split_trunk (several layers, one launch) against the per-layer launches, for a ragged batch and a
+    64-channel first layer.  Both are the same split-f16 convolution with float32 accumulation; since round 5 the trunk
+    sums a product's 32 input channels per v_mfma_f32_16x16x32_f16 where the per-layer kernel sums 16 per
+    v_mfma_f32_32x32x16_f16, so the two differ by float32 rounding of the accumulation order (they were bit-equal while
+    both used the long shape): equal to a few float32 ulps of the layer's largest activation after four layers, and
+    both within the same distance of a float64 convolution of the same split operands."""
     from iago_amd import ops
     torch.manual_seed(21)
     n = 37
-    a0 = ops.split_nchw((torch.rand(n, 64, 8, 8) * 2).cuda())
-    layers = []
+    x0 = (torch.rand(n, 64, 8, 8) * 2).cuda()
+    a0 = ops.split_nchw(x0)
+    layers, f64 = [], []
     cin = 64
     for k in range(4):
         w = (torch.randn(128, cin, 3, 3) / np.sqrt(9 * cin)).cuda()
-        layers.append(ops.split_weights(w) + ((torch.randn(128) * 0.1).cuda(),))
+        b = (torch.randn(128) * 0.1).cuda()
+        layers.append(ops.split_weights(w) + (b,))
+        f64.append((w.double(), b.double()))
         cin = 128
     ref = a0
     for w_hi, w_lo, b in layers:
         ref = ops.conv3x3_split(ref, w_hi, w_lo, b)
     got = ops.conv3x3_split_trunk(a0, layers)
-    assert torch.equal(got.hi, ref.hi) and torch.equal(got.lo, ref.lo)
+    g, r = ops.merge_nchw(got), ops.merge_nchw(ref)
+    scale = float(r.abs().max())
+    assert float((g - r).abs().max()) < 4e-6 * scale, (float((g - r).abs().max()), scale)
+    # ... and neither is further from the float64 result than the other by more than that
+    want = x0.double()
+    for w, b in f64:
+        want = torch.relu(torch.nn.functional.conv2d(want, w, b, padding=1))
+    eg, er = float((g.double() - want).abs().max()), float((r.double() - want).abs().max())
+    assert eg < 2e-5 * scale and er < 2e-5 * scale, (eg, er, scale)

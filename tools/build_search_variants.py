@@ -218,6 +218,19 @@ def walk_stamps_no_b(src):
     return s
 
 
+def rollout_no_conflicts():
+    """TIMING ONLY (wrong numbers): rollout_row_kernel.hip with the policy's table reads made bank-conflict-free (every
+    lane reads the slot of its own lane number instead of the entry its window selects): the upper bound of what a
+    table replicated per lane slot could gain (VERDICT r04 task 7).  -> tools/_build/rollout_noconf.so"""
+    body = open(os.path.join(CSRC, "rollout_row_body.hpp")).read()
+    body = patch(body, "fac[ky * 2 + pl] = *(const f4 *)(tb + idx + (ky * 2 + pl) * 1024);",
+                 "fac[ky * 2 + pl] = *(const f4 *)(tb + ((idx & 0u) | (L.l << 4)) + (ky * 2 + pl) * 1024);")
+    open(os.path.join(OUT, "rollout_row_body_noconf.hpp"), "w").write(body)
+    src = open(os.path.join(CSRC, "rollout_row_kernel.hip")).read()
+    src = patch(src, '#include "rollout_row_body.hpp"', '#include "rollout_row_body_noconf.hpp"')
+    return src
+
+
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT, exist_ok=True)
@@ -225,6 +238,17 @@ def main():
     objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "iago_amd", "_obj", "*.o"))) if "search_kernel" not in o]
     assert objs, "build the product first: python -m iago_amd.build"
     only = sys.argv[1:]
+    if "rollout_noconf" in only:
+        path = os.path.join(OUT, "rollout_noconf.hip")
+        open(path, "w").write(rollout_no_conflicts())
+        obj = os.path.join(OUT, "rollout_noconf.o")
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden",
+                               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", path, "-o", obj])
+        others = [o for o in sorted(glob.glob(os.path.join(ROOT, "iago_amd", "_obj", "*.o"))) if "rollout_row_kernel" not in o]
+        so = os.path.join(OUT, "rollout_noconf.so")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + others + [obj])
+        print(so)
+        return
     for name, fn in (("search_log", request_log), ("search_phases", phase_stamps), ("search_walkstamps", walk_stamps),
                      ("search_walkstamps_noa", walk_stamps_no_a), ("search_walkstamps_nob", walk_stamps_no_b)):
         if only and name not in only:
