@@ -327,7 +327,7 @@ def csrc_sha16():
     import hashlib
     h = hashlib.sha256()
     here = os.path.dirname(os.path.abspath(__file__))   # (the sources of THIS file's tree, wherever ROOT points)
-    for path in sorted(glob.glob(os.path.join(here, "iago_amd", "csrc", "*"))) + [os.path.join(here, "include", "iago_hip.h")]:
+    for path in sorted(glob.glob(os.path.join(here, "iago_amd", "csrc", "*"))) + sorted(glob.glob(os.path.join(here, "include", "*.h"))):
         with open(path, "rb") as f:
             h.update(os.path.basename(path).encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

@@ -31,9 +31,13 @@ SYMBOLS = [
     "iago_leaf_values",
     "iago_mcts_backup", "iago_mcts_mix_backup", "iago_mcts_best_move", "iago_mcts_advance_root", "iago_mcts_compact",
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
-    "iago_mcts_fresh_leaves", "iago_mcts_descend", "iago_value_rollout_async",
-    "iago_value_forward_batch", "iago_mcts_value_ahead_rows", "iago_mcts_value_ahead_store",
+    "iago_mcts_fresh_leaves", "iago_mcts_descend",
     "iago_mcts_search_persistent", "iago_mcts_search_capacity", "iago_selfplay_policy",
+]
+# include/iago_hip_experimental.h: two schedules of the per-playout engine that measured slower (game-asynchronous steps,
+# value look-ahead); opt-in through engine.BatchedMCTS(async_steps=True / value_ahead=True), off every default path
+EXPERIMENTAL_SYMBOLS = [
+    "iago_value_rollout_async", "iago_value_forward_batch", "iago_mcts_value_ahead_rows", "iago_mcts_value_ahead_store",
 ]
 
 
@@ -250,7 +254,7 @@ def lib():
     L.iago_mcts_search_persistent.argtypes = [C.POINTER(MctsSearchArgs), vp]
     L.iago_mcts_search_capacity.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.iago_selfplay_policy.argtypes = [C.POINTER(SelfplayPolicyArgs), vp]
-    for name in SYMBOLS[3:]:
+    for name in SYMBOLS[3:] + EXPERIMENTAL_SYMBOLS:
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

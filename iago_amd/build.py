@@ -27,7 +27,7 @@ def _stale():
         return True
     t = os.path.getmtime(SO)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + \
-        [os.path.join(HERE, "..", "include", "iago_hip.h"), os.path.abspath(__file__)]
+        glob.glob(os.path.join(HERE, "..", "include", "*.h")) + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

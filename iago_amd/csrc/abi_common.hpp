@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "../../include/iago_hip.h"
+#include "../../include/iago_hip_experimental.h" // (includes iago_hip.h)
 
 // Records `msg` as the thread's last error and returns `code`.
 int iago_fail(int code, const char *msg);

@@ -90,10 +90,13 @@ def _positions(G, golden_rules):
     return own, opp
 
 
-@pytest.mark.parametrize("async_steps,value_ahead,persistent", [(False, False, True), (False, False, False),
-                                                                (True, False, False), (False, True, False),
-                                                                (True, True, False)])
-@pytest.mark.parametrize("n_sims,n_sims2,G", [(100, 60, 320), (400, 37, 64)])
+# (the two engines that serve the path -- the persistent search and the lockstep per-playout launches -- at both sizes;
+# the schedules that measured slower and are fenced off in include/iago_hip_experimental.h -- game-asynchronous steps,
+# value look-ahead -- keep one smoke each: VERDICT r04 task 8)
+@pytest.mark.parametrize("n_sims,n_sims2,G,async_steps,value_ahead,persistent", [
+    (100, 60, 320, False, False, True), (400, 37, 64, False, False, True),
+    (100, 60, 320, False, False, False), (400, 37, 64, False, False, False),
+    (400, 37, 64, True, False, False), (400, 37, 64, True, True, False)])
 def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_sims, n_sims2, G, async_steps,
                                                      value_ahead, persistent):
     """async_steps=False: lockstep playouts, the default and what bench.py times.  True: the same
@@ -180,7 +183,7 @@ def test_production_search_trees_bit_exact_vs_oracle(shipped, golden_rules, n_si
     value.check_saturation()
 
 
-@pytest.mark.parametrize("async_steps", ["persistent", False, True, 2, 4])
+@pytest.mark.parametrize("async_steps", ["persistent", False, 2])
 def test_production_self_play_games_vs_oracle(shipped, async_steps):
     """Whole self-play games through SelfPlayEngine at the production defaults (what bench.py's
     PV-MCTS leg times), 20 playouts per move (n_thr = 15 needs > 15): every game's move list and

@@ -1,4 +1,6 @@
-"""The value look-ahead (iago_mcts_value_ahead, include/iago_hip.h; engine.BatchedMCTS(value_ahead=True)).
+"""The value look-ahead (iago_mcts_value_ahead, include/iago_hip_experimental.h; engine.BatchedMCTS(value_ahead=True)):
+an EXPERIMENTAL schedule of the per-playout engine -- built, tree-identical, measured slower (LABNOTES.md, round 4), off by
+default -- kept with a smoke test of each property.
 
 value_func(state) (MCTS.py:97-103) is evaluated for the children of a node when the node expands, as
 one batch off the playouts' critical path, instead of at each child's first visit (MCTS.py:123-124).
@@ -6,7 +8,7 @@ What must hold: (1) every value stored in a node -- whichever way it got there -
 output for THAT node's position, bit for bit (a wrong row -> node mapping or a batch-dependent kernel
 would show here); (2) the trees are the trees of the search without the look-ahead; (3) the look-ahead
 does take evaluations off the critical path.  The comparison of the production path with the oracle
-(tests/test_mcts_production_gpu.py) runs with the look-ahead on as well (it is the default).
+(tests/test_mcts_production_gpu.py) has one case with the look-ahead on.
 """
 import os
 
@@ -62,7 +64,7 @@ def _tree_arrays(m):
                                                              "n_children", "n_nodes", "root")}
 
 
-@pytest.mark.parametrize("use_graph,async_steps", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("use_graph,async_steps", [(True, False)])   # (one smoke: an engine fenced off as experimental)
 def test_trees_equal_with_and_without_value_ahead(nets, use_graph, async_steps):
     G, n_sims, n_sims2 = 96, 100, 45
     own, opp = _positions(G)
