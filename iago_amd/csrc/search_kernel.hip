@@ -140,6 +140,7 @@ struct SearchParams {
     // without a value at ITS first visit: the first in this very playout, the others a few playouts from now) are walked
     // through the value net beside the policy walk and put into the position table (< 0: off; needs the table)
     int32_t ahead_idle;
+    int32_t roll_defer; // rollouts: games a full pass of 16 may leave over for the next iteration (0: every game at once)
 };
 
 __device__ __forceinline__ u64 ld(const u64 *p) { return __hip_atomic_load(p, RLX_AGENT); }
@@ -300,8 +301,10 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
     float v_reply = 0.0f;
     int st_levels = 0, st_children = 0;
     long long iters = 0, idle_iters = 0;
+    long long roll_hist[4] = {0, 0, 0, 0}; // iterations with 0 / 1..16 / 17..20 / more games rolled out
     __shared__ int32_t roll_list[GAMES_PER_WG]; // games whose leaf is rolled out in this iteration, packed
-    __shared__ uint32_t roll_wave[BLOCK / 64];
+    __shared__ uint32_t roll_wave[BLOCK / 64], roll_wave_old[BLOCK / 64];
+    bool deferred = false; // this game's rollout was put off to the next iteration's first pass
     bool table_ready = false;                   // the rollout's factor table is in LDS (from the first pass on)
     // pacing: what this game has added to CTL_PROGRESS / whether CTL_PLAYING counts it; the workgroup's changes of an
     // iteration are collected in LDS and go out as one atomic each; pace[2]: the progress above which a game holds
@@ -703,29 +706,48 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
         // the others wait for a net: one pass of the 16-lanes-per-board body instead of two, most of the time).  A
         // board's game does not depend on its row: Philox counters are keyed by the game and its playout count
         const bool rolls = mine && need_z && (state == ST_ROLL || state == ST_ROLL_FRESH);
+        bool rolled = true; // this game's rollout ran in this iteration (or it needs none)
         {
+            // Passes of 16 boards.  A pass costs the same whether it plays 16 boards or one, and all games of the workgroup
+            // wait for it: when a full pass leaves only a few games over (at most S.roll_defer), they are played in the
+            // NEXT iteration's first pass, ahead of that iteration's own (17 .. 20 games rolled out in 16 % of the
+            // iterations, more than 20 in 32 %: LABNOTES.md, round 5).  Timing only: a game's rollout is keyed by its
+            // own playout count, whenever it runs.
             const uint64_t bal = __builtin_amdgcn_ballot_w64(rolls && r == 0u); // bit 8 j: game j of this wave
-            if ((tid & 63) == 0)
+            const uint64_t balo = __builtin_amdgcn_ballot_w64(rolls && deferred && r == 0u);
+            if ((tid & 63) == 0) {
                 roll_wave[tid >> 6] = (uint32_t)(((bal & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+                roll_wave_old[tid >> 6] = (uint32_t)(((balo & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+            }
             if (tid < GAMES_PER_WG)
                 roll_list[tid] = -1;
             __syncthreads();
-            uint32_t gm = 0u; // bit j: game j of the workgroup has a rollout
+            uint32_t gm = 0u, go = 0u; // bit j: game j of the workgroup has a rollout / one put off in the last iteration
 #pragma unroll
-            for (int w = 0; w < BLOCK / 64; w++)
+            for (int w = 0; w < BLOCK / 64; w++) {
                 gm |= roll_wave[w] << (8 * w);
-            if (rolls && r == 0u)
-                roll_list[__popc(gm & ((1u << (tid >> 3)) - 1u))] = (int32_t)g;
+                go |= roll_wave_old[w] << (8 * w);
+            }
+            const int n_roll = __popc(gm), rem = n_roll & 15;
+            const int n_now = (n_roll < 16 || rem > S.roll_defer) ? n_roll : n_roll - rem;
+            const uint32_t below = (1u << (tid >> 3)) - 1u;
+            // the games put off last time first, then this iteration's own, each in game order
+            const int rank = deferred ? __popc(go & below) : __popc(go) + __popc(gm & ~go & below);
+            const bool now = rolls && rank < n_now;
+            if (now && r == 0u)
+                roll_list[rank] = (int32_t)g;
+            deferred = rolls && !now;
+            rolled = !rolls || now;
             __syncthreads();
-            const int n_roll = __popc(gm);
+            roll_hist[n_roll == 0 ? 0 : n_roll <= 16 ? 1 : n_roll <= 20 ? 2 : 3]++; // (diagnostic: totals[10], [13..15])
 #pragma unroll 1
-            for (int at = 0; at < n_roll; at += 16) {
+            for (int at = 0; at < n_now; at += 16) {
                 iago_row::rollout_row_body<false, true, true>(R, 0u, roll_list + at, table_ready);
                 table_ready = true;
                 __syncthreads();
             }
         }
-        if (mine) {
+        if (mine && rolled) {
             if (state == ST_ROLL) {
                 backup_game(S, g, r, leaf, leaf_fresh, __uint_as_float(vbits), path_n);
                 n_done++;
@@ -800,6 +822,10 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
     if (tid == 0) {
         atomicAdd((unsigned long long *)&S.totals[2], (unsigned long long)iters);
         atomicAdd((unsigned long long *)&S.totals[6], (unsigned long long)idle_iters);
+        atomicAdd((unsigned long long *)&S.totals[10], (unsigned long long)roll_hist[0]);
+        atomicAdd((unsigned long long *)&S.totals[13], (unsigned long long)roll_hist[1]);
+        atomicAdd((unsigned long long *)&S.totals[14], (unsigned long long)roll_hist[2]);
+        atomicAdd((unsigned long long *)&S.totals[15], (unsigned long long)roll_hist[3]);
         atomicAdd((unsigned long long *)&S.totals[7], (unsigned long long)(wall_clock64() - t0));
         __hip_atomic_fetch_add(&S.ctl[CTL_FINISHED], 1u, RLX_AGENT);
     }
@@ -1187,6 +1213,11 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
     // (tuning knob: net workgroups that must poll for values to be walked ahead of their visit; -1 = never)
     const char *ahead_env = getenv("IAGO_PERSISTENT_AHEAD"); // (read per launch: the tests vary it)
     S.ahead_idle = ahead_env ? atoi(ahead_env) : 4;
+    // (tuning knob: games that a full pass of 16 rollouts may leave over for the next iteration)
+    const char *defer_env = getenv("IAGO_PERSISTENT_ROLL_DEFER"); // (read per launch: the tests vary it)
+    S.roll_defer = defer_env ? atoi(defer_env) : 10;
+    if (S.roll_defer < 0 || S.roll_defer > 15)
+        S.roll_defer = S.roll_defer < 0 ? 0 : 15;
     S.max_turns = a->max_turns;
     S.game_own = a->game_own;
     S.game_opp = a->game_opp;

@@ -189,12 +189,14 @@ def test_whole_games(nets, games, monkeypatch):
     assert a["n_turns"] % 2 == 0 and a["valid"].sum() > 40 * 50
 
 
-@pytest.mark.parametrize("pace,backlog,gpw,net", [("-1", "128", "32", None), ("1", "0", "32", 6), ("16", "4", "16", 24)])
-def test_scheduling_knobs_do_not_change_the_games(nets, pace, backlog, gpw, net, monkeypatch):
-    """Pacing of the leading games (held while requests queue), the games per game workgroup and the number of net
-    workgroups decide WHEN a game's playouts run, never what they are: whole games equal the default schedule's in
-    every move, visit count and rollout result.  (pace 1 / backlog 0: a game one playout ahead of the mean holds
-    whenever anything waits -- the pacing at its most intrusive.)"""
+@pytest.mark.parametrize("pace,backlog,gpw,net,defer", [("-1", "128", "32", None, "0"), ("1", "0", "32", 6, "15"),
+                                                        ("16", "4", "16", 24, "3"), ("16", "128", "24", None, "15")])
+def test_scheduling_knobs_do_not_change_the_games(nets, pace, backlog, gpw, net, defer, monkeypatch):
+    """Pacing of the leading games (held while requests queue), the games per game workgroup, the number of net
+    workgroups and the rollouts put off to the next iteration's pass (0: never; 15: whatever a full pass of 16 leaves
+    over) decide WHEN a game's playouts run, never what they are: whole games equal the default schedule's in every
+    move, visit count and rollout result.  (pace 1 / backlog 0: a game one playout ahead of the mean holds whenever
+    anything waits -- the pacing at its most intrusive.)"""
     engine, ops, policy, value, rw = nets
     res = []
     for variant in (False, True):
@@ -202,6 +204,7 @@ def test_scheduling_knobs_do_not_change_the_games(nets, pace, backlog, gpw, net,
             monkeypatch.setenv("IAGO_PERSISTENT_PACE", pace)
             monkeypatch.setenv("IAGO_PERSISTENT_PACE_BACKLOG", backlog)
             monkeypatch.setenv("IAGO_PERSISTENT_GPW", gpw)
+            monkeypatch.setenv("IAGO_PERSISTENT_ROLL_DEFER", defer)
         m = engine.BatchedMCTS(72, policy, value, rw, n_thr=15, capacity=2048, seed=5, persistent=True,
                                net_workgroups=net if variant else None, z_log_rows=64 * 30)
         assert m.games_per_workgroup == (int(gpw) if variant else 8)      # (72 games: 9 game workgroups of 8 by default)
