@@ -437,83 +437,99 @@ def _mcts_roofline(leaf, pol, dt, world, value_f32, policy_split3=False, persist
             "kernels": net_kernel_profiles(persistent)}
 
 
-def cpu_workers(kind, budget_s):
+CPU_WINDOWS = (("mcts", 8.0), ("python_loops", 4.0), ("sl_game", 4.0))   # kinds of CPU work and their timed windows (s)
+CPU_WINDOW_GAP = 1.5
+_cpu_pool = {}
+
+
+def cpu_workers(kind, budget_s=None):
     """the reference's own execution model "on P = os.cpu_count() independent
     worker processes, P stated" -- the reference is one single-threaded Python process per game
     (MCTS.py:139-147, mcts_self_play.py:25-29), so P of them side by side is what the host's
     cores give it.  P = host_cores() copies of this script in --cpu-worker mode (CHILD processes
-    that never touch the GPU), all timing the same `budget_s` window that starts at a common wall
-    clock instant after their imports; the aggregate is the sum of their counts over the window."""
+    that never touch the GPU) run ALL kinds of CPU work one after the other (CPU_WINDOWS: one import of
+    torch per process), every kind in a window of its own that starts at a common wall clock instant;
+    the aggregate of a kind is the sum of the workers' counts over its window."""
     import subprocess
-    P = min(host_cores(), 64)
-    start_at = time.time() + 20.0        # imports + warm-up of the slowest worker
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", kind,
-                               "--cpu-worker-budget", str(budget_s), "--cpu-worker-start", repr(start_at),
-                               "--cpu-worker-seed", str(i)],
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
-                              env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1"))
-             for i in range(P)]
-    rows = []
-    for pr in procs:
-        out, _ = pr.communicate(timeout=600)
-        if pr.returncode == 0 and out.strip():
-            rows.append(json.loads(out.strip().splitlines()[-1]))
-    if len(rows) != P:
-        return {"error": "%d of %d CPU workers finished" % (len(rows), P)}
-    window = max(r["seconds"] for r in rows)
-    late = max(r["late_s"] for r in rows)
-    return {"count": sum(r["count"] for r in rows), "seconds": window, "processes": P, "max_start_lag_s": late,
-            "steps": sum(r.get("steps", 0) for r in rows)}
+    if not _cpu_pool:
+        P = min(host_cores(), 64)
+        start_at = time.time() + 20.0        # imports + warm-up of the slowest worker
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "all",
+                                   "--cpu-worker-start", repr(start_at), "--cpu-worker-seed", str(i)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                  env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1"))
+                 for i in range(P)]
+        rows = []
+        for pr in procs:
+            out, _ = pr.communicate(timeout=600)
+            if pr.returncode == 0 and out.strip():
+                rows.append(json.loads(out.strip().splitlines()[-1]))
+        for k, _ in CPU_WINDOWS:
+            mine = [r[k] for r in rows if k in r]
+            if len(mine) != P:
+                _cpu_pool[k] = {"error": "%d of %d CPU workers finished" % (len(mine), P)}
+            else:
+                _cpu_pool[k] = {"count": sum(r["count"] for r in mine), "seconds": max(r["seconds"] for r in mine),
+                                "processes": P, "max_start_lag_s": max(r["late_s"] for r in mine),
+                                "steps": sum(r.get("steps", 0) for r in mine)}
+    return _cpu_pool[kind]
 
 
 def cpu_worker_main(kind, budget_s, start_at, seed):
-    """One worker of cpu_workers(): warm up, wait for the common start, run for budget_s."""
+    """One worker of cpu_workers(): warm every kind up, then per kind wait for the common start of its window and
+    run for its budget; ONE line on stdout: {kind: {count, steps, seconds, late_s}}."""
     w, b = shipped_rollout_weights()
     torch.set_num_threads(1)
-    count = steps = 0
-    if kind == "python_loops":
-        from iago_amd import network
-        from oracle import py_loops
-        ro = network.RolloutPolicy().eval()
-        with torch.no_grad():
-            ro.conv1.weight.copy_(torch.from_numpy(w.reshape(1, 2, 3, 3)))
-            ro.bias2.b.copy_(torch.from_numpy(b))
 
-        def policy(x):
+    def make(kind):
+        if kind == "python_loops":
+            from iago_amd import network
+            from oracle import py_loops
+            ro = network.RolloutPolicy().eval()
             with torch.no_grad():
-                return ro(torch.from_numpy(x)).numpy()
+                ro.conv1.weight.copy_(torch.from_numpy(w.reshape(1, 2, 3, 3)))
+                ro.bias2.b.copy_(torch.from_numpy(b))
 
-        s0 = np.zeros((8, 8), np.float32)
-        s0[4, 3] = s0[3, 4] = 1
-        s0[3, 3] = s0[4, 4] = 2
-        rs = np.random.RandomState(seed)
+            def policy(x):
+                with torch.no_grad():
+                    return ro(torch.from_numpy(x)).numpy()
 
-        def unit():
-            return 1, py_loops.simulate(s0, 1, policy, rs)[1]
-    elif kind == "mcts":
-        m = _cpu_mcts(w, b, seed)
-
-        def unit():   # 20 playouts of the worker's own game tree from the start position
+            s0 = np.zeros((8, 8), np.float32)
+            s0[4, 3] = s0[3, 4] = 1
+            s0[3, 3] = s0[4, 4] = 2
+            rs = np.random.RandomState(seed)
+            return lambda: (1, py_loops.simulate(s0, 1, policy, rs)[1])
+        if kind == "mcts":
             from oracle import oracle as orc
-            m.get_move(orc.initial_state(), 1, 20)
-            return 20, 0
-    elif kind == "sl_game":
-        play = _cpu_sl_game(seed)
+            m = _cpu_mcts(w, b, seed)
 
-        def unit():   # one SLPolicy-vs-SLPolicy game (src/rl_self_play.py:27-31)
-            return 1, play()
-    else:
+            def unit():   # 20 playouts of the worker's own game tree from the start position
+                m.get_move(orc.initial_state(), 1, 20)
+                return 20, 0
+            return unit
+        if kind == "sl_game":
+            play = _cpu_sl_game(seed)
+            return lambda: (1, play())   # one SLPolicy-vs-SLPolicy game (src/rl_self_play.py:27-31)
         raise SystemExit("unknown --cpu-worker kind %r" % kind)
-    unit()                                  # warm-up
-    late = max(0.0, time.time() - start_at)
-    while time.time() < start_at:
-        time.sleep(0.01)
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        c, st = unit()
-        count += c
-        steps += st
-    print(json.dumps({"count": count, "steps": steps, "seconds": time.perf_counter() - t0, "late_s": late}), flush=True)
+
+    windows = CPU_WINDOWS if kind == "all" else ((kind, budget_s),)
+    units = {k: make(k) for k, _ in windows}
+    for k in units:
+        units[k]()                           # warm-up
+    out, t_start = {}, start_at
+    for k, budget in windows:
+        late = max(0.0, time.time() - t_start)
+        while time.time() < t_start:
+            time.sleep(0.01)
+        count = steps = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            c, st = units[k]()
+            count += c
+            steps += st
+        out[k] = {"count": count, "steps": steps, "seconds": time.perf_counter() - t0, "late_s": late}
+        t_start += budget + CPU_WINDOW_GAP
+    print(json.dumps(out), flush=True)
 
 
 def _cpu_mcts(w, b, seed):
@@ -596,7 +612,7 @@ def mcts_cpu_baseline(n_sims=600, leaf_evals_per_game=None):
     one = {"value": n_sims / dt, "unit": "leaf-evals/s", "cores": 1, "kind": "port",
            "sample": "%d playouts of one game from the start position, oracle/mcts_py.py + "
                      "torch-CPU fp32 nets (1 thread) + C rollout, %.1f s" % (n_sims, dt)}
-    out = _all_cores("mcts", 8.0, "leaf-evals/s", "one game tree each, the same restatement")
+    out = _all_cores("mcts", None, "leaf-evals/s", "one game tree each, the same restatement")
     if "error" in out:
         out = dict(one, all_cores=out)
     else:
@@ -648,6 +664,8 @@ def reinforce_cpu_baseline(sl):
     import torch.nn.functional as F
     n = int(round(64 * sl.get("colour1_moves_per_game", 30.0)))
     torch.manual_seed(0)
+    threads0 = torch.get_num_threads()
+    torch.set_num_threads(min(host_cores(), 64))      # (the cores this process may really use, not the machine's)
     net = network.SLPolicy().train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
     x = (torch.rand(n, 2, 8, 8) < 0.3).float()
@@ -663,9 +681,11 @@ def reinforce_cpu_baseline(sl):
         opt.step()
         times.append(time.perf_counter() - t0)
     upd = min(times)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(threads0)
     ac = sl.get("all_cores", {})
     gps_all = ac.get("value")
-    out = {"unit": "sets/s", "kind": "port", "update_seconds": upd, "update_threads": torch.get_num_threads(),
+    out = {"unit": "sets/s", "kind": "port", "update_seconds": upd, "update_threads": nthreads,
            "update_rows": n,
            "one_core_games": {"value": 1.0 / (64.0 / sl["value"] + upd), "cores": 1,
                               "note": "64 games on one core + the update"},
@@ -870,7 +890,7 @@ def python_loop_baseline(w, b, budget_s=4.0):
            "sample": "%d rollout-policy games, oracle/py_loops.py (Python loops over a numpy board, "
                      "torch-CPU B=1 policy calls), %.1f s" % (games, dt),
            "board_steps_per_game": steps / max(games, 1)}
-    pw = cpu_workers("python_loops", 4.0)
+    pw = cpu_workers("python_loops")
     if "error" in pw:
         out["all_cores"] = pw
     else:
@@ -1371,7 +1391,7 @@ def main():
             roof["traffic"] = sk.get("hbm_bytes_per_launch") if prof.get("current") else None
             roof["profile"] = prof.get("profile")
             roof["profile_current"] = bool(prof.get("current"))
-            roof["rocprof_kernel_avg_ms"] = (sk.get("rocprof_avg_us") or 0.0) / 1e3 or None
+            roof["rocprof_kernel_avg_ms"] = ((sk.get("rocprof_avg_us") or 0.0) / 1e3 or None) if prof.get("current") else None
             if prof.get("current") and sk.get("frac") is not None:
                 roof["executed_frac_pmc"] = sk["frac"]     # SQ_INSTS_MFMA x 32,768 / duration / peak, committed profile
         else:

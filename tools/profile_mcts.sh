@@ -16,7 +16,9 @@ if [ "$MODE" = "full" ]; then TURNS=-1; SUF=_mcts_fullgame; elif [ "$MODE" = "pe
 OUT=$REPO/gpurun_out/prof_${TAG}${SUF}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --large-boards 0 --train-iters 0 --mcts-turns $TURNS $EAGER --mcts-only"
+# (round 5: the headline of bench.py IS this leg -- K whole-game batches, one search_kernel launch each; 1 warm-up + 5 timed
+# batches per pass: every launch of a pass is a whole batch, so rocprofv3's average is the average of whole batches)
+ARGS="--gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --mcts-turns $TURNS $EAGER --mcts-only"
 echo "python3 bench.py $ARGS" > "$OUT/command.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py $ARGS > "$OUT/trace.log" 2>&1
 # one pass per counter group (MI355X_MICROARCH.md: PMC in runs of their own, no trace domains);

@@ -60,9 +60,9 @@ for k in KERNELS:
             d["l2_read_gb_per_s_per_workgroup_64B_req"] = d["l2_read_bytes_per_launch_64B_req"] / wgs / d["avg_us"] / 1e3
             d["l2_read_gb_per_s_per_workgroup_128B_req"] = d["l2_read_bytes_per_launch_128B_req"] / wgs / d["avg_us"] / 1e3
 if "calls" in out["search_kernel"]:
-    out["search_kernel"]["note"] = ("one launch = a whole batch of games; the calls are the bench leg's warm-up batch (a few "
-                                    "turns: min_us) and the timed one (max_us): the counters and avg_us are means over both, "
-                                    "so every RATE (counter / time) is the sum over both launches divided by their total time")
+    out["search_kernel"]["note"] = ("one launch = a whole batch of games (1024 games x 100 playouts per move, played to the end); "
+                                    "every launch of the profiled command -- its warm-up batch and its timed ones -- is such a "
+                                    "batch: the counters and avg_us are means over all of them")
 cmd = os.path.join(src, "command.txt")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench  # noqa: E402  (csrc_sha16: the kernel sources this profile was taken on)
