@@ -311,11 +311,13 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
 
 
 MFMA_FLOP_32x32x16 = 2 * 32 * 32 * 16    # one v_mfma_f32_32x32x16_f16 wave-instruction
+MFMA_FLOP_16x16x32 = 2 * 16 * 16 * 32    # one v_mfma_f32_16x16x32_f16: the walks' K loops since round 5 (half the FLOPs, half the cycles)
 MIN_PROFILE_LAUNCHES = 100
 F16_PEAK_TF, F32_MATRIX_PEAK_TF = 2500.0, 157.3    # MI355X_MICROARCH.md: dense f16 MFMA / f32 matrix
 VALUE_FLOP, POLICY_FLOP = 122_994_944, 122_847_232   # algorithmic FLOPs per evaluation
-# wave-level MFMA instructions one evaluated board executes in the search's net kernels: blocks 2..8 =
-# (36 + 6 x 72) k-steps x (2 tiles x 3 or 6 MFMAs) x 4 waves (+ the Value head's 8 x 2 x 3 on one wave)
+# MFMA work one evaluated board executes in the search's net kernels, in units of 32,768 FLOP (one 32x32x16 instruction,
+# the shape of rounds 2-4; the K loops now issue two v_mfma_f32_16x16x32_f16 for each): blocks 2..8 = (36 + 6 x 72)
+# k16-steps x (2 tiles x 3 or 6 MFMAs) x 4 waves (+ the Value head's 8 x 2 x 3 on one wave)
 VALUE_MFMA_PER_BOARD = 468 * 6 * 4 + 48
 POLICY_MFMA_PER_BOARD = 468 * 12 * 4
 
@@ -373,14 +375,18 @@ def net_kernel_profiles(persistent=False):
             e = {"launches": k["calls"], "rocprof_avg_us": k["avg_us"],
                  "hbm_bytes_per_launch": k.get("hbm_bytes_per_launch")}
             if k.get("SQ_INSTS_MFMA"):
-                tf = k["SQ_INSTS_MFMA"] * MFMA_FLOP_32x32x16 / (k["avg_us"] * 1e-6) / 1e12
+                # (SQ_INSTS_MFMA counts wave-instructions of either shape: a profile of the round-5 walks is priced at
+                # the short shape's 16,384 FLOP -- the heads' few 32x32x16 instructions, 0.2 % of a walk, are undercounted)
+                short = prof.get("mfma_shape", "32x32x16") == "16x16x32"
+                unit = 0.5 if short else 1.0
+                tf = k["SQ_INSTS_MFMA"] * (MFMA_FLOP_16x16x32 if short else MFMA_FLOP_32x32x16) / (k["avg_us"] * 1e-6) / 1e12
                 e.update({"mfma_insts_per_launch": k["SQ_INSTS_MFMA"], "executed_tflops": tf,
                           "bound": "mfma", "peak": F16_PEAK_TF, "frac": tf / F16_PEAK_TF})
                 per_board, flop = {"value_rollout_kernel": (VALUE_MFMA_PER_BOARD, VALUE_FLOP),
                                    # (a launch of the two-launch forward walks half a net)
                                    "policy_resident_kernel": (POLICY_MFMA_PER_BOARD / 2, POLICY_FLOP / 2)}.get(name, (0, 0))
                 if per_board:
-                    boards = k["SQ_INSTS_MFMA"] / per_board
+                    boards = k["SQ_INSTS_MFMA"] * unit / per_board
                     useful = boards * flop / (k["avg_us"] * 1e-6) / 1e12
                     e.update({"boards_per_launch": boards, "useful_tflops": useful,
                               "useful_frac_f16_peak": useful / F16_PEAK_TF,

@@ -68,4 +68,5 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import bench  # noqa: E402  (csrc_sha16: the kernel sources this profile was taken on)
 print(json.dumps({"command": open(cmd).read().strip() if os.path.exists(cmd) else None,
                   "csrc_sha16": bench.csrc_sha16(),
+                  "mfma_shape": "16x16x32",   # the walks' K loops (round 5): SQ_INSTS_MFMA x 16,384 FLOP
                   "kernels": {k: v for k, v in out.items() if v}}, indent=1))
