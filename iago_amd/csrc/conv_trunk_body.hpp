@@ -102,14 +102,9 @@ extern __shared__ __align__(16) char trunk_lds[];
 // The work of one workgroup on the TB boards (rows) b0 .. b0 + TB - 1 of n_rows.
 // SRCH: the persistent search's form -- W.pos, W.res, W.w1s and W.head_w are all given (decided at compile time: as
 // run-time choices both forms' registers were live in the head and the kernel spilled 103 of them)
-// NW: waves of the workgroup, 4 (one per SIMD: a wave owns 32 output channels = two M tiles) or 8 (two per SIMD, 16 output
-// channels = one M tile each: one wave's MFMAs fill the other's LDS, load and epilogue waits; 256 registers per wave)
-template <bool FUSED, int TB, bool SRCH = false, int NW = 4>
+template <bool FUSED, int TB, bool SRCH = false>
 __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W, const int64_t b0, const int64_t n_rows)
 {
-    constexpr int NTHR = 64 * NW;   // threads of the workgroup
-    constexpr int CH = 128 / NW;    // output channels of a wave
-    constexpr int MT = CH / 16;     // its M tiles
     constexpr int NN = 4 * TB;      // 16-cell B tiles of a k-step: TB boards x 4 quarters
     char *const T = trunk_lds;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -122,18 +117,18 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
     if (PIECES && W.layer_lo > 0) {
         // a later piece of the walk: the boards' rows as the previous piece left them (all of a
         // thread's loads in flight together, then its LDS stores)
-        constexpr int PER = (TB * (IMG / 16) + NTHR - 1) / NTHR;
+        constexpr int PER = (TB * (IMG / 16) + 255) / 256;
         uint4 img[PER];
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            const int e = min(tid + i * NTHR, TB * (IMG / 16) - 1);
+            const int e = min(tid + i * 256, TB * (IMG / 16) - 1);
             const int board = e / (IMG / 16), off = e - board * (IMG / 16);
             const int64_t row = min(b0 + board, n_rows - 1);
             img[i] = ((const uint4 *)(W.scratch + row * IMG))[off];
         }
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            const int e = tid + i * NTHR;
+            const int e = tid + i * 256;
             const int board = e / (IMG / 16), off = e - board * (IMG / 16);
             if (e < TB * (IMG / 16))
                 *(uint4 *)(T + board * BS + off * 16) = img[i];
@@ -181,7 +176,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
         const float *w1s = W.w1s; // [64][18] weights, [64] biases
         if constexpr (!SRCH) {
             float *const st = (float *)(T + lds_alloc(TB) + head_lds(TB));
-            for (int e = tid; e < 64 * 18 / 4; e += NTHR)
+            for (int e = tid; e < 64 * 18 / 4; e += 256)
                 ((float4 *)st)[e] = ((const float4 *)P.w1)[e];
             if (tid < 16)
                 ((float4 *)(st + 64 * 18))[tid] = ((const float4 *)P.b1)[tid];
@@ -190,8 +185,8 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
         }
         // the weights of an output channel are wave-uniform: each is fetched once and used for the boards
 #pragma unroll 1
-        for (int g2 = 0; g2 < 8 / NW; g2++) {
-            const int grp = __builtin_amdgcn_readfirstlane(g2 * NW + wv); // channel block * 2 + half
+        for (int g2 = 0; g2 < 2; g2++) {
+            const int grp = __builtin_amdgcn_readfirstlane(g2 * 4 + wv); // channel block * 2 + half
             const int co0 = grp * 8;
             _Float16 h8[TB][8], l8[TB][8];
 #pragma unroll
@@ -225,7 +220,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
     } else {
         const int chunks0 = P.cin0 >> 4;
         const int pieces = TB * chunks0 * 128; // 16-byte pieces per hi / lo
-        for (int e = tid; e < pieces; e += NTHR) {
+        for (int e = tid; e < pieces; e += 256) {
             const int board = e / (chunks0 * 128), rem = e - board * chunks0 * 128;
             const int chunk = rem >> 7, cell = (rem >> 1) & 63, hp = rem & 1;
             // boards past the end of a ragged batch read the last board (results not stored)
@@ -267,17 +262,17 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
     const int L_lo = PIECES ? W.layer_lo : 0, L_hi = PIECES ? W.layer_hi : P.n_layers;
     for (int L = L_lo; L < L_hi; L++) {
         const int n_pairs = L == 0 ? (P.cin0 >> 5) : 4; // chunk pairs: 32 input channels each
-        // this lane's A operands: output channels CH wv + c16 (M tile 0) and, with two M tiles, + 16 (M tile 1), input channels
+        // this lane's A operands: output channels 32 wv + c16 (M tile 0) and + 16 (M tile 1), input channels
         // 8 (kq & 1) .. + 7 of chunk 2 cp + (kq >> 1); a chunk is 9 x 128 x 32 B, a tap 128 x 32 B further.  Addressed as
         // a wave-uniform base (the layer's weights + the k-step's offset: scalar registers) + this lane's byte offset
         const char *const wh = (const char *)P.w_hi[L], *const wl = (const char *)P.w_lo[L];
-        const uint32_t a_lane = (uint32_t)(((CH * wv + c16) * 2 + (kq & 1) + (kq >> 1) * (9 * 256)) * 16);
+        const uint32_t a_lane = (uint32_t)(((32 * wv + c16) * 2 + (kq & 1) + (kq >> 1) * (9 * 256)) * 16);
         auto a_load = [&](const char *base, uint32_t step_bytes, int m) -> u32x4 {
             return *(const u32x4 *)(base + step_bytes + a_lane + (uint32_t)m * 512u);
         };
-        float4v acc_main[MT][NN], acc_cross[MT][NN];
+        float4v acc_main[2][NN], acc_cross[2][NN];
 #pragma unroll
-        for (int m = 0; m < MT; m++)
+        for (int m = 0; m < 2; m++)
 #pragma unroll
             for (int n = 0; n < NN; n++)
 #pragma unroll
@@ -287,11 +282,11 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                 }
 
         // k-steps of 32 input channels: s = 9 cp + tap, 9 n_pairs of them
-        u32x4 a_hi[3][MT], a_lo[3][MT]; // k-steps s, s + 1, s + 2 (ring index = tap % 3) x the M tiles
+        u32x4 a_hi[3][2], a_lo[3][2]; // k-steps s, s + 1, s + 2 (ring index = tap % 3) x the two M tiles
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int m = 0; m < MT; m++) {
+            for (int m = 0; m < 2; m++) {
                 a_hi[i][m] = a_load(wh, (uint32_t)i * 4096u, m);
                 a_lo[i][m] = a_load(wl, (uint32_t)i * 4096u, m);
             }
@@ -327,56 +322,35 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                     tp2 = 8;
                 }
                 const uint32_t w2 = (uint32_t)(18 * cp2 + tp2) * 4096u; // (its four loads go out one per tile below)
-                half8 ah[MT], al[MT];
-#pragma unroll
-                for (int m = 0; m < MT; m++) {
-                    ah[m] = __builtin_bit_cast(half8, a_hi[tap % 3][m]);
-                    al[m] = __builtin_bit_cast(half8, a_lo[tap % 3][m]);
-                }
+                const half8 ah0 = __builtin_bit_cast(half8, a_hi[tap % 3][0]), ah1 = __builtin_bit_cast(half8, a_hi[tap % 3][1]);
+                const half8 al0 = __builtin_bit_cast(half8, a_lo[tap % 3][0]), al1 = __builtin_bit_cast(half8, a_lo[tap % 3][1]);
 #pragma unroll
                 for (int n = 0; n < NN; n++) {
                     const int tile = tap * NN + n, cur = tile % 4, nxt = (tile + 3) % 4;
                     // (past the last chunk pair: harmless reads 64 B further in the same rows)
                     const char *p = b_addr(tile + 3);
-                    if constexpr (MT == 2) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        IAGO_MFMA16(acc_cross[0][n], ah[0], bl[cur]);
-                        bh[nxt] = *(const half8 *)p;
-                        __builtin_amdgcn_sched_barrier(0);
-                        IAGO_MFMA16(acc_cross[1][n], ah[1], bl[cur]);
-                        bl[nxt] = *(const half8 *)(p + 256);
-                        __builtin_amdgcn_sched_barrier(0);
-                        IAGO_MFMA16(acc_main[0][n], ah[0], bh[cur]);
-                        // the A operands of k-step s + 2: one 16-byte load in this gap of each of the step's first four tiles
-                        if (n == 0)
-                            a_hi[(tap + 2) % 3][0] = a_load(wh, w2, 0);
-                        else if (n == 1)
-                            a_hi[(tap + 2) % 3][1] = a_load(wh, w2, 1);
-                        else if (n == 2)
-                            a_lo[(tap + 2) % 3][0] = a_load(wl, w2, 0);
-                        else if (n == 3)
-                            a_lo[(tap + 2) % 3][1] = a_load(wl, w2, 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        IAGO_MFMA16(acc_main[1][n], ah[1], bh[cur]);
-                        IAGO_MFMA16(acc_cross[0][n], al[0], bh[cur]);
-                        IAGO_MFMA16(acc_cross[1][n], al[1], bh[cur]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else {
-                        // one M tile per wave (two waves per SIMD): three MFMAs per tile, one read or load per gap
-                        __builtin_amdgcn_sched_barrier(0);
-                        IAGO_MFMA16(acc_cross[0][n], ah[0], bl[cur]);
-                        bh[nxt] = *(const half8 *)p;
-                        __builtin_amdgcn_sched_barrier(0);
-                        IAGO_MFMA16(acc_main[0][n], ah[0], bh[cur]);
-                        bl[nxt] = *(const half8 *)(p + 256);
-                        __builtin_amdgcn_sched_barrier(0);
-                        IAGO_MFMA16(acc_cross[0][n], al[0], bh[cur]);
-                        if (n == 0)
-                            a_hi[(tap + 2) % 3][0] = a_load(wh, w2, 0);
-                        else if (n == 1)
-                            a_lo[(tap + 2) % 3][0] = a_load(wl, w2, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_MFMA16(acc_cross[0][n], ah0, bl[cur]);
+                    bh[nxt] = *(const half8 *)p;
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_MFMA16(acc_cross[1][n], ah1, bl[cur]);
+                    bl[nxt] = *(const half8 *)(p + 256);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_MFMA16(acc_main[0][n], ah0, bh[cur]);
+                    // the A operands of k-step s + 2: one 16-byte load in this gap of each of the step's first four tiles
+                    if (n == 0)
+                        a_hi[(tap + 2) % 3][0] = a_load(wh, w2, 0);
+                    else if (n == 1)
+                        a_hi[(tap + 2) % 3][1] = a_load(wh, w2, 1);
+                    else if (n == 2)
+                        a_lo[(tap + 2) % 3][0] = a_load(wl, w2, 0);
+                    else if (n == 3)
+                        a_lo[(tap + 2) % 3][1] = a_load(wl, w2, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    IAGO_MFMA16(acc_main[1][n], ah1, bh[cur]);
+                    IAGO_MFMA16(acc_cross[0][n], al0, bh[cur]);
+                    IAGO_MFMA16(acc_cross[1][n], al1, bh[cur]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // next chunk pair of 32 input channels: 64 B further in every row (the zero rows are RS bytes of
@@ -395,10 +369,10 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
 
         // ---- epilogue: every wave has read T for the last time; bias, ReLU, split, back into T
         // bias of the 8 channels this lane finishes: 32 wv + 16 m + 4 kq + v
-        f2 bia[MT][2];
+        f2 bia[2][2];
 #pragma unroll
-        for (int m = 0; m < MT; m++) {
-            const float4 bq = *(const float4 *)(P.bias[L] + CH * wv + 16 * m + 4 * kq);
+        for (int m = 0; m < 2; m++) {
+            const float4 bq = *(const float4 *)(P.bias[L] + 32 * wv + 16 * m + 4 * kq);
             bia[m][0] = (f2){bq.x, bq.y};
             bia[m][1] = (f2){bq.z, bq.w};
         }
@@ -414,9 +388,9 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
 #pragma unroll
         for (int n = 0; n < NN; n++) {
             // D row 4 kq + v of M tile m, column c16: channel 32 wv + 16 m + 4 kq + v of cell 16 (n & 3) + c16, board n >> 2
-            char *row = T + wrow[n & 3] + (n >> 2) * BS + (CH * wv + 4 * kq) * 2;
+            char *row = T + wrow[n & 3] + (n >> 2) * BS + (32 * wv + 4 * kq) * 2;
 #pragma unroll
-            for (int m = 0; m < MT; m++) {
+            for (int m = 0; m < 2; m++) {
                 h2 hi[2], lo[2];
 #pragma unroll
                 for (int t2 = 0; t2 < 2; t2++) {
@@ -444,7 +418,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
 
     if (PIECES && W.layer_hi < P.n_layers) {
         // the next piece of the walk goes on from these rows
-        for (int e = tid; e < TB * (IMG / 16); e += NTHR) {
+        for (int e = tid; e < TB * (IMG / 16); e += 256) {
             const int board = e / (IMG / 16), off = e - board * (IMG / 16);
             if (b0 + board < n_rows)
                 ((uint4 *)(W.scratch + (b0 + board) * IMG))[off] = *(const uint4 *)(T + board * BS + off * 16);
@@ -579,7 +553,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
         return;
     }
     // ---- the last layer's activations: coalesced 16-byte stores, [n][8][64][16] hi and lo
-    for (int e = tid; e < TB * 1024; e += NTHR) {
+    for (int e = tid; e < TB * 1024; e += 256) {
         const int board = e >> 10, cb = (e >> 7) & 7, cell = (e >> 1) & 63, hp = e & 1;
         const int64_t b = b0 + board;
         if (b < P.n) {
@@ -592,7 +566,7 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
 
 // Workgroup `bid` of `nb` walks its rows with that stride (one pass unless the grid was capped:
 // the device-counted launch of the value cache, iago_value_forward_split).
-template <bool FUSED, int TB, int NW = 4>
+template <bool FUSED, int TB>
 __device__ __forceinline__ void trunk_walk(const TrunkRParams &P, const Piece &W, const int64_t bid, const int64_t nb)
 {
     int64_t n_rows = P.n;
@@ -604,7 +578,7 @@ __device__ __forceinline__ void trunk_walk(const TrunkRParams &P, const Piece &W
             return;
     }
     for (int64_t b0 = bid * TB; b0 < n_rows; b0 += nb * TB) {
-        trunk_item<FUSED, TB, false, NW>(P, W, b0, n_rows);
+        trunk_item<FUSED, TB>(P, W, b0, n_rows);
         __syncthreads(); // the next pass re-stages the LDS image the head just read
     }
 }

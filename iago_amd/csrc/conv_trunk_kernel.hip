@@ -33,15 +33,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     trunk_walk<FUSED, TB>(P, whole_walk(P), blockIdx.x, gridDim.x);
 }
 
-// The same walk by EIGHT waves, two per SIMD, 16 output channels each (256 registers per wave): one wave's MFMAs fill the
-// other's LDS, load and epilogue waits.  Experiment of round 5 (IAGO_WALK_WAVES=8 in iago_value_forward_batch;
-// tools/exp_walk_waves.py): the same products in the same order per output channel -- bit-identical values.
-template <int TB>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void trunk_resident_kernel_w8(TrunkRParams P)
-{
-    trunk_walk<true, TB, 8>(P, whole_walk(P), blockIdx.x, gridDim.x);
-}
-
 // The leaf evaluation of a playout (MCTS.py:123-125) in ONE launch: workgroups 0 .. n_ro-1 play
 // the rollouts of ALL leaves (the 16-lanes-per-board kernel's body), the others run the value net
 // on the leaves that have no stored value (one board per workgroup, device-side list).  With the
@@ -268,20 +259,6 @@ int iago_value_forward_batch(const iago_value_split_args *a, int32_t boards_per_
     int64_t grid = (a->n + tb - 1) / tb;
     if (grid > max_workgroups)
         grid = max_workgroups;
-    const char *ww = getenv("IAGO_WALK_WAVES"); // (experiment, read per call: tools/exp_walk_waves.py)
-    if (ww && atoi(ww) == 8 && tb <= 2) {
-        static std::atomic<uint64_t> c2{0}, c1{0};
-        if (tb == 2) {
-            if (iago_reserve_lds((const void *)trunk_resident_kernel_w8<2>, lds_alloc_fused(2), c2, "iago_value_forward_batch: LDS"))
-                return IAGO_ERR_HIP;
-            hipLaunchKernelGGL((trunk_resident_kernel_w8<2>), dim3((unsigned)grid), dim3(512), lds_alloc_fused(2), (hipStream_t)stream, P);
-        } else {
-            if (iago_reserve_lds((const void *)trunk_resident_kernel_w8<1>, lds_alloc_fused(1), c1, "iago_value_forward_batch: LDS"))
-                return IAGO_ERR_HIP;
-            hipLaunchKernelGGL((trunk_resident_kernel_w8<1>), dim3((unsigned)grid), dim3(512), lds_alloc_fused(1), (hipStream_t)stream, P);
-        }
-        return iago_check_launch("iago_value_forward_batch");
-    }
     if (tb == 4) {
         if (iago_reserve_lds((const void *)trunk_resident_kernel<true, 4>, lds_alloc_fused(4), configured4,
                              "iago_value_forward_batch: cannot reserve 148 KB of LDS"))
