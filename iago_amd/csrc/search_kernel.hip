@@ -705,6 +705,22 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
         // have one are packed into rows of 16 boards (about half of a workgroup's games reach a leaf in an iteration,
         // the others wait for a net: one pass of the 16-lanes-per-board body instead of two, most of the time).  A
         // board's game does not depend on its row: Philox counters are keyed by the game and its playout count
+        // the control words this iteration's end looks at (abort, the rings' depths for the pacing and the values-ahead gate,
+        // the games in play and their progress): eight loads in flight together HERE, under the rollouts -- read one after
+        // the other by thread 0 between the iteration's last two barriers they were up to six dependent round trips to L2
+        // (2 - 4 us of a 34 us iteration, with the whole workgroup waiting).  All of it is timing-only state, one
+        // iteration old at most when it is used.
+        uint32_t c_abort = 0u, c_idle = 0u, c_t0 = 0u, c_h0 = 0u, c_t1 = 0u, c_h1 = 0u, c_play = 0u, c_prog = 0u;
+        if (tid == 0) {
+            c_abort = __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT);
+            c_idle = __hip_atomic_load(&S.ctl[CTL_IDLE], RLX_AGENT);
+            c_t0 = __hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT);
+            c_h0 = __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT);
+            c_t1 = __hip_atomic_load(&S.ctl[ctl_tail(1)], RLX_AGENT);
+            c_h1 = __hip_atomic_load(&S.ctl[ctl_head(1)], RLX_AGENT);
+            c_play = __hip_atomic_load(&S.ctl[CTL_PLAYING], RLX_AGENT);
+            c_prog = __hip_atomic_load(&S.ctl[CTL_PROGRESS], RLX_AGENT);
+        }
         const bool rolls = mine && need_z && (state == ST_ROLL || state == ST_ROLL_FRESH);
         bool rolled = true; // this game's rollout ran in this iteration (or it needs none)
         {
@@ -781,7 +797,7 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
         const bool over = wall_clock64() - t0 > S.clock_limit;
         if (over && tid == 0)
             __hip_atomic_store(&S.ctl[CTL_ABORT], 1u, RLX_AGENT);
-        const int stop = __syncthreads_or(over || (tid == 0 && __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u));
+        const int stop = __syncthreads_or(over || (tid == 0 && c_abort != 0u));
         if (tid == 0) {
             if (pace[0])
                 __hip_atomic_fetch_add(&S.ctl[CTL_PROGRESS], (uint32_t)pace[0], RLX_AGENT);
@@ -791,18 +807,13 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             pace[1] = 0;
             int limit = 0x7fffffff;
             pace[3] = 0;
-            if (S.ahead_idle >= 0 && S.vtable_mask && T.n_games <= (int64_t)(QCAP / 2u) &&
-                __hip_atomic_load(&S.ctl[CTL_IDLE], RLX_AGENT) >= (uint32_t)S.ahead_idle &&
-                (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT)) <= 0 &&
-                (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(1)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(1)], RLX_AGENT)) <= 0)
+            const int32_t wait0 = (int32_t)(c_t0 - c_h0), wait1 = (int32_t)(c_t1 - c_h1);
+            if (S.ahead_idle >= 0 && S.vtable_mask && T.n_games <= (int64_t)(QCAP / 2u) && c_idle >= (uint32_t)S.ahead_idle &&
+                wait0 <= 0 && wait1 <= 0)
                 pace[3] = (int32_t)(QCAP / 2u) / S.n_game_wgs; // this iteration's share of the ring for requests nobody waits for
             if (S.pace_margin >= 0) {
-                const int32_t waiting =
-                    (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT)) +
-                    (int32_t)(__hip_atomic_load(&S.ctl[ctl_tail(1)], RLX_AGENT) - __hip_atomic_load(&S.ctl[ctl_head(1)], RLX_AGENT));
-                const uint32_t playing = __hip_atomic_load(&S.ctl[CTL_PLAYING], RLX_AGENT);
-                if (waiting > S.pace_backlog && playing != 0u && playing <= (uint32_t)T.n_games)
-                    limit = (int)(__hip_atomic_load(&S.ctl[CTL_PROGRESS], RLX_AGENT) / playing) + S.pace_margin;
+                if (wait0 + wait1 > S.pace_backlog && c_play != 0u && c_play <= (uint32_t)T.n_games)
+                    limit = (int)(c_prog / c_play) + S.pace_margin;
             }
             pace[2] = limit;
         }
