@@ -48,39 +48,60 @@ def request_log(s):
 
 
 def phase_stamps(s):
-    s = patch(s, '''    for (;;) {
-        bool busy = false; // this game did something in this iteration''', '''    long long ph[5] = {0, 0, 0, 0, 0};
+    """Game workgroup 0's iteration by phase (100 MHz stamps of thread 0): replies + moves, descent, the control
+    words' loads + the packing of the rollouts, the rollout passes, the backup of the rolled games, the end of the
+    iteration (two barriers, pacing); summed in iago_game_phases[0..5], the iterations in [7]."""
+    s = patch(s, "namespace {\nusing namespace iago;", "__device__ unsigned long long iago_game_phases[8];\nnamespace {\nusing namespace iago;")
+    s = patch(s, """    for (;;) {
+        bool busy = false; // this game did something in this iteration""", """    long long ph[6] = {0, 0, 0, 0, 0, 0};
     for (;;) {
         long long c_a = wall_clock64();
-        bool busy = false; // this game did something in this iteration''')
-    s = patch(s, '''            // ---- descent (MCTS.py:105-133): from the root, or on from the leaf whose priors arrived
-''', '''            { const long long c = wall_clock64(); ph[0] += c - c_a; c_a = c; }
+        bool busy = false; // this game did something in this iteration""")
+    s = patch(s, """            // ---- descent (MCTS.py:105-133): from the root, or on from the leaf whose priors arrived
+""", """            { const long long c = wall_clock64(); ph[0] += c - c_a; c_a = c; }
             // ---- descent (MCTS.py:105-133): from the root, or on from the leaf whose priors arrived
-''')
-    s = patch(s, '''        const bool rolls = mine && need_z && (state == ST_ROLL || state == ST_ROLL_FRESH);
-        {''', '''        const bool rolls = mine && need_z && (state == ST_ROLL || state == ST_ROLL_FRESH);
-        { const long long c = wall_clock64(); ph[1] += c - c_a; c_a = c; }
-        {''')
-    s = patch(s, '''        if (mine) {
-            if (state == ST_ROLL) {''', '''        { const long long c = wall_clock64(); ph[2] += c - c_a; c_a = c; }
-        if (mine) {
-            if (state == ST_ROLL) {''')
-    s = patch(s, '''        iters++;
+""")
+    s = patch(s, """        uint32_t c_abort = 0u, c_idle = 0u,""", """        { const long long c = wall_clock64(); ph[1] += c - c_a; c_a = c; }
+        uint32_t c_abort = 0u, c_idle = 0u,""")
+    s = patch(s, """#pragma unroll 1
+            for (int at = 0; at < n_now; at += 16) {""", """            { const long long c = wall_clock64(); ph[2] += c - c_a; c_a = c; }
+#pragma unroll 1
+            for (int at = 0; at < n_now; at += 16) {""")
+    s = patch(s, """        if (mine && rolled) {
+            if (state == ST_ROLL) {""", """        { const long long c = wall_clock64(); ph[3] += c - c_a; c_a = c; }
+        if (mine && rolled) {
+            if (state == ST_ROLL) {""")
+    s = patch(s, """        iters++;
         if (mine && r == 0u) {
-            const int prog''', '''        { const long long c = wall_clock64(); ph[3] += c - c_a; c_a = c; }
+            const int prog""", """        { const long long c = wall_clock64(); ph[4] += c - c_a; c_a = c; }
         iters++;
         if (mine && r == 0u) {
-            const int prog''')
-    s = patch(s, '''        if (!__syncthreads_or(busy)) {
-            idle_iters++;''', '''        { const long long c = wall_clock64(); ph[4] += c - c_a; c_a = c; }
+            const int prog""")
+    s = patch(s, """        if (!__syncthreads_or(busy)) {
+            idle_iters++;""", """        { const long long c = wall_clock64(); ph[5] += c - c_a; c_a = c; }
         if (!__syncthreads_or(busy)) {
-            idle_iters++;''')
-    s = patch(s, '''    if (tid == 0) {
-        atomicAdd((unsigned long long *)&S.totals[2], (unsigned long long)iters);''', '''    if (tid == 0 && blockIdx.x == 0)
-        for (int i = 0; i < 5; i++)
-            S.totals[11 + i] = ph[i];
+            idle_iters++;""")
+    s = patch(s, """    if (tid == 0) {
+        atomicAdd((unsigned long long *)&S.totals[2], (unsigned long long)iters);""", """    if (tid == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < 6; i++)
+            atomicAdd(&iago_game_phases[i], (unsigned long long)ph[i]);
+        atomicAdd(&iago_game_phases[7], (unsigned long long)iters);
+    }
     if (tid == 0) {
-        atomicAdd((unsigned long long *)&S.totals[2], (unsigned long long)iters);''')
+        atomicAdd((unsigned long long *)&S.totals[2], (unsigned long long)iters);""")
+    s += """
+extern "C" __attribute__((visibility("default"))) int iago_debug_game_phases(unsigned long long *host, int clear)
+{
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(iago_game_phases), 8 * 8) != hipSuccess)
+        return -1;
+    if (clear) {
+        static unsigned long long zeros[8];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(iago_game_phases), zeros, 8 * 8) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+"""
     return s
 
 
