@@ -153,9 +153,19 @@ __device__ __forceinline__ uint64_t flips_hw(uint64_t o, uint64_t p, uint32_t po
 // INDEXED (the persistent search): the 16 boards of the call are boards idx[0..15] (-1 = no board in that row of
 // lanes) instead of boards 16 block_id ..; `table_ready`: the factor table is in LDS already (an earlier call of
 // this workgroup put it there).
+// (INDEXED, the persistent search again) `hand`: the boards' positions and Philox stream offsets come from, and their results
+// go to, LDS arrays indexed by the board's number within the workgroup (idx[..] - base) -- written / read by this very
+// workgroup around the call: through global memory each was a store followed by a load of the same address, a round trip to
+// L2 at the head of every pass.
+struct RowHandoff {
+    const uint64_t *own, *opp; // [board of the workgroup]
+    const int32_t *stream;
+    int8_t *z;
+    int32_t base;              // idx[..] of the workgroup's board 0
+};
 template <bool DIAG, bool ASYNC = false, bool INDEXED = false>
 __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32_t block_id, const int32_t *idx = nullptr,
-                                                 const bool table_ready = false)
+                                                 const bool table_ready = false, const RowHandoff *hand = nullptr)
 {
     // T4[orientation][kernel row][plane][row half][5 window bits] -> factors of the 4 cells
     // (in TRUE cell order), 12 KB, gathered from the blob's row tables.  As-is orientation,
@@ -226,12 +236,20 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
         live = at >= 0;
         b = live ? at : 0;
     }
-    if constexpr (ASYNC) {
-        live = live && P.mask[b] != 0;
-        stream_id += live ? (uint32_t)P.stream_ids[b] : 0u;
+    uint64_t own, opp; // side to move, in this lane's orientation below
+    if (INDEXED && hand) {
+        const int slot = live ? (int)b - hand->base : 0;
+        stream_id += live ? (uint32_t)hand->stream[slot] : 0u;
+        own = live ? hand->own[slot] : 0ull;
+        opp = live ? hand->opp[slot] : 0ull;
+    } else {
+        if constexpr (ASYNC) {
+            live = live && P.mask[b] != 0;
+            stream_id += live ? (uint32_t)P.stream_ids[b] : 0u;
+        }
+        own = live ? P.own[b] : 0ull;
+        opp = live ? P.opp[b] : 0ull;
     }
-    uint64_t own = live ? P.own[b] : 0ull; // side to move, in this lane's orientation below
-    uint64_t opp = live ? P.opp[b] : 0ull;
     uint32_t stones = (uint32_t)__popcll(own | opp);
     if (rev) {
         own = rev64(own);
@@ -422,6 +440,8 @@ __device__ __forceinline__ void rollout_row_body(const HwParams &P, const uint32
 
     if (live && L.l == 0u) {
         const int d = __popcll(own) - __popcll(opp);
+        if (INDEXED && hand)
+            hand->z[(int)b - hand->base] = (int8_t)((d > 0) - (d < 0));
         P.z[b] = (int8_t)((d > 0) - (d < 0));
         if (P.final_own)
             P.final_own[b] = own;

@@ -229,13 +229,13 @@ __device__ __forceinline__ bool group8_all(bool x)
 // Node.update_recursive (MCTS.py:51-72) over the recorded path + the leaf mix (MCTS.py:123-125): the
 // arithmetic of mix_backup_path_kernel, 8 lanes per game.
 __device__ __forceinline__ void backup_game(const SearchParams &S, int64_t g, uint32_t r, int leaf, bool fresh, float vg,
-                                            int path_n)
+                                            int path_n, const int8_t zl, const int path_at)
 {
     const int64_t base = g * (int64_t)S.T.capacity;
     const float lmbda = S.lmbda;
     if (fresh && lmbda < 1.0f && r == 0u)
         S.T.nodes[base + leaf].v = vg; // value_func(leaf), now stored (the value cache)
-    const int8_t zg = lmbda > 0.0f ? S.z[g] : (int8_t)0;
+    const int8_t zg = lmbda > 0.0f ? zl : (int8_t)0; // (the rollout's result, from the workgroup's LDS)
     const float a = (lmbda < 1.0f) ? (float)(1.0 - (double)lmbda) * vg : 0.0f;
     const float b = (lmbda > 0.0f) ? (float)((double)lmbda * (double)zg) : 0.0f;
     const float lv = a + b;
@@ -249,9 +249,10 @@ __device__ __forceinline__ void backup_game(const SearchParams &S, int64_t g, ui
         }
     }
     const int len = path_n < S.path_stride ? path_n : S.path_stride;
-    const int32_t *path = S.path + g * (int64_t)S.path_stride;
+    const int32_t *const gpath = S.path + g * (int64_t)S.path_stride;
     for (int d = (int)r; d < len; d += 8) {
-        const int node = path[d];
+        // (path_at >= 0: the path is in the workgroup's LDS at that word; an LDS access, not a flat one)
+        const int node = path_at >= 0 ? ((const int32_t *)iago_trunk::trunk_lds)[path_at + d] : gpath[d];
         uint2 *nq = (uint2 *)&S.T.nodes[base + node];
         const uint2 old = *nq;
         const int n = (int)old.x + 1;                // MCTS.py:61
@@ -272,7 +273,18 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
     const bool exists = mine && g < T.n_games;
     const int64_t base = exists ? g * (int64_t)T.capacity : 0;
     const bool need_v = S.lmbda < 1.0f, need_z = S.lmbda > 0.0f;
-    int32_t *const path = S.path + (exists ? g : 0) * (int64_t)S.path_stride;
+    // the descent's recorded path (Node.update_recursive's ancestors): in the workgroup's dynamic LDS -- a game workgroup
+    // walks no net while it has games -- when 32 paths fit there, else in the caller's array.  (From global memory the
+    // backup was two dependent round trips to L2: the path entry, then the node.)
+    const bool path_lds = (size_t)S.games_per_wg * (size_t)S.path_stride * 4u <= (size_t)SEARCH_IMG_TOP;
+    const int path_at = path_lds ? (tid >> 3) * S.path_stride : -1; // word of the dynamic LDS where this game's path starts
+    int32_t *const gpath = S.path + (exists ? g : 0) * (int64_t)S.path_stride;
+    // positions, Philox stream offsets and results between the descent / backup and the rollout passes: LDS (RowHandoff)
+    __shared__ uint64_t h_own[GAMES_PER_WG], h_opp[GAMES_PER_WG];
+    __shared__ int32_t h_stream[GAMES_PER_WG];
+    __shared__ int8_t h_z[GAMES_PER_WG];
+    const iago_row::RowHandoff hand = {h_own, h_opp, h_stream, h_z, (int32_t)((int64_t)blockIdx.x * S.games_per_wg)};
+    const int gl = tid >> 3; // this game's number within the workgroup
 
     const bool whole = S.max_turns > 0;
     int state = (exists && S.active[g] != 0 && S.n_sims > 0) ? (whole ? ST_TURN : ST_READY) : ST_DONE;
@@ -340,7 +352,7 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             // one state per game)
             // ---- backup of the games whose value has arrived (their rollout ran when they descended)
             if (state == ST_HAVE_VALUE) {
-                backup_game(S, g, r, leaf, true, v_reply, path_n);
+                backup_game(S, g, r, leaf, true, v_reply, path_n, h_z[gl], path_at);
                 n_done++;
                 if (S.trace && r == 0u)
                     atomicAdd((unsigned long long *)&S.totals[9], 1ull); // (diagnostic: playouts over time)
@@ -490,8 +502,12 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             for (int depth = 0; depth < MAX_DEPTH; depth++) {
                 if (descending && !skip_record) {
                     if (r == 0u) {
-                        if (path_n < S.path_stride)
-                            path[path_n] = node;
+                        if (path_n < S.path_stride) {
+                            if (path_at >= 0)
+                                ((int32_t *)iago_trunk::trunk_lds)[path_at + path_n] = node;
+                            else
+                                gpath[path_n] = node;
+                        }
                         else
                             T.overflow[g] = 1; // deeper than the path buffer: reported like a full pool
                     }
@@ -692,6 +708,9 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                         S.cur_node[g] = node;
                         S.cur_own[g] = own;
                         S.cur_opp[g] = opp;
+                        h_own[gl] = own; // (what the rollout pass reads)
+                        h_opp[gl] = opp;
+                        h_stream[gl] = turn * S.n_sims + n_done;
                         if (ask)
                             send_request(S, KIND_VALUE, g, epoch, own, opp);
                     }
@@ -758,14 +777,14 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             roll_hist[n_roll == 0 ? 0 : n_roll <= 16 ? 1 : n_roll <= 20 ? 2 : 3]++; // (diagnostic: totals[10], [13..15])
 #pragma unroll 1
             for (int at = 0; at < n_now; at += 16) {
-                iago_row::rollout_row_body<false, true, true>(R, 0u, roll_list + at, table_ready);
+                iago_row::rollout_row_body<false, true, true>(R, 0u, roll_list + at, table_ready, &hand);
                 table_ready = true;
                 __syncthreads();
             }
         }
         if (mine && rolled) {
             if (state == ST_ROLL) {
-                backup_game(S, g, r, leaf, leaf_fresh, __uint_as_float(vbits), path_n);
+                backup_game(S, g, r, leaf, leaf_fresh, __uint_as_float(vbits), path_n, h_z[gl], path_at);
                 n_done++;
                 if (S.trace && r == 0u)
                     atomicAdd((unsigned long long *)&S.totals[9], 1ull);
