@@ -33,6 +33,7 @@ SYMBOLS = [
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
     "iago_mcts_fresh_leaves", "iago_mcts_descend",
     "iago_mcts_search_persistent", "iago_mcts_search_capacity", "iago_selfplay_policy",
+    "iago_conv3x3_wgrad_split",
 ]
 # include/iago_hip_experimental.h: two schedules of the per-playout engine that measured slower (game-asynchronous steps,
 # value look-ahead); opt-in through engine.BatchedMCTS(async_steps=True / value_ahead=True), off every default path
@@ -218,6 +219,7 @@ def lib():
     L.iago_value_forward_split.argtypes = [C.POINTER(ValueSplitArgs), vp]
     L.iago_policy_forward_split3.argtypes = [C.POINTER(PolicySplit3Args), vp]
     L.iago_value_rollout.argtypes = [C.POINTER(ValueSplitArgs), C.POINTER(RolloutArgs), vp]
+    L.iago_conv3x3_wgrad_split.argtypes = [vp, vp, vp, vp, i64, i32, vp, i32, vp, vp, vp]
     L.iago_split_nchw.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.iago_merge_nchw.argtypes = [vp, vp, vp, i64, i32, vp]
     L.iago_value_stem.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]

@@ -504,6 +504,28 @@ def conv3x3_split(a, w_hi, w_lo, bias, overflow=None):
     return SplitActs(hi, lo, 128)
 
 
+# ---- gradients of the REINFORCE update in split-f16 arithmetic (csrc/policy_grad_kernels.hip) ----
+
+WGRAD_GROUPS = 32   # groups of boards whose partial weight gradients are summed in order (a multiple of 8)
+
+
+def conv3x3_wgrad_split(dy, x, scale_exp=None, groups=WGRAD_GROUPS, part=None):
+    """Weight gradient of one 3x3 block: dy, x SplitActs (dy: 128 channels, times 2**scale_exp), returns
+    dW (128, cin, 3, 3) float32 (include/iago_hip.h)."""
+    cin = x.channels
+    if dy.channels != 128 or dy.n != x.n:
+        raise ValueError("conv3x3_wgrad_split: dy must be (n, 128) channels on the rows of x")
+    if part is None:
+        part = torch.empty((groups, 9, 128, cin), dtype=torch.float32, device=x.hi.device)
+    dw = torch.empty((128, cin, 3, 3), dtype=torch.float32, device=x.hi.device)
+    check(_lib.lib().iago_conv3x3_wgrad_split(_dev(dy.hi, torch.float16, "dy_hi"), _dev(dy.lo, torch.float16, "dy_lo"),
+                                              _dev(x.hi, torch.float16, "x_hi"), _dev(x.lo, torch.float16, "x_lo"),
+                                              x.n, cin, _dev(part, torch.float32, "part"), groups,
+                                              _dev(scale_exp, torch.int32, "scale_exp") if scale_exp is not None else None,
+                                              _dev(dw, torch.float32, "dw"), _stream()), "iago_conv3x3_wgrad_split")
+    return dw
+
+
 # ---- float32 small-batch convolution stack (policy net on expansions) ----------------
 
 def f32_weights(weight):

@@ -797,6 +797,26 @@ typedef struct iago_selfplay_policy_args {
 } iago_selfplay_policy_args;
 IAGO_API int iago_selfplay_policy(const iago_selfplay_policy_args *args, void *stream);
 
+/*
+ * ---- The gradients of the REINFORCE update of SLPolicy (src/train_rl.py:55-66: pred = model(x), loss =
+ * mean(softmax_cross_entropy(pred, y) * r), loss.backward()) in split-f16 arithmetic on the matrix units
+ * (csrc/policy_grad_kernels.hip), replacing the float32 convolutions of a tensor library in the update.
+ *
+ * A gradient tensor in split channel blocks carries a power-of-two scale: its hi / lo pieces hold dY * 2^e with e an
+ * int32 device word chosen so that the largest element sits near 2^14 (the f16 pieces then hold 22 bits of every
+ * element down to 2^-28 of the largest).
+ *
+ * iago_conv3x3_wgrad_split: the weight gradient of one 3x3 block (Block.__call__, network.py:5-13),
+ *   dW[co][ci][ky][kx] = 2^-e * sum over boards and cells of dY[b][co][y][x] * X[b][ci][y + ky - 1][x + kx - 1],
+ *   dy_hi / dy_lo [n][8][64][16] (the gradient at the block's pre-activations, zero where its ReLU was off, times
+ *   2^e), x_hi / x_lo [n][cin/16][64][16] (the block's input), cin 64 or 128; dw [128][cin][3][3] float32.
+ *   part: scratch, [groups][9][128][cin] float32 -- the boards are summed in `groups` (a multiple of 8) contiguous
+ *   groups, whose partial sums are added in group order (deterministic); scale_exp: the device word e, NULL = 0.
+ */
+IAGO_API int iago_conv3x3_wgrad_split(const void *dy_hi, const void *dy_lo, const void *x_hi, const void *x_lo,
+                                      int64_t n, int32_t cin, float *part, int32_t groups, const int32_t *scale_exp,
+                                      float *dw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

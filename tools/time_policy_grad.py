@@ -1,0 +1,35 @@
+"""Times the kernels of the split-f16 REINFORCE gradients (csrc/policy_grad_kernels.hip) on synthetic data."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from iago_amd import ops
+
+
+def timed(f, reps=20):
+    f()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        f()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    for cin in (128, 64):
+        x = ops.split_nchw(torch.relu(torch.randn(n, cin, 8, 8, device="cuda")))
+        dy = ops.split_nchw(torch.randn(n, 128, 8, 8, device="cuda"))
+        part = torch.empty((ops.WGRAD_GROUPS, 9, 128, cin), dtype=torch.float32, device="cuda")
+        us = timed(lambda: ops.conv3x3_wgrad_split(dy, x, part=part))
+        flop = 2.0 * n * 64 * 128 * cin * 9
+        print("wgrad n=%d cin=%d: %.1f us, %.0f TFLOP/s algorithmic, %.0f executed" % (n, cin, us, flop / us / 1e6, 3 * flop / us / 1e6))
+
+
+if __name__ == "__main__":
+    main()
