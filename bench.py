@@ -762,12 +762,13 @@ def reinforce_leg(n_iters, world, rank, dist, mcts_rounds=1):
     ReinforceTrainer.step_from_tuples (src/train_rl.py:55-66 on the gathered rows)."""
     from iago_amd import engine, network, ops
     from iago_amd.dist import shard_range
+    from iago_amd import train_rl
     from iago_amd.train_rl import ReinforceTrainer
     torch.manual_seed(0)
     db_before = miopen_find_db_state()
     tr = ReinforceTrainer(network.SLPolicy(), pool_dir=None, N=32, seed=rank)
     for _ in range(4):
-        tr.step()  # warm-up: MIOpen forward/backward kernel selection, allocator, weight-layout caches
+        tr.step()  # warm-up: allocator, weight-layout caches (autograd path: MIOpen's kernel selection)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -779,10 +780,9 @@ def reinforce_leg(n_iters, world, rank, dist, mcts_rounds=1):
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    # what decides the figure is which backward-convolution solvers MIOpen picked for the update (tuned ones from a
-    # find-db that holds THIS problem: ~10 ms; its immediate-mode fallback: ~40 ms): measured, not guessed -- one more
-    # set's update timed on its own after the timed region (the user db's mere presence says little: a db warmed by
-    # other problems still falls back here)
+    # one more set's update timed on its own after the timed region.  (IAGO_NATIVE_GRAD=0, autograd over the tensor
+    # library's float32 convolutions: which backward-convolution solvers MIOpen picked then decides the figure -- tuned
+    # ones from a find-db that holds THIS problem: ~10 ms; its immediate-mode fallback: ~40 ms)
     tup, _ = tr.play_set(tr.pick_opponent())
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -793,7 +793,13 @@ def reinforce_leg(n_iters, world, rank, dist, mcts_rounds=1):
            "tuples_per_iter": tuples / n_iters, "iters": n_iters, "ms_per_iter": dt / n_iters * 1e3,
            # the figure depends on this state (19 sets/s with the fallback solvers, 45 with tuned ones on one MI355X):
            # stated, not hidden
-           "update_ms": update_ms, "miopen_solvers": "tuned (find-db)" if update_ms < 20.0 else "immediate-mode fallback",
+           "update_ms": update_ms,
+           "update_engine": ("iago_policy_reinforce_grad: forward, loss and backward as split-f16 HIP kernels (3 MFMAs per "
+                             "product sum, float32 accumulation; gradients within 1e-5 of float64 autograd, "
+                             "tests/test_policy_grad_gpu.py) + ChainerAdam") if train_rl.NATIVE_GRAD else
+                            "torch autograd over MIOpen float32 convolutions + ChainerAdam",
+           "miopen_solvers": "not used" if train_rl.NATIVE_GRAD else
+                             ("tuned (find-db)" if update_ms < 20.0 else "immediate-mode fallback"),
            "miopen_find_db": db_before,
            "config": "64 policy-vs-policy games per set (SLPolicy, random init, fp32) + "
                      "double-softmax REINFORCE update, ChainerAdam + WD 5e-4"}

@@ -33,7 +33,8 @@ SYMBOLS = [
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
     "iago_mcts_fresh_leaves", "iago_mcts_descend",
     "iago_mcts_search_persistent", "iago_mcts_search_capacity", "iago_selfplay_policy",
-    "iago_conv3x3_wgrad_split",
+    "iago_conv3x3_wgrad_split", "iago_conv3x3_bwd_data_split", "iago_split_scaled",
+    "iago_policy_grad_workspace_bytes", "iago_policy_reinforce_grad",
 ]
 # include/iago_hip_experimental.h: two schedules of the per-playout engine that measured slower (game-asynchronous steps,
 # value look-ahead); opt-in through engine.BatchedMCTS(async_steps=True / value_ahead=True), off every default path
@@ -55,6 +56,23 @@ class RolloutArgs(C.Structure):
         ("z", C.c_void_p), ("final_own", C.c_void_p), ("final_opp", C.c_void_p),
         ("n_turns", C.c_void_p), ("trace", C.c_void_p), ("log_form", C.c_int),
         ("throughput_hint", C.c_int),
+    ]
+
+
+class PolicyGradArgs(C.Structure):
+    _fields_ = [
+        ("own", C.c_void_p), ("opp", C.c_void_p), ("action", C.c_void_p), ("reward", C.c_void_p),
+        ("n", C.c_int64), ("n_mean", C.c_int64),
+        ("w1", C.c_void_p), ("b1", C.c_void_p),
+        ("w_hi", C.c_void_p * 7), ("w_lo", C.c_void_p * 7), ("wt_hi", C.c_void_p * 7), ("wt_lo", C.c_void_p * 7),
+        ("bias", C.c_void_p * 7),
+        ("w9", C.c_void_p), ("b10", C.c_void_p),
+        ("g_w1", C.c_void_p), ("g_b1", C.c_void_p),
+        ("g_w", C.c_void_p * 7), ("g_b", C.c_void_p * 7),
+        ("g_w9", C.c_void_p), ("g_b10", C.c_void_p),
+        ("loss", C.c_void_p), ("probs", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("overflow", C.c_void_p),
     ]
 
 
@@ -220,6 +238,11 @@ def lib():
     L.iago_policy_forward_split3.argtypes = [C.POINTER(PolicySplit3Args), vp]
     L.iago_value_rollout.argtypes = [C.POINTER(ValueSplitArgs), C.POINTER(RolloutArgs), vp]
     L.iago_conv3x3_wgrad_split.argtypes = [vp, vp, vp, vp, i64, i32, vp, i32, vp, vp, vp]
+    L.iago_conv3x3_bwd_data_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, vp]
+    L.iago_split_scaled.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]
+    L.iago_policy_grad_workspace_bytes.argtypes = [i64]
+    L.iago_policy_grad_workspace_bytes.restype = i64
+    L.iago_policy_reinforce_grad.argtypes = [C.POINTER(PolicyGradArgs), vp]
     L.iago_split_nchw.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.iago_merge_nchw.argtypes = [vp, vp, vp, i64, i32, vp]
     L.iago_value_stem.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]

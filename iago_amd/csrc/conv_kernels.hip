@@ -82,7 +82,19 @@ struct ConvParams {
     int64_t n;
     int32_t n_chunks; // cin / 16
     uint32_t *overflow; // optional: set to 1 when an output left [0, 65000] or is NaN
+    // MODE_BWD (backward-data of a block, csrc/policy_grad_kernels.hip): x = the gradient at the block's
+    // pre-activations times 2^*scale_exp, w = the block's weights transposed and flipped, no bias; the output --
+    // times 2^-*scale_exp, zeroed where the saved activation of the block below (mask_hi / mask_lo, out_blocks
+    // channel blocks) is not positive -- goes out as float32 channel blocks, its largest magnitude to *max_bits
+    const int32_t *scale_exp;
+    const uint2 *mask_hi, *mask_lo; // [n][out_blocks][64][16] f16
+    f32x4 *y_f32;                   // [n][out_blocks][64][16] float32
+    uint32_t *max_bits;
+    int32_t out_blocks;
 };
+constexpr int MODE_FWD = 0, MODE_BWD = 1;
+constexpr int T_ROW32 = (COUT + 4) * 4;        // MODE_BWD's epilogue image: 132 floats per cell
+static_assert(TB * 64 * T_ROW32 <= LDS_BYTES, "float32 epilogue image must fit in the staging buffers");
 
 __device__ __forceinline__ half8 lds_half8(const char *p)
 {
@@ -152,6 +164,7 @@ __device__ __forceinline__ void mfma_step(const Frags &F, float16v (&acc_main)[N
 extern __shared__ __align__(16) char conv_lds[]; // the dynamic LDS of the two kernels below
 
 // One layer for the 4 boards of this workgroup (the whole kernel when launched per layer).
+template <int MODE = MODE_FWD>
 __device__ __forceinline__ void conv_layer(const ConvParams &P)
 {
     char *const lds = conv_lds;
@@ -162,7 +175,7 @@ __device__ __forceinline__ void conv_layer(const ConvParams &P)
     const int w = (tid >> 6) & (TB - 1), cs = tid >> 8, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int64_t b0 = (int64_t)blockIdx.x * TB;
 
-    const float my_bias = P.bias[tid & (COUT - 1)]; // parked in a register until the epilogue
+    const float my_bias = MODE == MODE_FWD ? P.bias[tid & (COUT - 1)] : 0.0f; // parked in a register until the epilogue
     // zero both X buffers once: the border cells of the padded planes stay zero
     for (int i = tid; i < 2 * X_BUF / 16; i += THREADS)
         ((uint4 *)xbuf)[i] = make_uint4(0, 0, 0, 0);
@@ -296,6 +309,52 @@ __device__ __forceinline__ void conv_layer(const ConvParams &P)
     }
     __syncthreads();
 
+    if (MODE == MODE_BWD) {
+        // ---- epilogue of the backward-data form: scale, transpose through LDS as float32, mask, coalesced stores
+        const float unscale = ldexpf(1.0f, -*P.scale_exp);
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int co = 32 * (NI * cs + i) + 8 * q + 4 * h;
+                    f32x4 v4;
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        v4[t] = (acc_main[i][j][4 * q + t] + acc_cross[i][j][4 * q + t] * (1.0f / 2048.0f)) * unscale;
+                    *(f32x4 *)(lds + (w * 64 + 32 * j + lane_cell) * T_ROW32 + co * 4) = v4;
+                }
+        __syncthreads();
+        float big = 0.0f;
+        const int per_board = P.out_blocks * 256; // 16-byte pieces of 4 channels
+        for (int e = tid; e < TB * per_board; e += THREADS) {
+            const int board = e / per_board, f = e - board * per_board;
+            const int cb = f >> 8, cell = (f >> 2) & 63, qt = f & 3;
+            const int64_t b = b0 + board;
+            if (b < P.n) {
+                f32x4 v4 = *(const f32x4 *)(lds + (board * 64 + cell) * T_ROW32 + (cb * 16 + qt * 4) * 4);
+                const int64_t at = b * per_board + f;
+                const uint2 mh = P.mask_hi[at], ml = P.mask_lo[at];
+                const __half2 *h2 = (const __half2 *)&mh, *l2 = (const __half2 *)&ml;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float xh = __half2float(t & 1 ? h2[t >> 1].y : h2[t >> 1].x);
+                    const float xl = __half2float(t & 1 ? l2[t >> 1].y : l2[t >> 1].x);
+                    if (!(xh + xl * (1.0f / 2048.0f) > 0.0f)) // the ReLU of the block below was off (network.py:13)
+                        v4[t] = 0.0f;
+                    big = fmaxf(big, fabsf(v4[t]));
+                }
+                P.y_f32[at] = v4;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            big = fmaxf(big, __shfl_xor(big, d));
+        if (lane == 0 && big > 0.0f)
+            atomicMax(P.max_bits, __float_as_uint(big));
+        return;
+    }
     // ---- epilogue: bias, ReLU, split, transpose through LDS, coalesced stores
     // D tile (i, j): lane holds cell 32j + cell_of_lane(r), channels 32i + 8(v>>2) + 4h + (v&3)
     char *const t_hi = lds, *const t_lo = lds + T_HALF;
@@ -348,6 +407,79 @@ __device__ __forceinline__ void conv_layer(const ConvParams &P)
 __global__ __launch_bounds__(THREADS) void conv3x3_split_kernel(ConvParams P)
 {
     conv_layer(P);
+}
+
+__global__ __launch_bounds__(THREADS) void conv3x3_bwd_data_kernel(ConvParams P)
+{
+    conv_layer<MODE_BWD>(P);
+}
+
+// float32 channel blocks -> split channel blocks times 2^e, e from the tensor's largest magnitude (13 - its exponent:
+// the largest element lands in [2^13, 2^14)); thread 0 publishes e.  A thread = 8 channels of a cell, a workgroup =
+// two (board, channel block) pairs; bias_part (optional) [workgroups][2][16]: the sums over the 64 cells of each pair
+// -- the bias gradient of the block, one more pass over these bytes saved (fixed order: deterministic)
+__global__ __launch_bounds__(256) void split_scaled_kernel(const f32x4 *x, const uint32_t *max_bits, uint4 *hi, uint4 *lo,
+                                                           int32_t *scale_exp, int64_t pieces, float *bias_part)
+{
+    __shared__ float wave_sum[4][16];
+    const uint32_t mb = *max_bits;
+    const int e = mb == 0u ? 0 : 13 - ((int)(mb >> 23) - 127);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0)
+        *scale_exp = e;
+    float raw[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        raw[k] = 0.0f;
+    if (t < pieces) {
+        const f32x4 a = x[2 * t], b = x[2 * t + 1];
+        __half h8[8], l8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            raw[k] = k < 4 ? a[k] : b[k - 4];
+            const float v = ldexpf(raw[k], e);
+            const __half vh = __float2half_rn(v);
+            h8[k] = vh;
+            l8[k] = __float2half_rn((v - __half2float(vh)) * 2048.0f);
+        }
+        hi[t] = *(const uint4 *)h8;
+        lo[t] = *(const uint4 *)l8;
+    }
+    if (!bias_part)
+        return;
+    // lanes of one parity hold the same 8 channels of 32 cells; wave w = cells 32 (w & 1) .. + 31 of pair w >> 1
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int d = 2; d <= 32; d <<= 1)
+            raw[k] += __shfl_xor(raw[k], d);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane < 2)
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            wave_sum[wv][8 * lane + k] = raw[k];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int pr = threadIdx.x >> 4, c = threadIdx.x & 15;
+        bias_part[(int64_t)blockIdx.x * 32 + threadIdx.x] = wave_sum[2 * pr][c] + wave_sum[2 * pr + 1][c];
+    }
+}
+
+// bias gradient: channel ch of `channels` = sum over the boards of the pair sums above; one wave per channel, lane l
+// takes boards l, l + 64, ..
+__global__ __launch_bounds__(64) void bias_reduce_kernel(const float *bias_part, int64_t n, int channels, float *db)
+{
+    const int ch = blockIdx.x, ncb = channels >> 4, cb = ch >> 4, c = ch & 15, lane = threadIdx.x;
+    float s = 0.0f;
+    for (int64_t b = lane; b < n; b += 64) {
+        const int64_t pair = b * ncb + cb;
+        s += bias_part[(pair >> 1) * 32 + (pair & 1) * 16 + c];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        s += __shfl_xor(s, d);
+    if (lane == 0)
+        db[ch] = s;
 }
 
 // Up to 8 consecutive layers in one launch.  A workgroup owns all 128 channels of its 4
@@ -821,7 +953,7 @@ int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, con
     if (iago_reserve_lds((const void *)conv3x3_split_kernel, LDS_BYTES, configured,
                          "iago_conv3x3_split: cannot reserve 159 KB of LDS"))
         return IAGO_ERR_HIP;
-    ConvParams P;
+    ConvParams P = {};
     P.x_hi = (const uint4 *)x_hi;
     P.x_lo = (const uint4 *)x_lo;
     P.w_hi = (const uint4 *)w_hi;
@@ -835,6 +967,57 @@ int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, con
     const unsigned grid = (unsigned)((n + TB - 1) / TB);
     hipLaunchKernelGGL(conv3x3_split_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, P);
     return iago_check_launch("iago_conv3x3_split");
+}
+
+int iago_conv3x3_bwd_data_split(const void *dy_hi, const void *dy_lo, const int32_t *scale_exp, const void *wt_hi,
+                                const void *wt_lo, const void *mask_hi, const void *mask_lo, int32_t out_channels,
+                                float *dx, uint32_t *max_bits, int64_t n, void *stream)
+{
+    if (n < 0 || (out_channels != 64 && out_channels != 128))
+        return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_bwd_data_split: out_channels must be 64 or 128");
+    if (n == 0)
+        return IAGO_OK;
+    if (!dy_hi || !dy_lo || !scale_exp || !wt_hi || !wt_lo || !mask_hi || !mask_lo || !dx || !max_bits)
+        return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_bwd_data_split: null pointer");
+    static std::atomic<uint64_t> configured{0};
+    if (iago_reserve_lds((const void *)conv3x3_bwd_data_kernel, LDS_BYTES, configured,
+                         "iago_conv3x3_bwd_data_split: cannot reserve 159 KB of LDS"))
+        return IAGO_ERR_HIP;
+    ConvParams P = {};
+    P.x_hi = (const uint4 *)dy_hi;
+    P.x_lo = (const uint4 *)dy_lo;
+    P.w_hi = (const uint4 *)wt_hi;
+    P.w_lo = (const uint4 *)wt_lo;
+    P.n = n;
+    P.n_chunks = 8;
+    P.scale_exp = scale_exp;
+    P.mask_hi = (const uint2 *)mask_hi;
+    P.mask_lo = (const uint2 *)mask_lo;
+    P.y_f32 = (f32x4 *)dx;
+    P.max_bits = max_bits;
+    P.out_blocks = out_channels / 16;
+    const unsigned grid = (unsigned)((n + TB - 1) / TB);
+    hipLaunchKernelGGL(conv3x3_bwd_data_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, P);
+    return iago_check_launch("iago_conv3x3_bwd_data_split");
+}
+
+int iago_split_scaled(const float *x, const uint32_t *max_bits, void *hi, void *lo, int32_t *scale_exp, int64_t n,
+                      int32_t channels, float *bias_part, float *bias_grad, void *stream)
+{
+    if (n < 0 || channels <= 0 || (channels % 16) != 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_split_scaled: channels must be a multiple of 16");
+    if (!x || !max_bits || !hi || !lo || !scale_exp)
+        return iago_fail(IAGO_ERR_INVALID, "iago_split_scaled: null pointer");
+    const int64_t pieces = n * (channels / 16) * 128;
+    const int64_t blocks = pieces ? (pieces + 255) / 256 : 1;
+    if ((bias_part == nullptr) != (bias_grad == nullptr))
+        return iago_fail(IAGO_ERR_INVALID, "iago_split_scaled: bias_part and bias_grad go together");
+    hipLaunchKernelGGL(split_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4 *)x, max_bits, (uint4 *)hi, (uint4 *)lo, scale_exp, pieces, bias_part);
+    if (bias_part && n > 0)
+        hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)channels), dim3(64), 0, (hipStream_t)stream,
+                           (const float *)bias_part, n, channels, bias_grad);
+    return iago_check_launch("iago_split_scaled");
 }
 
 int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32_t n_layers, int64_t n,

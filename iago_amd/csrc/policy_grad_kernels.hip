@@ -240,6 +240,203 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *part, in
     dw[((int64_t)co * cin + ci) * 9 + tap] = s;
 }
 
+
+// ---- The head of SLPolicy and the loss, forward and backward in one pass (network.py:29-47, src/train_rl.py:61-64):
+//   logits = conv9 (1x1, 128 -> 1, no bias) + bias10[cell];  p = softmax(logits)            (the model's output)
+//   c = softmax_cross_entropy(p, a) = logsumexp(p) - p[a]     (the reference applies log-softmax to the probabilities)
+//   loss = sum_b c_b z_b / n_true
+// and back: g = (z / n_true) (softmax(p) - onehot(a)), dlogits = p (g - <g, p>), dW9[c] = sum dlogits x8[c],
+// dbias10[cell] = sum dlogits, dY8[c][cell] = [x8 > 0] dlogits[cell] w9[c] (the gradient at block 8's pre-activations,
+// float32 channel blocks + the largest magnitude).  One wave per board at a time, lane = cell; float32 arithmetic on
+// the exact values hi + lo 2^-11.
+struct HeadGradParams {
+    const uint4 *x_hi, *x_lo;  // [n][8][64][16] f16: the output of block 8
+    const float *w9, *b10;     // [128], [64]
+    const int32_t *action;     // [n]
+    const float *reward;       // [n]
+    float inv_n;               // 1 / (rows the mean divides by)
+    int64_t n;
+    float4v *dy;               // [n][8][64][16] float32
+    uint32_t *max_bits;
+    float *part;               // [gridDim.x][193]: dW9 (128), dbias10 (64), loss (1) of each workgroup
+    float *probs;              // optional [n][64]: the model's output
+};
+constexpr int HEAD_PART = 193;
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void head_grad_kernel(HeadGradParams P)
+{
+    __shared__ float red[4][HEAD_PART];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float acc9[128];
+#pragma unroll
+    for (int c = 0; c < 128; c++)
+        acc9[c] = 0.0f;
+    float acc_b = 0.0f, acc_loss = 0.0f, big = 0.0f;
+    const float my_b10 = P.b10[lane];
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < P.n; b += (int64_t)gridDim.x * 4) {
+        float x[128];
+#pragma unroll
+        for (int cb = 0; cb < 8; cb++) {
+            const int64_t at = ((b * 8 + cb) * 64 + lane) * 2;
+            const uint4 h0 = P.x_hi[at], h1 = P.x_hi[at + 1], l0 = P.x_lo[at], l1 = P.x_lo[at + 1];
+            const __half2 *hh0 = (const __half2 *)&h0, *hh1 = (const __half2 *)&h1;
+            const __half2 *ll0 = (const __half2 *)&l0, *ll1 = (const __half2 *)&l1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float2 a = __half22float2(hh0[k]), c2 = __half22float2(ll0[k]);
+                const float2 d = __half22float2(hh1[k]), e2 = __half22float2(ll1[k]);
+                x[16 * cb + 2 * k] = a.x + c2.x * (1.0f / 2048.0f);
+                x[16 * cb + 2 * k + 1] = a.y + c2.y * (1.0f / 2048.0f);
+                x[16 * cb + 8 + 2 * k] = d.x + e2.x * (1.0f / 2048.0f);
+                x[16 * cb + 8 + 2 * k + 1] = d.y + e2.y * (1.0f / 2048.0f);
+            }
+        }
+        float logit = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 128; c++)
+            logit = fmaf(P.w9[c], x[c], logit);
+        logit += my_b10;
+        const float m = wave_max(logit);
+        const float ex = expf(logit - m);
+        const float p = ex / wave_sum(ex);                          // F.softmax, network.py:46
+        if (P.probs)
+            P.probs[b * 64 + lane] = p;
+        const int a = P.action[b];
+        const float z = P.reward[b];
+        // F.softmax_cross_entropy(pred, y): log-softmax of the probabilities (src/train_rl.py:62)
+        const float m2 = wave_max(p);
+        const float ex2 = expf(p - m2);
+        const float s2 = wave_sum(ex2);
+        const float lse = m2 + logf(s2);
+        const float p_a = __shfl(p, a & 63);
+        acc_loss += (lse - p_a) * z;
+        const float g = z * P.inv_n * (ex2 / s2 - (lane == a ? 1.0f : 0.0f));
+        const float dl = p * (g - wave_sum(g * p));                 // through the model's softmax
+        acc_b += dl;
+#pragma unroll
+        for (int cb = 0; cb < 8; cb++) {
+#pragma unroll
+            for (int qt = 0; qt < 4; qt++) {
+                float4v v;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int c = 16 * cb + 4 * qt + k;
+                    acc9[c] = fmaf(dl, x[c], acc9[c]);
+                    v[k] = x[c] > 0.0f ? dl * P.w9[c] : 0.0f;
+                    big = fmaxf(big, fabsf(v[k]));
+                }
+                P.dy[((b * 8 + cb) * 64 + lane) * 4 + qt] = v;
+            }
+        }
+    }
+    big = wave_max(big);
+    if (lane == 0 && big > 0.0f)
+        atomicMax(P.max_bits, __float_as_uint(big));
+#pragma unroll
+    for (int c = 0; c < 128; c++) {
+        const float s = wave_sum(acc9[c]);
+        if (lane == 0)
+            red[wv][c] = s;
+    }
+    red[wv][128 + lane] = acc_b;
+    if (lane == 0)
+        red[wv][192] = acc_loss; // (the same in every lane)
+    __syncthreads();
+    if (threadIdx.x < HEAD_PART)
+        P.part[(int64_t)blockIdx.x * HEAD_PART + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[j] = (j == 192 ? inv_n : 1) * sum over the workgroups' partial sums, in order
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float *part, int n_parts, float inv_n, float *dw9, float *db10,
+                                                          float *loss)
+{
+    const int j = threadIdx.x;
+    if (j >= HEAD_PART)
+        return;
+    float s = 0.0f;
+    for (int i = 0; i < n_parts; i++)
+        s += part[(int64_t)i * HEAD_PART + j];
+    if (j < 128)
+        dw9[j] = s;
+    else if (j < 192)
+        db10[j - 128] = s;
+    else
+        *loss = s * inv_n;
+}
+
+// ---- The weight and bias gradients of block 1 (3x3, 2 -> 64 on the planes of the board: plane 0 = the opponent's
+// stones, plane 1 = the mover's, game.py:168-174): dW1[co][plane][ky][kx] = sum over boards and cells of dY1[co][y][x]
+// [plane has a stone at (y + ky - 1, x + kx - 1)], db1[co] = sum dY1.  One wave per board at a time, lane = channel.
+constexpr int STEM_PART = 64 * 19;
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float *dy, const uint64_t *own, const uint64_t *opp, int64_t n,
+                                                         float *part)
+{
+    __shared__ float red[4][STEM_PART];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float acc[19];
+#pragma unroll
+    for (int k = 0; k < 19; k++)
+        acc[k] = 0.0f;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < n; b += (int64_t)gridDim.x * 4) {
+        const uint64_t pl[2] = {opp[b], own[b]};
+        const float *src = dy + ((b * 4 + (lane >> 4)) * 64) * 16 + (lane & 15);
+        for (int cell = 0; cell < 64; cell++) {
+            const float d = src[cell * 16];
+            const int y = cell >> 3, x = cell & 7;
+            acc[18] += d;
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const int yy = y + ky - 1, xx = x + kx - 1;
+                    const bool in = yy >= 0 && yy < 8 && xx >= 0 && xx < 8;
+                    const int bit = in ? yy * 8 + xx : 0;
+#pragma unroll
+                    for (int pn = 0; pn < 2; pn++)
+                        if (in && ((pl[pn] >> bit) & 1ull))
+                            acc[pn * 9 + ky * 3 + kx] += d;
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 19; k++)
+        red[wv][lane * 19 + k] = acc[k];
+    __syncthreads();
+    for (int j = threadIdx.x; j < STEM_PART; j += 256)
+        part[(int64_t)blockIdx.x * STEM_PART + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+}
+
+__global__ __launch_bounds__(256) void stem_reduce_kernel(const float *part, int n_parts, float *dw1, float *db1)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x; // (channel, 18 weights + 1 bias)
+    if (j >= STEM_PART)
+        return;
+    float s = 0.0f;
+    for (int i = 0; i < n_parts; i++)
+        s += part[(int64_t)i * STEM_PART + j];
+    const int co = j / 19, k = j - 19 * co;
+    if (k < 18)
+        dw1[co * 18 + k] = s;
+    else
+        db1[co] = s;
+}
+
 } // namespace
 
 extern "C" {
@@ -270,6 +467,113 @@ int iago_conv3x3_wgrad_split(const void *dy_hi, const void *dy_lo, const void *x
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)part, groups, cin, scale_exp, dw);
     return iago_check_launch("iago_conv3x3_wgrad_split");
+}
+
+
+static int64_t pg_round(int64_t b)
+{
+    return (b + 255) & ~(int64_t)255;
+}
+constexpr int PG_GRID = 256;        // workgroups of the head and block-1 kernels
+constexpr int PG_MAX_GROUPS = 64;
+
+int64_t iago_policy_grad_workspace_bytes(int64_t n)
+{
+    if (n < 0)
+        return -1;
+    int64_t b = 0;
+    b += 2 * pg_round(n * 8192) + 14 * pg_round(n * 16384);          // saved activations of blocks 1..8, hi + lo
+    b += pg_round(n * 32768) + 2 * pg_round(n * 16384);              // a gradient as float32 and as scaled pieces
+    b += pg_round((int64_t)PG_MAX_GROUPS * 9 * 128 * 128 * 4);       // partial weight gradients
+    b += pg_round(((n * 8 + 1) / 2) * 32 * 4);                       // partial bias gradients
+    b += pg_round((int64_t)PG_GRID * HEAD_PART * 4) + pg_round((int64_t)PG_GRID * STEM_PART * 4);
+    b += 256;                                                        // the tensors' largest magnitudes and scales
+    return b;
+}
+
+int iago_policy_reinforce_grad(const iago_policy_grad_args *A, void *stream)
+{
+    if (!A || A->n < 0 || A->n_mean <= 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_policy_reinforce_grad: bad arguments");
+    const int64_t n = A->n;
+    if (!A->own || !A->opp || !A->action || !A->reward || !A->w1 || !A->b1 || !A->w9 || !A->b10 || !A->g_w1 ||
+        !A->g_b1 || !A->g_w9 || !A->g_b10 || !A->loss || !A->workspace)
+        return iago_fail(IAGO_ERR_INVALID, "iago_policy_reinforce_grad: null pointer");
+    for (int k = 0; k < 7; k++)
+        if (!A->w_hi[k] || !A->w_lo[k] || !A->wt_hi[k] || !A->wt_lo[k] || !A->bias[k] || !A->g_w[k] || !A->g_b[k])
+            return iago_fail(IAGO_ERR_INVALID, "iago_policy_reinforce_grad: null pointer (blocks 2..8)");
+    if (A->workspace_bytes < iago_policy_grad_workspace_bytes(n) || ((uintptr_t)A->workspace & 255))
+        return iago_fail(IAGO_ERR_INVALID, "iago_policy_reinforce_grad: workspace too small or not 256-byte aligned "
+                                           "(iago_policy_grad_workspace_bytes)");
+    if (n == 0)
+        return iago_fail(IAGO_ERR_INVALID, "iago_policy_reinforce_grad: no rows");
+    hipStream_t st = (hipStream_t)stream;
+    char *at = (char *)A->workspace;
+    auto take = [&](int64_t bytes) {
+        char *p = at;
+        at += pg_round(bytes);
+        return (void *)p;
+    };
+    void *x_hi[8], *x_lo[8];
+    for (int k = 0; k < 8; k++) {
+        x_hi[k] = take(n * (k ? 16384 : 8192));
+        x_lo[k] = take(n * (k ? 16384 : 8192));
+    }
+    float *dyf = (float *)take(n * 32768);
+    void *dys_hi = take(n * 16384), *dys_lo = take(n * 16384);
+    float *wpart = (float *)take((int64_t)PG_MAX_GROUPS * 9 * 128 * 128 * 4);
+    float *bpart = (float *)take(((n * 8 + 1) / 2) * 32 * 4);
+    float *hpart = (float *)take((int64_t)PG_GRID * HEAD_PART * 4);
+    float *spart = (float *)take((int64_t)PG_GRID * STEM_PART * 4);
+    uint32_t *max_bits = (uint32_t *)take(256); // [0..7]: of the gradient at block k + 1's pre-activations; [16..23]: scales
+    int32_t *scale_exp = (int32_t *)(max_bits + 16);
+    if (hipMemsetAsync(max_bits, 0, 256, st) != hipSuccess)
+        return iago_fail(IAGO_ERR_HIP, "iago_policy_reinforce_grad: hipMemsetAsync failed");
+
+    // forward, every block's output kept (src/train_rl.py:61)
+    int rc = iago_value_stem_boards(A->own, A->opp, A->w1, A->b1, x_hi[0], x_lo[0], n, A->overflow, stream);
+    for (int k = 0; k < 7 && rc == IAGO_OK; k++)
+        rc = iago_conv3x3_split(x_hi[k], x_lo[k], A->w_hi[k], A->w_lo[k], A->bias[k], x_hi[k + 1], x_lo[k + 1], n,
+                                k ? 128 : 64, 128, A->overflow, stream);
+    if (rc != IAGO_OK)
+        return rc;
+    // head + loss, forward and backward (src/train_rl.py:61-65)
+    const float inv_n = 1.0f / (float)A->n_mean;
+    HeadGradParams H;
+    H.x_hi = (const uint4 *)x_hi[7];
+    H.x_lo = (const uint4 *)x_lo[7];
+    H.w9 = A->w9;
+    H.b10 = A->b10;
+    H.action = A->action;
+    H.reward = A->reward;
+    H.inv_n = inv_n;
+    H.n = n;
+    H.dy = (float4v *)dyf;
+    H.max_bits = max_bits + 7;
+    H.part = hpart;
+    H.probs = A->probs;
+    hipLaunchKernelGGL(head_grad_kernel, dim3(PG_GRID), dim3(256), 0, st, H);
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)hpart, PG_GRID, inv_n, A->g_w9,
+                       A->g_b10, A->loss);
+    // blocks 8 .. 2: the gradient at the block's pre-activations (float32 in dyf) -> its scaled pieces + the bias
+    // gradient; the weight gradient; the gradient at the pre-activations of the block below
+    for (int k = 6; k >= 0 && rc == IAGO_OK; k--) {
+        const int cin = k ? 128 : 64;
+        rc = iago_split_scaled(dyf, max_bits + k + 1, dys_hi, dys_lo, scale_exp + k + 1, n, 128, bpart, A->g_b[k], stream);
+        if (rc == IAGO_OK)
+            rc = iago_conv3x3_wgrad_split(dys_hi, dys_lo, x_hi[k], x_lo[k], n, cin, wpart, cin == 128 ? 32 : 64,
+                                          scale_exp + k + 1, A->g_w[k], stream);
+        if (rc == IAGO_OK)
+            rc = iago_conv3x3_bwd_data_split(dys_hi, dys_lo, scale_exp + k + 1, A->wt_hi[k], A->wt_lo[k], x_hi[k], x_lo[k],
+                                             cin, dyf, max_bits + k, n, stream);
+    }
+    if (rc != IAGO_OK)
+        return rc;
+    // block 1 from the float32 gradient at its pre-activations
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(PG_GRID), dim3(256), 0, st, (const float *)dyf, A->own, A->opp, n, spart);
+    hipLaunchKernelGGL(stem_reduce_kernel, dim3((STEM_PART + 255) / 256), dim3(256), 0, st, (const float *)spart, PG_GRID,
+                       A->g_w1, A->g_b1);
+    return iago_check_launch("iago_policy_reinforce_grad");
 }
 
 } // extern "C"

@@ -171,6 +171,44 @@ class SLPolicy(nn.Module, _NpzMixin):
             self.__dict__["_split3_cache"] = hit
         return hit[1]
 
+    def _bwd_layers(self):
+        """Blocks 2..8 in the backward-data form of iago_policy_reinforce_grad (transposed, flipped, two f16 pieces),
+        rebuilt when the weights change."""
+        from . import ops
+        ws = [getattr(self, "block%d" % k).conv.weight for k in range(2, 9)]
+        key = tuple((w._version, w.data_ptr()) for w in ws)
+        hit = self.__dict__.get("_bwd_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.split_weights_transposed_many(ws))
+            self.__dict__["_bwd_cache"] = hit
+        return hit[1]
+
+    def reinforce_grads(self, own, opp, action, reward, n_mean=None, probs=None):
+        """src/train_rl.py:61-65 on the matrix units in split-f16 arithmetic (iago_policy_reinforce_grad):
+        cleargrads + loss.backward() for loss = mean(softmax_cross_entropy(self(x), action) * reward); every
+        parameter's .grad is overwritten.  own / opp: the recorded positions (own = the mover).  Returns the loss
+        (0-dim device tensor).  The first two f16 pieces of the search path's three-piece weights are the forward's."""
+        from . import ops
+        convs = [getattr(self, "block%d" % k).conv for k in range(2, 9)]
+        params = [self.block1.conv.weight, self.block1.conv.bias, self.conv9.weight, self.bias10.b]
+        for c in convs:
+            params += [c.weight, c.bias]
+        for p in params:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise ValueError("reinforce_grads: float32 CUDA parameters expected")
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+        layers = [(hi, mid, bias) for hi, mid, lo, bias in self._split3_layers()]
+        grads = dict(w1=self.block1.conv.weight.grad, b1=self.block1.conv.bias.grad,
+                     w=[c.weight.grad for c in convs], b=[c.bias.grad for c in convs],
+                     w9=self.conv9.weight.grad, b10=self.bias10.b.grad)
+        n = own.numel()
+        return ops.policy_reinforce_grad(own.contiguous(), opp.contiguous(), action.to(torch.int32).contiguous(),
+                                         reward.to(torch.float32).contiguous(), n if n_mean is None else n_mean,
+                                         self.block1.conv.weight.detach(), self.block1.conv.bias.detach(), layers,
+                                         self._bwd_layers(), self.conv9.weight.detach(), self.bias10.b.detach(), grads,
+                                         probs=probs, overflow=self._overflow_flag(own.device))
+
     def _split3_template(self):
         """iago_policy_split3_args with this module's weights, rebuilt when they change."""
         from . import ops

@@ -526,6 +526,133 @@ def conv3x3_wgrad_split(dy, x, scale_exp=None, groups=WGRAD_GROUPS, part=None):
     return dw
 
 
+def split_weights_transposed(weight):
+    """The backward-data form of a (128, cin, 3, 3) block weight: split_weights of Wt[ci][co][ky][kx] =
+    W[co][ci][2-ky][2-kx], padded to 128 rows."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    wt = weight.detach().to(torch.float32).flip(2, 3).permute(1, 0, 2, 3)
+    if cin < 128:
+        wt = torch.cat([wt, torch.zeros((128 - cin, cout, 3, 3), dtype=torch.float32, device=wt.device)])
+    return split_weights(wt.contiguous())
+
+
+def split_weights_transposed_many(weights):
+    """split_weights_transposed of several block weights, the elementwise work of equally shaped ones on one stacked
+    tensor (the update re-splits all 7 blocks after every step)."""
+    out = [None] * len(weights)
+    groups = {}
+    for i, w in enumerate(weights):
+        groups.setdefault(tuple(w.shape), []).append(i)
+    for shape, idx in groups.items():
+        cout, cin, kh, kw = shape
+        if (kh, kw) != (3, 3) or cout != 128 or cin not in (64, 128):
+            raise ValueError("split_weights_transposed: need (128, 64|128, 3, 3) weights")
+        w = torch.stack([weights[i].detach().to(torch.float32) for i in idx])            # L, co, ci, ky, kx
+        wt = w.flip(3, 4).permute(0, 3, 4, 2, 1)                                          # L, ky', kx', ci, co
+        if cin < 128:
+            wt = torch.cat([wt, torch.zeros((len(idx), 3, 3, 128 - cin, cout), dtype=torch.float32, device=w.device)], 3)
+        wt = wt.reshape(len(idx), 3, 3, 128, cout // 16, 16).permute(0, 4, 1, 2, 3, 5).contiguous()
+        hi = wt.to(torch.float16)
+        lo = ((wt - hi.to(torch.float32)) * 2048.0).to(torch.float16)
+        for j, i in enumerate(idx):
+            out[i] = (hi[j], lo[j])
+    return out
+
+
+_grad_workspace = {}
+
+
+def policy_grad_workspace(device, n):
+    """The scratch of iago_policy_reinforce_grad for n rows on `device`: kept, grown in steps of 256 rows."""
+    need = int(_lib.lib().iago_policy_grad_workspace_bytes((n + 255) // 256 * 256))
+    ws = _grad_workspace.get(str(device))
+    if ws is None or ws.numel() < need:
+        _grad_workspace[str(device)] = ws = None      # (release before the larger allocation)
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _grad_workspace[str(device)] = ws
+    return ws
+
+
+def policy_reinforce_grad(own, opp, action, reward, n_mean, w1, b1, layers, layers_t, w9, b10, grads, probs=None,
+                          overflow=None):
+    """iago_policy_reinforce_grad (include/iago_hip.h): the gradients of mean(softmax_cross_entropy(model(x), a) * r)
+    (src/train_rl.py:61-65) written to `grads` = dict(w1, b1, w=[7], b=[7], w9, b10) of float32 tensors in the
+    parameters' shapes.  layers: 7 x (w_hi, w_lo, bias) as for conv3x3_split; layers_t: 7 x (wt_hi, wt_lo) from
+    split_weights_transposed.  Returns the loss (0-dim float32 device tensor)."""
+    n = own.numel()
+    dev = own.device
+    ws = policy_grad_workspace(dev, n)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    A = _lib.PolicyGradArgs()
+    A.own, A.opp = _dev(own, torch.int64, "own"), _dev(opp, torch.int64, "opp")
+    A.action, A.reward = _dev(action, torch.int32, "action"), _dev(reward, torch.float32, "reward")
+    A.n, A.n_mean = n, int(n_mean)
+    A.w1, A.b1 = _dev(w1, torch.float32, "w1"), _dev(b1, torch.float32, "b1")
+    for k in range(7):
+        A.w_hi[k], A.w_lo[k] = _dev(layers[k][0], torch.float16, "w_hi").value, _dev(layers[k][1], torch.float16, "w_lo").value
+        A.bias[k] = _dev(layers[k][2], torch.float32, "bias").value
+        A.wt_hi[k], A.wt_lo[k] = (_dev(layers_t[k][0], torch.float16, "wt_hi").value,
+                                  _dev(layers_t[k][1], torch.float16, "wt_lo").value)
+        A.g_w[k], A.g_b[k] = _dev(grads["w"][k], torch.float32, "g_w").value, _dev(grads["b"][k], torch.float32, "g_b").value
+    A.w9, A.b10 = _dev(w9, torch.float32, "w9"), _dev(b10, torch.float32, "b10")
+    A.g_w1, A.g_b1 = _dev(grads["w1"], torch.float32, "g_w1"), _dev(grads["b1"], torch.float32, "g_b1")
+    A.g_w9, A.g_b10 = _dev(grads["w9"], torch.float32, "g_w9"), _dev(grads["b10"], torch.float32, "g_b10")
+    A.loss = _dev(loss, torch.float32, "loss")
+    A.probs = _dev(probs, torch.float32, "probs") if probs is not None else None
+    A.workspace, A.workspace_bytes = ws.data_ptr(), ws.numel()
+    A.overflow = _flag(overflow)
+    check(_lib.lib().iago_policy_reinforce_grad(C.byref(A), _stream()), "iago_policy_reinforce_grad")
+    return loss
+
+
+def conv3x3_bwd_data_split(dy, scale_exp, wt_hi, wt_lo, saved, max_bits=None):
+    """Gradient at a block's input through the ReLU of the block below (saved: its SplitActs output).  Returns
+    (dx float32 (n, C/16, 64, 16), max_bits)."""
+    n, ch = dy.n, saved.channels
+    dx = torch.empty((n, ch // 16, 64, 16), dtype=torch.float32, device=dy.hi.device)
+    if max_bits is None:
+        max_bits = torch.zeros(1, dtype=torch.int32, device=dy.hi.device)
+    check(_lib.lib().iago_conv3x3_bwd_data_split(_dev(dy.hi, torch.float16, "dy_hi"), _dev(dy.lo, torch.float16, "dy_lo"),
+                                                 _dev(scale_exp, torch.int32, "scale_exp"),
+                                                 _dev(wt_hi, torch.float16, "wt_hi"), _dev(wt_lo, torch.float16, "wt_lo"),
+                                                 _dev(saved.hi, torch.float16, "mask_hi"), _dev(saved.lo, torch.float16, "mask_lo"),
+                                                 ch, _dev(dx, torch.float32, "dx"), _dev(max_bits, torch.int32, "max_bits"),
+                                                 n, _stream()), "iago_conv3x3_bwd_data_split")
+    return dx, max_bits
+
+
+def split_scaled(x, max_bits, bias_grad=False):
+    """float32 channel blocks (n, C/16, 64, 16) -> (SplitActs of x * 2**e, e as an int32 device word[, the sums
+    over boards and cells per channel])."""
+    n, nb = x.shape[0], x.shape[1]
+    hi = torch.empty((n, nb, 64, 16), dtype=torch.float16, device=x.device)
+    lo = torch.empty_like(hi)
+    e = torch.empty(1, dtype=torch.int32, device=x.device)
+    part = db = None
+    if bias_grad:
+        part = torch.empty(((n * nb + 1) // 2) * 32, dtype=torch.float32, device=x.device)
+        db = torch.empty(nb * 16, dtype=torch.float32, device=x.device)
+    check(_lib.lib().iago_split_scaled(_dev(x, torch.float32, "x"), _dev(max_bits, torch.int32, "max_bits"),
+                                       _dev(hi, torch.float16, "hi"), _dev(lo, torch.float16, "lo"),
+                                       _dev(e, torch.int32, "scale_exp"), n, nb * 16,
+                                       _dev(part, torch.float32, "bias_part") if bias_grad else None,
+                                       _dev(db, torch.float32, "bias_grad") if bias_grad else None,
+                                       _stream()), "iago_split_scaled")
+    return (SplitActs(hi, lo, nb * 16), e, db) if bias_grad else (SplitActs(hi, lo, nb * 16), e)
+
+
+def blocks_to_nchw(x):
+    """float32 channel blocks (n, C/16, 64, 16) -> (n, C, 8, 8)."""
+    n, nb = x.shape[0], x.shape[1]
+    return x.permute(0, 1, 3, 2).reshape(n, nb * 16, 8, 8)
+
+
+def nchw_to_blocks(x):
+    """(n, C, 8, 8) float32 -> channel blocks (n, C/16, 64, 16)."""
+    n, c = x.shape[0], x.shape[1]
+    return x.reshape(n, c // 16, 16, 64).permute(0, 1, 3, 2).contiguous()
+
+
 # ---- float32 small-batch convolution stack (policy net on expansions) ----------------
 
 def f32_weights(weight):

@@ -812,10 +812,64 @@ IAGO_API int iago_selfplay_policy(const iago_selfplay_policy_args *args, void *s
  *   2^e), x_hi / x_lo [n][cin/16][64][16] (the block's input), cin 64 or 128; dw [128][cin][3][3] float32.
  *   part: scratch, [groups][9][128][cin] float32 -- the boards are summed in `groups` (a multiple of 8) contiguous
  *   groups, whose partial sums are added in group order (deterministic); scale_exp: the device word e, NULL = 0.
+ *
+ * iago_conv3x3_bwd_data_split: the gradient at the INPUT of a 3x3 block, through the ReLU of the block below:
+ *   dx[b][ci][y][x] = [saved[b][ci][y][x] > 0] * 2^-e * sum over co and taps of dY[b][co][y - ky + 1][x - kx + 1] *
+ *   W[co][ci][ky][kx] -- iago_conv3x3_split's kernel on the transposed, flipped weights (wt_hi / wt_lo: the split of
+ *   Wt[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx], rows ci >= out_channels zero) with a float32 epilogue.
+ *   mask_hi / mask_lo [n][out_channels/16][64][16]: the saved activations of the block below (its output = this
+ *   block's input); dx [n][out_channels/16][64][16] float32 channel blocks; out_channels 64 or 128.
+ *   max_bits: device word, atomicMax of the bit patterns of |dx| (zero it before the call).
+ * iago_split_scaled: float32 channel blocks -> split channel blocks times 2^e with e = 13 - exponent of the largest
+ *   magnitude (*max_bits, as written by the call above); writes e to *scale_exp.  bias_part / bias_grad (both or
+ *   neither): scratch of ceil(n * channels / 32) * 32 floats and the sums over boards and cells per channel
+ *   [channels] -- the bias gradient of the block whose pre-activation gradient x is, from the same pass.
  */
+IAGO_API int iago_conv3x3_bwd_data_split(const void *dy_hi, const void *dy_lo, const int32_t *scale_exp,
+                                         const void *wt_hi, const void *wt_lo, const void *mask_hi,
+                                         const void *mask_lo, int32_t out_channels, float *dx, uint32_t *max_bits,
+                                         int64_t n, void *stream);
+IAGO_API int iago_split_scaled(const float *x, const uint32_t *max_bits, void *hi, void *lo, int32_t *scale_exp,
+                               int64_t n, int32_t channels, float *bias_part, float *bias_grad, void *stream);
 IAGO_API int iago_conv3x3_wgrad_split(const void *dy_hi, const void *dy_lo, const void *x_hi, const void *x_lo,
                                       int64_t n, int32_t cin, float *part, int32_t groups, const int32_t *scale_exp,
                                       float *dw, void *stream);
+/*
+ * iago_policy_reinforce_grad: the whole of src/train_rl.py:61-65 -- pred = model1(x), loss = mean(softmax_cross_entropy(
+ *   pred, y) * r), model1.cleargrads(), loss.backward() -- for n recorded rows: forward with every block's output kept
+ *   (iago_value_stem_boards on block1's weights, 7 x iago_conv3x3_split), the head and the loss forward and backward
+ *   (logits = conv9 + bias10, p = softmax, c = logsumexp(p) - p[a] as the reference computes it, dlogits through both
+ *   softmaxes), then per block 8 .. 2 iago_split_scaled (+ the bias gradient), iago_conv3x3_wgrad_split,
+ *   iago_conv3x3_bwd_data_split, and block 1's gradients from the float32 gradient at its pre-activations.  ~48
+ *   launches on `stream`, no host synchronisation; deterministic (fixed summation orders).
+ *   own / opp [n]: the recorded positions, own = the mover (the planes of game.py:168-174 are built in the kernel);
+ *   action [n] int32 (0..63); reward [n] float32 (z; rows added as padding carry 0); n_mean: the row count the mean
+ *   divides by.  w1 [64][2][3][3], b1 [64]; blocks 2..8 (index 0..6): w_hi / w_lo as for iago_conv3x3_split, wt_hi /
+ *   wt_lo the transposed form of iago_conv3x3_bwd_data_split, bias [128]; w9 [128], b10 [64].
+ *   g_*: the gradients, float32 in the parameters' own layouts ([co][ci][3][3]); loss: device float; probs: optional
+ *   [n][64], the model's output.  workspace: iago_policy_grad_workspace_bytes(n) bytes, 256-byte aligned (336 KB per
+ *   row + 40 MB).  overflow: see iago_conv3x3_split (the forward's activations).
+ */
+typedef struct iago_policy_grad_args {
+    const uint64_t *own, *opp;
+    const int32_t *action;
+    const float *reward;
+    int64_t n, n_mean;
+    const float *w1, *b1;
+    const void *w_hi[7], *w_lo[7], *wt_hi[7], *wt_lo[7];
+    const float *bias[7];
+    const float *w9, *b10;
+    float *g_w1, *g_b1;
+    float *g_w[7], *g_b[7];
+    float *g_w9, *g_b10;
+    float *loss;
+    float *probs;
+    void *workspace;
+    int64_t workspace_bytes;
+    uint32_t *overflow;
+} iago_policy_grad_args;
+IAGO_API int64_t iago_policy_grad_workspace_bytes(int64_t n);
+IAGO_API int iago_policy_reinforce_grad(const iago_policy_grad_args *args, void *stream);
 
 #ifdef __cplusplus
 }

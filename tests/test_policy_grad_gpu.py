@@ -30,3 +30,117 @@ def test_weight_gradient_of_a_block(n, cin):
     w32 = torch.zeros(128, cin, 3, 3, device="cuda", requires_grad=True)
     F.conv2d(x, w32, padding=1).backward(dy)
     assert rel_err(dw, w.grad) < 4 * max(rel_err(w32.grad, w.grad), 2e-7)
+
+
+@pytest.mark.parametrize("n,cin", [(3, 128), (130, 64), (1024, 128)])
+def test_input_gradient_of_a_block(n, cin):
+    """Backward-data through the ReLU of the block below, and the scaled split of its float32 result."""
+    from iago_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(7 * n + cin)
+    w = torch.randn(128, cin, 3, 3, device="cuda", generator=g) / (3.0 * cin ** 0.5)
+    pre = torch.randn(n, cin, 8, 8, device="cuda", generator=g)            # the block below, before its ReLU
+    dy = torch.randn(n, 128, 8, 8, device="cuda", generator=g) * 1e-6 * (torch.rand(n, 1, 1, 1, device="cuda", generator=g) ** 6)
+    e = 13 - int(np.floor(np.log2(float(dy.abs().max()))))
+    dys = ops.split_nchw(dy * 2.0 ** e)
+    saved = ops.split_nchw(torch.relu(pre))
+    wt_hi, wt_lo = ops.split_weights_transposed(w)
+    dx, max_bits = ops.conv3x3_bwd_data_split(dys, torch.tensor([e], dtype=torch.int32, device="cuda"), wt_hi, wt_lo, saved)
+    x64 = pre.double().requires_grad_(True)
+    F.conv2d(torch.relu(x64), w.double(), padding=1).backward(dy.double())
+    got = ops.blocks_to_nchw(dx)
+    assert rel_err(got, x64.grad) < 2e-6, rel_err(got, x64.grad)
+    assert bool((got[x64.grad == 0] == 0).all())      # the mask of the ReLU below (tiny rows may flush to zero besides)
+    assert int(max_bits.item()) == int(dx.abs().max().view(torch.int32).item())
+    s, e2, db = ops.split_scaled(dx, max_bits, bias_grad=True)
+    ref_db = got.double().sum(dim=(0, 2, 3))
+    assert float((db.double() - ref_db).abs().max()) <= 1e-5 * float(got.double().abs().sum(dim=(0, 2, 3)).max())
+    top = float(dx.abs().max()) * 2.0 ** int(e2.item())
+    assert 2 ** 13 <= top < 2 ** 14
+    back = (s.hi.float() + s.lo.float() / 2048.0) * 2.0 ** -int(e2.item())
+    assert float((back - dx).abs().max()) <= 2.0 ** -21 * float(dx.abs().max())
+
+
+def _rows(n, seed):
+    """n recorded learner positions from real policy-vs-policy games (own = the mover), their moves and results."""
+    from iago_amd import network, rl_self_play
+    torch.manual_seed(seed)
+    m = network.SLPolicy().cuda().eval()
+    r = rl_self_play.play_batch(m, m, 64, seed=seed)
+    valid = r["action"] >= 0
+    z = r["z"].reshape(1, -1).expand_as(r["action"])
+    own, opp, act, zz = r["own"][valid], r["opp"][valid], r["action"][valid], z[valid]
+    reps = (n + own.numel() - 1) // own.numel()
+    return [t.repeat(reps)[:n].contiguous() for t in (own, opp, act, zz)]
+
+
+def _relu_masks(model, own, opp):
+    """[x_k > 0] of blocks 1..8 as the split-f16 forward computes them (the same kernels as the update's forward)."""
+    from iago_amd import ops
+    a = ops.value_stem_boards(own, opp, model.block1.conv.weight.detach(), model.block1.conv.bias.detach())
+    masks = [ops.merge_nchw(a) > 0]
+    for (hi, mid, lo, bias) in model._split3_layers():
+        a = ops.conv3x3_split(a, hi, mid, bias)
+        masks.append(ops.merge_nchw(a) > 0)
+    return masks
+
+
+def _autograd64(model, own, opp, act, z, masks=None):
+    """The reference's loss and gradients in float64 autograd.  masks: take every ReLU's on / off decisions from
+    there instead of from the float64 pre-activations (a pre-activation within rounding of zero flips a ReLU between
+    two arithmetics, and ONE flipped cell moves a weight gradient -- a sum of cancelling terms -- by 1e-3 of its
+    largest entry: float32 autograd against float64 shows exactly that)."""
+    import copy
+    from iago_amd import ops
+    m64 = copy.deepcopy(model).double().train()
+    for p in m64.parameters():
+        p.grad = None
+    h = ops.encode_planes(own, opp).double()
+    for k in range(1, 9):
+        pre = getattr(m64, "block%d" % k).conv(h)
+        h = torch.relu(pre) if masks is None else pre * masks[k - 1]
+    pred = torch.softmax(m64.bias10(m64.conv9(h).reshape(-1, 64)), dim=1)
+    c = F.cross_entropy(pred, act.to(torch.int64), reduction="none")     # log-softmax AGAIN (src/train_rl.py:62)
+    loss = torch.sum(c * z.double()) / own.numel()
+    loss.backward()
+    return loss.detach(), {k: p.grad for k, p in m64.named_parameters()}
+
+
+@pytest.mark.parametrize("n,shipped", [(70, False), (1900, False), (1900, True)])
+def test_reinforce_gradients_against_float64_autograd(n, shipped):
+    """src/train_rl.py:61-65 through iago_policy_reinforce_grad against float64 autograd of the same loss, next to
+    what float32 autograd (the tensor library's convolutions) gives on the same rows."""
+    import os
+    from iago_amd import network, train_rl
+    own, opp, act, z = _rows(n, seed=n)
+    torch.manual_seed(5)
+    model = network.SLPolicy().cuda()
+    if shipped:
+        model.load_npz(os.path.join(os.path.dirname(__file__), "golden", "sl_model.npz"))
+    loss64, ref = _autograd64(model, own, opp, act, z, masks=_relu_masks(model, own, opp))
+    _, ref_plain = _autograd64(model, own, opp, act, z)
+    loss = model.reinforce_grads(own, opp, act, z)
+    model.check_saturation()
+    got = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    train_rl.reinforce_loss(model, own, opp, act, z).backward()
+    got32 = {k: p.grad for k, p in model.named_parameters()}
+    assert abs(float(loss) - float(loss64)) <= 1e-6 * max(1.0, abs(float(loss64)))
+
+    def worst(a, b):
+        return max(float((a[k].double() - b[k]).abs().max()) / float(b[k].abs().max()) for k in b)
+
+    print("max relative error per tensor: split-f16 %.2e with the same ReLU decisions, %.2e against plain float64 "
+          "(float32 autograd: %.2e)" % (worst(got, ref), worst(got, ref_plain), worst(got32, ref_plain)))
+    if not shipped:
+        assert worst(got, ref) < 1e-5
+    # the shipped net's distributions are near one-hot: its gradients are differences of nearly equal numbers (block8's
+    # bias gradient: 1e-6 at its largest, of terms of 1e-2), and float32 arithmetic itself is 1e-3 off there -- tensor
+    # by tensor the split-f16 kernels must be as close to float64 as float32 autograd is
+    for k in ref:
+        scale = float(ref[k].abs().max())
+        mine = float((got[k].double() - ref[k]).abs().max()) / scale
+        theirs = float((got32[k].double() - ref[k]).abs().max()) / scale
+        assert mine < 3 * theirs + 1e-5, (k, mine, theirs)
+    assert worst(got, ref_plain) < 3 * worst(got32, ref_plain) + 1e-5

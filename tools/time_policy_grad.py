@@ -33,3 +33,35 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def whole(n=1900):
+    """The whole update (gradients + ChainerAdam) on real rows, native against autograd."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from test_policy_grad_gpu import _rows
+    from iago_amd import network, train_rl
+    own, opp, act, z = _rows(n, seed=1)
+    model = network.SLPolicy().cuda()
+    opt = train_rl.ChainerAdam(model)
+
+    def native():
+        model.reinforce_grads(own, opp, act, z)
+
+    def native_step():
+        model.reinforce_grads(own, opp, act, z)
+        opt.update()
+
+    def autograd_step():
+        model.train()
+        for p in model.parameters():
+            p.grad = None
+        train_rl.reinforce_loss(model, own, opp, act, z, pad_to=512).backward()
+        opt.update()
+
+    print("n=%d rows: gradients %.0f us, gradients + Adam %.0f us" % (n, timed(native), timed(native_step)))
+    if len(sys.argv) > 2:
+        print("autograd + Adam %.0f us" % timed(autograd_step, reps=5))
+
+
+if __name__ == "__main__":
+    whole()
