@@ -34,7 +34,7 @@ SYMBOLS = [
     "iago_mcts_fresh_leaves", "iago_mcts_descend",
     "iago_mcts_search_persistent", "iago_mcts_search_capacity", "iago_selfplay_policy",
     "iago_conv3x3_wgrad_split", "iago_conv3x3_bwd_data_split", "iago_split_scaled",
-    "iago_policy_grad_workspace_bytes", "iago_policy_reinforce_grad",
+    "iago_policy_grad_workspace_bytes", "iago_policy_reinforce_grad", "iago_adam_chainer",
 ]
 # include/iago_hip_experimental.h: two schedules of the per-playout engine that measured slower (game-asynchronous steps,
 # value look-ahead); opt-in through engine.BatchedMCTS(async_steps=True / value_ahead=True), off every default path
@@ -56,6 +56,20 @@ class RolloutArgs(C.Structure):
         ("z", C.c_void_p), ("final_own", C.c_void_p), ("final_opp", C.c_void_p),
         ("n_turns", C.c_void_p), ("trace", C.c_void_p), ("log_form", C.c_int),
         ("throughput_hint", C.c_int),
+    ]
+
+
+ADAM_MAX_TENSORS = 24
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [
+        ("p", C.c_void_p * ADAM_MAX_TENSORS), ("g", C.c_void_p * ADAM_MAX_TENSORS),
+        ("m", C.c_void_p * ADAM_MAX_TENSORS), ("v", C.c_void_p * ADAM_MAX_TENSORS),
+        ("step", C.c_void_p * ADAM_MAX_TENSORS),
+        ("count", C.c_int64 * ADAM_MAX_TENSORS), ("n_tensors", C.c_int32),
+        ("alpha_t", C.c_float), ("one_minus_beta1", C.c_float), ("one_minus_beta2", C.c_float),
+        ("eps", C.c_float), ("weight_decay", C.c_float),
     ]
 
 
@@ -189,7 +203,7 @@ NODE_WORDS = 8   # sizeof(iago_mcts_node) / 4: n_visits, q, p, v, first_child, p
 
 
 _lib = None
-ABI_VERSION = 11   # iago_abi_version() of the include/iago_hip.h these bindings mirror
+ABI_VERSION = 12   # iago_abi_version() of the include/iago_hip.h these bindings mirror
 
 
 def lib():
@@ -243,6 +257,7 @@ def lib():
     L.iago_policy_grad_workspace_bytes.argtypes = [i64]
     L.iago_policy_grad_workspace_bytes.restype = i64
     L.iago_policy_reinforce_grad.argtypes = [C.POINTER(PolicyGradArgs), vp]
+    L.iago_adam_chainer.argtypes = [C.POINTER(AdamArgs), vp]
     L.iago_split_nchw.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.iago_merge_nchw.argtypes = [vp, vp, vp, i64, i32, vp]
     L.iago_value_stem.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ((uint4 *)(pg_lds + WG_X_AT))[i] = make_uint4(0, 0, 0, 0);
         ((uint4 *)(pg_lds + WG_BUF + WG_X_AT))[i] = make_uint4(0, 0, 0, 0);
     }
+    __syncthreads(); // (the first board's cells are written by OTHER threads than the ones that zeroed them)
     // staging: per board 1,024 16-byte pieces of dY (4 channel blocks x 64 cells x 2 halves x hi / lo) and 512 of X
     int dy_src[2], dy_dst[2];
 #pragma unroll
@@ -362,16 +363,20 @@ __global__ __launch_bounds__(256) void head_grad_kernel(HeadGradParams P)
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// out[j] = (j == 192 ? inv_n : 1) * sum over the workgroups' partial sums, in order
+// out[j] = (j == 192 ? inv_n : 1) * sum over the workgroups' partial sums: one wave per output, lane l takes the partial
+// sums l, l + 64, .. (a fixed order)
 __global__ __launch_bounds__(256) void head_reduce_kernel(const float *part, int n_parts, float inv_n, float *dw9, float *db10,
                                                           float *loss)
 {
-    const int j = threadIdx.x;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= HEAD_PART)
         return;
     float s = 0.0f;
-    for (int i = 0; i < n_parts; i++)
+    for (int i = lane; i < n_parts; i += 64)
         s += part[(int64_t)i * HEAD_PART + j];
+    s = wave_sum(s);
+    if (lane != 0)
+        return;
     if (j < 128)
         dw9[j] = s;
     else if (j < 192)
@@ -424,17 +429,66 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float *dy, const 
 
 __global__ __launch_bounds__(256) void stem_reduce_kernel(const float *part, int n_parts, float *dw1, float *db1)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x; // (channel, 18 weights + 1 bias)
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63; // (channel, 18 weights + 1 bias)
     if (j >= STEM_PART)
         return;
     float s = 0.0f;
-    for (int i = 0; i < n_parts; i++)
+    for (int i = lane; i < n_parts; i += 64)
         s += part[(int64_t)i * STEM_PART + j];
+    s = wave_sum(s);
+    if (lane != 0)
+        return;
     const int co = j / 19, k = j - 19 * co;
     if (k < 18)
         dw1[co * 18 + k] = s;
     else
         db1[co] = s;
+}
+
+
+// ---- chainer.optimizers.Adam + the WeightDecay hook (src/train_rl.py:24-26,66) over all parameters in one launch: the
+// documented rule operation by operation, each product, sum, root and quotient rounded on its own (no fused
+// multiply-adds), i.e. the bits of the elementwise float32 restatement in iago_amd/train_rl.py
+struct AdamParams {
+    float *p[IAGO_ADAM_MAX_TENSORS];
+    const float *g[IAGO_ADAM_MAX_TENSORS];
+    float *m[IAGO_ADAM_MAX_TENSORS], *v[IAGO_ADAM_MAX_TENSORS], *step[IAGO_ADAM_MAX_TENSORS];
+    int64_t end[IAGO_ADAM_MAX_TENSORS]; // running element counts
+    int32_t n_tensors;
+    float alpha_t, one_minus_beta1, one_minus_beta2, eps, weight_decay;
+};
+
+__global__ __launch_bounds__(256) void adam_chainer_kernel(AdamParams A)
+{
+#pragma clang fp contract(off) // (a product and the sum behind it must not fuse)
+    const int64_t total = A.end[A.n_tensors - 1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int s = 0;
+        while (i >= A.end[s])
+            s++;
+        const int64_t j = i - (s ? A.end[s - 1] : 0);
+        const float p = A.p[s][j], m = A.m[s][j], v = A.v[s][j];
+        // (plain operators: the pragma above covers THIS function's expressions, not those inside HIP's __f*_rn inlines)
+        const float wd_p = p * A.weight_decay;
+        const float g = A.g[s][j] + wd_p;                        // the hook: g += rate * w
+        const float dm = g - m;
+        const float dm2 = dm * A.one_minus_beta1;
+        const float m2 = m + dm2;                                // m += (1 - beta1)(g - m)
+        const float gg = g * g;
+        const float dv = gg - v;
+        const float dv2 = dv * A.one_minus_beta2;
+        const float v2 = v + dv2;                                // v += (1 - beta2)(g g - v)
+        const float root = sqrtf(v2); // (correctly rounded; HIP's __fsqrt_rn is the native approximation)
+        const float den = root + A.eps;
+        A.m[s][j] = m2;
+        A.v[s][j] = v2;
+        const float num = m2 * A.alpha_t;
+        const float step = num / den;                            // alpha_t m / (sqrt(v) + eps)
+        if (A.step[s])
+            A.step[s][j] = step; // (the caller subtracts it: its tensor library then knows the parameter changed)
+        else
+            A.p[s][j] = p - step;
+    }
 }
 
 } // namespace
@@ -553,7 +607,7 @@ int iago_policy_reinforce_grad(const iago_policy_grad_args *A, void *stream)
     H.part = hpart;
     H.probs = A->probs;
     hipLaunchKernelGGL(head_grad_kernel, dim3(PG_GRID), dim3(256), 0, st, H);
-    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)hpart, PG_GRID, inv_n, A->g_w9,
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((HEAD_PART + 3) / 4), dim3(256), 0, st, (const float *)hpart, PG_GRID, inv_n, A->g_w9,
                        A->g_b10, A->loss);
     // blocks 8 .. 2: the gradient at the block's pre-activations (float32 in dyf) -> its scaled pieces + the bias
     // gradient; the weight gradient; the gradient at the pre-activations of the block below
@@ -571,9 +625,39 @@ int iago_policy_reinforce_grad(const iago_policy_grad_args *A, void *stream)
         return rc;
     // block 1 from the float32 gradient at its pre-activations
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(PG_GRID), dim3(256), 0, st, (const float *)dyf, A->own, A->opp, n, spart);
-    hipLaunchKernelGGL(stem_reduce_kernel, dim3((STEM_PART + 255) / 256), dim3(256), 0, st, (const float *)spart, PG_GRID,
+    hipLaunchKernelGGL(stem_reduce_kernel, dim3((STEM_PART + 3) / 4), dim3(256), 0, st, (const float *)spart, PG_GRID,
                        A->g_w1, A->g_b1);
     return iago_check_launch("iago_policy_reinforce_grad");
+}
+
+
+int iago_adam_chainer(const iago_adam_args *a, void *stream)
+{
+    if (!a || a->n_tensors < 1 || a->n_tensors > IAGO_ADAM_MAX_TENSORS)
+        return iago_fail(IAGO_ERR_INVALID, "iago_adam_chainer: 1 .. IAGO_ADAM_MAX_TENSORS tensors expected");
+    AdamParams A;
+    int64_t total = 0;
+    for (int k = 0; k < a->n_tensors; k++) {
+        if (!a->p[k] || !a->g[k] || !a->m[k] || !a->v[k] || a->count[k] <= 0)
+            return iago_fail(IAGO_ERR_INVALID, "iago_adam_chainer: null pointer or empty tensor");
+        A.p[k] = a->p[k];
+        A.g[k] = a->g[k];
+        A.m[k] = a->m[k];
+        A.v[k] = a->v[k];
+        A.step[k] = a->step[k];
+        total += a->count[k];
+        A.end[k] = total;
+    }
+    A.n_tensors = a->n_tensors;
+    A.alpha_t = a->alpha_t;
+    A.one_minus_beta1 = a->one_minus_beta1;
+    A.one_minus_beta2 = a->one_minus_beta2;
+    A.eps = a->eps;
+    A.weight_decay = a->weight_decay;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(adam_chainer_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0,
+                       (hipStream_t)stream, A);
+    return iago_check_launch("iago_adam_chainer");
 }
 
 } // extern "C"

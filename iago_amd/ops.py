@@ -559,6 +559,24 @@ def split_weights_transposed_many(weights):
     return out
 
 
+def adam_chainer(params, grads, ms, vs, alpha_t, beta1, beta2, eps, weight_decay, steps=None):
+    """iago_adam_chainer: one launch for all (float32, contiguous, CUDA) parameters; m / v in place, the parameters
+    too unless `steps` (tensors that receive alpha_t m / (sqrt(v) + eps), for the caller to subtract) is given."""
+    if len(params) > _lib.ADAM_MAX_TENSORS:
+        raise ValueError("adam_chainer: at most %d tensors" % _lib.ADAM_MAX_TENSORS)
+    A = _lib.AdamArgs()
+    for k, (p, g, m, v) in enumerate(zip(params, grads, ms, vs)):
+        A.p[k], A.g[k] = _dev(p, torch.float32, "p").value, _dev(g, torch.float32, "g").value
+        A.m[k], A.v[k] = _dev(m, torch.float32, "m").value, _dev(v, torch.float32, "v").value
+        A.count[k] = p.numel()
+        if steps is not None:
+            A.step[k] = _dev(steps[k], torch.float32, "step").value
+    A.n_tensors = len(params)
+    A.alpha_t, A.one_minus_beta1, A.one_minus_beta2 = alpha_t, 1.0 - beta1, 1.0 - beta2
+    A.eps, A.weight_decay = eps, weight_decay
+    check(_lib.lib().iago_adam_chainer(C.byref(A), _stream()), "iago_adam_chainer")
+
+
 _grad_workspace = {}
 
 

@@ -71,6 +71,16 @@ class ChainerAdam(object):
             vs.append(self.state[n][1])
         if not ps:
             return
+        if (NATIVE_GRAD and len(ps) <= 24
+                and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ps + gs)):
+            # the same rule, the same roundings: ONE launch (iago_adam_chainer) for g, m, v and the step, then the
+            # subtraction as a tensor operation (it bumps p._version, the key of every cached weight layout) -- instead of
+            # 14 multi-tensor launches
+            steps = self.__dict__.setdefault("_steps", {})
+            ss = [steps.setdefault(id(p), torch.empty_like(p)) for p in ps]
+            ops.adam_chainer([p.detach() for p in ps], gs, ms, vs, a_t, self.beta1, self.beta2, self.eps, self.wd, steps=ss)
+            torch._foreach_sub_(ps, ss)
+            return
         # the rule above, operation by operation (each product and sum rounded on its own, as numpy rounds them), over
         # all parameters at once: 14 multi-tensor launches instead of 12 per parameter
         g = torch._foreach_add(gs, torch._foreach_mul(ps, self.wd))          # g = p.grad + wd * p
@@ -208,14 +218,9 @@ class ReinforceTrainer(object):
                     cache.popitem(last=False)
             cache[key] = m2
             return m2
-        m2 = self.__dict__.get("_opponent")
-        if m2 is None:   # one opponent module for the whole run, refilled per set
-            m2 = self._opponent = network.SLPolicy().to(self.device).eval()
-        # self-play against the current weights: device-to-device copies
-        with torch.no_grad():
-            for q, p1 in zip(m2.parameters(), self.model1.parameters()):
-                q.copy_(p1)
-        return m2
+        # no pool yet: self-play against the current weights -- the learner itself plays both colours (its weight pieces
+        # are split once; a copy would be re-split every set)
+        return self.model1
 
     def play_set(self, model2):
         """2N games; odd games carry the handicap stone (src/train_rl.py:41-47).
@@ -229,16 +234,19 @@ class ReinforceTrainer(object):
         r = rl_self_play.play_batch(self.model1, model2, hi - lo,
                                     handicap=ops.bits_to_tensor(hc[lo:hi], self.device),
                                     seed=self.seed, game_id_base=self.set_index * n_total + lo)
-        valid = (r["action"] >= 0)                       # (T1, B): the learner moved
-        z = r["z"].reshape(1, -1).expand_as(r["action"])
         T1, B = r["action"].shape
+        # the rows in which the learner moved, in (turn, game) order -- ONE compaction (a device-to-host count) for all
+        # columns
+        at = torch.nonzero(r["action"].reshape(-1) >= 0).reshape(-1)
+        cols = dict(own=r["own"].reshape(-1)[at], opp=r["opp"].reshape(-1)[at], action=r["action"].reshape(-1)[at],
+                    z=r["z"][at % B])
+        if idist.world_size() == 1:
+            return cols, int((r["z"] == 1).sum().item())
         # row key = (turn, global game): sorted by it the gathered batch is the one a single rank
         # playing all 2N games records (turn-major), whatever the number of ranks -- the update then
         # sums the same rows in the same order
-        key = (torch.arange(T1, device=valid.device).reshape(T1, 1) * n_total
-               + torch.arange(lo, hi, device=valid.device).reshape(1, B))
-        tup = _canonical(idist.gather_tuples(dict(own=r["own"][valid], opp=r["opp"][valid],
-                                                  action=r["action"][valid], z=z[valid], key=key[valid])))
+        cols["key"] = (at // B) * n_total + (lo + at % B)
+        tup = _canonical(idist.gather_tuples(cols))
         wins = idist.gather_tuples(dict(win=(r["z"] == 1).to(torch.int8)))["win"]
         return tup, int(wins.sum().item())
 

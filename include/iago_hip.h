@@ -871,6 +871,25 @@ typedef struct iago_policy_grad_args {
 IAGO_API int64_t iago_policy_grad_workspace_bytes(int64_t n);
 IAGO_API int iago_policy_reinforce_grad(const iago_policy_grad_args *args, void *stream);
 
+/*
+ * chainer.optimizers.Adam with the optimizer_hooks.WeightDecay hook as src/train_rl.py:24-26,66 call them, over all
+ * parameters in one launch (Chainer's documented rule, float32, every operation rounded on its own):
+ *   g = grad + weight_decay * w;  m += (1 - beta1)(g - m);  v += (1 - beta2)(g g - v);  w -= alpha_t m / (sqrt(v) + eps)
+ * with alpha_t = alpha sqrt(1 - beta2^t) / (1 - beta1^t) computed by the caller.  m / v are updated in place; w too
+ * where step[k] is NULL, otherwise the step alpha_t m / (sqrt(v) + eps) is written there and the caller subtracts it
+ * (a tensor library then sees its parameter change).
+ */
+#define IAGO_ADAM_MAX_TENSORS 24
+typedef struct iago_adam_args {
+    float *p[IAGO_ADAM_MAX_TENSORS];
+    const float *g[IAGO_ADAM_MAX_TENSORS];
+    float *m[IAGO_ADAM_MAX_TENSORS], *v[IAGO_ADAM_MAX_TENSORS], *step[IAGO_ADAM_MAX_TENSORS];
+    int64_t count[IAGO_ADAM_MAX_TENSORS];
+    int32_t n_tensors;
+    float alpha_t, one_minus_beta1, one_minus_beta2, eps, weight_decay;
+} iago_adam_args;
+IAGO_API int iago_adam_chainer(const iago_adam_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,7 +35,7 @@ def test_library_exports_every_symbol(so):
     L = _lib.lib()
     for name in header_symbols() + header_symbols("iago_hip_experimental.h"):
         assert hasattr(L, name), name
-    assert L.iago_abi_version() == _lib.ABI_VERSION == 11
+    assert L.iago_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_gfx950_code_object(so):
