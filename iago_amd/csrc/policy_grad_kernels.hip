@@ -15,8 +15,7 @@
 //   contraction runs over cells -- so both MFMA operands come out of LDS through ds_read_b64_tr_b16 (gfx950's
 //   transposed read: a lane gets 4 consecutive cells of ONE channel).  One workgroup = 64 output channels x 32 input
 //   channels x 9 taps (72 tiles of v_mfma_f32_16x16x32_f16, 18 per wave, 144 accumulator registers) over a group of
-//   boards; a board is one stage (K = 64 = two k-steps), double-buffered in LDS.  The three column taps of a row are
-//   windows of ONE 10-cell padded row per lane: 3 transposed reads + 4 v_alignbit instead of 6 reads.
+//   boards; a board is one stage (K = 64 = two k-steps), double-buffered in LDS.
 //   Partial sums per group of boards go to memory and are added up in a fixed order (deterministic).
 #include "abi_common.hpp"
 
@@ -30,9 +29,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((__vector_size__(8)));
 typedef __attribute__((address_space(3))) short4v lds_short4v;
 
-// (through the builtin: this loop feeds MFMAs from VALU results -- v_perm windows, register copies --, and the compiler
-// only keeps the wait states of that right when it knows the instruction; the asm form of the walks gave wrong sums
-// here.  The ISA has no accumulator copies in the loop: 108 MFMAs, 52 transposed reads, 72 VALU per board and wave)
+// (through the builtin: a first form of this loop fed MFMAs from VALU results -- v_perm windows, register copies --, and
+// the compiler only keeps the wait states of that right when it knows the instruction: the asm form of the walks gave
+// wrong sums there.  The ISA has no accumulator copies in the loop: 108 MFMAs, 88 transposed reads per board and wave)
 #define PG_MFMA16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0)
 
 // LDS images of one board: rows of 8 (dY) or 12 (X, padded: columns 0 and 9 are the zero border, 10 and 11 filler)
@@ -143,72 +142,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     auto compute = [&](int buf) {
         const int at = buf * WG_BUF + lane_off;
+        // A: this wave's two M tiles, both k-steps (16 reads); B: one (k-step, kernel row, kernel column) at a time --
+        // the padded row kq + 4s + ky of this lane's channel, cells kx .. kx + 7: two transposed reads per piece (a
+        // lane's rows may start anywhere: + 32 B per cell; windows cut out of one 12-cell read by v_alignbit and
+        // register copies measured slower) -- read TWO steps ahead of the six MFMAs that use it
+        half8 a_hi[2][2], a_lo[2][2];
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            half8 a_hi[2], a_lo[2];
+        for (int s = 0; s < 2; s++)
 #pragma unroll
             for (int mi = 0; mi < 2; mi++) {
                 const int pa = at + (2 * mh + mi) * WG_DY_CB + 4 * s * WG_ROWB;
-                a_hi[mi] = cat8(lds_tr(pa), lds_tr(pa + 128));
-                a_lo[mi] = cat8(lds_tr(pa + WG_DY_PIECE), lds_tr(pa + WG_DY_PIECE + 128));
+                a_hi[s][mi] = cat8(lds_tr(pa), lds_tr(pa + 128));
+                a_lo[s][mi] = cat8(lds_tr(pa + WG_DY_PIECE), lds_tr(pa + WG_DY_PIECE + 128));
             }
+        half8 b_hi[3], b_lo[3];
+        auto load_b = [&](int step, int slot) {
+            const int s = step / 9, ky = (step % 9) / 3, kx = step % 3;
+            const int pb = at + WG_X_AT + cbl * WG_X_CB + (4 * s + ky) * WG_ROWB + 32 * kx;
+            b_hi[slot] = cat8(lds_tr(pb), lds_tr(pb + 128));
+            b_lo[slot] = cat8(lds_tr(pb + WG_X_PIECE), lds_tr(pb + WG_X_PIECE + 128));
+        };
+        load_b(0, 0);
+        load_b(1, 1);
 #pragma unroll
-            for (int ky = 0; ky < 3; ky++) {
-                // the padded row kq + 4s + ky of this lane's channel: 12 cells = 6 dwords per piece
-                const int pb = at + WG_X_AT + cbl * WG_X_CB + (4 * s + ky) * WG_ROWB;
-                uint32_t dh[6], dl[6];
-#pragma unroll
-                for (int rd = 0; rd < 3; rd++) {
-                    const uint2 h = lds_tr(pb + 128 * rd), l = lds_tr(pb + WG_X_PIECE + 128 * rd);
-                    dh[2 * rd] = h.x, dh[2 * rd + 1] = h.y;
-                    dl[2 * rd] = l.x, dl[2 * rd + 1] = l.y;
-                }
-                // cells kx .. kx + 7 of the padded row: kx = 0 and 2 are whole dwords, kx = 1 four v_alignbit per piece
-                u32x4 w1h, w1l;
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    w1h[d] = __builtin_amdgcn_alignbit(dh[d + 1], dh[d], 16);
-                    w1l[d] = __builtin_amdgcn_alignbit(dl[d + 1], dl[d], 16);
-                }
-#pragma unroll
-                for (int kk = 0; kk < 3; kk++) {
-                    const int kx = kk == 0 ? 0 : kk == 1 ? 2 : 1;
-                    u32x4 wh, wl;
-                    if (kx == 1) {
-                        wh = w1h, wl = w1l;
-                    } else {
-#pragma unroll
-                        for (int d = 0; d < 4; d++) {
-                            wh[d] = dh[d + (kx >> 1)];
-                            wl[d] = dl[d + (kx >> 1)];
-                        }
-                    }
-                    const half8 b_hi = __builtin_bit_cast(half8, wh), b_lo = __builtin_bit_cast(half8, wl);
-                    const int t = 3 * ky + kx;
-                    PG_MFMA16(acc_c[0][t], a_hi[0], b_lo);
-                    PG_MFMA16(acc_c[1][t], a_hi[1], b_lo);
-                    PG_MFMA16(acc_m[0][t], a_hi[0], b_hi);
-                    PG_MFMA16(acc_m[1][t], a_hi[1], b_hi);
-                    PG_MFMA16(acc_c[0][t], a_lo[0], b_hi);
-                    PG_MFMA16(acc_c[1][t], a_lo[1], b_hi);
-                }
-            }
+        for (int step = 0; step < 18; step++) {
+            if (step + 2 < 18)
+                load_b(step + 2, (step + 2) % 3);
+            const int s = step / 9, t = step % 9, cur = step % 3;
+            PG_MFMA16(acc_c[0][t], a_hi[s][0], b_lo[cur]);
+            PG_MFMA16(acc_c[1][t], a_hi[s][1], b_lo[cur]);
+            PG_MFMA16(acc_m[0][t], a_hi[s][0], b_hi[cur]);
+            PG_MFMA16(acc_m[1][t], a_hi[s][1], b_hi[cur]);
+            PG_MFMA16(acc_c[0][t], a_lo[s][0], b_hi[cur]);
+            PG_MFMA16(acc_c[1][t], a_lo[s][1], b_hi[cur]);
         }
     };
 
+    // Boards b + 1 .. b + 3 are on their way (registers) while board b is multiplied: one board is 0.75 us of MFMAs, a
+    // load from beyond L2 takes longer than that under load.  Three register sets in rotation: the set of board b + 1
+    // goes to the other LDS buffer right after board b's MFMAs, and is re-issued for board b + 4 at the next turn.
     if (b_lo < b_hi)
         commit(fetch(b_lo), 0);
     __syncthreads();
-    for (int64_t b = b_lo; b < b_hi; b++) {
-        const int buf = (int)(b - b_lo) & 1;
-        const bool more = b + 1 < b_hi;
-        Staged G;
-        if (more)
-            G = fetch(b + 1);
-        compute(buf);
-        if (more)
-            commit(G, buf ^ 1);
+    const int64_t last = b_hi - 1;
+    auto clamp = [&](int64_t b) { return b < last ? b : last; }; // (past the end: a harmless repeat, never committed)
+    Staged S0, S1, S2;
+    if (b_lo < b_hi) {
+        S1 = fetch(clamp(b_lo + 1));
+        S2 = fetch(clamp(b_lo + 2));
+    }
+    auto turn = [&](int64_t b, Staged &next, Staged &refill) {
+        // next: board b + 1; refill: the set that held board b (committed a turn ago), now board b + 3
+        refill = fetch(clamp(b + 3));
+        compute((int)(b - b_lo) & 1);
+        if (b + 1 < b_hi)
+            commit(next, ((int)(b - b_lo) & 1) ^ 1);
         __syncthreads();
+    };
+    for (int64_t b = b_lo; b < b_hi; b += 3) {
+        turn(b, S1, S0);
+        if (b + 1 < b_hi)
+            turn(b + 1, S2, S1);
+        if (b + 2 < b_hi)
+            turn(b + 2, S0, S2);
     }
     // tile (mi, tap): the lane holds rows 4 kq + v (output channels), column lane & 15 (input channel)
     const int ci = ciq * 32 + cbl * 16 + (lane & 15);
