@@ -794,6 +794,12 @@ def reinforce_leg(n_iters, world, rank, dist, mcts_rounds=1):
            # the figure depends on this state (19 sets/s with the fallback solvers, 45 with tuned ones on one MI355X):
            # stated, not hidden
            "update_ms": update_ms,
+           # the update's matrix work: forward + input gradients + weight gradients = 3 x 122.85 MFLOP per row
+           # (SURVEY 8d's per-evaluation figure), each product sum as 3 f16 MFMAs; Adam, the weight pieces and the
+           # gathers are inside update_ms
+           "update_rows": int(tup["z"].numel()),
+           "update_tflops_algorithmic": 3 * 122.85e6 * int(tup["z"].numel()) / (update_ms * 1e-3) / 1e12,
+           "update_frac_f16_peak_executed": 9 * 122.85e6 * int(tup["z"].numel()) / (update_ms * 1e-3) / 1e12 / 2500.0,
            "update_engine": ("iago_policy_reinforce_grad: forward, loss and backward as split-f16 HIP kernels (3 MFMAs per "
                              "product sum, float32 accumulation; gradients within 1e-5 of float64 autograd, "
                              "tests/test_policy_grad_gpu.py) + ChainerAdam") if train_rl.NATIVE_GRAD else
