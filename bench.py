@@ -30,8 +30,8 @@ Nested, none of them `value`: `rollout` (BASELINE configs[1], the headline of ro
 played to the end by the fused rollout kernel, with its own HBM / VALU roofline and CPU baselines;
 --rollout-only prints it as the line's headline), `mcts.per_playout_launches` (the same games on the per-playout
 engine), `mcts400` / `mcts_nthr1` (one batch of whole games at 400 playouts per move -- one GPU's share of
-configs[3] -- / with n_thr = 1) and their `*_opening` samples, `reinforce` (configs[4] in miniature, with the
-CPU side beside it), `configs0` (one SL-vs-SL game on the CPU restatement), `mcts_single_game`.
+configs[3] -- / with n_thr = 1) and their `*_opening` samples, `reinforce` (configs[4] in miniature: a set's 64 games as one
+launch, the update -- forward, loss, backward, Adam -- as this repository's split-f16 kernels; with the CPU side beside it), `configs0` (one SL-vs-SL game on the CPU restatement), `mcts_single_game`.
 """
 import argparse
 import ctypes

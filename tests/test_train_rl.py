@@ -78,6 +78,12 @@ def test_reinforce_loss_matches_numpy_gpu():
     loss = reinforce_loss(model, ops.bits_to_tensor(own), ops.bits_to_tensor(opp),
                           torch.from_numpy(y).cuda(), torch.from_numpy(r).cuda())
     assert abs(float(loss.item()) - numpy_loss(params, x, y, r)) < 1e-5
+    # the same through iago_policy_reinforce_grad (the update's HIP kernels): the loss and the model's output
+    probs = torch.empty(24, 64, device="cuda")
+    native = model.reinforce_grads(ops.bits_to_tensor(own), ops.bits_to_tensor(opp), torch.from_numpy(y).cuda(),
+                                   torch.from_numpy(r).cuda(), probs=probs)
+    assert abs(float(native.item()) - numpy_loss(params, x, y, r)) < 1e-5
+    assert float(np.abs(probs.cpu().numpy() - nets_np.sl_policy(x, params)).max()) < 1e-5
 
 
 @pytest.mark.gpu
