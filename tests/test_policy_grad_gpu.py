@@ -105,7 +105,7 @@ def _autograd64(model, own, opp, act, z, masks=None):
     return loss.detach(), {k: p.grad for k, p in m64.named_parameters()}
 
 
-@pytest.mark.parametrize("n,shipped", [(70, False), (1900, False), (1900, True)])
+@pytest.mark.parametrize("n,shipped", [(1, False), (5, True), (70, False), (1900, False), (1900, True)])
 def test_reinforce_gradients_against_float64_autograd(n, shipped):
     """src/train_rl.py:61-65 through iago_policy_reinforce_grad against float64 autograd of the same loss, next to
     what float32 autograd (the tensor library's convolutions) gives on the same rows."""
@@ -189,3 +189,21 @@ def test_fused_adam_equals_the_elementwise_rule_bit_for_bit():
         for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
             assert torch.equal(pa, pb), (t, n)
             assert torch.equal(oa.state[n][0], ob.state[n][0]) and torch.equal(oa.state[n][1], ob.state[n][1]), (t, n)
+
+
+def test_bad_arguments_are_refused():
+    """The entry points of the update check what they are given (status codes, nothing launched)."""
+    import ctypes as C
+    from iago_amd import _lib
+    L = _lib.lib()
+    assert L.iago_policy_grad_workspace_bytes(-1) == -1
+    assert L.iago_policy_grad_workspace_bytes(2048) > 2048 * 304 * 1024    # 304 KB per row + 40 MB
+    a = _lib.PolicyGradArgs()
+    assert L.iago_policy_reinforce_grad(C.byref(a), None) == -1          # n_mean 0, null pointers
+    assert b"iago_policy_reinforce_grad" in L.iago_last_error()
+    assert L.iago_conv3x3_wgrad_split(None, None, None, None, 4, 96, None, 32, None, None, None) == -1   # cin
+    assert L.iago_conv3x3_wgrad_split(None, None, None, None, 4, 128, None, 12, None, None, None) == -1  # groups % 8
+    assert L.iago_conv3x3_bwd_data_split(None, None, None, None, None, None, None, 32, None, None, 4, None) == -1
+    assert L.iago_split_scaled(None, None, None, None, None, 4, 24, None, None, None) == -1
+    ad = _lib.AdamArgs()
+    assert L.iago_adam_chainer(C.byref(ad), None) == -1                  # no tensors
