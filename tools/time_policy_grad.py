@@ -22,11 +22,12 @@ def timed(f, reps=20):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    ops.WGRAD_GROUPS = int(os.environ.get("WGRAD_GROUPS", ops.WGRAD_GROUPS))
     for cin in (128, 64):
         x = ops.split_nchw(torch.relu(torch.randn(n, cin, 8, 8, device="cuda")))
         dy = ops.split_nchw(torch.randn(n, 128, 8, 8, device="cuda"))
         part = torch.empty((ops.WGRAD_GROUPS, 9, 128, cin), dtype=torch.float32, device="cuda")
-        us = timed(lambda: ops.conv3x3_wgrad_split(dy, x, part=part))
+        us = timed(lambda: ops.conv3x3_wgrad_split(dy, x, part=part, groups=ops.WGRAD_GROUPS))
         flop = 2.0 * n * 64 * 128 * cin * 9
         print("wgrad n=%d cin=%d: %.1f us, %.0f TFLOP/s algorithmic, %.0f executed" % (n, cin, us, flop / us / 1e6, 3 * flop / us / 1e6))
 
