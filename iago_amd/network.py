@@ -186,8 +186,10 @@ class SLPolicy(nn.Module, _NpzMixin):
     def reinforce_grads(self, own, opp, action, reward, n_mean=None, probs=None):
         """src/train_rl.py:61-65 on the matrix units in split-f16 arithmetic (iago_policy_reinforce_grad):
         cleargrads + loss.backward() for loss = mean(softmax_cross_entropy(self(x), action) * reward); every
-        parameter's .grad is overwritten.  own / opp: the recorded positions (own = the mover).  Returns the loss
-        (0-dim device tensor).  The first two f16 pieces of the search path's three-piece weights are the forward's."""
+        parameter's .grad is overwritten.  own / opp: the recorded positions (own = the mover); action in 0 .. 63 (not
+        checked on the device).  Returns the loss (0-dim device tensor).  The first two f16 pieces of the search
+        path's three-piece weights are the forward's.  The kernels' scratch (304 KB per row + 40 MB, kept between
+        calls) is freed by ops.release_grad_workspace()."""
         from . import ops
         convs = [getattr(self, "block%d" % k).conv for k in range(2, 9)]
         params = [self.block1.conv.weight, self.block1.conv.bias, self.conv9.weight, self.bias10.b]

@@ -591,6 +591,11 @@ def policy_grad_workspace(device, n):
     return ws
 
 
+def release_grad_workspace():
+    """Free the scratch policy_grad_workspace keeps (304 KB per row of the largest batch seen + 40 MB)."""
+    _grad_workspace.clear()
+
+
 def policy_reinforce_grad(own, opp, action, reward, n_mean, w1, b1, layers, layers_t, w9, b10, grads, probs=None,
                           overflow=None):
     """iago_policy_reinforce_grad (include/iago_hip.h): the gradients of mean(softmax_cross_entropy(model(x), a) * r)
