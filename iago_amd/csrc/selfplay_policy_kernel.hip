@@ -23,6 +23,9 @@ namespace {
 using namespace iago;
 using namespace iago_policy;
 
+constexpr int STAGE_FLOATS = 64 * 18 + 64 + 128 + 64;          // a model's block1 weights + biases, conv9, bias10
+constexpr int SELFPLAY_LDS = LDS_BYTES + 2 * STAGE_FLOATS * 4; // the walk's image + both models' small weights
+
 struct SelfplayParams {
     uint64_t *own, *opp;          // [n] in: start (own = colour 1, the first mover); out: the final boards (own = colour 1)
     uint64_t *row_own, *row_opp;  // [n] the rows the policy walks read (= P1.own / P2.own)
@@ -40,7 +43,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     __shared__ double srow[2][64];
     __shared__ int s_action;
+    // The walk's hand-offs stay in LDS (the persistent search's form of policy_item): the position in, the distribution
+    // out -- through the row arrays and P.probs each was a store to global memory read back by this very workgroup, a round
+    // trip to L2 (~2 us) in front of and behind every walk; both models' block1 and head weights are staged once per
+    // workgroup above the walk's image instead of once per walk.  (The rows and the distributions are still WRITTEN to
+    // memory, as the interface says; nothing waits for those stores.)
+    __shared__ uint32_t s_pos[8];
+    __shared__ float s_probs[64];
     const int tid = threadIdx.x;
+    float *const stage = (float *)(policy_lds + LDS_BYTES);
+    float *const w1s[2] = {stage, stage + STAGE_FLOATS};
+    float *const heads[2] = {stage + (64 * 18 + 64), stage + STAGE_FLOATS + (64 * 18 + 64)};
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const PolicyParams &P = m ? P2 : P1;
+        for (int e = tid; e < 64 * 18 / 4; e += 256)
+            ((float4 *)w1s[m])[e] = ((const float4 *)P.w1)[e];
+        if (tid < 16)
+            ((float4 *)(w1s[m] + 64 * 18))[tid] = ((const float4 *)P.b1)[tid];
+        if (tid < 128)
+            heads[m][tid] = P.w9[tid];
+        if (tid < 64)
+            heads[m][128 + tid] = P.b10[tid];
+    }
+    __syncthreads();
     const Lane8 L = make_lane8(threadIdx.x); // (every group of 8 lanes computes the game's board functions: one value in all)
     for (int64_t g = blockIdx.x; g < S.n; g += gridDim.x) {
         uint64_t own = S.own[g], opp = S.opp[g];
@@ -48,7 +74,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         bool pass_flg = false, done = false;
         int ended = S.max_turns;
         // one turn of the game with the mover's net (two call sites: each walk reads its own parameter block)
-        auto turn = [&](const PolicyParams &P, const int t) __attribute__((always_inline)) {
+        auto turn = [&](const PolicyParams &P, const int m, const int t) __attribute__((always_inline)) {
             const uint64_t lg = group8_legal(to_lane(own, L), to_lane(opp, L), L);
             const bool placed = lg != 0ull && !done; // the mover has a move (and the game is not over)
             int a = -1;
@@ -56,13 +82,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (tid == 0) {
                     S.row_own[g] = own;
                     S.row_opp[g] = opp;
+                    s_pos[2] = (uint32_t)own, s_pos[3] = (uint32_t)(own >> 32);
+                    s_pos[4] = (uint32_t)opp, s_pos[5] = (uint32_t)(opp >> 32);
                 }
                 __syncthreads();
-                policy_item(P, g); // model(make_state_var(state, color)), src/rl_self_play.py:113-116
+                // model(make_state_var(state, color)), src/rl_self_play.py:113-116
+                policy_item<true>(P, g, s_pos, s_probs, w1s[m], heads[m]);
                 __syncthreads();
                 if (tid < 64) {
+                    P.probs[g * 64 + tid] = s_probs[tid];
                     const double u = sample_uniform(S.key0, S.key1, S.id_base + (uint32_t)g, (uint32_t)t, 0u);
-                    const int drawn = sample_wave(P.probs + g * 64, lg, u, srow, tid);
+                    const int drawn = sample_wave(s_probs, lg, u, srow, tid);
                     if (tid == 0)
                         s_action = drawn;
                 }
@@ -103,8 +133,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         };
 #pragma unroll 1
         for (int t = 0; t < S.max_turns; t += 2) {
-            turn(P1, t);
-            turn(P2, t + 1);
+            turn(P1, 0, t);
+            turn(P2, 1, t + 1);
         }
         if (tid == 0) {
             S.own[g] = own; // an even number of swaps: colour 1 again
@@ -136,8 +166,8 @@ extern "C" int iago_selfplay_policy(const iago_selfplay_policy_args *a, void *st
         return iago_fail(IAGO_ERR_INVALID, "iago_selfplay_policy: both models read their rows from the SAME own / opp arrays of "
                                            ">= n rows (the launch writes them), no gather list, no device count");
     static std::atomic<uint64_t> configured{0};
-    if (iago_reserve_lds((const void *)selfplay_policy_kernel, LDS_BYTES, configured,
-                         "iago_selfplay_policy: cannot reserve 52 KB of LDS"))
+    if (iago_reserve_lds((const void *)selfplay_policy_kernel, SELFPLAY_LDS, configured,
+                         "iago_selfplay_policy: cannot reserve 70 KB of LDS"))
         return IAGO_ERR_HIP;
     SelfplayParams S;
     S.own = a->own;
@@ -155,6 +185,6 @@ extern "C" int iago_selfplay_policy(const iago_selfplay_policy_args *a, void *st
     S.n_turns = a->n_turns;
     S.bad_probs = a->bad_probs;
     const unsigned grid = (unsigned)(a->n < 256 ? a->n : 256); // one game per workgroup, one workgroup per CU
-    hipLaunchKernelGGL(selfplay_policy_kernel, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, S, P1, P2);
+    hipLaunchKernelGGL(selfplay_policy_kernel, dim3(grid), dim3(256), SELFPLAY_LDS, (hipStream_t)stream, S, P1, P2);
     return iago_check_launch("iago_selfplay_policy");
 }
