@@ -524,8 +524,26 @@ static int64_t pg_round(int64_t b)
 {
     return (b + 255) & ~(int64_t)255;
 }
-constexpr int PG_GRID = 256;        // workgroups of the head and block-1 kernels
+constexpr int PG_GRID = 256;        // workgroups of the head and block-1 kernels (grid-stride over the boards: any device)
 constexpr int PG_MAX_GROUPS = 64;
+
+// groups of boards of a weight-gradient launch: one workgroup per CU (groups x 2 x cin / 32 workgroups), a multiple of 8
+// (the workgroups of a group share an XCD), at most PG_MAX_GROUPS (the partial sums' scratch)
+static int pg_groups(int cin)
+{
+    static std::atomic<int> cus{0};
+    int n = cus.load(std::memory_order_acquire);
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+            v = 256;
+        cus.store(v, std::memory_order_release);
+        n = v;
+    }
+    int g = n / (2 * (cin / 32)) / 8 * 8;
+    return g < 8 ? 8 : g > PG_MAX_GROUPS ? PG_MAX_GROUPS : g;
+}
 
 int64_t iago_policy_grad_workspace_bytes(int64_t n)
 {
@@ -611,7 +629,7 @@ int iago_policy_reinforce_grad(const iago_policy_grad_args *A, void *stream)
         const int cin = k ? 128 : 64;
         rc = iago_split_scaled(dyf, max_bits + k + 1, dys_hi, dys_lo, scale_exp + k + 1, n, 128, bpart, A->g_b[k], stream);
         if (rc == IAGO_OK)
-            rc = iago_conv3x3_wgrad_split(dys_hi, dys_lo, x_hi[k], x_lo[k], n, cin, wpart, cin == 128 ? 32 : 64,
+            rc = iago_conv3x3_wgrad_split(dys_hi, dys_lo, x_hi[k], x_lo[k], n, cin, wpart, pg_groups(cin),
                                           scale_exp + k + 1, A->g_w[k], stream);
         if (rc == IAGO_OK)
             rc = iago_conv3x3_bwd_data_split(dys_hi, dys_lo, scale_exp + k + 1, A->wt_hi[k], A->wt_lo[k], x_hi[k], x_lo[k],
