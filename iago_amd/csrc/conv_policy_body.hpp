@@ -74,7 +74,12 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
                                             const float *head_w = nullptr)
 {
     char *const T = policy_lds;
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    // (SRCH: an opaque copy of the thread id, so that the per-thread address tables are this walk's own values and not
+    // hoisted out of the net workgroups' loop into spilled registers: conv_trunk_body.hpp, trunk_item)
+    int tid_ = threadIdx.x;
+    if constexpr (SRCH)
+        asm volatile("" : "+v"(tid_));
+    const int tid = tid_, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int64_t b = P.index ? P.index[row_id] : row_id;
 
     // ---- the zero area, then block1 (3x3, 2 -> 64, bias, ReLU; network.py:17-19) in float32

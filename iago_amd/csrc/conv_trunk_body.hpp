@@ -107,7 +107,14 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
 {
     constexpr int NN = 4 * TB;      // 16-cell B tiles of a k-step: TB boards x 4 quarters
     char *const T = trunk_lds;
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    // (SRCH: the walk is called from the net workgroups' loop.  Everything below that depends on the thread alone -- the
+    // 36 B-operand addresses, the rows of the epilogue, the A operands' lane offset -- would be hoisted out of that loop,
+    // kept live across both nets' walks and, there being no registers for it, spilled to scratch memory and reloaded
+    // walk after walk.  An opaque copy of the thread id makes them this walk's own values: recomputed, never spilled)
+    int tid_ = threadIdx.x;
+    if constexpr (SRCH)
+        asm volatile("" : "+v"(tid_));
+    const int tid = tid_, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
 
     // ---- the zero areas, then the input of the first layer
     if (tid < TB * (ZB / 16))
@@ -439,11 +446,16 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
         // (from LDS where the persistent search keeps the head's weights: fetched from global memory per walk they were
         // 96 KB through the CU's L2 port and, streamed past by the trunks' weights, mostly L2 misses -- 6.6 us of a
         // pair's walk under load: LABNOTES.md, round 5)
+        // (SRCH: the row comes out of LDS right before fc10 -- sixteen reads in flight under the tap sums; held from
+        // here on, its 64 registers and the 64 of block9's weights below were more than the search kernel has: the
+        // weights went to scratch memory and came back one dword at a time in front of every MFMA of block9, a chain of
+        // dependent global-memory round trips in every walk's head: LABNOTES.md, round 6)
         float4 w10row[16];
+        if constexpr (!SRCH) {
 #pragma unroll
-        for (int c = 0; c < 16; c++)
-            w10row[c] = SRCH ? ((const float4 *)(W.head_w + HEAD_W_W10))[c * 128 + (tid & 127)]
-                             : ((const float4 *)(P.w10 + (tid & 127) * 64))[c];
+            for (int c = 0; c < 16; c++)
+                w10row[c] = ((const float4 *)(P.w10 + (tid & 127) * 64))[c];
+        }
         const float w11j = SRCH ? ((const float *)(W.head_w + HEAD_W_W11))[tid & 127] : P.w11[tid & 127];
         const float b9 = SRCH ? *(const float *)(W.head_w + HEAD_W_B9) : P.b9[0];
         const int lane_cell = cell_of_lane(r); // (this block's 32x32x16 lane map: output row r, k half h)
@@ -460,16 +472,21 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
                 }
             // (all sixteen 16-byte loads in flight together: one L2 round trip instead of eight dependent ones -- the
             // head of a pair took 8.4 us under load with a load, a wait and three MFMAs per chunk: LABNOTES.md, round 5)
-            u32x4 w9a[8], w9b[8];
+            // (SRCH: the weights are in LDS -- a chunk's two reads go out with its B operands, nothing is held)
+            u32x4 w9a[SRCH ? 1 : 8], w9b[SRCH ? 1 : 8];
+            if constexpr (!SRCH) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                w9a[c] = SRCH ? ((const u32x4 *)W.head_w)[c * 64 + r * 2 + h] : w9h[c * 64];
-                w9b[c] = SRCH ? ((const u32x4 *)(W.head_w + HEAD_W_W9LO))[c * 64 + r * 2 + h] : w9l[c * 64];
+                for (int c = 0; c < 8; c++) {
+                    w9a[c] = w9h[c * 64];
+                    w9b[c] = w9l[c * 64];
+                }
             }
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const half8 ah = __builtin_bit_cast(half8, w9a[c]);
-                const half8 al = __builtin_bit_cast(half8, w9b[c]);
+                const half8 ah = SRCH ? *(const half8 *)(W.head_w + (c * 64 + r * 2 + h) * 16)
+                                      : __builtin_bit_cast(half8, w9a[SRCH ? 0 : c]);
+                const half8 al = SRCH ? *(const half8 *)(W.head_w + HEAD_W_W9LO + (c * 64 + r * 2 + h) * 16)
+                                      : __builtin_bit_cast(half8, w9b[SRCH ? 0 : c]);
 #pragma unroll
                 for (int jt = 0; jt < 2; jt++) {
                     const int jj = 2 * wv + jt; // wave-uniform: board jj >> 1, cell half jj & 1
@@ -493,6 +510,11 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
             }
         }
         __syncthreads();
+        if constexpr (SRCH) {
+#pragma unroll
+            for (int c = 0; c < 16; c++)
+                w10row[c] = ((const float4 *)(W.head_w + HEAD_W_W10))[c * 128 + (tid & 127)];
+        }
         if (tid < NC) {
             const int cell = tid & 63, y = cell >> 3, x = cell & 7;
             float s9 = 0.0f;
