@@ -16,30 +16,36 @@ IAGO_ROLLOUT_TABLE_FLOATS = 3 * 2 * 256 * 8 + 64 + 4 + 2 * 512
 ROLLOUT_MODE_INDEX = 3 * 2 * 256 * 8 + 64  # blob[mode] == 1.0: product form
 TRACE_PASS = 0xFF
 
-# every symbol include/iago_hip.h declares (tests/test_abi.py checks the list
-# against the header and the built library)
+# every symbol include/iago_hip.h declares -- the drop-in boundary: what a binding of the reference's hot path calls
+# (tests/test_abi.py checks the lists against the headers and the built library)
 SYMBOLS = [
     "iago_abi_version", "iago_last_error", "iago_device_count",
     "iago_legal_moves", "iago_apply_moves", "iago_play_turn", "iago_encode_planes", "iago_encode_planes_indexed",
-    "iago_judge",
-    "iago_sample_moves", "iago_augment8", "iago_bias_relu",
-    "iago_conv3x3_split", "iago_conv3x3_split_trunk", "iago_split_nchw", "iago_merge_nchw", "iago_value_stem", "iago_value_stem_boards", "iago_value_head",
-    "iago_value_forward_split", "iago_value_rollout",
-    "iago_conv3x3_f32", "iago_stem_f32", "iago_stem_f32_boards", "iago_policy_head", "iago_policy_forward_split3",
+    "iago_judge", "iago_sample_moves", "iago_augment8",
     "iago_rollout_build_table", "iago_rollout",
-    "iago_mcts_reset", "iago_mcts_select", "iago_mcts_expand", "iago_mcts_pending",
-    "iago_leaf_values",
-    "iago_mcts_backup", "iago_mcts_mix_backup", "iago_mcts_best_move", "iago_mcts_advance_root", "iago_mcts_compact",
-    "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_expand_cached",
-    "iago_mcts_fresh_leaves", "iago_mcts_descend",
+    "iago_policy_forward_split3", "iago_value_forward_split", "iago_value_rollout",
+    "iago_mcts_reset", "iago_leaf_values", "iago_mcts_best_move", "iago_mcts_advance_root", "iago_mcts_compact",
+    "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_descend",
     "iago_mcts_search_persistent", "iago_mcts_search_capacity", "iago_selfplay_policy",
-    "iago_conv3x3_wgrad_split", "iago_conv3x3_bwd_data_split", "iago_split_scaled",
     "iago_policy_grad_workspace_bytes", "iago_policy_reinforce_grad", "iago_adam_chainer",
 ]
-# include/iago_hip_experimental.h: two schedules of the per-playout engine that measured slower (game-asynchronous steps,
-# value look-ahead); opt-in through engine.BatchedMCTS(async_steps=True / value_ahead=True), off every default path
+# include/iago_hip_layers.h: single blocks, the ends of the nets, format conversions, a block's three gradient kernels
+# (the modules' planes-fed forwards of small batches, the layer-by-layer cross-checks of the fused kernels)
+LAYER_SYMBOLS = [
+    "iago_bias_relu", "iago_conv3x3_split", "iago_conv3x3_split_trunk", "iago_split_nchw", "iago_merge_nchw",
+    "iago_value_stem", "iago_value_stem_boards", "iago_value_head",
+    "iago_conv3x3_f32", "iago_stem_f32", "iago_stem_f32_boards", "iago_policy_head",
+    "iago_conv3x3_wgrad_split", "iago_conv3x3_bwd_data_split", "iago_split_scaled",
+]
+# include/iago_hip_experimental.h, outside the boundary: two schedules of the per-playout engine that measured slower
+# (game-asynchronous steps, value look-ahead: engine.BatchedMCTS(async_steps=True / value_ahead=True)); the per-phase forms
+# of a playout (arbitrary callables as nets, the IAGO_FUSED_* = 0 knobs); the persistent search split by role
+# (IAGO_SEARCH_SPLIT / BatchedMCTS(split=...): measured no faster)
 EXPERIMENTAL_SYMBOLS = [
     "iago_value_rollout_async", "iago_value_forward_batch", "iago_mcts_value_ahead_rows", "iago_mcts_value_ahead_store",
+    "iago_mcts_select", "iago_mcts_expand", "iago_mcts_pending", "iago_mcts_backup", "iago_mcts_mix_backup",
+    "iago_mcts_expand_cached", "iago_mcts_fresh_leaves",
+    "iago_mcts_search_streams_create", "iago_mcts_search_streams_destroy", "iago_mcts_search_split",
 ]
 
 
@@ -203,7 +209,7 @@ NODE_WORDS = 8   # sizeof(iago_mcts_node) / 4: n_visits, q, p, v, first_child, p
 
 
 _lib = None
-ABI_VERSION = 12   # iago_abi_version() of the include/iago_hip.h these bindings mirror
+ABI_VERSION = 13   # iago_abi_version() of the include/iago_hip.h these bindings mirror
 
 
 def lib():
@@ -293,8 +299,11 @@ def lib():
     L.iago_mcts_value_ahead_store.argtypes = [tp, vap, vp]
     L.iago_mcts_search_persistent.argtypes = [C.POINTER(MctsSearchArgs), vp]
     L.iago_mcts_search_capacity.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.iago_mcts_search_streams_create.argtypes = [i32, C.POINTER(vp)]
+    L.iago_mcts_search_streams_destroy.argtypes = [vp]
+    L.iago_mcts_search_split.argtypes = [C.POINTER(MctsSearchArgs), vp, vp]
     L.iago_selfplay_policy.argtypes = [C.POINTER(SelfplayPolicyArgs), vp]
-    for name in SYMBOLS[3:] + EXPERIMENTAL_SYMBOLS:
+    for name in SYMBOLS[3:] + LAYER_SYMBOLS + EXPERIMENTAL_SYMBOLS:
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -43,7 +43,7 @@ int iago_reserve_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done,
 
 extern "C" {
 
-int iago_abi_version(void) { return 12; }
+int iago_abi_version(void) { return 13; }
 
 const char *iago_last_error(void) { return g_err; }
 

@@ -141,6 +141,7 @@ struct SearchParams {
     // through the value net beside the policy walk and put into the position table (< 0: off; needs the table)
     int32_t ahead_idle;
     int32_t roll_defer; // rollouts: games a full pass of 16 may leave over for the next iteration (0: every game at once)
+    int32_t path_lds_cap; // bytes of the launch's dynamic LDS a game workgroup may keep its games' recorded paths in
 };
 
 __device__ __forceinline__ u64 ld(const u64 *p) { return __hip_atomic_load(p, RLX_AGENT); }
@@ -276,7 +277,7 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
     // the descent's recorded path (Node.update_recursive's ancestors): in the workgroup's dynamic LDS -- a game workgroup
     // walks no net while it has games -- when 32 paths fit there, else in the caller's array.  (From global memory the
     // backup was two dependent round trips to L2: the path entry, then the node.)
-    const bool path_lds = (size_t)S.games_per_wg * (size_t)S.path_stride * 4u <= (size_t)SEARCH_IMG_TOP;
+    const bool path_lds = (size_t)S.games_per_wg * (size_t)S.path_stride * 4u <= (size_t)S.path_lds_cap;
     const int path_at = path_lds ? (tid >> 3) * S.path_stride : -1; // word of the dynamic LDS where this game's path starts
     int32_t *const gpath = S.path + (exists ? g : 0) * (int64_t)S.path_stride;
     // positions, Philox stream offsets and results between the descent / backup and the rollout passes: LDS (RowHandoff)
@@ -861,28 +862,17 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
     }
 }
 
-// One grid: the game workgroups first (they are dispatched first, so all of them are resident whatever else
-// holds CUs; a net workgroup never waits for another net workgroup, so one that finds no CU free simply starts
-// late), then the net workgroups.  A game workgroup whose games are done serves the queue like the others.
-// (Measured and dropped: the game workgroups as a launch of their own -- 197 instead of 512 registers, two
-// per CU, 224 net workgroups: no faster (the launch is not bound by the number of net workgroups), and two
-// launches that need each other are only as safe as the guess of how many CUs are free: LABNOTES.md.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void search_kernel(
-    SearchParams S, iago_row::HwParams R, iago_trunk::TrunkRParams VP, iago_policy::PolicyParams PP)
+// A NET workgroup: ticket -> entry -> walk -> reply, until every game workgroup has finished.
+// The two kinds of net work have a ring each and a HOME on the chip: the workgroups of `policy_xcds` of the 8
+// XCDs (workgroup i of a launch runs on XCD i mod 8) serve the POLICY ring, the others the VALUE ring, so that an
+// XCD's 4 MB L2 holds ONE net's weights (3.9 / 5.8 MB) instead of thrashing on both; a workgroup whose home ring is
+// empty serves the other one (no CU idles while work waits).
+// Two VALUE entries that are in the ring together are walked as a PAIR (trunk_item<true, 2>: the two boards
+// share the weight stream, which bounds the one-board walk: 46 instead of 70 us of CU time per board; the same
+// products in the same order per board: bit-identical values).
+__device__ __forceinline__ void net_workgroup(const SearchParams &S, const iago_trunk::TrunkRParams &VP,
+                                              const iago_policy::PolicyParams &PP, const long long t0)
 {
-    const long long t0 = wall_clock64();
-    if (blockIdx.x == 0 && threadIdx.x == 0) // (what the launch was given: the host sized the grid from the device)
-        __hip_atomic_store(&S.ctl[CTL_NET_WGS], (uint32_t)gridDim.x - (uint32_t)S.n_game_wgs, RLX_AGENT);
-    if ((int)blockIdx.x < S.n_game_wgs)
-        game_workgroup(S, R, t0);
-    // ---- NET workgroup: ticket -> entry -> walk -> reply, until every game workgroup has finished.
-    // The two kinds of net work have a ring each and a HOME on the chip: the workgroups of `policy_xcds` of the 8
-    // XCDs (workgroup i runs on XCD i mod 8) serve the POLICY ring, the others the VALUE ring, so that an XCD's
-    // 4 MB L2 holds ONE net's weights (3.9 / 5.8 MB) instead of thrashing on both; a workgroup whose home ring is
-    // empty serves the other one (no CU idles while work waits).
-    // Two VALUE entries that are in the ring together are walked as a PAIR (trunk_item<true, 2>: the two boards
-    // share the weight stream, which bounds the one-board walk: 46 instead of 70 us of CU time per board; the same
-    // products in the same order per board: bit-identical values).
     __shared__ __align__(16) uint32_t job[32]; // up to two entries of 6 words (kind | game, reply tag, own lo / hi, opp lo / hi); [28..]: status, count
     const int tid = threadIdx.x;
     const int64_t row0 = 4 * (int64_t)blockIdx.x; // this workgroup's rows of wg_own / wg_opp / out / probs (two in use)
@@ -1088,6 +1078,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ONE grid: the game workgroups first (they are dispatched first, so all of them are resident whatever else
+// holds CUs; a net workgroup never waits for another net workgroup, so one that finds no CU free simply starts
+// late), then the net workgroups.  A game workgroup whose games are done serves the queue like the others.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void search_kernel(
+    SearchParams S, iago_row::HwParams R, iago_trunk::TrunkRParams VP, iago_policy::PolicyParams PP)
+{
+    const long long t0 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) // (what the launch was given: the host sized the grid from the device)
+        __hip_atomic_store(&S.ctl[CTL_NET_WGS], (uint32_t)gridDim.x - (uint32_t)S.n_game_wgs, RLX_AGENT);
+    if ((int)blockIdx.x < S.n_game_wgs)
+        game_workgroup(S, R, t0);
+    net_workgroup(S, VP, PP, t0);
+}
+
+// The same search as TWO launches that run together, one per role (iago_mcts_search_split: each on a stream of its own
+// whose CU mask gives it CUs no other launch of the process gets -- co-residency by construction, not by a guess of how
+// many CUs are free).  Each role is compiled for its own register budget: the game workgroups (VALU and latency: lone
+// waves) as a kernel of at most 256 registers, TWO workgroups per CU, so that a wave's waits are another wave's issue
+// slots; the net workgroups without the game code in their allocation.  Same device functions, same protocol, same
+// trees; the single launch above stays the form for streams that cannot be masked.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void search_game_kernel(SearchParams S,
+                                                                                                   iago_row::HwParams R)
+{
+    game_workgroup(S, R, wall_clock64());
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void search_net_kernel(
+    SearchParams S, iago_trunk::TrunkRParams VP, iago_policy::PolicyParams PP)
+{
+    const long long t0 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(&S.ctl[CTL_NET_WGS], (uint32_t)gridDim.x, RLX_AGENT);
+    net_workgroup(S, VP, PP, t0);
+}
+
 } // namespace
 
 namespace {
@@ -1123,7 +1148,17 @@ extern "C" int iago_mcts_search_capacity(int32_t *cus, int32_t *workgroups_per_c
     return IAGO_OK;
 }
 
-extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void *stream)
+// The CU-masked streams of the role split (iago_mcts_search_streams_create): the game launch's, the net launch's, and
+// the events that order both after the caller's stream and the caller's stream after both.
+struct iago_search_streams {
+    int device;
+    int32_t cus, game_cus;
+    hipStream_t game, net;
+    hipEvent_t ready, game_done, net_done;
+};
+
+namespace {
+int search_launch(const iago_mcts_search_args *a, void *stream, iago_search_streams *sp)
 {
     if (!a || !a->tree || !a->value || !a->policy || !a->rollout)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: null args");
@@ -1167,7 +1202,35 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
         return rc;
     if (a->max_cus < 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_persistent: max_cus < 0");
-    const int64_t resident = (int64_t)(a->max_cus > 0 && a->max_cus < cus ? a->max_cus : cus) * per_cu;
+    int64_t resident = (int64_t)(a->max_cus > 0 && a->max_cus < cus ? a->max_cus : cus) * per_cu;
+    // the games' recorded paths in the launch's dynamic LDS when they fit there (else in the caller's array)
+    int path_lds_cap = SEARCH_IMG_TOP, game_lds = 0;
+    if (sp) {
+        // Role split: the game launch has sp->game_cus CUs of its own and the net launch all the others.  A game
+        // workgroup keeps its paths in LDS when TWO workgroups with them fit a CU (else in the caller's array)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev != sp->device || sp->cus != cus)
+            return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_split: the streams belong to another device");
+        if (a->max_cus != 0)
+            return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_split: max_cus must be 0 (the split owns the device's CUs)");
+        const size_t want = (size_t)gpw * (size_t)a->path_stride * 4u;
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, (const void *)search_game_kernel) != hipSuccess)
+            return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_split: hipFuncGetAttributes failed");
+        game_lds = (want + fa.sharedSizeBytes + 256u) * 2u <= (size_t)160 * 1024u ? (int)want : 0;
+        path_lds_cap = game_lds;
+        static std::atomic<uint64_t> configured_game{0};
+        if (game_lds && iago_reserve_lds((const void *)search_game_kernel, 96 * 1024, configured_game,
+                                         "iago_mcts_search_split: cannot reserve the game workgroups' LDS"))
+            return IAGO_ERR_HIP;
+        int per_game = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_game, (const void *)search_game_kernel, 256, (size_t)game_lds) != hipSuccess)
+            return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_split: the device does not answer");
+        if (n_game_wgs > (int64_t)sp->game_cus * per_game)
+            return iago_fail(IAGO_ERR_CAPACITY, "iago_mcts_search_split: the game workgroups do not fit the game launch's CUs "
+                                                "(more game CUs, fewer games per launch, or the single launch)");
+        resident = n_game_wgs + (int64_t)(cus - sp->game_cus) * per_cu;
+    }
     if (n_game_wgs + 1 > resident)
         return iago_fail(IAGO_ERR_CAPACITY, "iago_mcts_search_persistent: the game workgroups and one net workgroup do not "
                                             "fit the device together (fewer games per launch, or the per-playout launches)");
@@ -1248,6 +1311,7 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
     S.roll_defer = defer_env ? atoi(defer_env) : 10;
     if (S.roll_defer < 0 || S.roll_defer > 15)
         S.roll_defer = S.roll_defer < 0 ? 0 : 15;
+    S.path_lds_cap = path_lds_cap;
     S.max_turns = a->max_turns;
     S.game_own = a->game_own;
     S.game_opp = a->game_opp;
@@ -1280,6 +1344,98 @@ extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void 
         hipMemsetAsync(a->rep_v, 0, (size_t)tree->n_games * 8, (hipStream_t)stream) != hipSuccess ||
         hipMemsetAsync(a->rep_p, 0, (size_t)tree->n_games * 512, (hipStream_t)stream) != hipSuccess)
         return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_persistent: hipMemsetAsync failed");
-    hipLaunchKernelGGL(search_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, S, R, VP, PP);
-    return iago_check_launch("iago_mcts_search_persistent");
+    if (!sp) {
+        hipLaunchKernelGGL(search_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, S, R, VP, PP);
+        return iago_check_launch("iago_mcts_search_persistent");
+    }
+    // both launches after everything queued on the caller's stream so far (the zeroing above included), the caller's
+    // stream after both.  The game launch first: the net workgroups leave when the game workgroups have finished
+    static std::atomic<uint64_t> configured_net{0};
+    if (iago_reserve_lds((const void *)search_net_kernel, lds, configured_net,
+                         "iago_mcts_search_split: cannot reserve the nets' LDS image"))
+        return IAGO_ERR_HIP;
+    if (hipEventRecord(sp->ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(sp->game, sp->ready, 0) != hipSuccess ||
+        hipStreamWaitEvent(sp->net, sp->ready, 0) != hipSuccess)
+        return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_split: cannot order the launches after the stream");
+    hipLaunchKernelGGL(search_game_kernel, dim3((unsigned)n_game_wgs), dim3(256), game_lds, sp->game, S, R);
+    int rc = iago_check_launch("iago_mcts_search_split (game launch)");
+    if (rc == IAGO_OK) {
+        hipLaunchKernelGGL(search_net_kernel, dim3((unsigned)net_wgs), dim3(256), lds, sp->net, S, VP, PP);
+        rc = iago_check_launch("iago_mcts_search_split (net launch)");
+    }
+    // (also after a failed launch: whatever did start is waited for by the caller's stream)
+    if (hipEventRecord(sp->game_done, sp->game) != hipSuccess || hipEventRecord(sp->net_done, sp->net) != hipSuccess ||
+        hipStreamWaitEvent((hipStream_t)stream, sp->game_done, 0) != hipSuccess ||
+        hipStreamWaitEvent((hipStream_t)stream, sp->net_done, 0) != hipSuccess)
+        return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_split: cannot order the stream after the launches");
+    return rc;
+}
+} // namespace
+
+extern "C" int iago_mcts_search_persistent(const iago_mcts_search_args *a, void *stream)
+{
+    return search_launch(a, stream, nullptr);
+}
+
+extern "C" int iago_mcts_search_split(const iago_mcts_search_args *a, iago_search_streams *streams, void *stream)
+{
+    if (!streams)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_split: null streams");
+    return search_launch(a, stream, streams);
+}
+
+extern "C" int iago_mcts_search_streams_create(int32_t game_cus, iago_search_streams **out)
+{
+    if (!out)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_streams_create: null pointer");
+    *out = nullptr;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_streams_create: the device does not answer");
+    // (a multiple of 8 from every side: mask bit i is a CU of XCD i mod 8 -- tools/exp_cu_mask.hip --, so both launches
+    // get the same number of CUs on every XCD and workgroup i of a launch still runs on XCD i mod 8)
+    if (game_cus < 8 || game_cus % 8 != 0 || cus % 8 != 0 || game_cus > cus / 2)
+        return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_streams_create: game_cus is a multiple of 8, at most half the "
+                                           "device's CUs");
+    uint32_t gm[32] = {0}, nm[32] = {0};
+    if (cus > 1024)
+        return iago_fail(IAGO_ERR_CAPACITY, "iago_mcts_search_streams_create: more CUs than the mask holds");
+    for (int i = 0; i < cus; i++)
+        (i < game_cus ? gm : nm)[i / 32] |= 1u << (i % 32);
+    iago_search_streams *sp = new iago_search_streams();
+    sp->device = dev;
+    sp->cus = cus;
+    sp->game_cus = game_cus;
+    const uint32_t words = (uint32_t)((cus + 31) / 32);
+    bool ok = hipExtStreamCreateWithCUMask(&sp->game, words, gm) == hipSuccess;
+    ok = ok && hipExtStreamCreateWithCUMask(&sp->net, words, nm) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&sp->ready, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&sp->game_done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&sp->net_done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        iago_mcts_search_streams_destroy(sp);
+        return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_streams_create: no CU-masked streams on this device (use the single "
+                                       "launch, iago_mcts_search_persistent)");
+    }
+    *out = sp;
+    return IAGO_OK;
+}
+
+extern "C" int iago_mcts_search_streams_destroy(iago_search_streams *sp)
+{
+    if (!sp)
+        return IAGO_OK;
+    if (sp->game)
+        (void)hipStreamDestroy(sp->game);
+    if (sp->net)
+        (void)hipStreamDestroy(sp->net);
+    if (sp->ready)
+        (void)hipEventDestroy(sp->ready);
+    if (sp->game_done)
+        (void)hipEventDestroy(sp->game_done);
+    if (sp->net_done)
+        (void)hipEventDestroy(sp->net_done);
+    delete sp;
+    return IAGO_OK;
 }

@@ -34,6 +34,19 @@ def _p(t):
 
 _stream = ops._stream   # the current HIP stream as a void*
 
+_SEARCH_STREAMS = {}    # (device, game CUs) -> iago_search_streams* (None: this runtime gives no CU-masked streams)
+
+
+def _search_streams(game_cus):
+    """The process's CU-masked streams of the role-split search on the current device (iago_mcts_search_streams_create:
+    created once, kept for the life of the process), or None where they cannot be had."""
+    key = (torch.cuda.current_device(), int(game_cus))
+    if key not in _SEARCH_STREAMS:
+        h = C.c_void_p()
+        rc = _lib.lib().iago_mcts_search_streams_create(int(game_cus), C.byref(h))
+        _SEARCH_STREAMS[key] = h if rc == 0 and h.value else None
+    return _SEARCH_STREAMS[key]
+
 
 def suggest_capacity(n_sims, n_thr=15, moves=64, branching=12):
     """Nodes per game that a whole self-play game needs without ever compacting the pools:
@@ -157,7 +170,7 @@ class BatchedMCTS(object):
                  n_thr=15, capacity=4096, seed=0, game_id_base=0, device="cuda", use_graph=False,
                  sync_free=None, lookahead=None, lookahead_slots=None, value_cache=None, lookahead_overlap=None,
                  z_log_rows=0, async_steps=None, async_parts=None, value_ahead=None, persistent=None,
-                 net_workgroups=None, max_cus=None):
+                 net_workgroups=None, max_cus=None, split=None):
         if n_thr < 1:
             raise ValueError("n_thr must be >= 1")
         # (what the caller asked for explicitly, before the defaults below fill the options in: any of these selects
@@ -244,6 +257,18 @@ class BatchedMCTS(object):
         self.max_cus = int(max_cus if max_cus is not None else os.environ.get("IAGO_PERSISTENT_CUS", "0"))
         self.resident_workgroups = self._search_capacity()
         n_gw = -(-n_games // self.games_per_workgroup)
+        # Role split (iago_mcts_search_split): the game workgroups as a launch of their own, two per CU on `split` CUs
+        # (a multiple of 8), the net workgroups on all the others -- two CU-masked streams, co-resident by construction.
+        # Same trees.  split=None / IAGO_SEARCH_SPLIT: game CUs, 0 = the single launch.  Not with max_cus (the split
+        # owns the device); a runtime without CU-masked streams falls back to the single launch.
+        want_split = int(split if split is not None else os.environ.get("IAGO_SEARCH_SPLIT", "0"))
+        self.split_cus, self._split = 0, None
+        if want_split > 0 and self.max_cus <= 0 and self.resident_workgroups > 0:
+            while 2 * want_split < n_gw:                    # (two game workgroups per CU)
+                want_split += 8
+            if want_split % 8 == 0 and want_split <= self.resident_workgroups // 2:
+                self._split = _search_streams(want_split)
+                self.split_cus = want_split if self._split else 0
         can_p = (self.resident_workgroups > 0 and 2 * n_gw <= self.resident_workgroups
                  and can_cache and getattr(value_fn, "search_args", None) is not None
                  and getattr(policy_fn, "search_args", None) is not None and getattr(policy_fn, "split3", False)
@@ -397,6 +422,8 @@ class BatchedMCTS(object):
                 net_workgroups = int(os.environ.get("IAGO_PERSISTENT_NET", "0")) or max(32, 8 * n_games)
             # (an upper bound: the launch itself takes no more than fit beside the game workgroups)
             self.net_workgroups = max(1, min(int(net_workgroups), self.resident_workgroups - n_gw))
+            if self.split_cus:   # (one net workgroup on every CU that is not the games')
+                self.net_workgroups = max(1, min(int(net_workgroups), self.resident_workgroups - self.split_cus))
             grid = n_gw + self.net_workgroups
             self.PATH_STRIDE = 520
             i64 = torch.int64
@@ -1087,7 +1114,10 @@ class BatchedMCTS(object):
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        check(_lib.lib().iago_mcts_search_persistent(C.byref(a), _stream()), "iago_mcts_search_persistent")
+        if self._split is not None:
+            check(_lib.lib().iago_mcts_search_split(C.byref(a), self._split, _stream()), "iago_mcts_search_split")
+        else:
+            check(_lib.lib().iago_mcts_search_persistent(C.byref(a), _stream()), "iago_mcts_search_persistent")
         if ev is not None:
             e1.record()
             ev.append((e0, e1))

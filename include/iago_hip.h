@@ -214,86 +214,11 @@ IAGO_API int iago_rollout(const iago_rollout_args *args, void *stream);
 /* ------------------------------------------------------------------- nets */
 
 /*
- * In place x[b][c][:] = max(x[b][c][:] + bias[c], 0) on a float32 NCHW tensor
- * with 8x8 planes (hw = 64): the bias + ReLU epilogue of Block.__call__
- * (network.py:9-13: Convolution2D with bias, then F.relu) as ONE pass, for the
- * inference path of the PyTorch modules (MIOpen's convolution is called
- * without bias; PyTorch would otherwise run a bias-add and a ReLU kernel).
- * x: [n][channels][64] floats, 16-byte aligned; bias: [channels].
+ * The nets of network.py as whole-net launches.  Arithmetic, operand formats ("split f16": a float32 operand as two or
+ * three f16 pieces, float32 accumulation; weights [cin/16][3][3][cout][16]) and the `overflow` word (set to 1 when an
+ * activation left the f16 range or was NaN before the clamp: the call's results are saturated, not the reference's) are
+ * described with the layer-level entry points in iago_hip_layers.h (iago_conv3x3_split).
  */
-IAGO_API int iago_bias_relu(float *x, const float *bias, int64_t n, int32_t channels, void *stream);
-
-/*
- * The 3x3 convolution + bias + ReLU of Block.__call__ (network.py:5-13) on 8x8 boards
- * for the inference path of the Value net (network.py:66-96; evaluated once per
- * playout, MCTS.py:110-131), on the MFMA units in "split f16" arithmetic: every
- * float32 operand a is carried as a_hi = f16(a), a_lo = f16((a - a_hi) * 2^11), a
- * product sum is w_hi*x_hi + 2^-11 * (w_hi*x_lo + w_lo*x_hi) with float32
- * accumulation (22-bit products; the whole Value forward stays within 1e-6 of the
- * float32 one).
- *
- * Activations between layers are "split channel blocks": two f16 arrays
- * hi, lo [n][channels/16][64 cells][16 channels].  iago_split_nchw /
- * iago_merge_nchw convert from / to float32 NCHW [n][channels][8][8].
- * Weights: two f16 arrays [cin/16][3][3][cout][16] (kernel row, kernel column, output
- * channel, input channel within the block) split the same way; bias float32 [cout].
- * cout must be 128, cin a multiple of 32.  All pointers 16-byte aligned.
- *
- * Range: an f16 "hi" part holds |a| <= 65504, so activations are clamped to [0, 65000]
- * (inputs of iago_split_nchw to [-65000, 65000]) -- the float32 reference has no such
- * bound.  `overflow` (every function below that writes split channel blocks; optional, NULL
- * = no report) is a device word the kernel sets to 1 when a value was outside that range
- * or NaN BEFORE the clamp, i.e. when the results of this call are saturated and no longer
- * the reference's.  The caller zeroes it, reads it at its next synchronisation point and
- * falls back to the float32 kernels (iago_conv3x3_f32 / MIOpen) or raises.
- */
-IAGO_API int iago_conv3x3_split(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo,
-                                const float *bias, void *y_hi, void *y_lo, int64_t n, int32_t cin,
-                                int32_t cout, uint32_t *overflow, void *stream);
-/*
- * The ends of the Value net around the split-f16 convolutions, in float32 arithmetic:
- * iago_value_stem: block1 = conv3x3 2 -> 64 + bias + ReLU (network.py:68-70) from the
- *   float32 planes [n][2][8][8] of iago_encode_planes to split channel blocks
- *   [n][4][64][16]; w1 [64][2][3][3], b1 [64] as the reference stores them.
- * iago_value_head: block9 = conv3x3 128 -> 1 + bias + ReLU, fc10 (64 -> 128, no bias),
- *   fc11 (128 -> 1, no bias) with train=False (network.py:78-96; MCTS.py:86), from
- *   split channel blocks [n][8][64][16] to out [n]; w9 [1][128][3][3], b9 [1],
- *   w10 [128][64], w11 [1][128].
- */
-IAGO_API int iago_value_stem(const float *planes, const float *w1, const float *b1, void *y_hi, void *y_lo,
-                             int64_t n, uint32_t *overflow, void *stream);
-/* iago_value_stem straight from the boards (own = side to move): iago_encode_planes fused in. */
-IAGO_API int iago_value_stem_boards(const uint64_t *own, const uint64_t *opp, const float *w1, const float *b1,
-                                    void *y_hi, void *y_lo, int64_t n, uint32_t *overflow, void *stream);
-IAGO_API int iago_value_head(const void *x_hi, const void *x_lo, const float *w9, const float *b9,
-                             const float *w10, const float *w11, float *out, int64_t n, void *stream);
-/*
- * float32 convolutions for SMALL batches: the policy net on the expansions of a playout
- * (MCTS.py:109-121 evaluates SLPolicy on the few games whose leaf reached n_thr visits).
- * Exact float32 products on the matrix units, one board spread over 4 workgroups.
- * iago_conv3x3_f32: y = relu(conv3x3(x, w) + bias) (Block.__call__, network.py:9-13),
- *   x [n][cin][8][8], y [n][128][8][8] float32; cin 64 or 128, cout 128; w re-laid as
- *   [4 groups of 32 output channels][9 taps][cin][32] float32.
- * iago_stem_f32: SLPolicy.block1, conv3x3 2 -> 64 + bias + ReLU, planes [n][2][8][8] ->
- *   y [n][64][8][8]; w1 [64][2][3][3].
- * iago_policy_head: conv9 (1x1, 128 -> 1, no bias) + bias10 + softmax (network.py:29-47):
- *   x [n][128][8][8] -> probs [n][64]; w9 [128], b10 [64].
- * n_dev: optional device-side board count (see iago_encode_planes_indexed); iago_conv3x3_f32
- *   then runs a fixed grid whose workgroups walk the (board, channel group) items.
- */
-IAGO_API int iago_conv3x3_f32(const float *x, const float *w, const float *bias, float *y, int64_t n,
-                              int32_t cin, int32_t cout, const int32_t *n_dev, void *stream);
-IAGO_API int iago_stem_f32(const float *planes, const float *w1, const float *b1, float *y, int64_t n,
-                           const int32_t *n_dev, void *stream);
-/* iago_stem_f32 straight from the boards: row b of y is block1 of board index[b] (int64
- * gather list, NULL = identity; own = side to move) -- iago_encode_planes_indexed fused in:
- * what a playout runs on the leaves it expands. */
-IAGO_API int iago_stem_f32_boards(const uint64_t *own, const uint64_t *opp, const int64_t *index,
-                                  const float *w1, const float *b1, float *y, int64_t n,
-                                  const int32_t *n_dev, void *stream);
-IAGO_API int iago_policy_head(const float *x, const float *w9, const float *b10, float *probs, int64_t n,
-                              const int32_t *n_dev, void *stream);
-
 /*
  * The WHOLE SLPolicy net (SLPolicy.__call__, network.py:15-47: 8 x [conv3x3 + bias + ReLU], conv
  * 1x1 128 -> 1, per-cell bias, softmax) in ONE launch on the f16 matrix units with float32-exact
@@ -328,23 +253,6 @@ typedef struct iago_policy_split3_args {
                                launches */
 } iago_policy_split3_args;
 IAGO_API int iago_policy_forward_split3(const iago_policy_split3_args *args, void *stream);
-/*
- * Up to 8 consecutive iago_conv3x3_split layers in ONE launch (blocks 2..8 of the Value
- * net): a workgroup owns all 128 channels of its 4 boards, so it runs the layers back to
- * back on its own intermediate activations.  Layer k reads the y buffers of layer k-1;
- * every layer writes buffers of its own.  cout = 128 throughout, cin of layer 0 a
- * multiple of 32.
- */
-typedef struct iago_conv_split_layer {
-    const void *x_hi, *x_lo; /* input activations  [n][cin/16][64][16] f16 */
-    const void *w_hi, *w_lo; /* weights            [cin/16][3][3][128][16] f16 */
-    const float *bias;       /* [128] */
-    void *y_hi, *y_lo;       /* output activations [n][8][64][16] f16 */
-    int32_t cin;
-    int32_t reserved;
-} iago_conv_split_layer;
-IAGO_API int iago_conv3x3_split_trunk(const iago_conv_split_layer *layers, int32_t n_layers, int64_t n,
-                                      uint32_t *overflow, void *stream);
 /*
  * The WHOLE Value net (Value.__call__(x, train=False), network.py:66-96, as MCTS.playout calls
  * it, MCTS.py:123-124) in ONE launch: iago_value_stem(_boards) + the 7-layer
@@ -388,10 +296,6 @@ IAGO_API int iago_value_forward_split(const iago_value_split_args *args, void *s
  */
 IAGO_API int iago_value_rollout(const iago_value_split_args *args, const iago_rollout_args *rollout,
                                 void *stream);
-IAGO_API int iago_split_nchw(const float *x, void *hi, void *lo, int64_t n, int32_t channels,
-                             uint32_t *overflow, void *stream);
-IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n, int32_t channels,
-                             void *stream);
 
 /* ------------------------------------------------------------------- MCTS */
 
@@ -439,81 +343,11 @@ typedef struct iago_mcts_tree {
 IAGO_API int iago_mcts_reset(const iago_mcts_tree *tree, const uint8_t *mask, void *stream);
 
 /*
- * Descend from the cursor to a leaf with Node.select (MCTS.py:39-49,75-76):
- * child score = Q + c_puct*P*sqrt(parent.n)/(0.01+n), argmax, first wins;
- * apply the chosen move to the cursor board (GameFunctions.place_stone,
- * game.py:180-207; -1 = pass) and switch sides (MCTS.py:130-133).
- * This is the non-leaf branch of MCTS.playout (MCTS.py:129-133).
- *   from_root != 0: the cursor starts at the game's root with board
- *     (root_own, root_opp) (own = side to move at the root);
- *   from_root == 0: it continues from (cur_node, cur_own, cur_opp) -- used after
- *     an expansion, mirroring the recursion of MCTS.py:121.
- * Games with active[g] == 0 are skipped.  On return, per active game:
- *   cur_node/cur_own/cur_opp: the leaf and its position (own = side to move),
- *   needs_expand: 1 iff leaf.n_visits >= n_thr (MCTS.py:109),
- *   legal: the leaf's legal-move mask (game.py:210-235) when needs_expand.
- * stats (optional, int32 [n_games][2]): ACCUMULATES per game the levels
- * descended and the children scored by this call -- the harness turns them
- * into the algorithmic bytes of the tree arrays.
- */
-IAGO_API int iago_mcts_select(const iago_mcts_tree *tree, const uint64_t *root_own,
-                              const uint64_t *root_opp, const uint8_t *active, float c_puct,
-                              int32_t n_thr, int from_root, int32_t *cur_node, uint64_t *cur_own,
-                              uint64_t *cur_opp, uint8_t *needs_expand, uint64_t *legal,
-                              int32_t *stats, void *stream);
-
-/*
- * Expand the leaves listed in `games` (int32 game ids, n_expand of them):
- * MCTS.playout's expansion branch (MCTS.py:110-120) + Node.expand
- * (MCTS.py:27-37).  0 legal moves: one pass child (-1) with prior 1; exactly
- * one: that child with prior 1 (no net); otherwise one child per legal move,
- * ascending, with prior probs[i][a] (raw softmax entry, not renormalised,
- * MCTS.py:96-98).  probs: float32 [n_expand][64], row i belongs to games[i]
- * (rows of single-move / pass leaves are ignored and may be garbage).
- * A game whose pool is full gets overflow[g] = 1 and is left unexpanded.
- * n_dev: optional device-side count (see iago_encode_planes_indexed): min(n_expand, *n_dev)
- * leaves are expanded.
- */
-IAGO_API int iago_mcts_expand(const iago_mcts_tree *tree, const int32_t *games, int64_t n_expand,
-                              const int32_t *cur_node, const uint64_t *legal, const float *probs,
-                              const int32_t *n_dev, void *stream);
-
-/*
- * The games a playout has to expand before it can go on (MCTS.py:109: the leaf reached
- * n_thr visits): pending[g] = needs_expand[g] && active[g] (0/1), their ids in ascending
- * order as index[] (int64) and games[] (int32, what iago_mcts_expand takes), *count =
- * how many.  index / games must hold n entries.  One small launch in place of a mask,
- * a stream compaction and a type conversion.  total (optional): a device int64 that
- * accumulates the counts (the number of policy evaluations of a search, read once at its end).
- */
-IAGO_API int iago_mcts_pending(const uint8_t *needs_expand, const uint8_t *active, int64_t n,
-                               uint8_t *pending, int64_t *index, int32_t *games, int32_t *count,
-                               int64_t *total, void *stream);
-
-/*
  * leaf_value = (1-lmbda)*v + lmbda*z in the reference's float32 arithmetic
  * (MCTS.py:123-125); v may be NULL when lmbda >= 1, z when lmbda <= 0.
  */
 IAGO_API int iago_leaf_values(const float *v, const int8_t *z, float lmbda, float *leaf_value,
                               int64_t n, void *stream);
-
-/*
- * Node.update_recursive (MCTS.py:51-72) from cur_node up to the root of every
- * active game: n += 1; Q += (leaf_value - Q)/n; the SAME value at every
- * level (the reference does not flip the sign).
- */
-IAGO_API int iago_mcts_backup(const iago_mcts_tree *tree, const uint8_t *active,
-                              const int32_t *cur_node, const float *leaf_value, void *stream);
-
-/*
- * iago_leaf_values + iago_mcts_backup in one launch (MCTS.py:123-127): leaf_value[g] =
- * (1-lmbda)*v[g] + lmbda*z[g] for every game, backed up along the path of the active
- * ones.  counter: optional device word incremented by one (the playout number that
- * iago_rollout_args.stream_id_dev reads when the playouts replay from a hipGraph).
- */
-IAGO_API int iago_mcts_mix_backup(const iago_mcts_tree *tree, const uint8_t *active,
-                                  const int32_t *cur_node, const float *v, const int8_t *z, float lmbda,
-                                  float *leaf_value, uint32_t *counter, void *stream);
 
 /*
  * MCTS.get_move's final choice (MCTS.py:147): the most visited child of the
@@ -614,9 +448,6 @@ IAGO_API int iago_mcts_mix_backup_lookahead(const iago_mcts_tree *tree, const ui
                                             const iago_mcts_lookahead *la, void *stream);
 IAGO_API int iago_mcts_store_priors(const iago_mcts_lookahead *la, const float *probs, int64_t *total,
                                     void *stream);
-IAGO_API int iago_mcts_expand_cached(const iago_mcts_tree *tree, const uint8_t *active, const uint8_t *needs_expand,
-                                     const int32_t *cur_node, const uint64_t *legal, const iago_mcts_lookahead *la,
-                                     uint8_t *expanded, void *stream);
 
 /*
  * Value cache.  MCTS.playout evaluates value_func(state) at every visit of a leaf
@@ -632,8 +463,6 @@ IAGO_API int iago_mcts_expand_cached(const iago_mcts_tree *tree, const uint8_t *
  * expansion and iago_mcts_advance_root mark new nodes as not evaluated; after a change of the
  * value net's weights the caller fills `v` with NaN.
  */
-IAGO_API int iago_mcts_fresh_leaves(const iago_mcts_tree *tree, const uint8_t *active, const int32_t *cur_node,
-                                    int64_t *index, int32_t *count, int64_t *total, void *stream);
 /*
  * The whole descent of a playout in one launch: iago_mcts_select from the root, for the games
  * whose leaf has n_visits >= n_thr iago_mcts_expand_cached and the continued iago_mcts_select
@@ -800,41 +629,9 @@ IAGO_API int iago_selfplay_policy(const iago_selfplay_policy_args *args, void *s
 /*
  * ---- The gradients of the REINFORCE update of SLPolicy (src/train_rl.py:55-66: pred = model(x), loss =
  * mean(softmax_cross_entropy(pred, y) * r), loss.backward()) in split-f16 arithmetic on the matrix units
- * (csrc/policy_grad_kernels.hip), replacing the float32 convolutions of a tensor library in the update.
+ * (csrc/policy_grad_kernels.hip), replacing the float32 convolutions of a tensor library in the update.  Its layer-level
+ * pieces (iago_conv3x3_wgrad_split, iago_conv3x3_bwd_data_split, iago_split_scaled) are in iago_hip_layers.h.
  *
- * A gradient tensor in split channel blocks carries a power-of-two scale: its hi / lo pieces hold dY * 2^e with e an
- * int32 device word chosen so that the largest element sits near 2^14 (the f16 pieces then hold 22 bits of every
- * element down to 2^-28 of the largest).
- *
- * iago_conv3x3_wgrad_split: the weight gradient of one 3x3 block (Block.__call__, network.py:5-13),
- *   dW[co][ci][ky][kx] = 2^-e * sum over boards and cells of dY[b][co][y][x] * X[b][ci][y + ky - 1][x + kx - 1],
- *   dy_hi / dy_lo [n][8][64][16] (the gradient at the block's pre-activations, zero where its ReLU was off, times
- *   2^e), x_hi / x_lo [n][cin/16][64][16] (the block's input), cin 64 or 128; dw [128][cin][3][3] float32.
- *   part: scratch, [groups][9][128][cin] float32 -- the boards are summed in `groups` (a multiple of 8) contiguous
- *   groups, whose partial sums are added in group order (deterministic); scale_exp: the device word e, NULL = 0.
- *
- * iago_conv3x3_bwd_data_split: the gradient at the INPUT of a 3x3 block, through the ReLU of the block below:
- *   dx[b][ci][y][x] = [saved[b][ci][y][x] > 0] * 2^-e * sum over co and taps of dY[b][co][y - ky + 1][x - kx + 1] *
- *   W[co][ci][ky][kx] -- iago_conv3x3_split's kernel on the transposed, flipped weights (wt_hi / wt_lo: the split of
- *   Wt[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx], rows ci >= out_channels zero) with a float32 epilogue.
- *   mask_hi / mask_lo [n][out_channels/16][64][16]: the saved activations of the block below (its output = this
- *   block's input); dx [n][out_channels/16][64][16] float32 channel blocks; out_channels 64 or 128.
- *   max_bits: device word, atomicMax of the bit patterns of |dx| (zero it before the call).
- * iago_split_scaled: float32 channel blocks -> split channel blocks times 2^e with e = 13 - exponent of the largest
- *   magnitude (*max_bits, as written by the call above); writes e to *scale_exp.  bias_part / bias_grad (both or
- *   neither): scratch of ceil(n * channels / 32) * 32 floats and the sums over boards and cells per channel
- *   [channels] -- the bias gradient of the block whose pre-activation gradient x is, from the same pass.
- */
-IAGO_API int iago_conv3x3_bwd_data_split(const void *dy_hi, const void *dy_lo, const int32_t *scale_exp,
-                                         const void *wt_hi, const void *wt_lo, const void *mask_hi,
-                                         const void *mask_lo, int32_t out_channels, float *dx, uint32_t *max_bits,
-                                         int64_t n, void *stream);
-IAGO_API int iago_split_scaled(const float *x, const uint32_t *max_bits, void *hi, void *lo, int32_t *scale_exp,
-                               int64_t n, int32_t channels, float *bias_part, float *bias_grad, void *stream);
-IAGO_API int iago_conv3x3_wgrad_split(const void *dy_hi, const void *dy_lo, const void *x_hi, const void *x_lo,
-                                      int64_t n, int32_t cin, float *part, int32_t groups, const int32_t *scale_exp,
-                                      float *dw, void *stream);
-/*
  * iago_policy_reinforce_grad: the whole of src/train_rl.py:61-65 -- pred = model1(x), loss = mean(softmax_cross_entropy(
  *   pred, y) * r), model1.cleargrads(), loss.backward() -- for n recorded rows: forward with every block's output kept
  *   (iago_value_stem_boards on block1's weights, 7 x iago_conv3x3_split), the head and the loss forward and backward
@@ -848,7 +645,9 @@ IAGO_API int iago_conv3x3_wgrad_split(const void *dy_hi, const void *dy_lo, cons
  *   wt_lo the transposed form of iago_conv3x3_bwd_data_split, bias [128]; w9 [128], b10 [64].
  *   g_*: the gradients, float32 in the parameters' own layouts ([co][ci][3][3]); loss: device float; probs: optional
  *   [n][64], the model's output.  workspace: iago_policy_grad_workspace_bytes(n) bytes, 256-byte aligned (304 KB per
- *   row + 40 MB).  overflow: see iago_conv3x3_split (the forward's activations).
+ *   row + 40 MB).  overflow: see iago_conv3x3_split (the forward's activations: bit 0); bit 1 is raised when an action
+ *   lies outside 0 .. 63 (the reference's F.softmax_cross_entropy raises there): that call's loss and gradients
+ *   must not be used.
  */
 typedef struct iago_policy_grad_args {
     const uint64_t *own, *opp;

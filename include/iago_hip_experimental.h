@@ -1,5 +1,7 @@
 /*
- * iago_hip_experimental.h -- entry points of two schedules of the PER-PLAYOUT search engine that were built, proven
+ * iago_hip_experimental.h -- entry points outside the drop-in boundary: (1) two schedules of the PER-PLAYOUT search engine
+ * (game-asynchronous steps, value look-ahead), (2) the per-phase forms of a playout that the one-launch descent and the
+ * persistent search superseded, (3) the persistent search split by role into two co-resident launches.  (1) and (3) were built, proven
  * tree-identical to the reference's order of evaluation and MEASURED SLOWER than the engines that serve the path
  * (the persistent search, iago_mcts_search_persistent, wherever the split-f16 Value net and the
  * three-piece SLPolicy apply and the batch fits one launch; the lockstep per-playout launches of include/iago_hip.h
@@ -12,6 +14,7 @@
 #define IAGO_HIP_EXPERIMENTAL_H
 
 #include "iago_hip.h"
+#include "iago_hip_layers.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -107,6 +110,114 @@ IAGO_API int iago_mcts_value_ahead_store(const iago_mcts_tree *tree, const iago_
  */
 IAGO_API int iago_value_forward_batch(const iago_value_split_args *args, int32_t boards_per_workgroup,
                                       int32_t max_workgroups, void *stream);
+
+/*
+ * ---- The per-phase forms of a playout (rounds 1 - 2): one launch per phase of MCTS.playout (MCTS.py:105-133).  Superseded
+ * twice -- by iago_mcts_descend + iago_mcts_mix_backup_lookahead (one-launch descent and backup, iago_hip.h) and by the
+ * persistent search --; they remain what engine.BatchedMCTS drives for ARBITRARY callables as nets (one host
+ * synchronisation per playout: the stand-in nets of the parity tests) and behind the IAGO_FUSED_* = 0 knobs.
+ */
+/*
+ * Descend from the cursor to a leaf with Node.select (MCTS.py:39-49,75-76):
+ * child score = Q + c_puct*P*sqrt(parent.n)/(0.01+n), argmax, first wins;
+ * apply the chosen move to the cursor board (GameFunctions.place_stone,
+ * game.py:180-207; -1 = pass) and switch sides (MCTS.py:130-133).
+ * This is the non-leaf branch of MCTS.playout (MCTS.py:129-133).
+ *   from_root != 0: the cursor starts at the game's root with board
+ *     (root_own, root_opp) (own = side to move at the root);
+ *   from_root == 0: it continues from (cur_node, cur_own, cur_opp) -- used after
+ *     an expansion, mirroring the recursion of MCTS.py:121.
+ * Games with active[g] == 0 are skipped.  On return, per active game:
+ *   cur_node/cur_own/cur_opp: the leaf and its position (own = side to move),
+ *   needs_expand: 1 iff leaf.n_visits >= n_thr (MCTS.py:109),
+ *   legal: the leaf's legal-move mask (game.py:210-235) when needs_expand.
+ * stats (optional, int32 [n_games][2]): ACCUMULATES per game the levels
+ * descended and the children scored by this call -- the harness turns them
+ * into the algorithmic bytes of the tree arrays.
+ */
+IAGO_API int iago_mcts_select(const iago_mcts_tree *tree, const uint64_t *root_own,
+                              const uint64_t *root_opp, const uint8_t *active, float c_puct,
+                              int32_t n_thr, int from_root, int32_t *cur_node, uint64_t *cur_own,
+                              uint64_t *cur_opp, uint8_t *needs_expand, uint64_t *legal,
+                              int32_t *stats, void *stream);
+
+/*
+ * Expand the leaves listed in `games` (int32 game ids, n_expand of them):
+ * MCTS.playout's expansion branch (MCTS.py:110-120) + Node.expand
+ * (MCTS.py:27-37).  0 legal moves: one pass child (-1) with prior 1; exactly
+ * one: that child with prior 1 (no net); otherwise one child per legal move,
+ * ascending, with prior probs[i][a] (raw softmax entry, not renormalised,
+ * MCTS.py:96-98).  probs: float32 [n_expand][64], row i belongs to games[i]
+ * (rows of single-move / pass leaves are ignored and may be garbage).
+ * A game whose pool is full gets overflow[g] = 1 and is left unexpanded.
+ * n_dev: optional device-side count (see iago_encode_planes_indexed): min(n_expand, *n_dev)
+ * leaves are expanded.
+ */
+IAGO_API int iago_mcts_expand(const iago_mcts_tree *tree, const int32_t *games, int64_t n_expand,
+                              const int32_t *cur_node, const uint64_t *legal, const float *probs,
+                              const int32_t *n_dev, void *stream);
+
+/*
+ * The games a playout has to expand before it can go on (MCTS.py:109: the leaf reached
+ * n_thr visits): pending[g] = needs_expand[g] && active[g] (0/1), their ids in ascending
+ * order as index[] (int64) and games[] (int32, what iago_mcts_expand takes), *count =
+ * how many.  index / games must hold n entries.  One small launch in place of a mask,
+ * a stream compaction and a type conversion.  total (optional): a device int64 that
+ * accumulates the counts (the number of policy evaluations of a search, read once at its end).
+ */
+IAGO_API int iago_mcts_pending(const uint8_t *needs_expand, const uint8_t *active, int64_t n,
+                               uint8_t *pending, int64_t *index, int32_t *games, int32_t *count,
+                               int64_t *total, void *stream);
+
+/*
+ * Node.update_recursive (MCTS.py:51-72) from cur_node up to the root of every
+ * active game: n += 1; Q += (leaf_value - Q)/n; the SAME value at every
+ * level (the reference does not flip the sign).
+ */
+IAGO_API int iago_mcts_backup(const iago_mcts_tree *tree, const uint8_t *active,
+                              const int32_t *cur_node, const float *leaf_value, void *stream);
+
+/*
+ * iago_leaf_values + iago_mcts_backup in one launch (MCTS.py:123-127): leaf_value[g] =
+ * (1-lmbda)*v[g] + lmbda*z[g] for every game, backed up along the path of the active
+ * ones.  counter: optional device word incremented by one (the playout number that
+ * iago_rollout_args.stream_id_dev reads when the playouts replay from a hipGraph).
+ */
+IAGO_API int iago_mcts_mix_backup(const iago_mcts_tree *tree, const uint8_t *active,
+                                  const int32_t *cur_node, const float *v, const int8_t *z, float lmbda,
+                                  float *leaf_value, uint32_t *counter, void *stream);
+
+/* iago_mcts_expand for every active game with needs_expand, priors from the look-ahead's cache (iago_mcts_lookahead,
+ * iago_hip.h); expanded[g] = 1 for those games, else 0 */
+IAGO_API int iago_mcts_expand_cached(const iago_mcts_tree *tree, const uint8_t *active, const uint8_t *needs_expand,
+                                     const int32_t *cur_node, const uint64_t *legal, const iago_mcts_lookahead *la,
+                                     uint8_t *expanded, void *stream);
+
+/* the active games whose leaf (cur_node) has no stored value yet: index[0 .. *count), ascending; *total += *count when
+ * given (the value cache of iago_hip.h; iago_mcts_descend lists them in the same launch as the descent) */
+IAGO_API int iago_mcts_fresh_leaves(const iago_mcts_tree *tree, const uint8_t *active, const int32_t *cur_node,
+                                    int64_t *index, int32_t *count, int64_t *total, void *stream);
+
+
+/*
+ * ---- The persistent search split by role (round 6: built, bit-identical, measured NO FASTER: LABNOTES.md).
+ */
+/*
+ * The same search as TWO launches that run together, one per role: the game workgroups (two per CU: a kernel of its
+ * own register budget) on a stream masked to `game_cus` CUs, the net workgroups on a stream masked to all the other
+ * CUs of the device -- co-resident by construction.  Same arguments, same protocol, bit-identical trees, moves and
+ * records (MCTS.py:105-154, game.py:117-142); max_cus must be 0.
+ *   iago_mcts_search_streams_create: the two CU-masked streams and their events for the CURRENT device, once per
+ *     process and device (game_cus: a multiple of 8, at most half the device's CUs; IAGO_ERR_HIP where the runtime
+ *     gives no CU-masked streams: use iago_mcts_search_persistent there).  _destroy releases them.
+ *   iago_mcts_search_split: both launches start after everything queued on `stream` so far, and `stream` continues
+ *     after both; IAGO_ERR_CAPACITY when the game workgroups do not fit game_cus CUs (two per CU with their paths in
+ *     LDS, else as many as fit).  No host synchronisation.
+ */
+typedef struct iago_search_streams iago_search_streams;
+IAGO_API int iago_mcts_search_streams_create(int32_t game_cus, iago_search_streams **out);
+IAGO_API int iago_mcts_search_streams_destroy(iago_search_streams *streams);
+IAGO_API int iago_mcts_search_split(const iago_mcts_search_args *args, iago_search_streams *streams, void *stream);
 
 #ifdef __cplusplus
 }

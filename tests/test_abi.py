@@ -23,19 +23,26 @@ def header_symbols(name="iago_hip.h"):
 
 def test_header_matches_symbol_list(so):
     assert header_symbols() == sorted(_lib.SYMBOLS)
-    # the schedules that measured slower are fenced off in a header of their own (VERDICT r04 task 8)
+    # the layer-level entry points have a header of their own; the schedules that measured slower, the per-phase forms
+    # the one-launch descent superseded and the role split are fenced off in a third (VERDICT r04 task 8, r05 task 7)
+    assert header_symbols("iago_hip_layers.h") == sorted(_lib.LAYER_SYMBOLS)
     assert header_symbols("iago_hip_experimental.h") == sorted(_lib.EXPERIMENTAL_SYMBOLS)
-    assert not set(_lib.SYMBOLS) & set(_lib.EXPERIMENTAL_SYMBOLS)
+    assert len(set(_lib.SYMBOLS) | set(_lib.LAYER_SYMBOLS) | set(_lib.EXPERIMENTAL_SYMBOLS)) == \
+        len(_lib.SYMBOLS) + len(_lib.LAYER_SYMBOLS) + len(_lib.EXPERIMENTAL_SYMBOLS)
+    # the boundary stays a boundary (VERDICT r05 task 7): 30 entry points, a header under 700 lines
+    assert len(_lib.SYMBOLS) <= 30
+    assert len(open(os.path.join(ROOT, "include", "iago_hip.h")).read().splitlines()) < 700
 
 
 def test_library_exports_every_symbol(so):
     out = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
     exported = set(re.findall(r" T (iago_\w+)", out))
-    assert set(header_symbols()) | set(header_symbols("iago_hip_experimental.h")) <= exported
+    every = header_symbols() + header_symbols("iago_hip_layers.h") + header_symbols("iago_hip_experimental.h")
+    assert set(every) <= exported
     L = _lib.lib()
-    for name in header_symbols() + header_symbols("iago_hip_experimental.h"):
+    for name in every:
         assert hasattr(L, name), name
-    assert L.iago_abi_version() == _lib.ABI_VERSION == 12
+    assert L.iago_abi_version() == _lib.ABI_VERSION == 13
 
 
 def test_gfx950_code_object(so):

@@ -365,3 +365,33 @@ def test_whole_games_fall_back_to_the_turn_loop_when_a_pool_is_small(nets, monke
     monkeypatch.setattr(engine, "suggest_capacity", lambda *a, **k: 64)
     check(256, 1)
     big.close()
+
+
+def test_role_split_builds_the_same_trees(nets):
+    """The persistent search split by role (include/iago_hip_experimental.h: iago_mcts_search_split -- the game
+    workgroups as a launch of their own, two per CU, on a stream masked to `split` CUs; the net workgroups on a stream
+    masked to all the others): the same trees, values, rollout results as the single launch, no clock-limit abort, one
+    net workgroup per CU that is not the games'.  (Measured no faster than the single launch: LABNOTES.md, round 6.)"""
+    engine, ops, policy, value, rw = nets
+    G, n_sims, n_sims2 = 96, 100, 45
+    own, opp = _positions(G)
+    a, ta = _run(nets, G, n_sims, n_sims2, own, opp, (5,), persistent=True)
+    b, tb = _run(nets, G, n_sims, n_sims2, own, opp, (5,), persistent=True, split=8)
+    if b._split is None:
+        pytest.skip("this runtime gives no CU-masked streams")
+    assert a._split is None and b.split_cus == 8 and b.net_workgroups == b.resident_workgroups - 8
+    assert int(b._ps["ctl"][3].item()) == 0 and int(b._ps["ctl"][7].item()) == b.net_workgroups
+    for k in ("n_visits", "q", "p", "first_child", "parent", "action", "n_children", "n_nodes", "root", "leaf_value", "z_log"):
+        assert np.array_equal(ta[k], tb[k]), k
+    # whole games: 256 games x 30 playouts, the split launch against the single one, record for record
+    res = []
+    for split in (0, 16):
+        m = engine.BatchedMCTS(256, policy, value, rw, n_thr=15, capacity=engine.suggest_capacity(30, 15, moves=64), seed=9,
+                               persistent=True, split=split)
+        r = engine.SelfPlayEngine(m).play(30, record=True)
+        res.append((r.move.cpu().numpy().copy(), r.pi.cpu().numpy().copy(), r.z.cpu().numpy().copy(), r.n_turns))
+        assert (m._split is not None) == bool(split)
+        m.close()
+    assert res[0][3] == res[1][3]
+    for x, y in zip(res[0][:3], res[1][:3]):
+        assert np.array_equal(x, y)
