@@ -208,6 +208,7 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
         plays, gathers = [x * 1e-6 for x in plays], [x * 1e-6 for x in gathers]
         diag = {"ranks_seen": int(dist.get_world_size()), "ranks_reporting": sorted(int(r) for r in ranks),
                 "rank_play_seconds_min": min(plays), "rank_play_seconds_max": max(plays),
+                "per_rank_games_per_sec": [n_games * steps / max(x, 1e-9) for x in plays] if full_games else None,
                 "gather_ms_per_step_max": max(gathers) / max(steps, 1) * 1e3,
                 "ranks_played_different_games": len(set(sums)) == world,
                 "backend": dist.get_backend()}
@@ -299,8 +300,9 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
             "flops_per_unit": {"value_evaluation": VALUE_FLOP, "policy_evaluation": POLICY_FLOP},
             "executed_tflops": executed, "executed_frac": executed / F16_PEAK_TF,
             "executed_definition": "f16 MFMA FLOPs issued: 3 MFMAs per product of the Value net, 6 per product of "
-                                   "SLPolicy (float32-grade results on f16 matrix units) x 32,768 FLOP per "
-                                   "v_mfma_f32_32x32x16_f16, counted from the evaluations this run executed",
+                                   "SLPolicy (float32-grade results on f16 matrix units), counted from the evaluations "
+                                   "this run executed in units of 32,768 FLOP = two v_mfma_f32_16x16x32_f16 (the K loops' "
+                                   "shape since round 5: 16,384 FLOP each) or one v_mfma_f32_32x32x16_f16 (the heads)",
             "achieved_definition": "ALGORITHMIC FLOPs (SURVEY.md 8(d): 122.99 MFLOP per Value evaluation, 122.85 "
                                    "per SLPolicy evaluation) of the evaluations executed / the launches' duration",
             "useful_x_f32_matrix_peak": useful / F32_MATRIX_PEAK_TF,
@@ -1194,6 +1196,74 @@ def spawn_ranks(n):
     return status
 
 
+def value_spread(n_games, n_sims, this_value, pattern="r06*_bench.json"):
+    """min / max of `value` over the committed bench lines of this round's boxes (profiles/r06*_bench.json: one-GPU
+    lines of the same workload) and this run: the pool's boxes differ by several per cent."""
+    import glob
+    vals, files = [], []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
+        try:
+            with open(path) as f:
+                d = json.loads(f.read().strip().splitlines()[-1])
+            c = d.get("config", {})
+            if (d.get("metric") == "self-play games/sec" and d.get("n_gpus") == 1 and c.get("games_per_gpu") == n_games
+                    and c.get("sims_per_move") == n_sims and c.get("full_games")):
+                vals.append(float(d["value"]))
+                files.append(os.path.basename(path))
+        except (OSError, ValueError, KeyError, IndexError):
+            continue
+    every = vals + [float(this_value)]
+    return {"min": min(every), "max": max(every), "boxes": len(every), "committed_lines": files,
+            "note": "games/s of this workload on one GPU: the committed lines of this round's boxes and this run"}
+
+
+def preflight(dist, world, rank, device, json_fd, timeout_s=60.0, uuid=None, on="cuda"):
+    """Before anything is timed on N > 1 ranks: ONE 1-element all-reduce and one all-gather of the ranks' device
+    uuids, polled for at most `timeout_s` (no blocking wait: a collective that never completes must not hang the
+    run).  Checks sum(rank) == N (N - 1) / 2 and that every rank sits on a DIFFERENT device.  On failure rank 0 (or
+    whichever rank notices, if rank 0 is the one that hangs) prints one JSON line with "error" and the process exits
+    non-zero at once (os._exit: no destructor waits on a dead communicator; nothing is re-executed).  Returns the
+    dict that goes into the line."""
+    t0 = time.perf_counter()
+    if uuid is None:   # (uuid / on: the CPU test of this function, tests/test_dist_cpu.py)
+        props = torch.cuda.get_device_properties(device)
+        uuid = str(getattr(props, "uuid", "")) or "%s#%d" % (props.name, device)
+    code = torch.tensor(list(uuid.encode()[:48].ljust(48, b" ")), dtype=torch.uint8, device=on)
+    one = torch.tensor([rank], dtype=torch.int64, device=on)
+    every = torch.empty(world * 48, dtype=torch.uint8, device=on)
+
+    def fail(msg):
+        out = {"error": "preflight: " + msg, "n_gpus": world, "rank": rank, "backend": dist.get_backend(),
+               "device": device, "device_uuid": uuid, "seconds": time.perf_counter() - t0}
+        sys.stdout.flush()
+        os.write(json_fd if rank == 0 else 2, (json.dumps(out) + "\n").encode())
+        os._exit(3)
+
+    def finish(work, what):
+        while not work.is_completed():
+            if time.perf_counter() - t0 > timeout_s:
+                fail("%s did not complete within %.0f s (rank %d of %d, backend %s)" % (what, timeout_s, rank, world,
+                                                                                       dist.get_backend()))
+            time.sleep(0.005)
+        work.wait()
+
+    finish(dist.all_reduce(one, async_op=True), "the 1-element all-reduce")
+    finish(dist.all_gather_into_tensor(every, code, async_op=True) if dist.get_backend() == "nccl" else
+           dist.all_gather(list(every.view(world, 48).unbind(0)), code, async_op=True), "the all-gather of the device uuids")
+    if on == "cuda":
+        torch.cuda.synchronize()
+    got = int(one.item())
+    if got != world * (world - 1) // 2:
+        fail("all-reduce of the ranks gave %d, expected %d" % (got, world * (world - 1) // 2))
+    uuids = [bytes(r.tolist()).decode().strip() for r in every.view(world, 48).cpu()]
+    shared = os.environ.get("IAGO_BENCH_DEVICE") is not None   # the one-GPU rehearsal: every rank on one device
+    if not shared and len(set(uuids)) != world:
+        fail("ranks share a device: %s" % uuids)
+    return {"seconds": time.perf_counter() - t0, "allreduce_sum_of_ranks": got, "distinct_devices": len(set(uuids)),
+            "device_check": "skipped (rehearsal: IAGO_BENCH_DEVICE puts every rank on one device)" if shared else "ok",
+            "backend": dist.get_backend()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1220,6 +1290,9 @@ def main():
                     help="REINFORCE iterations of the training leg (0 = skip)")
     ap.add_argument("--mcts-games", type=int, default=1024)
     ap.add_argument("--mcts-sims", type=int, default=100)
+    ap.add_argument("--mcts-nthr", type=int, default=15,
+                    help="n_thr of the headline leg (MCTS.py:80,109; 15 = the reference's; 1 for profiles of the mcts_nthr1 variant)")
+    ap.add_argument("--no-saturated", action="store_true", help="skip the 2048- / 4096-game batches (`mcts_saturated`)")
     ap.add_argument("--mcts-turns", type=int, default=-1,
                     help="headline leg: -1 = play the games to the end (default), N > 0 = a bounded "
                          "sample of the first N turns (rehearsals)")
@@ -1289,6 +1362,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    pre = preflight(dist, world, rank, device, json_fd) if (dist is not None and world > 1) else None
 
     def log(msg):   # progress on stderr: a long run shows where it is
         if rank == 0:
@@ -1341,7 +1415,7 @@ def main():
     log("configs[2]: %d warm-up + %d timed batches of %d games x %d playouts per move%s"
         % (W, K, args.mcts_games, args.mcts_sims, "" if full else " (first %d turns)" % args.mcts_turns))
     mcts = mcts_leg(args.mcts_games, args.mcts_sims, max(args.mcts_turns, 0), full, world, rank, dist,
-                    value_f32=args.mcts_value_f32, use_graph=not args.mcts_eager,
+                    value_f32=args.mcts_value_f32, use_graph=not args.mcts_eager, n_thr=args.mcts_nthr,
                     persistent=False if (args.mcts_per_playout or args.mcts_eager) else None,
                     steps=K, warmup_steps=W, fresh_table=not args.keep_table)
     log("configs[2]: %.3f s per batch, %.2f M leaf-evals/s" % (mcts["seconds"] / K, mcts["leaf_evals_per_sec"] / 1e6))
@@ -1360,7 +1434,7 @@ def main():
         outs = {}
         keys = ("leaf_evals_per_sec", "games_per_sec", "leaf_evals", "policy_evals", "value_evals", "seconds", "turns_played",
                 "sims_per_move", "games_per_gpu", "n_thr", "policy_lookahead", "value_cache", "tree_nodes_used_max",
-                "tree_capacity", "config", "batches_replayed_turn_by_turn")
+                "tree_capacity", "config", "batches_replayed_turn_by_turn", "kernel_roofline")
         if turns_arg < 0:
             log("%s: one batch of whole games" % name)
             r = mcts_leg(args.mcts_games, sims, 0, True, world, rank, dist, n_thr=n_thr, use_graph=not args.mcts_eager,
@@ -1368,12 +1442,16 @@ def main():
             outs[name] = {k: r[k] for k in keys if k in r}
             outs[name]["config"] = outs[name]["config"].replace("configs[2]", what)
             outs[name]["sample"] = "one batch of whole games (games_per_sec), a fresh position table"
+            if "kernel_roofline" in outs[name]:   # (same keys as the headline's `roofline`; measured in this run)
+                outs[name]["roofline"] = dict(outs[name].pop("kernel_roofline"), traffic=None)
+                if r.get("persistent"):
+                    outs[name]["totals"] = r["persistent"]["totals"]
         n_open = 4 if sims >= 400 else 8
         if turns_arg != 0:
             n_open = n_open if turns_arg < 0 else turns_arg
             r = mcts_leg(args.mcts_games, sims, n_open, False, world, rank, dist, n_thr=n_thr, use_graph=not args.mcts_eager,
                          persistent=False if args.mcts_eager else None, steps=1, warmup_steps=0)
-            o = {k: r[k] for k in keys if k in r}
+            o = {k: r[k] for k in keys if k in r and k != "kernel_roofline"}
             o["config"] = o["config"].replace("configs[2]", what)
             o["sample"] = ("the first %d turns of the games only (NOT a game rate: the openings of games from one start position "
                            "repeat each other's positions)" % n_open)
@@ -1388,6 +1466,24 @@ def main():
         # "also report n_thr = 1" (MCTS.py:80,109): every leaf expands at its second visit --
         # the policy net inside every playout
         more.update(variant("mcts_nthr1", args.mcts_sims, 1, args.nthr1_turns, "configs[2] with n_thr = 1"))
+    saturated = None
+    if extras and full and world == 1 and not args.no_saturated and not args.mcts_eager and not args.mcts_per_playout:
+        # what the same kernel sustains OUTSIDE the latency-bound regime BASELINE's batch of 1024 is: one batch each of
+        # 2048 and 4096 whole games per launch (the ABI's limit: the game workgroups may take half the device)
+        saturated = {}
+        for n_g in (2048, 4096):
+            log("mcts_saturated: one batch of %d whole games" % n_g)
+            r = mcts_leg(n_g, args.mcts_sims, 0, True, world, rank, None, steps=1, warmup_steps=0)
+            kr2 = r.get("kernel_roofline") or {}
+            saturated[str(n_g)] = {"games_per_launch": n_g, "games_per_sec": r.get("games_per_sec"),
+                                   "leaf_evals_per_sec": r["leaf_evals_per_sec"], "seconds": r["seconds"],
+                                   "kernel_ms": kr2.get("kernel_ms"), "frac": kr2.get("frac"),
+                                   "executed_frac": kr2.get("executed_frac"),
+                                   "game_workgroups": (r.get("persistent") or {}).get("game_workgroups"),
+                                   "net_workgroups": (r.get("persistent") or {}).get("net_workgroups"),
+                                   "batches_replayed_turn_by_turn": r.get("batches_replayed_turn_by_turn")}
+        saturated["note"] = ("one batch each, whole games, same nets and constants as the headline; the headline's 1024 games per "
+                             "launch is BASELINE configs[2]'s batch")
     train = None
     if args.train_iters > 0 and not args.mcts_only:
         log("configs[4] in miniature: REINFORCE sets")
@@ -1448,6 +1544,9 @@ def main():
                          "rank_play_seconds_min": mcts["ranks"]["rank_play_seconds_min"],
                          "rank_play_seconds_max": mcts["ranks"]["rank_play_seconds_max"],
                          "gather_ms": mcts["ranks"]["gather_ms_per_step_max"],
+                         "per_rank_games_per_sec_min": min(mcts["ranks"]["per_rank_games_per_sec"] or [0.0]),
+                         "per_rank_games_per_sec_max": max(mcts["ranks"]["per_rank_games_per_sec"] or [0.0]),
+                         "preflight": pre,
                          "ranks_played_different_games": mcts["ranks"]["ranks_played_different_games"]})
         if "per_playout_launches" in mcts:
             line["leaf_evals_per_sec_per_playout_launches"] = mcts["per_playout_launches"]["leaf_evals_per_sec"]
@@ -1456,6 +1555,9 @@ def main():
             line["mcts_useful_tflops"] = rl["useful_tflops"]
             line["mcts_useful_frac_f16_peak"] = rl["useful_frac_f16_peak"]
             line["mcts_executed_frac_f16_peak"] = rl["frac"]
+        if saturated is not None:
+            line["mcts_saturated"] = saturated
+        line["value_spread"] = value_spread(args.mcts_games, args.mcts_sims, line["value"])
         line["mcts"] = mcts
         for k, v in more.items():
             line[k] = v

@@ -257,6 +257,7 @@ struct HeadGradParams {
     uint32_t *max_bits;
     float *part;               // [gridDim.x][193]: dW9 (128), dbias10 (64), loss (1) of each workgroup
     float *probs;              // optional [n][64]: the model's output
+    uint32_t *bad;             // optional: bit 1 raised when an action is outside 0 .. 63 (F.softmax_cross_entropy would raise)
 };
 constexpr int HEAD_PART = 193;
 
@@ -315,6 +316,8 @@ __global__ __launch_bounds__(256) void head_grad_kernel(HeadGradParams P)
             P.probs[b * 64 + lane] = p;
         const int a = P.action[b];
         const float z = P.reward[b];
+        if ((uint32_t)a >= 64u && lane == 0 && P.bad)
+            atomicOr(P.bad, 2u); // (the row's loss and gradient mean nothing: the caller must not use this update)
         // F.softmax_cross_entropy(pred, y): log-softmax of the probabilities (src/train_rl.py:62)
         const float m2 = wave_max(p);
         const float ex2 = expf(p - m2);
@@ -531,14 +534,18 @@ constexpr int PG_MAX_GROUPS = 64;
 // (the workgroups of a group share an XCD), at most PG_MAX_GROUPS (the partial sums' scratch)
 static int pg_groups(int cin)
 {
-    static std::atomic<int> cus{0};
-    int n = cus.load(std::memory_order_acquire);
+    // (asked of the runtime once per device, as iago_mcts_search_capacity does: a process may drive devices of
+    // different sizes, and the partial sums' grouping -- hence the gradients' last bits -- follows the device)
+    static std::atomic<int> known[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        dev = 0;
+    int n = known[dev & 63].load(std::memory_order_acquire);
     if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
             v = 256;
-        cus.store(v, std::memory_order_release);
+        known[dev & 63].store(v, std::memory_order_release);
         n = v;
     }
     int g = n / (2 * (cin / 32)) / 8 * 8;
@@ -620,6 +627,7 @@ int iago_policy_reinforce_grad(const iago_policy_grad_args *A, void *stream)
     H.max_bits = max_bits + 7;
     H.part = hpart;
     H.probs = A->probs;
+    H.bad = A->overflow;
     hipLaunchKernelGGL(head_grad_kernel, dim3(PG_GRID), dim3(256), 0, st, H);
     hipLaunchKernelGGL(head_reduce_kernel, dim3((HEAD_PART + 3) / 4), dim3(256), 0, st, (const float *)hpart, PG_GRID, inv_n, A->g_w9,
                        A->g_b10, A->loss);

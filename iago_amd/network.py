@@ -183,11 +183,13 @@ class SLPolicy(nn.Module, _NpzMixin):
             self.__dict__["_bwd_cache"] = hit
         return hit[1]
 
+    GRAD_CHUNK_ROWS = int(os.environ.get("IAGO_GRAD_CHUNK_ROWS", "8192"))   # 2.5 GB of scratch per chunk
+
     def reinforce_grads(self, own, opp, action, reward, n_mean=None, probs=None):
         """src/train_rl.py:61-65 on the matrix units in split-f16 arithmetic (iago_policy_reinforce_grad):
         cleargrads + loss.backward() for loss = mean(softmax_cross_entropy(self(x), action) * reward); every
-        parameter's .grad is overwritten.  own / opp: the recorded positions (own = the mover); action in 0 .. 63 (not
-        checked on the device).  Returns the loss (0-dim device tensor).  The first two f16 pieces of the search
+        parameter's .grad is overwritten.  own / opp: the recorded positions (own = the mover); action in 0 .. 63 (an
+        action outside raises bit 1 of the module's overflow word: ReinforceTrainer reads it before Adam).  Returns the loss (0-dim device tensor).  The first two f16 pieces of the search
         path's three-piece weights are the forward's.  The kernels' scratch (304 KB per row + 40 MB, kept between
         calls) is freed by ops.release_grad_workspace()."""
         from . import ops
@@ -205,11 +207,33 @@ class SLPolicy(nn.Module, _NpzMixin):
                      w=[c.weight.grad for c in convs], b=[c.bias.grad for c in convs],
                      w9=self.conv9.weight.grad, b10=self.bias10.b.grad)
         n = own.numel()
-        return ops.policy_reinforce_grad(own.contiguous(), opp.contiguous(), action.to(torch.int32).contiguous(),
-                                         reward.to(torch.float32).contiguous(), n if n_mean is None else n_mean,
-                                         self.block1.conv.weight.detach(), self.block1.conv.bias.detach(), layers,
-                                         self._bwd_layers(), self.conv9.weight.detach(), self.bias10.b.detach(), grads,
-                                         probs=probs, overflow=self._overflow_flag(own.device))
+        n_mean = n if n_mean is None else n_mean
+        own, opp = own.contiguous(), opp.contiguous()
+        action, reward = action.to(torch.int32).contiguous(), reward.to(torch.float32).contiguous()
+        layers_t = self._bwd_layers()
+
+        def rows(lo, hi):
+            return ops.policy_reinforce_grad(own[lo:hi], opp[lo:hi], action[lo:hi], reward[lo:hi], n_mean,
+                                             self.block1.conv.weight.detach(), self.block1.conv.bias.detach(), layers,
+                                             layers_t, self.conv9.weight.detach(), self.bias10.b.detach(), grads,
+                                             probs=None if probs is None else probs[lo:hi],
+                                             overflow=self._overflow_flag(own.device))
+        # The kernels' scratch is 304 KB per row: a PV-MCTS round of 1024 games (~61 k rows, both colours) would take
+        # 18 GB at once.  Larger batches run in chunks of GRAD_CHUNK_ROWS rows, every chunk dividing by the same
+        # n_mean, the chunks' gradients added in chunk order (deterministic); a batch within one chunk is one call.
+        chunk = self.GRAD_CHUNK_ROWS
+        if n <= chunk:
+            return rows(0, n)
+        total = [torch.zeros_like(p) for p in params]
+        loss = None
+        for lo in range(0, n, chunk):
+            part = rows(lo, min(n, lo + chunk))
+            loss = part if loss is None else loss + part
+            for t, p in zip(total, params):
+                t += p.grad
+        for t, p in zip(total, params):
+            p.grad.copy_(t)
+        return loss
 
     def _split3_template(self):
         """iago_policy_split3_args with this module's weights, rebuilt when they change."""

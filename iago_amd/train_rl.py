@@ -28,7 +28,7 @@ import torch
 import torch.nn.functional as F
 
 from . import dist as idist
-from . import engine, network, ops, rl_self_play
+from . import _lib, engine, network, ops, rl_self_play
 
 
 POOL_CACHE = 64   # opponent snapshots kept as ready modules (3.8 MB of parameters + 5.8 MB of weight pieces each)
@@ -253,11 +253,26 @@ class ReinforceTrainer(object):
     def _update(self, own, opp, actions, rewards):
         """src/train_rl.py:55-66 on a gathered batch: loss, backward, Adam step; every replica
         then takes rank 0's parameters (one collective)."""
-        if NATIVE_GRAD and isinstance(self.model1, network.SLPolicy) and own.is_cuda:
+        # (the split-f16 kernels clamp at the f16 range like the three-piece forward: a model set to `split3 = False`
+        # -- the documented remedy when activations leave that range -- takes float32 autograd here as well)
+        if (NATIVE_GRAD and isinstance(self.model1, network.SLPolicy) and getattr(self.model1, "split3", False)
+                and own.is_cuda):
             loss = self.model1.reinforce_grads(own, opp, actions, rewards)
+            # the forward's saturation word and the loss in ONE read-back, BEFORE Adam is applied and broadcast: the
+            # gradients of a clamped net (or of a row with an action outside 0 .. 63) must not reach the parameters
+            flag = self.model1._overflow_flag(own.device)
+            loss_v, bad = torch.stack([loss.to(torch.float64), flag[0].to(torch.float64)]).tolist()
+            if bad:
+                flag.zero_()
+                raise _lib.IagoError(
+                    "REINFORCE update: %s; no update was applied.  Set `model1.split3 = False` (float32 forward and "
+                    "autograd update) or IAGO_NATIVE_GRAD=0 (float32 autograd update only)"
+                    % ("an action lies outside 0 .. 63" if int(bad) & 2 else
+                       "an activation of the update's forward left the f16 range of the split kernels (|a| > 65000) "
+                       "or is NaN"))
             self.opt.update()
             idist.broadcast_tensors(list(self.model1.parameters()))  # replicas stay identical
-            return loss
+            return torch.tensor(loss_v, dtype=torch.float32)
         self.model1.train()
         for p in self.model1.parameters():
             p.grad = None

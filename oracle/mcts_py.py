@@ -71,9 +71,11 @@ class MCTS(object):
         self.lmbda, self.c_puct, self.n_thr = lmbda, c_puct, n_thr
         self.n_leaf_evals = 0
         self.n_policy_evals = 0
+        self.max_path = 0  # (test diagnostic: nodes on the deepest playout's path, the root included)
 
     def playout(self, state, color, node):  # MCTS.py:105-133 minus the broken node.copy()
         c = color
+        depth = 1
         while True:
             if node.is_leaf():
                 if node.n_visits >= self.n_thr:  # MCTS.py:109
@@ -97,10 +99,12 @@ class MCTS(object):
                     assert leaf_value == orc.leaf_value(self.lmbda, v, z)
                 node.update_recursive(leaf_value)  # MCTS.py:127
                 self.n_leaf_evals += 1
+                self.max_path = max(self.max_path, depth)
                 return leaf_value
             action, node = node.select(self.c_puct)  # MCTS.py:130
             state = orc.place_stone(state, action, c)  # MCTS.py:131 (-1 = pass: unchanged)
             c = 3 - c
+            depth += 1
 
     def get_move(self, state, color, n_sims):  # MCTS.py:139-147
         for _ in range(n_sims):

@@ -29,13 +29,14 @@ import torch
 from oracle import mcts_py
 from oracle import oracle as orc
 from tests.conftest import GOLDEN
+from tests.bench_batch_util import Probe as _Probe, rebuild as _rebuild
 
 pytestmark = pytest.mark.gpu
 
 START = (0x0000000810000000, 0x0000001008000000)
 
 
-def _engine(n_sims, max_turns, z_rows):
+def _engine(n_sims, max_turns, z_rows, n_thr=15):
     """bench.mcts_leg's engine, to the letter (nets, weights, seeds, capacity, defaults)."""
     from iago_amd import engine, network, ops
     g = json.load(open(os.path.join(GOLDEN, "simulate.json")))
@@ -44,21 +45,22 @@ def _engine(n_sims, max_turns, z_rows):
     policy = network.SLPolicy().cuda().eval()
     value = network.Value().cuda().eval()
     value.split_f16 = True
-    m = engine.BatchedMCTS(1024, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0, n_thr=15, seed=7,
+    m = engine.BatchedMCTS(1024, policy, value, ops.RolloutWeights(w, b), lmbda=0.5, c_puct=1.0, n_thr=n_thr, seed=7,
                            game_id_base=0, persistent=True, z_log_rows=z_rows,
-                           capacity=engine.suggest_capacity(n_sims, 15, moves=64 if max_turns > 64 else max_turns + 4))
+                           capacity=engine.suggest_capacity(n_sims, n_thr, moves=64 if max_turns > 64 else max_turns + 4))
     assert m.persistent and m.value_cache and m.games_per_workgroup == 32
     eng = engine.SelfPlayEngine(m, max_turns=max_turns)
     m.warmup()
     return engine, ops, policy, value, m, eng
 
 
-def _play(n_sims, max_turns, z_rows):
-    engine, ops, policy, value, m, eng = _engine(n_sims, max_turns, z_rows)
+def _play(n_sims, max_turns, z_rows, n_thr=15):
+    engine, ops, policy, value, m, eng = _engine(n_sims, max_turns, z_rows, n_thr)
     m._ps["totals"].zero_()
     res = eng.play(n_sims, record=True)
     assert getattr(eng, "n_replayed", 0) == 0        # the one-launch path, not the turn loop
-    out = dict(ops=ops, policy=policy, value=value, n_sims=n_sims, T=res.n_turns,
+    assert int(m.tree.overflow.sum().item()) == 0    # no pool filled up, no descent deeper than the path buffer
+    out = dict(ops=ops, policy=policy, value=value, n_sims=n_sims, n_thr=n_thr, T=res.n_turns, path_stride=m.PATH_STRIDE,
                own=ops.tensor_to_bits(res.own), opp=ops.tensor_to_bits(res.opp),
                valid=res.valid.cpu().numpy(), move=res.move.cpu().numpy(), pi=res.pi.cpu().numpy(),
                z=res.z.cpu().numpy(), game_turns=res.game_turns.cpu().numpy(),
@@ -78,6 +80,49 @@ def batch100():
 @pytest.fixture(scope="module")
 def batch400():
     return _play(400, 8, 8 * 400)
+
+
+@pytest.fixture(scope="module")
+def whole400():
+    """What bench.py's `mcts400` leg times: ONE launch of 1024 WHOLE games x 400 playouts per move."""
+    return _play(400, 128, 128 * 400)
+
+
+@pytest.fixture(scope="module")
+def whole_nthr1():
+    """What bench.py's `mcts_nthr1` leg times: ONE launch of 1024 whole games x 100 playouts at n_thr = 1."""
+    return _play(100, 128, 128 * 100, n_thr=1)
+
+
+def _rebuild_in_workers(B, jobs, tmp_path, n_workers=4):
+    """jobs: [(game, turns to rebuild, compare from turn)] spread over worker processes (tests/rebuild_worker.py: the
+    Python restatement of MCTS.py with the nets' outputs from the production kernels on one board, each worker its
+    own HIP context).  Returns (searches compared, {game: deepest path})."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for w in range(n_workers):
+        mine = jobs[w::n_workers]
+        if not mine:
+            continue
+        arrays = dict(n_sims=B["n_sims"], n_thr=B["n_thr"], games=np.array([j[0] for j in mine]),
+                      n_turns=np.array([j[1] for j in mine]), compare_from=np.array([j[2] for j in mine]))
+        for g, _, _ in mine:
+            arrays["pi_%d" % g], arrays["move_%d" % g] = B["pi"][:, g], B["move"][:, g]
+            arrays["zlog_%d" % g] = B["zlog"][:B["zn"][g], g]
+            arrays["game_turns_%d" % g] = B["game_turns"][g]
+        src, dst = os.path.join(str(tmp_path), "job%d.npz" % w), os.path.join(str(tmp_path), "job%d.json" % w)
+        np.savez(src, **arrays)
+        procs.append((subprocess.Popen([sys.executable, os.path.join(root, "tests", "rebuild_worker.py"), src, dst], cwd=root), dst))
+    n, depth = 0, {}
+    for p, dst in procs:
+        rc = p.wait(timeout=600)
+        out = json.load(open(dst))
+        assert rc == 0 and "error" not in out, out.get("error")
+        n += sum(out["compared"].values())
+        depth.update({int(g): d for g, d in out["max_path"].items()})
+    return n, depth
 
 
 def _replay_records(B, whole):
@@ -102,7 +147,7 @@ def _replay_records(B, whole):
                     assert np.all(row[[x for x in range(64) if x not in acts]] == 0), (g, t)
                     assert a == int(np.argmax(row)) and row[a] > 0, (g, t)      # first most-visited child (MCTS.py:147)
                     # the root was a leaf for its first visits, then every playout went to a child (MCTS.py:109)
-                    assert int(row.sum()) >= n_sims - 15, (g, t)   # (+ the visits the reused subtree brought)
+                    assert int(row.sum()) >= n_sims - B["n_thr"], (g, t)   # (+ the visits the reused subtree brought)
                     orc.place_stone(state, a, color)
                     stone_num += 1
                     pass_flg = False
@@ -124,73 +169,6 @@ def _replay_records(B, whole):
         else:
             assert B["game_turns"][g] == T, g
     return n_rec
-
-
-class _Probe(object):
-    """policy_fn / value_fn of the oracle: the production kernels on ONE board, memoised."""
-
-    def __init__(self, B):
-        self.ops, self.policy, self.value = B["ops"], B["policy"], B["value"]
-        self.p_cache, self.v_cache = {}, {}
-        self.idx = torch.zeros(1, dtype=torch.int64, device="cuda")
-        self.one = torch.ones(1, dtype=torch.int32, device="cuda")
-        self.out = torch.zeros(1, dtype=torch.float32, device="cuda")
-
-    def _boards(self, x):
-        x = np.asarray(x, np.float32).reshape(2, 64)
-        own = sum(1 << a for a in range(64) if x[1, a] == 1.0)   # channel 1 = side to move
-        opp = sum(1 << a for a in range(64) if x[0, a] == 1.0)
-        return (own, opp), self.ops.bits_to_tensor([own]), self.ops.bits_to_tensor([opp])
-
-    def policy_fn(self, x):
-        key, o, p = self._boards(x)
-        if key not in self.p_cache:
-            self.p_cache[key] = self.policy.forward_boards_split3(o, p).cpu().numpy().reshape(64).copy()
-        return self.p_cache[key]
-
-    def value_fn(self, x):
-        key, o, p = self._boards(x)
-        if key not in self.v_cache:
-            with torch.no_grad():
-                self.value.forward_boards_counted(o, p, self.idx, self.one, self.out)
-            self.v_cache[key] = np.float32(self.out.cpu().numpy()[0])
-        return self.v_cache[key]
-
-
-def _rebuild(B, probe, g, n_turns):
-    """(ii): game g's first n_turns turns searched again by the oracle's MCTS.py restatement: root visit counts by
-    action and moves equal the launch's records.  Returns the searches compared."""
-    n_sims = B["n_sims"]
-    it = iter(B["zlog"][:B["zn"][g], g])
-    om = mcts_py.MCTS(probe.policy_fn, probe.value_fn, lambda s, c: int(next(it)), lmbda=0.5, c_puct=1.0, n_thr=15)
-    state = orc.initial_state()
-    stone_num, pass_flg, t, n_cmp = 4, False, 0, 0
-    while stone_num < 64 and t < n_turns:
-        for color in (1, 2):
-            acts = orc.legal_actions(state, color)
-            if len(acts) > 0:
-                a = om.get_move(state, color, n_sims)
-                want = np.zeros(64, np.int64)
-                for act, ch in om.root.children.items():
-                    want[act] = ch.n_visits
-                assert B["pi"][t, g].tolist() == want.tolist(), (g, t)
-                assert int(B["move"][t, g]) == a, (g, t)
-                om.update_with_move(a)
-                orc.place_stone(state, a, color)
-                stone_num += 1
-                pass_flg = False
-                n_cmp += 1
-            else:
-                if pass_flg:
-                    stone_num = 64
-                pass_flg = True
-                om.update_with_move(-1)
-            t += 1
-            if t >= n_turns:
-                break
-    if n_turns >= B["game_turns"][g]:
-        assert next(it, None) is None, g      # the oracle consumed exactly the playouts the launch ran
-    return n_cmp
 
 
 def _audit_table(B, n_walk):
@@ -257,3 +235,34 @@ def test_config3_share_on_the_persistent_search(batch400):
     used, walked = _audit_table(B, 4096)
     assert used > 10_000 and walked == 4096
     assert B["leaf_evals"] == 1024 * 8 * 400
+
+
+def test_whole_games_at_400_playouts_through_the_oracle(whole400, tmp_path):
+    """VERDICT r05, hole (i): the launch the bench's `mcts400` leg times, whole games.  All records of the 1024 games
+    through the C oracle; 2 whole games and the LAST 6 searches of 8 more rebuilt by oracle/mcts_py.MCTS -- the endgame
+    of a 400-playout game is where the kernel's pass-chain rule lives (MCTS.py:109-117: under a finished game a pass
+    child under a pass child, one level every n_thr visits; the last turns descend through ~65 levels per playout) and
+    where the recorded path is longest: the oracle's own deepest path must fit the path buffer; the table audited."""
+    B = whole400
+    n = _replay_records(B, whole=True)
+    assert n > 1024 * 58 and B["leaf_evals"] == int(B["valid"].sum()) * 400
+    jobs = [(g, 128, 0) for g in (1, 640)]                                           # whole games, every search
+    jobs += [(g, 128, max(int(B["game_turns"][g]) - 8, 0)) for g in range(77, 1024, 128)]   # the last 6+ searches of 8 games
+    n_cmp, depth = _rebuild_in_workers(B, jobs, tmp_path)
+    assert n_cmp >= 2 * 55 + 8 * 6
+    assert len(depth) == 10 and 30 < max(depth.values()) < B["path_stride"], depth
+    print("deepest oracle path per rebuilt game:", depth)
+    used, walked = _audit_table(B, 2048)
+    assert used > 200_000 and walked == 2048
+
+
+def test_whole_games_at_n_thr_1_through_the_oracle(whole_nthr1, tmp_path):
+    """VERDICT r05, hole (ii): the launch the bench's `mcts_nthr1` leg times (n_thr = 1: every leaf expands at its
+    second visit, the policy net inside every playout; MCTS.py:80,109): records through the oracle, the first 4
+    searches of 8 games rebuilt."""
+    B = whole_nthr1
+    n = _replay_records(B, whole=True)
+    assert n > 1024 * 58 and B["leaf_evals"] == int(B["valid"].sum()) * 100
+    assert B["totals"][1] > 500_000                         # the policy net at (nearly) every playout
+    n_cmp, depth = _rebuild_in_workers(B, [(g, 4, 0) for g in range(9, 1024, 128)], tmp_path, n_workers=2)
+    assert n_cmp == 8 * 4

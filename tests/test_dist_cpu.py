@@ -136,3 +136,48 @@ def test_bench_refuses_thin_kernel_profiles(tmp_path, monkeypatch):
     os.remove(str(prof / "r98_mcts_fullgame_pmc_summary.json"))
     got = bench.net_kernel_profiles()
     assert got["profile"] == "r97_mcts_fullgame_pmc_summary.json" and got["current"] is True
+
+
+def _preflight_worker(rank, world, port, mode, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("IAGO_BENCH_DEVICE", None)
+    import time
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fd = os.open(os.path.join(out_dir, "rank%d.json" % rank), os.O_WRONLY | os.O_CREAT)
+    if mode == "absent" and rank == 1:
+        time.sleep(20)           # never enters the collective while rank 0 waits (its limit: 3 s)
+        os._exit(0)
+    uuid = "GPU-shared" if mode == "shared" else "GPU-%d" % rank
+    got = bench.preflight(dist, world, rank, 0, fd, timeout_s=3.0, uuid=uuid, on="cpu")
+    os.write(fd, (__import__("json").dumps(got) + "\n").encode())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ok", "shared", "absent"])
+def test_bench_preflight(mode, tmp_path):
+    """bench.py's check before an N > 1 run is timed: a 1-element all-reduce (sum of the ranks) and the ranks' device
+    uuids, polled under a time limit.  Two ranks on one device, or a rank that never joins the collective, end the
+    run with ONE JSON line carrying "error" on rank 0's stdout and a non-zero exit -- no hang."""
+    import json
+    world = 2
+    port = 29000 + (os.getpid() + 13 + {"ok": 0, "shared": 1, "absent": 2}[mode]) % 2000
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_preflight_worker, args=(r, world, port, mode, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    procs[0].join(timeout=120)
+    assert procs[0].exitcode is not None
+    line = json.loads(open(os.path.join(str(tmp_path), "rank0.json")).read().strip().splitlines()[-1])
+    if mode == "ok":
+        procs[1].join(timeout=60)
+        assert procs[0].exitcode == 0 and procs[1].exitcode == 0
+        assert line["allreduce_sum_of_ranks"] == 1 and line["distinct_devices"] == 2 and line["device_check"] == "ok"
+    else:
+        assert procs[0].exitcode == 3 and "error" in line
+        assert ("share a device" in line["error"]) if mode == "shared" else ("did not complete" in line["error"])
+        if mode == "absent":
+            procs[1].kill()          # (this very process object: not a pattern)
+        procs[1].join(timeout=60)

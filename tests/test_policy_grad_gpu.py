@@ -211,3 +211,68 @@ def test_bad_arguments_are_refused():
     assert L.iago_split_scaled(None, None, None, None, None, 4, 24, None, None, None) == -1
     ad = _lib.AdamArgs()
     assert L.iago_adam_chainer(C.byref(ad), None) == -1                  # no tensors
+
+
+def test_rows_in_chunks_give_the_one_call_gradients(monkeypatch):
+    """Batches beyond GRAD_CHUNK_ROWS rows run in chunks (the kernels' scratch is 304 KB per row), every chunk dividing
+    by the whole batch's row count, the chunks' gradients added in chunk order: the one-call gradients within float32
+    rounding of the sums, the same bits from run to run."""
+    from iago_amd import network
+    own, opp, act, z = _rows(700, seed=11)
+    torch.manual_seed(3)
+    model = network.SLPolicy().cuda()
+    loss1 = model.reinforce_grads(own, opp, act, z)
+    one = {k: p.grad.clone() for k, p in model.named_parameters()}
+    monkeypatch.setattr(network.SLPolicy, "GRAD_CHUNK_ROWS", 256)
+    probs = torch.empty(700, 64, device="cuda")
+    loss3 = model.reinforce_grads(own, opp, act, z, probs=probs)
+    three = {k: p.grad.clone() for k, p in model.named_parameters()}
+    loss3b = model.reinforce_grads(own, opp, act, z)
+    assert abs(float(loss1) - float(loss3)) <= 1e-6 * max(1.0, abs(float(loss1)))
+    for k in one:
+        assert rel_err(three[k], one[k]) < 2e-6, (k, rel_err(three[k], one[k]))
+        assert torch.equal(three[k], dict(model.named_parameters())[k].grad), k      # deterministic
+    assert float(loss3) == float(loss3b)
+    assert float((probs.sum(dim=1) - 1).abs().max()) < 1e-5                           # every chunk wrote its rows
+
+
+def test_an_action_outside_the_board_raises_the_flag_and_the_trainer_applies_nothing(tmp_path):
+    """F.softmax_cross_entropy raises on a label outside 0 .. 63 (src/train_rl.py:62); the head kernel raises bit 1
+    of the module's overflow word, and ReinforceTrainer reads the word BEFORE Adam: no update, no broadcast."""
+    from iago_amd import network, _lib
+    from iago_amd.train_rl import ReinforceTrainer
+    own, opp, act, z = _rows(40, seed=2)
+    torch.manual_seed(4)
+    model = network.SLPolicy().cuda()
+    model.reinforce_grads(own, opp, act, z)
+    assert int(model._overflow_flag(own.device).item()) == 0
+    bad = act.clone()
+    bad[7] = -1                                   # a pass, as rl_self_play records it
+    model.reinforce_grads(own, opp, bad, z)
+    assert int(model._overflow_flag(own.device).item()) & 2
+    model._overflow_flag(own.device).zero_()
+    tr = ReinforceTrainer(model, pool_dir=str(tmp_path), N=2, seed=1)
+    before = {k: v.copy() for k, v in model.npz_dict().items()}
+    with pytest.raises(_lib.IagoError, match="outside 0 .. 63"):
+        tr._update(own, opp, bad, z)
+    after = model.npz_dict()
+    assert all(np.array_equal(before[k], after[k]) for k in before) and tr.opt.t == 0
+    assert int(model._overflow_flag(own.device).item()) == 0          # cleared with the error
+    tr._update(own, opp, act, z)                                       # the next good batch goes through
+    assert tr.opt.t == 1
+
+
+def test_a_float32_model_takes_the_autograd_update(tmp_path, monkeypatch):
+    """`split3 = False` is the documented remedy when activations leave the f16 range: the update then runs through
+    float32 autograd as well, not through the split-f16 kernels."""
+    from iago_amd import network
+    from iago_amd.train_rl import ReinforceTrainer
+    own, opp, act, z = _rows(40, seed=6)
+    torch.manual_seed(8)
+    model = network.SLPolicy().cuda()
+    model.split3 = False
+    called = []
+    monkeypatch.setattr(network.SLPolicy, "reinforce_grads", lambda self, *a, **k: called.append(1))
+    tr = ReinforceTrainer(model, pool_dir=str(tmp_path), N=2, seed=1)
+    loss = tr._update(own, opp, act, z)
+    assert not called and np.isfinite(float(loss.item())) and tr.opt.t == 1
