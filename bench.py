@@ -228,6 +228,9 @@ def mcts_leg(n_games, n_sims, n_turns, full_games, world, rank, dist, value_f32=
            "persistent": ({"net_workgroups": getattr(m, "net_workgroups_launched", m.net_workgroups),
                            "game_workgroups": -(-n_games // m.games_per_workgroup),
                            "resident_workgroups_of_the_device": m.resident_workgroups,
+                           # (0: ONE launch, every workgroup a CU of its own; else the role split: the game workgroups as a
+                           # launch of their own, two per CU on this many CUs, the net workgroups on all the others)
+                           "role_split_game_cus": int(getattr(m, "split_cus", 0)),
                            "totals": totals,
                            "totals_legend": "[0] value evaluations on a game's critical path, [1] policy evaluations, [2] "
                                             "game-workgroup iterations, [3] pair walks, [4] / [5] net workgroups' waiting / "
@@ -810,7 +813,32 @@ def reinforce_leg(n_iters, world, rank, dist, mcts_rounds=1):
                              ("tuned (find-db)" if update_ms < 20.0 else "immediate-mode fallback"),
            "miopen_find_db": db_before,
            "config": "64 policy-vs-policy games per set (SLPolicy, random init, fp32) + "
-                     "double-softmax REINFORCE update, ChainerAdam + WD 5e-4"}
+                     "double-softmax REINFORCE update, ChainerAdam + WD 5e-4",
+           "scaling_note": "the reference-sized set is a latency chain (60 sequential one-board policy walks per game): "
+                           "sharding its 64 games over N GPUs does not shorten it; with N > 1 see weak_scaling_set"}
+    if world > 1:
+        # The reference-sized set cannot speed up with N: its 64 games are 60 sequential one-board policy walks each
+        # (a latency chain of ~6 ms on as many CUs as there are games), sharded they take the same 6 ms on every GPU.
+        # The form that scales (SURVEY 8d-5 allows "64+ games"): 64 games PER RANK, one update on the gathered
+        # 64 x N games' rows (src/train_rl.py:41-66 with N = 32 x world).
+        torch.manual_seed(0)
+        tw = ReinforceTrainer(network.SLPolicy(), pool_dir=None, N=32 * world, seed=rank)
+        for _ in range(min(2, n_iters)):
+            tw.step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        tw.gather_seconds, n_t = 0.0, 0
+        for _ in range(n_iters):
+            n_t += tw.step()["n_tuples"]
+        torch.cuda.synchronize()
+        dist.barrier()
+        dtw = time.perf_counter() - t0
+        out["weak_scaling_set"] = {"games_per_set": 64 * world, "games_per_rank": 64, "sets_per_sec": n_iters / dtw,
+                                   "games_per_sec": 64 * world * n_iters / dtw, "tuples_per_iter": n_t / n_iters,
+                                   "ms_per_iter": dtw / n_iters * 1e3, "gather_ms": tw.gather_seconds / n_iters * 1e3,
+                                   "config": "64 policy-vs-policy games per RANK per set, the set's rows all-gathered, one "
+                                             "double-softmax REINFORCE update on all of them on every rank"}
     if mcts_rounds > 0:
         w, b = shipped_rollout_weights()
         games, sims = 64, 20
@@ -1480,10 +1508,13 @@ def main():
                                    "kernel_ms": kr2.get("kernel_ms"), "frac": kr2.get("frac"),
                                    "executed_frac": kr2.get("executed_frac"),
                                    "game_workgroups": (r.get("persistent") or {}).get("game_workgroups"),
+                                   "role_split_game_cus": (r.get("persistent") or {}).get("role_split_game_cus"),
                                    "net_workgroups": (r.get("persistent") or {}).get("net_workgroups"),
                                    "batches_replayed_turn_by_turn": r.get("batches_replayed_turn_by_turn")}
         saturated["note"] = ("one batch each, whole games, same nets and constants as the headline; the headline's 1024 games per "
-                             "launch is BASELINE configs[2]'s batch")
+                             "launch is BASELINE configs[2]'s batch.  Beyond 32 game workgroups the engine splits the search by "
+                             "role (role_split_game_cus: two game workgroups per CU on that many CUs, one net workgroup on each "
+                             "of the others)")
     train = None
     if args.train_iters > 0 and not args.mcts_only:
         log("configs[4] in miniature: REINFORCE sets")
@@ -1576,6 +1607,8 @@ def main():
         if train is not None:
             line["reinforce"] = train
             line["reinforce_iters_per_sec"] = train["iters_per_sec"]
+            if "weak_scaling_set" in train:
+                line["reinforce_weak_games_per_sec"] = train["weak_scaling_set"]["games_per_sec"]
             line["reinforce_miopen_find_db"] = train["miopen_find_db"]
             line["reinforce_update_ms"] = train["update_ms"]
             line["reinforce_miopen_solvers"] = train["miopen_solvers"]

@@ -26,7 +26,8 @@ SYMBOLS = [
     "iago_policy_forward_split3", "iago_value_forward_split", "iago_value_rollout",
     "iago_mcts_reset", "iago_leaf_values", "iago_mcts_best_move", "iago_mcts_advance_root", "iago_mcts_compact",
     "iago_mcts_mix_backup_lookahead", "iago_mcts_store_priors", "iago_mcts_descend",
-    "iago_mcts_search_persistent", "iago_mcts_search_capacity", "iago_selfplay_policy",
+    "iago_mcts_search_persistent", "iago_mcts_search_capacity", "iago_mcts_search_streams_create",
+    "iago_mcts_search_streams_destroy", "iago_mcts_search_split", "iago_selfplay_policy",
     "iago_policy_grad_workspace_bytes", "iago_policy_reinforce_grad", "iago_adam_chainer",
 ]
 # include/iago_hip_layers.h: single blocks, the ends of the nets, format conversions, a block's three gradient kernels
@@ -39,13 +40,11 @@ LAYER_SYMBOLS = [
 ]
 # include/iago_hip_experimental.h, outside the boundary: two schedules of the per-playout engine that measured slower
 # (game-asynchronous steps, value look-ahead: engine.BatchedMCTS(async_steps=True / value_ahead=True)); the per-phase forms
-# of a playout (arbitrary callables as nets, the IAGO_FUSED_* = 0 knobs); the persistent search split by role
-# (IAGO_SEARCH_SPLIT / BatchedMCTS(split=...): measured no faster)
+# of a playout (arbitrary callables as nets, the IAGO_FUSED_* = 0 knobs)
 EXPERIMENTAL_SYMBOLS = [
     "iago_value_rollout_async", "iago_value_forward_batch", "iago_mcts_value_ahead_rows", "iago_mcts_value_ahead_store",
     "iago_mcts_select", "iago_mcts_expand", "iago_mcts_pending", "iago_mcts_backup", "iago_mcts_mix_backup",
     "iago_mcts_expand_cached", "iago_mcts_fresh_leaves",
-    "iago_mcts_search_streams_create", "iago_mcts_search_streams_destroy", "iago_mcts_search_split",
 ]
 
 
@@ -305,6 +304,7 @@ def lib():
     L.iago_selfplay_policy.argtypes = [C.POINTER(SelfplayPolicyArgs), vp]
     for name in SYMBOLS[3:] + LAYER_SYMBOLS + EXPERIMENTAL_SYMBOLS:
         getattr(L, name).restype = C.c_int
+    L.iago_policy_grad_workspace_bytes.restype = i64   # (bytes: beyond 2^31 from ~7,000 rows on)
     _lib = L
     return L
 

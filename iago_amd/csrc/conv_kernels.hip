@@ -328,24 +328,41 @@ __device__ __forceinline__ void conv_layer(const ConvParams &P)
         __syncthreads();
         float big = 0.0f;
         const int per_board = P.out_blocks * 256; // 16-byte pieces of 4 channels
-        for (int e = tid; e < TB * per_board; e += THREADS) {
-            const int board = e / per_board, f = e - board * per_board;
-            const int cb = f >> 8, cell = (f >> 2) & 63, qt = f & 3;
-            const int64_t b = b0 + board;
-            if (b < P.n) {
-                f32x4 v4 = *(const f32x4 *)(lds + (board * 64 + cell) * T_ROW32 + (cb * 16 + qt * 4) * 4);
-                const int64_t at = b * per_board + f;
-                const uint2 mh = P.mask_hi[at], ml = P.mask_lo[at];
-                const __half2 *h2 = (const __half2 *)&mh, *l2 = (const __half2 *)&ml;
+        // (eight pieces per thread at a time, their sixteen mask loads in flight together: one piece after the other --
+        // a loop whose bound the compiler does not know -- every piece waited for its own two loads, 32 dependent round
+        // trips per thread: the 36 us this kernel took longer than the forward form; LABNOTES.md, round 6)
+        constexpr int EU = 8;
+        for (int e0 = tid; e0 < TB * per_board; e0 += THREADS * EU) {
+            uint2 mh[EU], ml[EU];
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const float xh = __half2float(t & 1 ? h2[t >> 1].y : h2[t >> 1].x);
-                    const float xl = __half2float(t & 1 ? l2[t >> 1].y : l2[t >> 1].x);
-                    if (!(xh + xl * (1.0f / 2048.0f) > 0.0f)) // the ReLU of the block below was off (network.py:13)
-                        v4[t] = 0.0f;
-                    big = fmaxf(big, fabsf(v4[t]));
+            for (int u = 0; u < EU; u++) {
+                const int e = e0 + u * THREADS;
+                const int board = e / per_board, f = e - board * per_board;
+                const bool ok = e < TB * per_board && b0 + board < P.n;
+                const int64_t at = ok ? (b0 + board) * per_board + f : 0;
+                mh[u] = P.mask_hi[at];
+                ml[u] = P.mask_lo[at];
+            }
+#pragma unroll
+            for (int u = 0; u < EU; u++) {
+                const int e = e0 + u * THREADS;
+                const int board = e / per_board, f = e - board * per_board;
+                const int cb = f >> 8, cell = (f >> 2) & 63, qt = f & 3;
+                const int64_t b = b0 + board;
+                if (e < TB * per_board && b < P.n) {
+                    f32x4 v4 = *(const f32x4 *)(lds + (board * 64 + cell) * T_ROW32 + (cb * 16 + qt * 4) * 4);
+                    const int64_t at = b * per_board + f;
+                    const __half2 *h2 = (const __half2 *)&mh[u], *l2 = (const __half2 *)&ml[u];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const float xh = __half2float(t & 1 ? h2[t >> 1].y : h2[t >> 1].x);
+                        const float xl = __half2float(t & 1 ? l2[t >> 1].y : l2[t >> 1].x);
+                        if (!(xh + xl * (1.0f / 2048.0f) > 0.0f)) // the ReLU of the block below was off (network.py:13)
+                            v4[t] = 0.0f;
+                        big = fmaxf(big, fabsf(v4[t]));
+                    }
+                    P.y_f32[at] = v4;
                 }
-                P.y_f32[at] = v4;
             }
         }
 #pragma unroll

@@ -125,17 +125,17 @@ __device__ __forceinline__ void policy_item(const PolicyParams &P, const int64_t
             _Float16 p0[8], p1[8], p2[8];
 #pragma unroll
             for (int k = 0; k < 8; k += 2) {
+                // two output channels per packed FMA (a lone wave pays per instruction, not per lane-operation): each
+                // channel's chain of 18 fused multiply-adds in the same order as one by one
+                const float *wa = w1s + (co0 + k) * 18, *wb = wa + 18; // [co][ci][ky][kx]
+                f2 acc = (f2){w1s[64 * 18 + co0 + k], w1s[64 * 18 + co0 + k + 1]};
+#pragma unroll
+                for (int j = 0; j < 18; j++)
+                    acc = __builtin_elementwise_fma((f2){wa[j], wb[j]}, (f2){in[j], in[j]}, acc);
+                saturated |= !(acc.x <= 65000.0f) || !(acc.y <= 65000.0f);
                 f2 v;
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float *wk = w1s + (co0 + k + e) * 18; // [co][ci][ky][kx]
-                    float acc = w1s[64 * 18 + co0 + k + e];
-#pragma unroll
-                    for (int j = 0; j < 18; j++)
-                        acc = fmaf(wk[j], in[j], acc);
-                    saturated |= !(acc <= 65000.0f);
-                    v[e] = fminf(fmaxf(acc, 0.0f), 65000.0f);
-                }
+                v.x = fminf(fmaxf(acc.x, 0.0f), 65000.0f);
+                v.y = fminf(fmaxf(acc.y, 0.0f), 65000.0f);
                 h2 a0, a1, a2;
                 split3(v, a0, a1, a2);
                 p0[k] = a0.x, p0[k + 1] = a0.y;

@@ -204,12 +204,32 @@ __device__ __forceinline__ void trunk_item(const TrunkRParams &P, const Piece &W
 #pragma unroll
                 for (int j = 0; j < 18; j++)
                     wreg[j] = wk[j];
+                // boards in pairs per packed FMA (a lone wave pays per instruction, not per lane-operation): each board's
+                // chain of 18 fused multiply-adds in the same order as one by one
+                float accs[TB];
+                if constexpr (TB % 2 == 0) {
+#pragma unroll
+                    for (int bp = 0; bp < TB; bp += 2) {
+                        f2 acc = (f2){bk, bk};
+#pragma unroll
+                        for (int j = 0; j < 18; j++)
+                            acc = __builtin_elementwise_fma((f2){wreg[j], wreg[j]}, (f2){in[bp][j], in[bp + 1][j]}, acc);
+                        accs[bp] = acc.x;
+                        accs[bp + 1] = acc.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int board = 0; board < TB; board++) {
+                        float acc = bk;
+#pragma unroll
+                        for (int j = 0; j < 18; j++)
+                            acc = fmaf(wreg[j], in[board][j], acc);
+                        accs[board] = acc;
+                    }
+                }
 #pragma unroll
                 for (int board = 0; board < TB; board++) {
-                    float acc = bk;
-#pragma unroll
-                    for (int j = 0; j < 18; j++)
-                        acc = fmaf(wreg[j], in[board][j], acc);
+                    const float acc = accs[board];
                     saturated |= !(acc <= 65000.0f);
                     const float v = fminf(fmaxf(acc, 0.0f), 65000.0f);
                     const _Float16 vh = (_Float16)v;

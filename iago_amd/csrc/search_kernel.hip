@@ -313,8 +313,11 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
     bool may_expand = false, leaf_fresh = false;
     float v_reply = 0.0f;
     int st_levels = 0, st_children = 0;
-    long long iters = 0, idle_iters = 0;
-    long long roll_hist[4] = {0, 0, 0, 0}; // iterations with 0 / 1..16 / 17..20 / more games rolled out
+    // (diagnostic counters of the workgroup, kept by thread 0 in LDS: as per-thread 64-bit registers they were 12 VGPRs
+    // live across the whole loop -- what the game launch of the role split spilled to scratch memory)
+    __shared__ uint32_t wg_count[6]; // [0] iterations, [1] idle iterations, [2..5] iterations with 0 / 1..16 / 17..20 / more games rolled out
+    if (tid < 6)
+        wg_count[tid] = 0u;
     __shared__ int32_t roll_list[GAMES_PER_WG]; // games whose leaf is rolled out in this iteration, packed
     __shared__ uint32_t roll_wave[BLOCK / 64], roll_wave_old[BLOCK / 64];
     bool deferred = false; // this game's rollout was put off to the next iteration's first pass
@@ -775,7 +778,8 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             deferred = rolls && !now;
             rolled = !rolls || now;
             __syncthreads();
-            roll_hist[n_roll == 0 ? 0 : n_roll <= 16 ? 1 : n_roll <= 20 ? 2 : 3]++; // (diagnostic: totals[10], [13..15])
+            if (tid == 0)
+                wg_count[2 + (n_roll == 0 ? 0 : n_roll <= 16 ? 1 : n_roll <= 20 ? 2 : 3)]++; // (diagnostic: totals[10], [13..15])
 #pragma unroll 1
             for (int at = 0; at < n_now; at += 16) {
                 iago_row::rollout_row_body<false, true, true>(R, 0u, roll_list + at, table_ready, &hand);
@@ -796,14 +800,16 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                 state = ST_WAIT_VALUE;
             }
         }
-        if (S.trace && blockIdx.x == 0 && tid == 0 && iters < S.trace_rows - T.n_games) {
+        if (S.trace && blockIdx.x == 0 && tid == 0 && (int64_t)wg_count[0] < S.trace_rows - T.n_games) {
+            const int64_t iters = (int64_t)wg_count[0];
             S.trace[4 * iters + 0] = wall_clock64() - t0;
             S.trace[4 * iters + 1] = __hip_atomic_load(&S.ctl[ctl_tail(0)], RLX_AGENT) + __hip_atomic_load(&S.ctl[ctl_tail(1)], RLX_AGENT);
             S.trace[4 * iters + 2] = __hip_atomic_load(&S.ctl[ctl_head(0)], RLX_AGENT) + __hip_atomic_load(&S.ctl[ctl_head(1)], RLX_AGENT);
             S.trace[4 * iters + 3] = (int64_t)__hip_atomic_load(&S.ctl[CTL_FINISHED], RLX_AGENT) |
                                      (__hip_atomic_load(&S.totals[9], RLX_AGENT) << 8);
         }
-        iters++;
+        if (tid == 0)
+            wg_count[0]++;
         if (mine && r == 0u) {
             const int prog = state == ST_DONE ? 0 : turn * S.n_sims + n_done;
             if (prog != contrib)
@@ -842,7 +848,8 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
         if (all_done || stop)
             break;
         if (!__syncthreads_or(busy)) {
-            idle_iters++;
+            if (tid == 0)
+                wg_count[1]++;
             __builtin_amdgcn_s_sleep(32); // every game waits for a reply: poll again in ~1 us
         }
     }
@@ -851,12 +858,12 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
         S.stats[2 * g + 1] += st_children;
     }
     if (tid == 0) {
-        atomicAdd((unsigned long long *)&S.totals[2], (unsigned long long)iters);
-        atomicAdd((unsigned long long *)&S.totals[6], (unsigned long long)idle_iters);
-        atomicAdd((unsigned long long *)&S.totals[10], (unsigned long long)roll_hist[0]);
-        atomicAdd((unsigned long long *)&S.totals[13], (unsigned long long)roll_hist[1]);
-        atomicAdd((unsigned long long *)&S.totals[14], (unsigned long long)roll_hist[2]);
-        atomicAdd((unsigned long long *)&S.totals[15], (unsigned long long)roll_hist[3]);
+        atomicAdd((unsigned long long *)&S.totals[2], (unsigned long long)wg_count[0]);
+        atomicAdd((unsigned long long *)&S.totals[6], (unsigned long long)wg_count[1]);
+        atomicAdd((unsigned long long *)&S.totals[10], (unsigned long long)wg_count[2]);
+        atomicAdd((unsigned long long *)&S.totals[13], (unsigned long long)wg_count[3]);
+        atomicAdd((unsigned long long *)&S.totals[14], (unsigned long long)wg_count[4]);
+        atomicAdd((unsigned long long *)&S.totals[15], (unsigned long long)wg_count[5]);
         atomicAdd((unsigned long long *)&S.totals[7], (unsigned long long)(wall_clock64() - t0));
         __hip_atomic_fetch_add(&S.ctl[CTL_FINISHED], 1u, RLX_AGENT);
     }
@@ -1097,7 +1104,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // many CUs are free).  Each role is compiled for its own register budget: the game workgroups (VALU and latency: lone
 // waves) as a kernel of at most 256 registers, TWO workgroups per CU, so that a wave's waits are another wave's issue
 // slots; the net workgroups without the game code in their allocation.  Same device functions, same protocol, same
-// trees; the single launch above stays the form for streams that cannot be masked.
+// trees.  What it buys is CUs: in the single launch every game workgroup holds a CU alone (512 registers per lane), so
+// beyond 32 game workgroups each one is a net workgroup less -- 2048 games: 64 + 192 workgroups, 17.1 M leaf-evals/s;
+// split: 64 game workgroups on 32 CUs + 224 net workgroups, 18.3 M; 4096 games 10.8 -> 15.1 M; at 1024 games (32 + 224
+// either way) the two forms measure the same and the single launch stays (LABNOTES.md, round 6).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void search_game_kernel(SearchParams S,
                                                                                                    iago_row::HwParams R)
 {
@@ -1117,6 +1127,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 namespace {
 constexpr int search_lds() { return SEARCH_IMG_TOP + iago_trunk::W1_LDS + iago_policy::W1_LDS + iago_trunk::HEAD_W_LDS + 192 * 4; }
+
+// (iago_mcts_search_streams_create: one launch per masked stream of a kernel that needs more scratch memory per lane than
+// the game launch does, so that the runtime sizes the streams' scratch ONCE, before any launch that another launch waits
+// for: a stream's first dispatch with a private segment is held until the host has allocated it)
+__global__ void search_scratch_warm_kernel(uint32_t *out, int n)
+{
+    volatile uint32_t a[64];
+    for (int i = 0; i < 64; i++)
+        a[i] = (uint32_t)(i * n) + threadIdx.x;
+    uint32_t sum = 0;
+    for (int i = 0; i < 64; i++)
+        sum += a[(i * 7 + n) & 63];
+    if (n == 0x7fffffff && out)
+        out[0] = sum;
+}
 } // namespace
 
 extern "C" int iago_mcts_search_capacity(int32_t *cus, int32_t *workgroups_per_cu)
@@ -1412,6 +1437,12 @@ extern "C" int iago_mcts_search_streams_create(int32_t game_cus, iago_search_str
     ok = ok && hipEventCreateWithFlags(&sp->ready, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&sp->game_done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&sp->net_done, hipEventDisableTiming) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(search_scratch_warm_kernel, dim3(1), dim3(64), 0, sp->game, (uint32_t *)nullptr, 1);
+        hipLaunchKernelGGL(search_scratch_warm_kernel, dim3(1), dim3(64), 0, sp->net, (uint32_t *)nullptr, 1);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(sp->game) == hipSuccess &&
+             hipStreamSynchronize(sp->net) == hipSuccess;
+    }
     if (!ok) {
         (void)hipGetLastError();
         iago_mcts_search_streams_destroy(sp);

@@ -259,16 +259,23 @@ class BatchedMCTS(object):
         n_gw = -(-n_games // self.games_per_workgroup)
         # Role split (iago_mcts_search_split): the game workgroups as a launch of their own, two per CU on `split` CUs
         # (a multiple of 8), the net workgroups on all the others -- two CU-masked streams, co-resident by construction.
-        # Same trees.  split=None / IAGO_SEARCH_SPLIT: game CUs, 0 = the single launch.  Not with max_cus (the split
-        # owns the device); a runtime without CU-masked streams falls back to the single launch.
-        want_split = int(split if split is not None else os.environ.get("IAGO_SEARCH_SPLIT", "0"))
+        # Same trees.  Default ("auto"): wherever the games need more than 32 workgroups -- in the single launch every
+        # game workgroup holds a CU alone, so beyond 32 of them each one is a net workgroup less; two per CU give the CUs
+        # back (1536 / 2048 / 4096 games: 17.4 -> 17.9, 17.1 -> 18.3, 10.8 -> 15.1 M leaf-evals/s; 1024 games: no
+        # difference, the single launch stays; LABNOTES.md, round 6).  split / IAGO_SEARCH_SPLIT: game CUs, 0 = always the single
+        # launch.  Not with max_cus (the split owns the device); a runtime without CU-masked streams falls back to
+        # the single launch.
+        want = split if split is not None else os.environ.get("IAGO_SEARCH_SPLIT", "auto")
+        if want == "auto":
+            # (32-game workgroups only: the smaller workgroups of batches up to 960 games measure slower two per CU --
+            # 640 / 768 / 896 games at 16 per workgroup: 14.9 / 16.3 / 16.6 M single, 13.5 / 15.1 / 16.3 M split)
+            want_split = (8 * (-(-n_gw // 16)) if (n_gw > 32 and self.games_per_workgroup == _lib.SEARCH_GAMES_PER_WORKGROUP)
+                          else 0)                                     # (two game workgroups per CU)
+        else:
+            want_split = int(want)
         self.split_cus, self._split = 0, None
-        if want_split > 0 and self.max_cus <= 0 and self.resident_workgroups > 0:
-            while 2 * want_split < n_gw:                    # (two game workgroups per CU)
-                want_split += 8
-            if want_split % 8 == 0 and want_split <= self.resident_workgroups // 2:
-                self._split = _search_streams(want_split)
-                self.split_cus = want_split if self._split else 0
+        while want_split > 0 and 2 * want_split < n_gw:
+            want_split += 8
         can_p = (self.resident_workgroups > 0 and 2 * n_gw <= self.resident_workgroups
                  and can_cache and getattr(value_fn, "search_args", None) is not None
                  and getattr(policy_fn, "search_args", None) is not None and getattr(policy_fn, "split3", False)
@@ -290,6 +297,10 @@ class BatchedMCTS(object):
         if self.persistent:
             if not self.value_cache:
                 raise ValueError("persistent needs the value cache")
+            if (want_split > 0 and want_split % 8 == 0 and self.max_cus <= 0
+                    and want_split <= self.resident_workgroups // 2):
+                self._split = _search_streams(want_split)     # (None: no CU-masked streams here -> the single launch)
+                self.split_cus = want_split if self._split else 0
             lookahead, async_steps, value_ahead, use_graph = 0, False, False, False
             self.use_graph = False
         can = (self.sync_free and getattr(policy_fn, "forward_counted_boards", None) is not None)

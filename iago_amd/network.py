@@ -183,7 +183,7 @@ class SLPolicy(nn.Module, _NpzMixin):
             self.__dict__["_bwd_cache"] = hit
         return hit[1]
 
-    GRAD_CHUNK_ROWS = int(os.environ.get("IAGO_GRAD_CHUNK_ROWS", "8192"))   # 2.5 GB of scratch per chunk
+    GRAD_CHUNK_ROWS = int(os.environ.get("IAGO_GRAD_CHUNK_ROWS", "4096"))   # 1.25 GB of scratch per chunk
 
     def reinforce_grads(self, own, opp, action, reward, n_mean=None, probs=None):
         """src/train_rl.py:61-65 on the matrix units in split-f16 arithmetic (iago_policy_reinforce_grad):

@@ -22,6 +22,7 @@ import collections
 import glob
 import math
 import os
+import time
 
 import numpy as np
 import torch
@@ -177,6 +178,7 @@ class ReinforceTrainer(object):
         self.rs = np.random.RandomState(seed)
         self.models, self.cnt, self.set_index = 1, 0, 0
         self.log = []
+        self.gather_seconds = 0.0   # time spent in the all-gathers of the sets' tuples so far (N > 1)
         self.sync_replicas()
 
     @classmethod
@@ -246,9 +248,12 @@ class ReinforceTrainer(object):
         # playing all 2N games records (turn-major), whatever the number of ranks -- the update then
         # sums the same rows in the same order
         cols["key"] = (at // B) * n_total + (lo + at % B)
+        t0 = time.perf_counter()
         tup = _canonical(idist.gather_tuples(cols))
         wins = idist.gather_tuples(dict(win=(r["z"] == 1).to(torch.int8)))["win"]
-        return tup, int(wins.sum().item())
+        n_win = int(wins.sum().item())                   # (a read-back: the gathers have completed)
+        self.gather_seconds += time.perf_counter() - t0  # (bench.py: `gather_ms` of the weak-scaling set)
+        return tup, n_win
 
     def _update(self, own, opp, actions, rewards):
         """src/train_rl.py:55-66 on a gathered batch: loss, backward, Adam step; every replica

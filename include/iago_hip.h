@@ -1,27 +1,20 @@
 /*
- * iago_hip.h -- C ABI of the MI355X (gfx950) Othello self-play hot path.
- *
- * This is the drop-in boundary for the hot path of shionhonda/IaGo (board
- * rules, plane encoding, leaf rollout, PV-MCTS tree arithmetic).  The
- * reference has no FFI layer: the path is in-process Python method calls on
- * ONE (8,8) float32 board.  Each entry point below is the batched restatement
- * of one of those methods and cites the reference interface it replaces
- * (file:line in the reference repository).  INTEGRATION.md shows the ctypes
- * stubs a maintainer of the reference would add.
+ * iago_hip.h -- C ABI of the MI355X (gfx950) Othello self-play hot path: the drop-in boundary for the hot path of
+ * shionhonda/IaGo (board rules, plane encoding, leaf rollout, the nets, PV-MCTS, the self-play drivers, the REINFORCE
+ * update).  The reference has no FFI layer: the path is in-process Python method calls on ONE (8,8) float32 board.  Each
+ * entry point below is the batched restatement of one of those methods and cites the reference interface it replaces
+ * (file:line in the reference repository); INTEGRATION.md shows the ctypes stubs a maintainer of the reference would add.
+ * Sibling headers of the same library: iago_hip_layers.h (single layers of the nets, format conversions),
+ * iago_hip_experimental.h (superseded and measured-slower forms, outside the boundary).
  *
  * Conventions
- *   - Boards are bitboards: one 64-bit word per colour, bit a = row*8 + col
- *     (the reference's action index, game.py:184).  `own` holds the stones of
- *     the side to move, `opp` the other side's.
- *   - Every pointer is a CALLER-OWNED DEVICE pointer (hipMalloc / a torch
- *     tensor's data_ptr()) unless the parameter is documented as host memory.
- *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.
- *     Calls only enqueue work: no host synchronisation, no allocation, no
- *     internal threads; re-entrant.
- *   - Return value: IAGO_OK (0) or a negative iago_status; nothing is thrown
- *     across the ABI.  iago_last_error() returns a thread-local message.
- *   - There is NO CPU fallback: without a HIP device every launch fails with
- *     IAGO_ERR_HIP.
+ *   - Boards are bitboards: one 64-bit word per colour, bit a = row*8 + col (the reference's action index,
+ *     game.py:184).  `own` holds the stones of the side to move, `opp` the other side's.
+ *   - Every pointer is a CALLER-OWNED DEVICE pointer (hipMalloc / a torch tensor's data_ptr()) unless the parameter is
+ *     documented as host memory.  `stream` is a hipStream_t passed as void*; NULL = the default stream.  Calls only
+ *     enqueue work: no host synchronisation, no allocation, no internal threads; re-entrant.
+ *   - Return value: IAGO_OK (0) or a negative iago_status; nothing is thrown across the ABI.  iago_last_error() returns a
+ *     thread-local message.  There is NO CPU fallback: without a HIP device every launch fails with IAGO_ERR_HIP.
  */
 #ifndef IAGO_HIP_H
 #define IAGO_HIP_H
@@ -58,25 +51,19 @@ IAGO_API int iago_device_count(void);
 /* ------------------------------------------------------------------ rules */
 
 /*
- * legal[b] = bit mask of the legal moves of `own` on board b.
- * Replaces GameFunctions.legal_actions(state, color) (game.py:210-235),
- * GameEnv.valid_pos(color) (rl_env.py:114-138), Simulate.legal_actions
- * (mcts_self_play.py:64-89), rl_self_play.Game.legal_actions
- * (src/rl_self_play.py:63-88).  The reference's ascending action list is the
- * ascending set-bit order of the mask.
+ * legal[b] = bit mask of the legal moves of `own` on board b.  Replaces GameFunctions.legal_actions(state, color)
+ * (game.py:210-235), GameEnv.valid_pos(color) (rl_env.py:114-138), Simulate.legal_actions (mcts_self_play.py:64-89),
+ * rl_self_play.Game.legal_actions (src/rl_self_play.py:63-88).  The reference's ascending action list is the ascending
+ * set-bit order of the mask.
  */
-IAGO_API int iago_legal_moves(const uint64_t *own, const uint64_t *opp, uint64_t *legal, int64_t n,
-                     void *stream);
+IAGO_API int iago_legal_moves(const uint64_t *own, const uint64_t *opp, uint64_t *legal, int64_t n, void *stream);
 
 /*
- * In place: own[b] |= bit(action[b]) | flips, opp[b] &= ~(flips | bit), where flips are
- * the opponent runs bracketed from action[b] in the 8 directions.  action -1
- * (IAGO_PASS) leaves the board unchanged.  Like the reference, NO legality
- * check: an illegal or occupied target is overwritten and whatever it brackets
- * is flipped.  The side to move is NOT switched (the caller swaps own/opp).
- * Replaces GameFunctions.place_stone(state, action, color) (game.py:180-207),
- * GameEnv.place_stone (rl_env.py:88-112), mcts_self_play.py:36-62,
- * src/rl_self_play.py:36-61.   action: int8[n].
+ * In place: own[b] |= bit(action[b]) | flips, opp[b] &= ~(flips | bit), where flips are the opponent runs bracketed from
+ * action[b] in the 8 directions.  action -1 (IAGO_PASS) leaves the board unchanged.  Like the reference, NO legality
+ * check: an illegal or occupied target is overwritten and whatever it brackets is flipped.  The side to move is NOT
+ * switched (the caller swaps own/opp).  Replaces GameFunctions.place_stone(state, action, color) (game.py:180-207),
+ * GameEnv.place_stone (rl_env.py:88-112), mcts_self_play.py:36-62, src/rl_self_play.py:36-61.   action: int8[n].
  */
 IAGO_API int iago_apply_moves(uint64_t *own, uint64_t *opp, const int8_t *action, int64_t n, void *stream);
 
@@ -99,15 +86,12 @@ IAGO_API int iago_play_turn(uint64_t *own, uint64_t *opp, const int8_t *action, 
                             uint64_t *legal, uint8_t *active_next, int64_t n, void *stream);
 
 /*
- * planes: float32 (n,2,8,8) NCHW; channel 0 = opp (the opponent of the side
- * to move), channel 1 = own.  Replaces GameFunctions.make_state_var(state,
- * color) (game.py:168-174; copies mcts_self_play.py:91-97,
- * src/rl_self_play.py:102-108).  The un-swapped observation of GameEnv
- * (rl_env.py:36-38,70-72: [state==1, state==2]) is the same call with
- * own = player-2 stones and opp = player-1 stones.
+ * planes: float32 (n,2,8,8) NCHW; channel 0 = opp (the opponent of the side to move), channel 1 = own.  Replaces
+ * GameFunctions.make_state_var(state, color) (game.py:168-174; copies mcts_self_play.py:91-97,
+ * src/rl_self_play.py:102-108).  The un-swapped observation of GameEnv (rl_env.py:36-38,70-72: [state==1, state==2]) is
+ * the same call with own = player-2 stones and opp = player-1 stones.
  */
-IAGO_API int iago_encode_planes(const uint64_t *own, const uint64_t *opp, float *planes, int64_t n,
-                       void *stream);
+IAGO_API int iago_encode_planes(const uint64_t *own, const uint64_t *opp, float *planes, int64_t n, void *stream);
 /* The same for a gather list: row b of `planes` encodes board index[b] (int64; each in
  * [0, number of boards)): the planes of the few games a playout expands (MCTS.py:109-113).
  *
@@ -120,24 +104,18 @@ IAGO_API int iago_encode_planes(const uint64_t *own, const uint64_t *opp, float 
 IAGO_API int iago_encode_planes_indexed(const uint64_t *own, const uint64_t *opp, const int64_t *index,
                                         float *planes, int64_t n, const int32_t *n_dev, void *stream);
 
-/*
- * z[b] = sign(popcount(own) - popcount(opp)) as int8.  Replaces
- * Simulate.judge(color) (mcts_self_play.py:113-121), GameEnv.judge
- * (rl_env.py:141-149), rl_self_play.Game.judge (src/rl_self_play.py:91-100).
- */
+/* z[b] = sign(popcount(own) - popcount(opp)) as int8.  Replaces Simulate.judge(color) (mcts_self_play.py:113-121),
+ * GameEnv.judge (rl_env.py:141-149), rl_self_play.Game.judge (src/rl_self_play.py:91-100). */
 IAGO_API int iago_judge(const uint64_t *own, const uint64_t *opp, int8_t *z, int64_t n, void *stream);
 
 /*
- * Masked sampling of one move per board from a policy's probabilities:
- * Simulate.get_action / rl_self_play.Game.get_action (mcts_self_play.py:100-106,
- * src/rl_self_play.py:111-122): p = prob(float32) * valid(float64 0/1),
- * normalised by its float64 sum, then numpy.random.choice = inverse CDF
- * (cumsum / last, first index with cdf > u).  Arithmetic is float64 in cell
- * order, bit-identical to oracle/othello_oracle.c (orc_masked_probs +
- * orc_choice_cdf).  probs: float32 [n][64]; legal: masks from
- * iago_legal_moves; action: int8 [n], -1 where legal == 0.
- * u per board: uniforms[b] (float64, optional) or the Philox draw
- * (id_base + b, step>>2, stream_id, 0)[step&3] >> 8 scaled to [0,1).
+ * Masked sampling of one move per board from a policy's probabilities: Simulate.get_action /
+ * rl_self_play.Game.get_action (mcts_self_play.py:100-106, src/rl_self_play.py:111-122): p = prob(float32) *
+ * valid(float64 0/1), normalised by its float64 sum, then numpy.random.choice = inverse CDF (cumsum / last, first index
+ * with cdf > u).  Arithmetic is float64 in cell order, bit-identical to oracle/othello_oracle.c (orc_masked_probs +
+ * orc_choice_cdf).  probs: float32 [n][64]; legal: masks from iago_legal_moves; action: int8 [n], -1 where legal == 0.
+ * u per board: uniforms[b] (float64, optional) or the Philox draw (id_base + b, step>>2, stream_id, 0)[step&3] >> 8
+ * scaled to [0,1).
  */
 IAGO_API int iago_sample_moves(const float *probs, const uint64_t *legal, const double *uniforms,
                                uint64_t seed, uint32_t id_base, uint32_t step, uint32_t stream_id,
@@ -590,6 +568,22 @@ IAGO_API int iago_mcts_search_persistent(const iago_mcts_search_args *args, void
  * net workgroups it ran with.
  */
 IAGO_API int iago_mcts_search_capacity(int32_t *cus, int32_t *workgroups_per_cu);
+/*
+ * The same search as TWO launches that run together, one per role: the game workgroups (a kernel of its own register
+ * budget: two per CU) on a stream masked to `game_cus` CUs, the net workgroups on a stream masked to all the other CUs
+ * of the device -- co-resident by construction.  Same arguments, protocol, trees, moves and records (MCTS.py:105-154,
+ * game.py:117-142); max_cus must be 0.  For batches whose games need more than 32 workgroups: in the single launch
+ * every game workgroup holds a CU alone (2048 games: 17.1 -> 18.3 M leaf-evals/s, 4096 games: 10.8 -> 15.1 M).
+ *   iago_mcts_search_streams_create: the two streams and their events for the CURRENT device, once per process and
+ *     device (game_cus: a multiple of 8, at most half the device's CUs; IAGO_ERR_HIP where the runtime gives no
+ *     CU-masked streams: use iago_mcts_search_persistent there).  _destroy releases them.
+ *   iago_mcts_search_split: both launches start after everything queued on `stream` so far, `stream` continues after
+ *     both; IAGO_ERR_CAPACITY when the game workgroups do not fit game_cus CUs.  No host synchronisation.
+ */
+typedef struct iago_search_streams iago_search_streams;
+IAGO_API int iago_mcts_search_streams_create(int32_t game_cus, iago_search_streams **out);
+IAGO_API int iago_mcts_search_streams_destroy(iago_search_streams *streams);
+IAGO_API int iago_mcts_search_split(const iago_mcts_search_args *args, iago_search_streams *streams, void *stream);
 
 /*
  * Whole policy-vs-policy games -- src/rl_self_play.py:8-149, Game(model1, model2)() for n games -- in ONE launch: a

@@ -1,7 +1,7 @@
 /*
  * iago_hip_experimental.h -- entry points outside the drop-in boundary: (1) two schedules of the PER-PLAYOUT search engine
  * (game-asynchronous steps, value look-ahead), (2) the per-phase forms of a playout that the one-launch descent and the
- * persistent search superseded, (3) the persistent search split by role into two co-resident launches.  (1) and (3) were built, proven
+ * persistent search superseded.  (1) were built, proven
  * tree-identical to the reference's order of evaluation and MEASURED SLOWER than the engines that serve the path
  * (the persistent search, iago_mcts_search_persistent, wherever the split-f16 Value net and the
  * three-piece SLPolicy apply and the batch fits one launch; the lockstep per-playout launches of include/iago_hip.h
@@ -199,25 +199,6 @@ IAGO_API int iago_mcts_fresh_leaves(const iago_mcts_tree *tree, const uint8_t *a
                                     int64_t *index, int32_t *count, int64_t *total, void *stream);
 
 
-/*
- * ---- The persistent search split by role (round 6: built, bit-identical, measured NO FASTER: LABNOTES.md).
- */
-/*
- * The same search as TWO launches that run together, one per role: the game workgroups (two per CU: a kernel of its
- * own register budget) on a stream masked to `game_cus` CUs, the net workgroups on a stream masked to all the other
- * CUs of the device -- co-resident by construction.  Same arguments, same protocol, bit-identical trees, moves and
- * records (MCTS.py:105-154, game.py:117-142); max_cus must be 0.
- *   iago_mcts_search_streams_create: the two CU-masked streams and their events for the CURRENT device, once per
- *     process and device (game_cus: a multiple of 8, at most half the device's CUs; IAGO_ERR_HIP where the runtime
- *     gives no CU-masked streams: use iago_mcts_search_persistent there).  _destroy releases them.
- *   iago_mcts_search_split: both launches start after everything queued on `stream` so far, and `stream` continues
- *     after both; IAGO_ERR_CAPACITY when the game workgroups do not fit game_cus CUs (two per CU with their paths in
- *     LDS, else as many as fit).  No host synchronisation.
- */
-typedef struct iago_search_streams iago_search_streams;
-IAGO_API int iago_mcts_search_streams_create(int32_t game_cus, iago_search_streams **out);
-IAGO_API int iago_mcts_search_streams_destroy(iago_search_streams *streams);
-IAGO_API int iago_mcts_search_split(const iago_mcts_search_args *args, iago_search_streams *streams, void *stream);
 
 #ifdef __cplusplus
 }

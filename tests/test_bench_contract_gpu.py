@@ -76,3 +76,13 @@ def test_headline_is_the_pv_mcts_leg_under_the_clock():
     assert t["fresh_per_step"] is True and t["hits"] == t["hits_same_game"] + t["hits_cross_game"] > 0
     assert t["hits_same_game"] > 0 and t["hits_cross_game"] > 0
     assert m["batches_replayed_turn_by_turn"] == 0
+    # round 6: what the same kernel sustains outside the latency regime of BASELINE's 1024-game batch -- one batch each
+    # of 2048 and 4096 games per launch (beyond 32 game workgroups the search is split by role), and the spread of
+    # `value` over this round's boxes
+    sat = a["mcts_saturated"]
+    assert set(sat) >= {"2048", "4096"} and sat["2048"]["games_per_launch"] == 2048
+    for k, cus in (("2048", (32, 0)), ("4096", (64, 0))):
+        assert sat[k]["games_per_sec"] > 0 and 0 < sat[k]["frac"] < sat[k]["executed_frac"] < 1
+        assert sat[k]["role_split_game_cus"] in cus and sat[k]["batches_replayed_turn_by_turn"] == 0
+    assert m["persistent"]["role_split_game_cus"] == 0          # (256 games: the single launch)
+    assert a["value_spread"]["min"] <= a["value_spread"]["max"] and a["value_spread"]["boxes"] >= 1

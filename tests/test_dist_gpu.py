@@ -200,6 +200,12 @@ def test_bench_five_ranks_rehearsal_on_one_gpu():
     assert line["reinforce"]["iters"] == 1 and line["reinforce"]["mcts_fed"]["rounds"] == 1
     assert line["reinforce"]["mcts_fed"]["tuples_per_round"] > 64 * 40      # all 64 games of the round, gathered
     assert "cpu_baseline" not in line
+    # round 6: the check before anything is timed (a 1-element all-reduce: 0 + 1 + 2 + 3 + 4; the device check is skipped
+    # in the rehearsal, where every rank sits on the one GPU), the per-rank rates, the REINFORCE set that scales
+    assert line["preflight"]["allreduce_sum_of_ranks"] == 10 and "skipped" in line["preflight"]["device_check"]
+    assert 0 < line["per_rank_games_per_sec_min"] <= line["per_rank_games_per_sec_max"]
+    ws = line["reinforce"]["weak_scaling_set"]
+    assert ws["games_per_set"] == 5 * 64 and ws["tuples_per_iter"] > 5 * 64 * 20 and ws["gather_ms"] > 0.0
 
 
 def test_bench_launcher_propagates_a_killed_rank():

@@ -261,7 +261,11 @@ def test_too_many_games_take_the_per_playout_launches(nets):
     with pytest.raises(ValueError):
         engine.BatchedMCTS(4128, policy, value, rw, n_thr=15, capacity=64, persistent=True)
     m2 = engine.BatchedMCTS(4096, policy, value, rw, n_thr=15, capacity=64)
-    assert m2.persistent and m2.net_workgroups == 128
+    # (128 game workgroups: the role split by default -- two per CU on 64 CUs, a net workgroup on each of the other 192;
+    # the single launch, one game workgroup per CU, has 128 left)
+    assert m2.persistent and (m2.split_cus, m2.net_workgroups) in ((64, 192), (0, 128))
+    m3 = engine.BatchedMCTS(4096, policy, value, rw, n_thr=15, capacity=64, split=0)
+    assert m3.persistent and m3._split is None and m3.net_workgroups == 128
 
 
 def _cu_masked_stream(n_cus):
@@ -368,10 +372,10 @@ def test_whole_games_fall_back_to_the_turn_loop_when_a_pool_is_small(nets, monke
 
 
 def test_role_split_builds_the_same_trees(nets):
-    """The persistent search split by role (include/iago_hip_experimental.h: iago_mcts_search_split -- the game
-    workgroups as a launch of their own, two per CU, on a stream masked to `split` CUs; the net workgroups on a stream
-    masked to all the others): the same trees, values, rollout results as the single launch, no clock-limit abort, one
-    net workgroup per CU that is not the games'.  (Measured no faster than the single launch: LABNOTES.md, round 6.)"""
+    """The persistent search split by role (iago_mcts_search_split -- the game workgroups as a launch of their own, two
+    per CU, on a stream masked to `split` CUs; the net workgroups on a stream masked to all the others; the engine's
+    default beyond 32 game workgroups): the same trees, values, rollout results as the single launch, no clock-limit
+    abort, one net workgroup per CU that is not the games'."""
     engine, ops, policy, value, rw = nets
     G, n_sims, n_sims2 = 96, 100, 45
     own, opp = _positions(G)

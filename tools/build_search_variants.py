@@ -155,7 +155,8 @@ def walk_stamps(src):
     # final sum + store) and 28 (block1: entry -> weights staged)
     t = patch(t, "        // the weights of an output channel are wave-uniform: each is fetched once",
               "        iago_stamp(wst, 24);\n        // the weights of an output channel are wave-uniform: each is fetched once")
-    t = patch(t, "        __syncthreads();\n        if (tid < NC) {", "        iago_stamp(wst, 25);\n        __syncthreads();\n        iago_stamp(wst, 26);\n        if (tid < NC) {")
+    t = patch(t, "        __syncthreads();\n        if constexpr (SRCH) {\n#pragma unroll\n            for (int c = 0; c < 16; c++)\n                w10row[c] = ((const float4 *)(W.head_w",
+              "        iago_stamp(wst, 25);\n        __syncthreads();\n        iago_stamp(wst, 26);\n        if constexpr (SRCH) {\n#pragma unroll\n            for (int c = 0; c < 16; c++)\n                w10row[c] = ((const float4 *)(W.head_w")
     t = patch(t, "        __syncthreads();\n        if ((tid >> 7) * 2 < TB) {", "        __syncthreads();\n        iago_stamp(wst, 27);\n        if ((tid >> 7) * 2 < TB) {")
     t = patch(t, "        __syncthreads();\n        if (tid < TB && b0 + tid < n_rows) {", "        __syncthreads();\n        iago_stamp(wst, 28);\n        if (tid < TB && b0 + tid < n_rows) {")
     t = patch(t, "            atomicAdd(&g[31], 1ull);\n", "            atomicAdd(&g[31], 1ull);\n"
@@ -239,6 +240,20 @@ def walk_stamps_no_b(src):
     return s
 
 
+def epilogue_writes_no_conflicts(src):
+    """TIMING ONLY (wrong numbers): the walks' epilogues write their f16 pieces to conflict-free addresses (8 bytes per
+    lane, the 16 lanes of a ds_write_b64 group 8 bytes apart) instead of the cells' rows, whose 544-byte stride -- chosen
+    for the K loops' ds_read_b128 -- puts the 16 cells of a group on 4 banks (4-way).  What SQ_LDS_BANK_CONFLICT and the
+    walk lose without those conflicts (VERDICT r05 task 3a)."""
+    t = open(os.path.join(CSRC, "conv_trunk_body.hpp")).read()
+    t = patch(t, "            char *row = T + wrow[n & 3] + (n >> 2) * BS + (32 * wv + 4 * kq) * 2;",
+              "            char *row = T + (n >> 2) * BS + (n & 3) * 8192 + c16 * 8 + kq * 128 + wv * 1024; (void)wrow;")
+    t = patch(t, "                *(uint2 *)(row + 32 * m) =", "                *(uint2 *)(row + 512 * m) =")
+    t = patch(t, "                *(uint2 *)(row + 32 * m + 256) =", "                *(uint2 *)(row + 512 * m + 4096) =")
+    open(os.path.join(OUT, "conv_trunk_body_epiwrite.hpp"), "w").write(t)
+    return patch(src, '#include "conv_trunk_body.hpp" // (brings rollout_row_body.hpp)', '#include "conv_trunk_body_epiwrite.hpp"')
+
+
 def rollout_no_conflicts():
     """TIMING ONLY (wrong numbers): rollout_row_kernel.hip with the policy's table reads made bank-conflict-free (every
     lane reads the slot of its own lane number instead of the entry its window selects): the upper bound of what a
@@ -271,7 +286,8 @@ def main():
         print(so)
         return
     for name, fn in (("search_log", request_log), ("search_phases", phase_stamps), ("search_walkstamps", walk_stamps),
-                     ("search_walkstamps_noa", walk_stamps_no_a), ("search_walkstamps_nob", walk_stamps_no_b)):
+                     ("search_walkstamps_noa", walk_stamps_no_a), ("search_walkstamps_nob", walk_stamps_no_b),
+                     ("search_epiwrite", epilogue_writes_no_conflicts)):
         if only and name not in only:
             continue
         path = os.path.join(OUT, name + ".hip")

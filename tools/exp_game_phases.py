@@ -14,18 +14,21 @@ L.iago_debug_game_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * 8)()
 w, b = bench.shipped_rollout_weights()
 NAMES = ("replies + moves", "descent", "control words + packing", "rollout passes", "backup", "end of iteration")
+# python tools/exp_game_phases.py [playouts per move = 100] [n_thr = 15]   (round 6: 400 / 15 = configs[3]'s share, 100 / 1)
+SIMS = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+N_THR = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 for games, turns in ((1024, 128), (1024, 12), (64, 128)):
     torch.manual_seed(0)
     policy, value = network.SLPolicy().cuda().eval(), network.Value().cuda().eval()
-    m = engine.BatchedMCTS(games, policy, value, ops.RolloutWeights(w, b), n_thr=15, seed=7, persistent=True,
-                           capacity=engine.suggest_capacity(100, 15, moves=64))
+    m = engine.BatchedMCTS(games, policy, value, ops.RolloutWeights(w, b), n_thr=N_THR, seed=7, persistent=True, split=0,
+                           capacity=engine.suggest_capacity(SIMS, N_THR, moves=64))
     eng = engine.SelfPlayEngine(m, max_turns=turns)
     L.iago_debug_game_phases(buf, 1)
-    eng.play(100, record=False)
+    eng.play(SIMS, record=False)
     torch.cuda.synchronize()
     L.iago_debug_game_phases(buf, 1)
     t = list(buf)
     it = max(1, t[7])
-    print("games %d, %d turns: game workgroup 0: %d iterations, %.1f us each:" % (games, turns, it, sum(t[:6]) / it / 100.0))
+    print("%d playouts per move, n_thr %d; games %d, %d turns: game workgroup 0: %d iterations, %.1f us each:" % (SIMS, N_THR, games, turns, it, sum(t[:6]) / it / 100.0))
     print("   " + ";  ".join("%s %.2f" % (n, x / it / 100.0) for n, x in zip(NAMES, t[:6])))
     m.close()

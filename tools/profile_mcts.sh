@@ -13,12 +13,16 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 #                                      launch per whole self-play game -> profiles/*_mcts_persistent_*
 EAGER="--mcts-eager"
 if [ "$MODE" = "full" ]; then TURNS=-1; SUF=_mcts_fullgame; elif [ "$MODE" = "persistent" ]; then TURNS=-1; SUF=_mcts_persistent; EAGER=""; else TURNS=4; SUF=_mcts; fi
+SUF=${PROFILE_SUF:-$SUF}
 OUT=$REPO/gpurun_out/prof_${TAG}${SUF}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # (round 5: the headline of bench.py IS this leg -- K whole-game batches, one search_kernel launch each; 1 warm-up + 5 timed
 # batches per pass: every launch of a pass is a whole batch, so rocprofv3's average is the average of whole batches)
-ARGS="--gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --mcts-turns $TURNS $EAGER --mcts-only"
+# PROFILE_ARGS: extra bench arguments of the headline leg (round 6: "--mcts-sims 400" = one GPU's share of configs[3],
+# "--mcts-nthr 1" = the n_thr = 1 variant), PROFILE_SUF: what the output directory and the committed summaries are called
+# (e.g. _mcts400_persistent); PROFILE_STEPS: timed batches per pass
+ARGS="--gpus 1 --steps ${PROFILE_STEPS:-5} --warmup 1 --no-cpu-baseline --mcts-turns $TURNS $EAGER --mcts-only ${PROFILE_ARGS:-}"
 echo "python3 bench.py $ARGS" > "$OUT/command.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py $ARGS > "$OUT/trace.log" 2>&1
 # one pass per counter group (MI355X_MICROARCH.md: PMC in runs of their own, no trace domains);
