@@ -416,6 +416,30 @@ def net_kernel_profiles(persistent=False):
     return None
 
 
+def variant_profile(tag):
+    """The search kernel's figures from the committed rocprofv3 profile of a variant of the headline leg
+    (profiles/r*_<tag>_persistent_pmc_summary.json: tools/profile_mcts.sh with PROFILE_ARGS / PROFILE_SUF), quoted
+    only when it was taken on these kernel sources."""
+    import glob
+    now = csrc_sha16()
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_persistent_pmc_summary.json" % tag)))):
+        with open(path) as f:
+            prof = json.load(f)
+        k = prof.get("kernels", {}).get("search_kernel")
+        if not k or k.get("calls", 0) * k.get("avg_us", 0.0) < 1e5:
+            continue
+        cur = prof.get("csrc_sha16") == now
+        out = {"profile": os.path.basename(path), "profile_current": cur, "profile_command": prof.get("command")}
+        if cur:
+            tf = k["SQ_INSTS_MFMA"] * MFMA_FLOP_16x16x32 / (k["avg_us"] * 1e-6) / 1e12
+            out.update({"traffic": k.get("hbm_bytes_per_launch"), "rocprof_kernel_avg_ms": k["avg_us"] / 1e3,
+                        "executed_frac_pmc": tf / F16_PEAK_TF, "l2_hit_rate": k.get("l2_hit_rate"),
+                        "lds_bank_conflict_share": (k["SQ_LDS_BANK_CONFLICT"] / k["SQ_LDS_IDX_ACTIVE"]
+                                                    if k.get("SQ_LDS_IDX_ACTIVE") else None)})
+        return out
+    return {"profile": None, "profile_current": False}
+
+
 def _mcts_roofline(leaf, pol, dt, world, value_f32, policy_split3=False, persistent=False):  # leaf = value-net evaluations executed
     """The convolutions bound this leg.  f32 path: float32 matrix/vector peak 157.3
     TFLOP/s.  Split-f16 path: the Value convolutions of blocks 2..8 (122.68 MFLOP per
@@ -1472,6 +1496,7 @@ def main():
             outs[name]["sample"] = "one batch of whole games (games_per_sec), a fresh position table"
             if "kernel_roofline" in outs[name]:   # (same keys as the headline's `roofline`; measured in this run)
                 outs[name]["roofline"] = dict(outs[name].pop("kernel_roofline"), traffic=None)
+                outs[name]["roofline"].update(variant_profile("mcts400" if sims >= 400 else "mctsnthr1"))
                 if r.get("persistent"):
                     outs[name]["totals"] = r["persistent"]["totals"]
         n_open = 4 if sims >= 400 else 8
