@@ -106,7 +106,7 @@ def test_one_training_set_on_gpu(tmp_path):
 @pytest.mark.gpu
 def test_step_from_pv_mcts_tuples_gpu():
     """BASELINE configs[4] as it is worded: PV-MCTS self-play tuples feed the REINFORCE update.
-    64 games x 20 playouts per move -> SelfPlayResult.tuples() (own, opp, move, z from the mover's view)
+    32 games x 20 playouts per move (6 turns) -> SelfPlayResult.tuples() (own, opp, move, z from the mover's view)
     -> ReinforceTrainer.step_from_tuples: the loss equals the float64 numpy restatement of
     src/train_rl.py:55-66 on exactly those rows (x = the mover's planes, y = the move, r = z), one
     Adam step is taken, and colour = 1 restricts the batch to the learner's plies as the reference
@@ -124,12 +124,12 @@ def test_step_from_pv_mcts_tuples_gpu():
     with open(os.path.join(GOLDEN, "simulate.json")) as f:
         g = json.load(f)
     tr.model1.eval()
-    m = engine.BatchedMCTS(64, tr.model1, value, ops.RolloutWeights(g["shipped_w"], g["shipped_b"]), n_thr=15,
+    m = engine.BatchedMCTS(32, tr.model1, value, ops.RolloutWeights(g["shipped_w"], g["shipped_b"]), n_thr=15,
                            capacity=4096, seed=2)      # (the default engine: the persistent search)
     res = engine.SelfPlayEngine(m, max_turns=6).play(20)
     tup = res.tuples()
     n = int(tup["z"].numel())
-    assert n == 64 * 6 and set(tup) >= {"own", "opp", "move", "z", "colour", "game", "turn"}
+    assert n == 32 * 6 and set(tup) >= {"own", "opp", "move", "z", "colour", "game", "turn"}
     # float64 restatement on the same rows, in the canonical (turn, game) order the trainer sorts into
     order = np.lexsort((tup["game"].cpu().numpy(), tup["turn"].cpu().numpy()))
     own, opp = ops.tensor_to_bits(tup["own"])[order], ops.tensor_to_bits(tup["opp"])[order]
@@ -144,7 +144,7 @@ def test_step_from_pv_mcts_tuples_gpu():
     assert tr.opt.t == 1 and any(not np.array_equal(before[k], v) for k, v in tr.model1.npz_dict().items())
     # the learner's plies only
     one = tr.step_from_tuples(tup, colour=1)
-    assert one["n_tuples"] == int((tup["colour"] == 1).sum().item()) == 64 * 3 and tr.opt.t == 2
+    assert one["n_tuples"] == int((tup["colour"] == 1).sum().item()) == 32 * 3 and tr.opt.t == 2
 
 
 @pytest.mark.gpu
