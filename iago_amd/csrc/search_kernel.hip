@@ -1239,18 +1239,32 @@ int search_launch(const iago_mcts_search_args *a, void *stream, iago_search_stre
         if (a->max_cus != 0)
             return iago_fail(IAGO_ERR_INVALID, "iago_mcts_search_split: max_cus must be 0 (the split owns the device's CUs)");
         const size_t want = (size_t)gpw * (size_t)a->path_stride * 4u;
-        hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, (const void *)search_game_kernel) != hipSuccess)
-            return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_split: hipFuncGetAttributes failed");
-        game_lds = (want + fa.sharedSizeBytes + 256u) * 2u <= (size_t)160 * 1024u ? (int)want : 0;
+        // (asked of the runtime once per device and LDS size: every launch comes through here)
+        static std::atomic<int32_t> static_lds{-1};
+        int32_t fixed = static_lds.load(std::memory_order_acquire);
+        if (fixed < 0) {
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, (const void *)search_game_kernel) != hipSuccess)
+                return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_split: hipFuncGetAttributes failed");
+            fixed = (int32_t)fa.sharedSizeBytes;
+            static_lds.store(fixed, std::memory_order_release);
+        }
+        game_lds = (want + (size_t)fixed + 256u) * 2u <= (size_t)160 * 1024u ? (int)want : 0;
         path_lds_cap = game_lds;
         static std::atomic<uint64_t> configured_game{0};
         if (game_lds && iago_reserve_lds((const void *)search_game_kernel, 96 * 1024, configured_game,
                                          "iago_mcts_search_split: cannot reserve the game workgroups' LDS"))
             return IAGO_ERR_HIP;
+        static std::atomic<uint64_t> occ_known[64]; // per device: LDS bytes << 8 | workgroups per CU (+ 1 << 63: valid)
         int per_game = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_game, (const void *)search_game_kernel, 256, (size_t)game_lds) != hipSuccess)
-            return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_split: the device does not answer");
+        const uint64_t seen = occ_known[dev & 63].load(std::memory_order_acquire);
+        if ((seen >> 63) && ((seen >> 8) & 0xFFFFFFull) == (uint64_t)game_lds) {
+            per_game = (int)(seen & 0xFF);
+        } else {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_game, (const void *)search_game_kernel, 256, (size_t)game_lds) != hipSuccess)
+                return iago_fail(IAGO_ERR_HIP, "iago_mcts_search_split: the device does not answer");
+            occ_known[dev & 63].store((1ull << 63) | ((uint64_t)game_lds << 8) | (uint64_t)(per_game & 0xFF), std::memory_order_release);
+        }
         if (n_game_wgs > (int64_t)sp->game_cus * per_game)
             return iago_fail(IAGO_ERR_CAPACITY, "iago_mcts_search_split: the game workgroups do not fit the game launch's CUs "
                                                 "(more game CUs, fewer games per launch, or the single launch)");

@@ -258,6 +258,17 @@ def epilogue_writes_no_conflicts(src):
     return patch(src, '#include "conv_trunk_body.hpp" // (brings rollout_row_body.hpp)', '#include "conv_trunk_body_epiwrite.hpp"')
 
 
+def unroll2(src):
+    """The chunk-pair loops of the walks' K loops unrolled by two (n_pairs is 2 or 4): half the loop-top waits and address
+    updates, twice the code (round 5 measured this once, on a slow box, without an A/B partner)."""
+    for name in ("conv_trunk_body", "conv_policy_body"):
+        t = open(os.path.join(CSRC, name + ".hpp")).read()
+        t = patch(t, "        for (int cp = 0; cp < n_pairs; cp++) {", "#pragma unroll 2\n        for (int cp = 0; cp < n_pairs; cp++) {")
+        open(os.path.join(OUT, name + "_unroll2.hpp"), "w").write(t)
+    s = patch(src, '#include "conv_trunk_body.hpp" // (brings rollout_row_body.hpp)', '#include "conv_trunk_body_unroll2.hpp"')
+    return patch(s, '#include "conv_policy_body.hpp"', '#include "conv_policy_body_unroll2.hpp"')
+
+
 def rollout_no_conflicts():
     """TIMING ONLY (wrong numbers): rollout_row_kernel.hip with the policy's table reads made bank-conflict-free (every
     lane reads the slot of its own lane number instead of the entry its window selects): the upper bound of what a
@@ -291,7 +302,7 @@ def main():
         return
     for name, fn in (("search_log", request_log), ("search_phases", phase_stamps), ("search_walkstamps", walk_stamps),
                      ("search_walkstamps_noa", walk_stamps_no_a), ("search_walkstamps_nob", walk_stamps_no_b),
-                     ("search_epiwrite", epilogue_writes_no_conflicts)):
+                     ("search_epiwrite", epilogue_writes_no_conflicts), ("search_unroll2", unroll2)):
         if only and name not in only:
             continue
         if not only and name in ("search_walkstamps_noa", "search_walkstamps_nob"):
