@@ -1526,7 +1526,22 @@ def main():
         saturated = {}
         for n_g in (2048, 4096):
             log("mcts_saturated: one batch of %d whole games" % n_g)
-            r = mcts_leg(n_g, args.mcts_sims, 0, True, world, rank, None, steps=1, warmup_steps=0)
+            failed = None
+            try:
+                r = mcts_leg(n_g, args.mcts_sims, 0, True, world, rank, None, steps=1, warmup_steps=0)
+            except Exception as e:      # (a side leg never takes the line down: the same batch on the single launch)
+                failed = "%s: %s" % (type(e).__name__, str(e)[:300])
+                log("mcts_saturated: %s -- again as one launch" % failed)
+                torch.cuda.synchronize()
+                keep = os.environ.get("IAGO_SEARCH_SPLIT")
+                os.environ["IAGO_SEARCH_SPLIT"] = "0"
+                try:
+                    r = mcts_leg(n_g, args.mcts_sims, 0, True, world, rank, None, steps=1, warmup_steps=0)
+                finally:
+                    if keep is None:
+                        del os.environ["IAGO_SEARCH_SPLIT"]
+                    else:
+                        os.environ["IAGO_SEARCH_SPLIT"] = keep
             kr2 = r.get("kernel_roofline") or {}
             saturated[str(n_g)] = {"games_per_launch": n_g, "games_per_sec": r.get("games_per_sec"),
                                    "leaf_evals_per_sec": r["leaf_evals_per_sec"], "seconds": r["seconds"],
@@ -1536,6 +1551,8 @@ def main():
                                    "role_split_game_cus": (r.get("persistent") or {}).get("role_split_game_cus"),
                                    "net_workgroups": (r.get("persistent") or {}).get("net_workgroups"),
                                    "batches_replayed_turn_by_turn": r.get("batches_replayed_turn_by_turn")}
+            if failed:
+                saturated[str(n_g)]["role_split_failed"] = failed
         saturated["note"] = ("one batch each, whole games, same nets and constants as the headline; the headline's 1024 games per "
                              "launch is BASELINE configs[2]'s batch.  Beyond 32 game workgroups the engine splits the search by "
                              "role (role_split_game_cus: two game workgroups per CU on that many CUs, one net workgroup on each "

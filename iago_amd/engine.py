@@ -1210,8 +1210,11 @@ class BatchedMCTS(object):
         """The errors of a search from the host copy of error_flags()."""
         overflow, err, sat_v, sat_p, gave_up = (int(x) for x in flags)
         if gave_up:
-            raise _lib.IagoError("the persistent search gave up after %d ms (a reply never came: is another job on the "
-                                 "device, or fewer CUs free than workgroups?); the trees are incomplete" % self.time_limit_ms)
+            raise _lib.IagoError("the persistent search gave up at its clock limit (%d ms for a search, 60 s for whole games: a "
+                                 "reply never came -- is another job on the device, or fewer CUs free than workgroups?%s); the "
+                                 "trees are incomplete"
+                                 % (self.time_limit_ms, "  This was the role split (two launches on CU-masked streams): "
+                                    "split=0 / IAGO_SEARCH_SPLIT=0 selects the single launch" if self._split is not None else ""))
         if overflow != 0:
             raise _lib.IagoError("MCTS node pool exhausted (or a search path deeper than 512): "
                                  "raise `capacity` (%d nodes per game)" % self.tree.capacity)

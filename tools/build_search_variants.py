@@ -258,6 +258,16 @@ def epilogue_writes_no_conflicts(src):
     return patch(src, '#include "conv_trunk_body.hpp" // (brings rollout_row_body.hpp)', '#include "conv_trunk_body_epiwrite.hpp"')
 
 
+def unroll4(src):
+    """... unrolled by four: no back-edge inside a layer (4 chunk pairs; the first layer's 2 run the remainder loop)."""
+    for name in ("conv_trunk_body", "conv_policy_body"):
+        t = open(os.path.join(CSRC, name + ".hpp")).read()
+        t = patch(t, "        for (int cp = 0; cp < n_pairs; cp++) {", "#pragma unroll 4\n        for (int cp = 0; cp < n_pairs; cp++) {")
+        open(os.path.join(OUT, name + "_unroll4.hpp"), "w").write(t)
+    s = patch(src, '#include "conv_trunk_body.hpp" // (brings rollout_row_body.hpp)', '#include "conv_trunk_body_unroll4.hpp"')
+    return patch(s, '#include "conv_policy_body.hpp"', '#include "conv_policy_body_unroll4.hpp"')
+
+
 def unroll2(src):
     """The chunk-pair loops of the walks' K loops unrolled by two (n_pairs is 2 or 4): half the loop-top waits and address
     updates, twice the code (round 5 measured this once, on a slow box, without an A/B partner)."""
@@ -302,7 +312,7 @@ def main():
         return
     for name, fn in (("search_log", request_log), ("search_phases", phase_stamps), ("search_walkstamps", walk_stamps),
                      ("search_walkstamps_noa", walk_stamps_no_a), ("search_walkstamps_nob", walk_stamps_no_b),
-                     ("search_epiwrite", epilogue_writes_no_conflicts), ("search_unroll2", unroll2)):
+                     ("search_epiwrite", epilogue_writes_no_conflicts), ("search_unroll2", unroll2), ("search_unroll4", unroll4)):
         if only and name not in only:
             continue
         if not only and name in ("search_walkstamps_noa", "search_walkstamps_nob"):
