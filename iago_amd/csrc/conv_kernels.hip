@@ -1027,11 +1027,12 @@ int iago_split_scaled(const float *x, const uint32_t *max_bits, void *hi, void *
         return iago_fail(IAGO_ERR_INVALID, "iago_split_scaled: null pointer");
     const int64_t pieces = n * (channels / 16) * 128;
     const int64_t blocks = pieces ? (pieces + 255) / 256 : 1;
-    if ((bias_part == nullptr) != (bias_grad == nullptr))
-        return iago_fail(IAGO_ERR_INVALID, "iago_split_scaled: bias_part and bias_grad go together");
+    if (bias_grad && !bias_part)
+        return iago_fail(IAGO_ERR_INVALID, "iago_split_scaled: bias_grad needs bias_part");
     hipLaunchKernelGGL(split_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const f32x4 *)x, max_bits, (uint4 *)hi, (uint4 *)lo, scale_exp, pieces, bias_part);
-    if (bias_part && n > 0)
+    // (bias_part alone: the partial sums only -- iago_policy_reinforce_grad reduces those of all blocks in one launch)
+    if (bias_part && bias_grad && n > 0)
         hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)channels), dim3(64), 0, (hipStream_t)stream,
                            (const float *)bias_part, n, channels, bias_grad);
     return iago_check_launch("iago_split_scaled");

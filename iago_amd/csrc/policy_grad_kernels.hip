@@ -238,6 +238,78 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *part, in
 }
 
 
+// The partial sums of ALL blocks of an update in one launch (iago_policy_reinforce_grad): per block k the weight gradient's
+// groups (wgrad_reduce_kernel's arithmetic: the groups in order, then 2^-e) and the bias gradient's pair sums
+// (bias_reduce_kernel's, conv_kernels.hip: a wave per channel, lane l takes boards l, l + 64, .., then the xor tree) -- the
+// same sums in the same order as the per-block launches, which were 14 launches of mostly latency (23 us per block).
+__device__ __forceinline__ float wave_sum_xor(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d);
+    return v;
+}
+struct ReduceAllParams {
+    const float *wpart[7], *bpart[7];
+    float *dw[7], *db[7];
+    const int32_t *scale_exp[7];
+    int32_t groups[7], cin[7];
+    int32_t w_block0[8]; // first workgroup of block k's weights; [7] = first workgroup of the biases
+    int64_t n;
+};
+__global__ __launch_bounds__(256) void grad_reduce_all_kernel(ReduceAllParams P)
+{
+    const int b = blockIdx.x;
+    if (b < P.w_block0[7]) {
+        int k = 0;
+#pragma unroll
+        for (int i = 1; i < 7; i++)
+            k += b >= P.w_block0[i] ? 1 : 0;
+        // (by-value parameter arrays indexed at run time go through scratch memory: select with compile-time indices)
+        const float *part = P.wpart[0];
+        float *dw = P.dw[0];
+        const int32_t *se = P.scale_exp[0];
+        int groups = P.groups[0], cin = P.cin[0], first = P.w_block0[0];
+#pragma unroll
+        for (int i = 1; i < 7; i++)
+            if (k == i) {
+                part = P.wpart[i], dw = P.dw[i], se = P.scale_exp[i];
+                groups = P.groups[i], cin = P.cin[i], first = P.w_block0[i];
+            }
+        const int t = (b - first) * 256 + threadIdx.x; // (tap, co, ci)
+        const int total = 9 * 128 * cin;
+        if (t >= total)
+            return;
+        float s = 0.0f;
+        for (int g = 0; g < groups; g++)
+            s += part[(int64_t)g * total + t];
+        s = ldexpf(s, -*se);
+        const int ci = t % cin, co = (t / cin) & 127, tap = t / (cin * 128);
+        dw[((int64_t)co * cin + ci) * 9 + tap] = s;
+        return;
+    }
+    // biases: 4 channels per workgroup (a wave each), 128 channels per block
+    const int j = (b - P.w_block0[7]) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int k = j >> 7, ch = j & 127;
+    if (k >= 7)
+        return;
+    const float *bp = P.bpart[0];
+    float *db = P.db[0];
+#pragma unroll
+    for (int i = 1; i < 7; i++)
+        if (k == i)
+            bp = P.bpart[i], db = P.db[i];
+    const int cb = ch >> 4, c = ch & 15;
+    float s = 0.0f;
+    for (int64_t bd = lane; bd < P.n; bd += 64) {
+        const int64_t pair = bd * 8 + cb;
+        s += bp[(pair >> 1) * 32 + (pair & 1) * 16 + c];
+    }
+    s = wave_sum_xor(s);
+    if (lane == 0)
+        db[ch] = s;
+}
+
 // ---- The head of SLPolicy and the loss, forward and backward in one pass (network.py:29-47, src/train_rl.py:61-64):
 //   logits = conv9 (1x1, 128 -> 1, no bias) + bias10[cell];  p = softmax(logits)            (the model's output)
 //   c = softmax_cross_entropy(p, a) = logsumexp(p) - p[a]     (the reference applies log-softmax to the probabilities)
@@ -499,7 +571,7 @@ int iago_conv3x3_wgrad_split(const void *dy_hi, const void *dy_lo, const void *x
 {
     if (n < 0 || (cin != 64 && cin != 128) || groups < 8 || (groups % 8) != 0)
         return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_wgrad_split: cin must be 64 or 128, groups a multiple of 8");
-    if (!dy_hi || !dy_lo || !x_hi || !x_lo || !part || !dw)
+    if (!dy_hi || !dy_lo || !x_hi || !x_lo || !part)
         return iago_fail(IAGO_ERR_INVALID, "iago_conv3x3_wgrad_split: null pointer");
     static std::atomic<uint64_t> configured{0};
     if (iago_reserve_lds((const void *)wgrad_split_kernel, WG_LDS, configured,
@@ -517,8 +589,9 @@ int iago_conv3x3_wgrad_split(const void *dy_hi, const void *dy_lo, const void *x
     const unsigned grid = (unsigned)(groups * 2 * (cin / 32));
     hipLaunchKernelGGL(wgrad_split_kernel, dim3(grid), dim3(256), WG_LDS, (hipStream_t)stream, P);
     const int total = 9 * 128 * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float *)part, groups, cin, scale_exp, dw);
+    if (dw) // (NULL: the partial sums only -- iago_policy_reinforce_grad reduces those of all blocks in one launch)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)part, groups, cin, scale_exp, dw);
     return iago_check_launch("iago_conv3x3_wgrad_split");
 }
 
@@ -559,8 +632,9 @@ int64_t iago_policy_grad_workspace_bytes(int64_t n)
     int64_t b = 0;
     b += 2 * pg_round(n * 8192) + 14 * pg_round(n * 16384);          // saved activations of blocks 1..8, hi + lo
     b += pg_round(n * 32768) + 2 * pg_round(n * 16384);              // a gradient as float32 and as scaled pieces
-    b += pg_round((int64_t)PG_MAX_GROUPS * 9 * 128 * 128 * 4);       // partial weight gradients
-    b += pg_round(((n * 8 + 1) / 2) * 32 * 4);                       // partial bias gradients
+    b += 6 * pg_round((int64_t)PG_MAX_GROUPS * 9 * 128 * 128 * 4) +
+         pg_round((int64_t)PG_MAX_GROUPS * 9 * 128 * 64 * 4);        // partial weight gradients, a buffer per block
+    b += 7 * pg_round(((n * 8 + 1) / 2) * 32 * 4);                   // partial bias gradients, a buffer per block
     b += pg_round((int64_t)PG_GRID * HEAD_PART * 4) + pg_round((int64_t)PG_GRID * STEM_PART * 4);
     b += 256;                                                        // the tensors' largest magnitudes and scales
     return b;
@@ -596,8 +670,12 @@ int iago_policy_reinforce_grad(const iago_policy_grad_args *A, void *stream)
     }
     float *dyf = (float *)take(n * 32768);
     void *dys_hi = take(n * 16384), *dys_lo = take(n * 16384);
-    float *wpart = (float *)take((int64_t)PG_MAX_GROUPS * 9 * 128 * 128 * 4);
-    float *bpart = (float *)take(((n * 8 + 1) / 2) * 32 * 4);
+    // (partial sums of the weight and bias gradients: a buffer per block, reduced by ONE launch at the end)
+    float *wpart[7], *bpart[7];
+    for (int k = 0; k < 7; k++) {
+        wpart[k] = (float *)take((int64_t)PG_MAX_GROUPS * 9 * 128 * (k ? 128 : 64) * 4);
+        bpart[k] = (float *)take(((n * 8 + 1) / 2) * 32 * 4);
+    }
     float *hpart = (float *)take((int64_t)PG_GRID * HEAD_PART * 4);
     float *spart = (float *)take((int64_t)PG_GRID * STEM_PART * 4);
     uint32_t *max_bits = (uint32_t *)take(256); // [0..7]: of the gradient at block k + 1's pre-activations; [16..23]: scales
@@ -635,16 +713,35 @@ int iago_policy_reinforce_grad(const iago_policy_grad_args *A, void *stream)
     // gradient; the weight gradient; the gradient at the pre-activations of the block below
     for (int k = 6; k >= 0 && rc == IAGO_OK; k--) {
         const int cin = k ? 128 : 64;
-        rc = iago_split_scaled(dyf, max_bits + k + 1, dys_hi, dys_lo, scale_exp + k + 1, n, 128, bpart, A->g_b[k], stream);
+        rc = iago_split_scaled(dyf, max_bits + k + 1, dys_hi, dys_lo, scale_exp + k + 1, n, 128, bpart[k], nullptr, stream);
         if (rc == IAGO_OK)
-            rc = iago_conv3x3_wgrad_split(dys_hi, dys_lo, x_hi[k], x_lo[k], n, cin, wpart, pg_groups(cin),
-                                          scale_exp + k + 1, A->g_w[k], stream);
+            rc = iago_conv3x3_wgrad_split(dys_hi, dys_lo, x_hi[k], x_lo[k], n, cin, wpart[k], pg_groups(cin),
+                                          scale_exp + k + 1, nullptr, stream);
         if (rc == IAGO_OK)
             rc = iago_conv3x3_bwd_data_split(dys_hi, dys_lo, scale_exp + k + 1, A->wt_hi[k], A->wt_lo[k], x_hi[k], x_lo[k],
                                              cin, dyf, max_bits + k, n, stream);
     }
     if (rc != IAGO_OK)
         return rc;
+    {
+        ReduceAllParams Rp;
+        int at_block = 0;
+        for (int k = 0; k < 7; k++) {
+            const int cin = k ? 128 : 64;
+            Rp.wpart[k] = wpart[k];
+            Rp.bpart[k] = bpart[k];
+            Rp.dw[k] = A->g_w[k];
+            Rp.db[k] = A->g_b[k];
+            Rp.scale_exp[k] = scale_exp + k + 1;
+            Rp.groups[k] = pg_groups(cin);
+            Rp.cin[k] = cin;
+            Rp.w_block0[k] = at_block;
+            at_block += (9 * 128 * cin + 255) / 256;
+        }
+        Rp.w_block0[7] = at_block;
+        Rp.n = n;
+        hipLaunchKernelGGL(grad_reduce_all_kernel, dim3((unsigned)(at_block + 7 * 128 / 4)), dim3(256), 0, st, Rp);
+    }
     // block 1 from the float32 gradient at its pre-activations
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(PG_GRID), dim3(256), 0, st, (const float *)dyf, A->own, A->opp, n, spart);
     hipLaunchKernelGGL(stem_reduce_kernel, dim3((STEM_PART + 3) / 4), dim3(256), 0, st, (const float *)spart, PG_GRID,

@@ -190,7 +190,7 @@ class SLPolicy(nn.Module, _NpzMixin):
         cleargrads + loss.backward() for loss = mean(softmax_cross_entropy(self(x), action) * reward); every
         parameter's .grad is overwritten.  own / opp: the recorded positions (own = the mover); action in 0 .. 63 (an
         action outside raises bit 1 of the module's overflow word: ReinforceTrainer reads it before Adam).  Returns the loss (0-dim device tensor).  The first two f16 pieces of the search
-        path's three-piece weights are the forward's.  The kernels' scratch (304 KB per row + 40 MB, kept between
+        path's three-piece weights are the forward's.  The kernels' scratch (308 KB per row + 247 MB, kept between
         calls) is freed by ops.release_grad_workspace()."""
         from . import ops
         convs = [getattr(self, "block%d" % k).conv for k in range(2, 9)]
@@ -218,7 +218,7 @@ class SLPolicy(nn.Module, _NpzMixin):
                                              layers_t, self.conv9.weight.detach(), self.bias10.b.detach(), grads,
                                              probs=None if probs is None else probs[lo:hi],
                                              overflow=self._overflow_flag(own.device))
-        # The kernels' scratch is 304 KB per row: a PV-MCTS round of 1024 games (~61 k rows, both colours) would take
+        # The kernels' scratch is 308 KB per row: a PV-MCTS round of 1024 games (~61 k rows, both colours) would take
         # 18 GB at once.  Larger batches run in chunks of GRAD_CHUNK_ROWS rows, every chunk dividing by the same
         # n_mean, the chunks' gradients added in chunk order (deterministic); a batch within one chunk is one call.
         chunk = self.GRAD_CHUNK_ROWS

@@ -592,7 +592,7 @@ def policy_grad_workspace(device, n):
 
 
 def release_grad_workspace():
-    """Free the scratch policy_grad_workspace keeps (304 KB per row of the largest batch seen + 40 MB)."""
+    """Free the scratch policy_grad_workspace keeps (308 KB per row of the largest batch seen + 247 MB)."""
     _grad_workspace.clear()
 
 

@@ -639,10 +639,10 @@ IAGO_API int iago_selfplay_policy(const iago_selfplay_policy_args *args, void *s
  *   divides by.  w1 [64][2][3][3], b1 [64]; blocks 2..8 (index 0..6): w_hi / w_lo as for iago_conv3x3_split, wt_hi /
  *   wt_lo the transposed form of iago_conv3x3_bwd_data_split, bias [128]; w9 [128], b10 [64].
  *   g_*: the gradients, float32 in the parameters' own layouts ([co][ci][3][3]); loss: device float; probs: optional
- *   [n][64], the model's output.  workspace: iago_policy_grad_workspace_bytes(n) bytes, 256-byte aligned (304 KB per
- *   row + 40 MB).  overflow: see iago_conv3x3_split (the forward's activations: bit 0); bit 1 is raised when an action
- *   lies outside 0 .. 63 (the reference's F.softmax_cross_entropy raises there): that call's loss and gradients
- *   must not be used.
+ *   [n][64], the model's output.  workspace: iago_policy_grad_workspace_bytes(n) bytes, 256-byte aligned (308 KB per
+ *   row + 247 MB: every block keeps its partial sums for the one reduction at the end).  overflow: see
+ *   iago_conv3x3_split (the forward's activations: bit 0); bit 1 is raised when an action lies outside 0 .. 63 (the
+ *   reference's F.softmax_cross_entropy raises there): that call's loss and gradients must not be used.
  */
 typedef struct iago_policy_grad_args {
     const uint64_t *own, *opp;

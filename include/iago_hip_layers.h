@@ -132,7 +132,8 @@ IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n
  *   dy_hi / dy_lo [n][8][64][16] (the gradient at the block's pre-activations, zero where its ReLU was off, times
  *   2^e), x_hi / x_lo [n][cin/16][64][16] (the block's input), cin 64 or 128; dw [128][cin][3][3] float32.
  *   part: scratch, [groups][9][128][cin] float32 -- the boards are summed in `groups` (a multiple of 8) contiguous
- *   groups, whose partial sums are added in group order (deterministic); scale_exp: the device word e, NULL = 0.
+ *   groups, whose partial sums are added in group order (deterministic); scale_exp: the device word e, NULL = 0;
+ *   dw = NULL: the partial sums only.
  *
  * iago_conv3x3_bwd_data_split: the gradient at the INPUT of a 3x3 block, through the ReLU of the block below:
  *   dx[b][ci][y][x] = [saved[b][ci][y][x] > 0] * 2^-e * sum over co and taps of dY[b][co][y - ky + 1][x - kx + 1] *
@@ -142,9 +143,11 @@ IAGO_API int iago_merge_nchw(const void *hi, const void *lo, float *y, int64_t n
  *   block's input); dx [n][out_channels/16][64][16] float32 channel blocks; out_channels 64 or 128.
  *   max_bits: device word, atomicMax of the bit patterns of |dx| (zero it before the call).
  * iago_split_scaled: float32 channel blocks -> split channel blocks times 2^e with e = 13 - exponent of the largest
- *   magnitude (*max_bits, as written by the call above); writes e to *scale_exp.  bias_part / bias_grad (both or
- *   neither): scratch of ceil(n * channels / 32) * 32 floats and the sums over boards and cells per channel
- *   [channels] -- the bias gradient of the block whose pre-activation gradient x is, from the same pass.
+ *   magnitude (*max_bits, as written by the call above); writes e to *scale_exp.  bias_part (optional): scratch of
+ *   ceil(n * channels / 32) * 32 floats, the sums over the cells per (board, channel); bias_grad (optional, needs
+ *   bias_part): their sums over the boards per channel [channels] -- the bias gradient of the block whose
+ *   pre-activation gradient x is, from the same pass (bias_part alone: the caller reduces, as
+ *   iago_policy_reinforce_grad does for all blocks in one launch).
  */
 IAGO_API int iago_conv3x3_bwd_data_split(const void *dy_hi, const void *dy_lo, const int32_t *scale_exp,
                                          const void *wt_hi, const void *wt_lo, const void *mask_hi,

@@ -201,7 +201,7 @@ def test_bad_arguments_are_refused():
     from iago_amd import _lib
     L = _lib.lib()
     assert L.iago_policy_grad_workspace_bytes(-1) == -1
-    assert L.iago_policy_grad_workspace_bytes(2048) > 2048 * 304 * 1024    # 304 KB per row + 40 MB
+    assert L.iago_policy_grad_workspace_bytes(2048) > 2048 * 304 * 1024    # 308 KB per row + 247 MB
     a = _lib.PolicyGradArgs()
     assert L.iago_policy_reinforce_grad(C.byref(a), None) == -1          # n_mean 0, null pointers
     assert b"iago_policy_reinforce_grad" in L.iago_last_error()
@@ -214,7 +214,7 @@ def test_bad_arguments_are_refused():
 
 
 def test_rows_in_chunks_give_the_one_call_gradients(monkeypatch):
-    """Batches beyond GRAD_CHUNK_ROWS rows run in chunks (the kernels' scratch is 304 KB per row), every chunk dividing
+    """Batches beyond GRAD_CHUNK_ROWS rows run in chunks (the kernels' scratch is 308 KB per row), every chunk dividing
     by the whole batch's row count, the chunks' gradients added in chunk order: the one-call gradients within float32
     rounding of the sums, the same bits from run to run."""
     from iago_amd import network
