@@ -1,13 +1,13 @@
 /*
- * iago_hip_experimental.h -- entry points outside the drop-in boundary: (1) two schedules of the PER-PLAYOUT search engine
- * (game-asynchronous steps, value look-ahead), (2) the per-phase forms of a playout that the one-launch descent and the
- * persistent search superseded.  (1) were built, proven
- * tree-identical to the reference's order of evaluation and MEASURED SLOWER than the engines that serve the path
- * (the persistent search, iago_mcts_search_persistent, wherever the split-f16 Value net and the
- * three-piece SLPolicy apply and the batch fits one launch; the lockstep per-playout launches of include/iago_hip.h
- * otherwise): game-asynchronous steps (round 3) and the value look-ahead (round 4).  They stay in the library so that the
- * measurements of LABNOTES.md can be repeated (engine.BatchedMCTS(async_steps=True) / (value_ahead=True)); nothing on the
- * product's default paths calls them, and they are not part of the drop-in boundary INTEGRATION.md describes.
+ * iago_hip_experimental.h -- entry points of the library OUTSIDE the drop-in boundary INTEGRATION.md describes:
+ *   (1) two schedules of the PER-PLAYOUT search engine -- game-asynchronous steps (round 3) and the value look-ahead (round
+ *       4) --, built, proven tree-identical to the reference's order of evaluation and MEASURED SLOWER than the engines that
+ *       serve the path (the persistent search wherever the split-f16 Value net and the three-piece
+ *       SLPolicy apply and the batch fits one launch, the lockstep per-playout launches of iago_hip.h otherwise).  They stay
+ *       so that the measurements of LABNOTES.md can be repeated (engine.BatchedMCTS(async_steps=True) / (value_ahead=True));
+ *       nothing on the product's default paths calls them;
+ *   (2) the per-phase forms of a playout (rounds 1 - 2), superseded by the one-launch descent / backup of iago_hip.h and by
+ *       the persistent search: what engine.BatchedMCTS drives for arbitrary callables as nets.
  * Conventions as in iago_hip.h.
  */
 #ifndef IAGO_HIP_EXPERIMENTAL_H
