@@ -675,8 +675,8 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
                             const uint64_t c_own = opp & ~f2 & ~bit2, c_opp = own | f2 | bit2; // the child: the other side moves
                             uint32_t known = 0u, by = 0u;
                             // (the ring holds QCAP entries: at most one per game that waits -- <= QCAP / 2 games when this
-                            // is on -- and at most QCAP / 2 of these, handed out as a budget per workgroup and iteration
-                            // while the ring was empty: pace[3])
+                            // is on -- and these, handed out as a budget per workgroup and iteration while the ring was
+                            // empty, two iterations' worth of which fit beside the games' own: pace[3])
                             if (r == 0u && !vtable_get(S, c_own, c_opp, known, by) && atomicSub(&pace[3], 1) > 0)
                                 send_request(S, KIND_VALUE, (int64_t)NOBODY, (uint32_t)g, c_own, c_opp); // (reply tag: the sender)
                         }
@@ -836,7 +836,10 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
             const int32_t wait0 = (int32_t)(c_t0 - c_h0), wait1 = (int32_t)(c_t1 - c_h1);
             if (S.ahead_idle >= 0 && S.vtable_mask && T.n_games <= (int64_t)(QCAP / 2u) && c_idle >= (uint32_t)S.ahead_idle &&
                 wait0 <= 0 && wait1 <= 0)
-                pace[3] = (int32_t)(QCAP / 2u) / S.n_game_wgs; // this iteration's share of the ring for requests nobody waits for
+                // this iteration's share of the ring for requests nobody waits for: the games' own requests (at most one
+                // each) and TWO iterations' worth of these (the workgroups look at the rings at different moments: a second
+                // burst can be on its way before the first shows in anybody's snapshot) fit the ring together
+                pace[3] = (int32_t)((QCAP - (uint32_t)T.n_games) / 2u) / S.n_game_wgs;
             if (S.pace_margin >= 0) {
                 if (wait0 + wait1 > S.pace_backlog && c_play != 0u && c_play <= (uint32_t)T.n_games)
                     limit = (int)(c_prog / c_play) + S.pace_margin;
