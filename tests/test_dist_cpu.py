@@ -181,3 +181,37 @@ def test_bench_preflight(mode, tmp_path):
         if mode == "absent":
             procs[1].kill()          # (this very process object: not a pattern)
         procs[1].join(timeout=60)
+
+
+def test_bench_value_spread_and_variant_profiles(tmp_path, monkeypatch):
+    """`value_spread`: min / max of `value` over the committed one-GPU lines of the same workload and this run;
+    `variant_profile`: a variant leg's profile figures are quoted only from a profile taken on these kernel sources."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    line = {"metric": "self-play games/sec", "n_gpus": 1, "value": 2900.0,
+            "config": {"games_per_gpu": 1024, "sims_per_move": 100, "full_games": True}}
+    (prof / "r06a_bench.json").write_text(json.dumps(line) + "\n")
+    (prof / "r06b_bench.json").write_text(json.dumps(dict(line, value=2850.0)) + "\n")
+    (prof / "r06c_bench.json").write_text(json.dumps(dict(line, value=9999.0, n_gpus=8)) + "\n")          # not a one-GPU line
+    (prof / "r06d_bench.json").write_text(json.dumps(dict(line, value=1.0, config=dict(line["config"], games_per_gpu=256))) + "\n")
+    (prof / "r06e_bench.json").write_text("not json\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got = bench.value_spread(1024, 100, 2925.0)
+    assert got["min"] == 2850.0 and got["max"] == 2925.0 and got["boxes"] == 3
+    assert got["committed_lines"] == ["r06a_bench.json", "r06b_bench.json"]
+    k = {"calls": 4, "avg_us": 1.7e6, "SQ_INSTS_MFMA": 1.29e11, "hbm_bytes_per_launch": 1.5e12, "l2_hit_rate": 0.9,
+         "SQ_LDS_BANK_CONFLICT": 2.0, "SQ_LDS_IDX_ACTIVE": 10.0}
+    (prof / "r06a_mcts400_persistent_pmc_summary.json").write_text(json.dumps(
+        {"command": "x", "csrc_sha16": "0000", "kernels": {"search_kernel": k}}))
+    stale = bench.variant_profile("mcts400")
+    assert stale["profile"] == "r06a_mcts400_persistent_pmc_summary.json" and stale["profile_current"] is False
+    assert "traffic" not in stale
+    (prof / "r06b_mcts400_persistent_pmc_summary.json").write_text(json.dumps(
+        {"command": "y", "csrc_sha16": bench.csrc_sha16(), "kernels": {"search_kernel": k}}))
+    cur = bench.variant_profile("mcts400")
+    assert cur["profile_current"] is True and cur["traffic"] == 1.5e12 and abs(cur["rocprof_kernel_avg_ms"] - 1700.0) < 1e-9
+    assert abs(cur["executed_frac_pmc"] - 1.29e11 * 16384 / 1.7 / 1e12 / 2500.0) < 1e-9 and cur["lds_bank_conflict_share"] == 0.2
+    assert bench.variant_profile("mctsnthr1") == {"profile": None, "profile_current": False}
