@@ -860,6 +860,12 @@ __device__ __forceinline__ void game_workgroup(const SearchParams &S, const iago
         S.stats[2 * g] += st_levels;
         S.stats[2 * g + 1] += st_children;
     }
+    // (a launch that gave up: what every unfinished game was waiting for, for the post-mortem -- the trees are void anyway:
+    // cur_node = the reply tag it waits for, leaf_value = its state; tools/debug_split_abort.py)
+    if (exists && r == 0u && state != ST_DONE && __hip_atomic_load(&S.ctl[CTL_ABORT], RLX_AGENT) != 0u) {
+        S.cur_node[g] = (int32_t)epoch;
+        S.leaf_value[g] = (float)state;
+    }
     if (tid == 0) {
         atomicAdd((unsigned long long *)&S.totals[2], (unsigned long long)wg_count[0]);
         atomicAdd((unsigned long long *)&S.totals[6], (unsigned long long)wg_count[1]);
@@ -1271,7 +1277,13 @@ int search_launch(const iago_mcts_search_args *a, void *stream, iago_search_stre
         if (n_game_wgs > (int64_t)sp->game_cus * per_game)
             return iago_fail(IAGO_ERR_CAPACITY, "iago_mcts_search_split: the game workgroups do not fit the game launch's CUs "
                                                 "(more game CUs, fewer games per launch, or the single launch)");
-        resident = n_game_wgs + (int64_t)(cus - sp->game_cus) * per_cu;
+        // The net launch takes at most 7/8 of the device's CUs (224 of 256), whatever the game launch leaves.  Measured, not
+        // understood: with 232 .. 240 net workgroups beside a game launch on 16 / 24 CUs, about one batch in 60 froze --
+        // the LAST workgroups of the net launch (block index >= 224: exactly those, in every post-mortem) each took a
+        // ticket, stopped executing in the same 100 us, and went on the moment the game launch had ended (at its clock
+        // limit); with at most 224, 960 batches in a row on the same settings: none (LABNOTES.md, round 6)
+        const int64_t net_cus = cus - (sp->game_cus > cus / 8 ? sp->game_cus : cus / 8);
+        resident = n_game_wgs + net_cus * per_cu;
     }
     if (n_game_wgs + 1 > resident)
         return iago_fail(IAGO_ERR_CAPACITY, "iago_mcts_search_persistent: the game workgroups and one net workgroup do not "

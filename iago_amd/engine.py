@@ -433,8 +433,10 @@ class BatchedMCTS(object):
                 net_workgroups = int(os.environ.get("IAGO_PERSISTENT_NET", "0")) or max(32, 8 * n_games)
             # (an upper bound: the launch itself takes no more than fit beside the game workgroups)
             self.net_workgroups = max(1, min(int(net_workgroups), self.resident_workgroups - n_gw))
-            if self.split_cus:   # (one net workgroup on every CU that is not the games')
-                self.net_workgroups = max(1, min(int(net_workgroups), self.resident_workgroups - self.split_cus))
+            if self.split_cus:   # (one net workgroup on every CU that is not the games', at most 7/8 of the device's CUs:
+                # the library's cap -- beyond it the net launch's last workgroups were seen to stall, LABNOTES.md round 6)
+                self.net_workgroups = max(1, min(int(net_workgroups), self.resident_workgroups
+                                                 - max(self.split_cus, self.resident_workgroups // 8)))
             grid = n_gw + self.net_workgroups
             self.PATH_STRIDE = 520
             i64 = torch.int64
@@ -1112,7 +1114,8 @@ class BatchedMCTS(object):
         a.wg_own, a.wg_opp = ps["wg_own"].data_ptr(), ps["wg_opp"].data_ptr()
         if game is not None:
             a.max_turns = int(game["max_turns"])
-            a.time_limit_ms = max(self.time_limit_ms, 60000)   # (a whole game of 400-playout searches takes seconds)
+            # (a whole game of 400-playout searches takes seconds; IAGO_PERSISTENT_GAME_LIMIT_MS: the lab's shorter limit)
+            a.time_limit_ms = max(self.time_limit_ms, int(os.environ.get("IAGO_PERSISTENT_GAME_LIMIT_MS", "60000")))
             a.game_own, a.game_opp, a.n_turns = game["own"].data_ptr(), game["opp"].data_ptr(), game["n_turns"].data_ptr()
             a.rec_own, a.rec_opp = game["rec_own"].data_ptr(), game["rec_opp"].data_ptr()
             a.rec_valid, a.rec_move, a.rec_pi = (game["rec_valid"].data_ptr(), game["rec_move"].data_ptr(),

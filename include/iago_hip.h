@@ -578,7 +578,8 @@ IAGO_API int iago_mcts_search_capacity(int32_t *cus, int32_t *workgroups_per_cu)
  *     device (game_cus: a multiple of 8, at most half the device's CUs; IAGO_ERR_HIP where the runtime gives no
  *     CU-masked streams: use iago_mcts_search_persistent there).  _destroy releases them.
  *   iago_mcts_search_split: both launches start after everything queued on `stream` so far, `stream` continues after
- *     both; IAGO_ERR_CAPACITY when the game workgroups do not fit game_cus CUs.  No host synchronisation.  One call at a
+ *     both; IAGO_ERR_CAPACITY when the game workgroups do not fit game_cus CUs.  The net launch takes one workgroup
+ *     per CU that is not the games', at most 7/8 of the device's CUs.  No host synchronisation.  One call at a
  *     time per `streams` object (its events order the launches); destroy it only when the device has finished with it.
  */
 typedef struct iago_search_streams iago_search_streams;

@@ -258,6 +258,79 @@ def epilogue_writes_no_conflicts(src):
     return patch(src, '#include "conv_trunk_body.hpp" // (brings rollout_row_body.hpp)', '#include "conv_trunk_body_epiwrite.hpp"')
 
 
+def reply_times(s):
+    """Post-mortem of a launch that gave up (round 6): per game, in the `trace` buffer, [0] the clock at its last request,
+    [1] the clock at which a net workgroup wrote the reply to that request's mailbox (value or priors), [2] the clock at
+    which its workgroup left the loop, [3] state | reply tag << 8 (tools/debug_split_abort.py)."""
+    s = patch(s, "if (S.trace && blockIdx.x == 0 && tid == 0 && (int64_t)wg_count[0] <", "if (false && S.trace && blockIdx.x == 0 && tid == 0 && (int64_t)wg_count[0] <")
+    s = patch(s, "if (S.trace && r == 0u && g < S.trace_rows) {", "if (false && S.trace && r == 0u && g < S.trace_rows) {")
+    s = patch(s, """    atomicAdd((unsigned long long *)&S.totals[(uint32_t)g == NOBODY ? 11 : kind], 1ull);
+}""", """    atomicAdd((unsigned long long *)&S.totals[(uint32_t)g == NOBODY ? 11 : kind], 1ull);
+    if (S.trace && (uint32_t)g != NOBODY && g < S.trace_rows)
+        S.trace[4 * g + 0] = wall_clock64();
+}""")
+    s = patch(s, """                    st(&S.rep_v[(int64_t)(job[6 * tid] & 0x7FFFFFFFu)], ((u64)job[6 * tid + 1] << 32) | bits);""",
+              """                    st(&S.rep_v[(int64_t)(job[6 * tid] & 0x7FFFFFFFu)], ((u64)job[6 * tid + 1] << 32) | bits);
+                if (S.trace && (job[6 * tid] & 0x7FFFFFFFu) != NOBODY && (int)(job[6 * tid] & 0x7FFFFFFFu) < S.trace_rows)
+                    S.trace[4 * (int64_t)(job[6 * tid] & 0x7FFFFFFFu) + 1] = wall_clock64();""")
+    s = patch(s, """                st(&S.rep_p[(int64_t)(job[0] & 0x7FFFFFFFu) * 64 + tid], ((u64)job[1] << 32) | __float_as_uint(res_p[tid]));""",
+              """                st(&S.rep_p[(int64_t)(job[0] & 0x7FFFFFFFu) * 64 + tid], ((u64)job[1] << 32) | __float_as_uint(res_p[tid]));
+            if (S.trace && tid == 0 && (int)(job[0] & 0x7FFFFFFFu) < S.trace_rows)
+                S.trace[4 * (int64_t)(job[0] & 0x7FFFFFFFu) + 1] = wall_clock64();""")
+    s = patch(s, """        S.cur_node[g] = (int32_t)epoch;
+        S.leaf_value[g] = (float)state;""", """        S.cur_node[g] = (int32_t)epoch;
+        S.leaf_value[g] = (float)state;
+        if (S.trace && g < S.trace_rows) {
+            S.trace[4 * g + 2] = wall_clock64();
+            S.trace[4 * g + 3] = (int64_t)state | ((int64_t)epoch << 8);
+        }""")
+    # ... and per net workgroup (rows 4096 + blockIdx.x): [0] the clock at its last loop top, [1] the clock when it last began
+    # to wait for a ticket, [2] ring << 32 | ticket it last waited for, [3] stage (1 loop top, 2 waiting in fetch, 3 fetched,
+    # 4 left the kernel)
+    s = patch(s, """        const long long c0 = wall_clock64();
+        if (put_e) {""", """        const long long c0 = wall_clock64();
+        if (S.trace && tid == 0 && 4096 + (int)blockIdx.x < S.trace_rows) {
+            S.trace[4 * (4096 + (int64_t)blockIdx.x) + 0] = c0;
+            S.trace[4 * (4096 + (int64_t)blockIdx.x) + 3] = 1;
+        }
+        if (put_e) {""")
+    s = patch(s, """        u64 x = 0;
+        int status = 0;
+        for (uint32_t spins = 0;; spins++) {""", """        u64 x = 0;
+        int status = 0;
+        if (S.trace && tid == 0 && 4096 + (int)blockIdx.x < S.trace_rows && max_spins == 0u) {
+            S.trace[4 * (4096 + (int64_t)blockIdx.x) + 1] = wall_clock64();
+            S.trace[4 * (4096 + (int64_t)blockIdx.x) + 2] = ((int64_t)q << 32) | t;
+            S.trace[4 * (4096 + (int64_t)blockIdx.x) + 3] = 2;
+        }
+        for (uint32_t spins = 0;; spins++) {""")
+    s = patch(s, """        if (status == 0 && tid < 6)
+            job[6 * which + tid] = (uint32_t)x;
+        return status;""", """        if (status == 0 && tid < 6)
+            job[6 * which + tid] = (uint32_t)x;
+        if (S.trace && tid == 0 && 4096 + (int)blockIdx.x < S.trace_rows && max_spins == 0u)
+            S.trace[4 * (4096 + (int64_t)blockIdx.x) + 3] = 3 + 10 * status;
+        return status;""")
+    s = patch(s, """        if (job[28] != 0u) {
+            if (tid == 0) {""", """        if (job[28] != 0u) {
+            if (S.trace && tid == 0 && 4096 + (int)blockIdx.x < S.trace_rows)
+                S.trace[4 * (4096 + (int64_t)blockIdx.x) + 3] += 100;
+            if (tid == 0) {""")
+    # the ticket of a game's last request
+    s = patch(s, """    if (S.trace && (uint32_t)g != NOBODY && g < S.trace_rows)
+        S.trace[4 * g + 0] = wall_clock64();""", """    if (S.trace && (uint32_t)g != NOBODY && g < S.trace_rows) {
+        S.trace[4 * g + 0] = wall_clock64();
+        S.trace[4 * g + 3] = ((int64_t)kind << 32) | t;
+    }""")
+    return s
+
+
+def atomic_stores(s):
+    """Experiment (round 6): every granule of the protocol written by an atomic exchange instead of an agent-scope store."""
+    return patch(s, "__device__ __forceinline__ void st(u64 *p, u64 x) { __hip_atomic_store(p, x, RLX_AGENT); }",
+                 "__device__ __forceinline__ void st(u64 *p, u64 x) { (void)__hip_atomic_exchange(p, x, RLX_AGENT); }")
+
+
 def unroll4(src):
     """... unrolled by four: no back-edge inside a layer (4 chunk pairs; the first layer's 2 run the remainder loop)."""
     for name in ("conv_trunk_body", "conv_policy_body"):
@@ -312,10 +385,11 @@ def main():
         return
     for name, fn in (("search_log", request_log), ("search_phases", phase_stamps), ("search_walkstamps", walk_stamps),
                      ("search_walkstamps_noa", walk_stamps_no_a), ("search_walkstamps_nob", walk_stamps_no_b),
-                     ("search_epiwrite", epilogue_writes_no_conflicts), ("search_unroll2", unroll2), ("search_unroll4", unroll4)):
+                     ("search_epiwrite", epilogue_writes_no_conflicts), ("search_unroll2", unroll2), ("search_unroll4", unroll4),
+                     ("search_replytimes", reply_times), ("search_atomicst", atomic_stores)):
         if only and name not in only:
             continue
-        if not only and name in ("search_walkstamps_noa", "search_walkstamps_nob"):
+        if not only and name in ("search_walkstamps_noa", "search_walkstamps_nob", "search_unroll4"):
             continue   # (timing-only builds of round 5's first K loops: their anchors are of that code; kept for the record)
         path = os.path.join(OUT, name + ".hip")
         open(path, "w").write(fn(src))
