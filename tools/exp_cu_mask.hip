@@ -45,6 +45,31 @@ __global__ __launch_bounds__(256) void where_kernel(uint32_t *out, long long spi
     }
 }
 
+// A workgroup that only keeps time: loops until `ticks` have passed and records the longest gap between two turns of its
+// loop (100 MHz ticks) -- a workgroup that is not executed for a while shows up as a gap (round 6: the net launch's last
+// workgroups stalled while a second launch ran on the other CUs).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void beat_kernel(long long *gap, long long *turns,
+                                                                                                long long ticks)
+{
+    extern __shared__ char big[];
+    if (threadIdx.x == 0) {
+        big[0] = 1;
+        const long long t0 = wall_clock64();
+        long long last = t0, worst = 0, n = 0;
+        for (;;) {
+            const long long now = wall_clock64();
+            worst = now - last > worst ? now - last : worst;
+            last = now;
+            n++;
+            if (now - t0 > ticks)
+                break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+        gap[blockIdx.x] = worst;
+        turns[blockIdx.x] = n;
+    }
+}
+
 static int make_stream(const std::vector<int> &bits, int total, hipStream_t *s)
 {
     std::vector<uint32_t> words((total + 31) / 32, 0u);
@@ -155,6 +180,49 @@ int main()
         describe("  B", h.data() + 1024, total - 32);
         CHECK(hipStreamDestroy(sa));
         CHECK(hipStreamDestroy(sb));
+    }
+    // Do the last workgroups of a launch on the big mask stall while a second launch runs on the small one?  A: 2 x g
+    // workgroups (two per CU, 80 KB of LDS each) on the first g CUs, B: one workgroup (138 KB of LDS, one wave per SIMD) on
+    // each of the other CUs; both keep time for 300 ms; B's longest gaps by block index
+    long long *gap = nullptr, *turns = nullptr;
+    CHECK(hipMalloc(&gap, 2 * 512 * 8));
+    CHECK(hipMalloc(&turns, 2 * 512 * 8));
+    CHECK(hipFuncSetAttribute((const void *)beat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 138 * 1024));
+    for (int g : {16, 24, 32}) {
+        for (int rep = 0; rep < 3; rep++) {
+            hipStream_t sa, sb;
+            std::vector<int> a, b;
+            for (int i = 0; i < total; i++)
+                (i < g ? a : b).push_back(i);
+            if (make_stream(a, total, &sa) || make_stream(b, total, &sb))
+                return 1;
+            CHECK(hipMemset(gap, 0, 2 * 512 * 8));
+            CHECK(hipDeviceSynchronize());
+            const int nb = total - g;
+            hipLaunchKernelGGL(beat_kernel, dim3(2 * g), dim3(256), 78 * 1024, sa, gap + 512, turns + 512, 30000000ll);
+            hipLaunchKernelGGL(beat_kernel, dim3(nb), dim3(256), 138 * 1024, sb, gap, turns, 30000000ll);
+            CHECK(hipDeviceSynchronize());
+            std::vector<long long> hg(1024), ht(1024);
+            CHECK(hipMemcpy(hg.data(), gap, 1024 * 8, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(ht.data(), turns, 1024 * 8, hipMemcpyDeviceToHost));
+            int stalled = 0, first = -1;
+            long long worst = 0;
+            for (int i = 0; i < nb; i++) {
+                if (hg[i] > 100000) { // > 1 ms without a turn of the loop
+                    stalled++;
+                    first = first < 0 ? i : first;
+                }
+                worst = hg[i] > worst ? hg[i] : worst;
+            }
+            long long worst_a = 0;
+            for (int i = 0; i < 2 * g; i++)
+                worst_a = hg[512 + i] > worst_a ? hg[512 + i] : worst_a;
+            printf("beat: %d game-side CUs (%d workgroups) + %d workgroups on the rest: B's longest gap %.1f us, %d of B's workgroups "
+                   "with a gap > 1 ms (first: block %d); A's longest gap %.1f us\n", g, 2 * g, nb, worst / 100.0, stalled, first,
+                   worst_a / 100.0);
+            CHECK(hipStreamDestroy(sa));
+            CHECK(hipStreamDestroy(sb));
+        }
     }
     return 0;
 }
