@@ -163,7 +163,7 @@ def test_bench_preflight(mode, tmp_path):
     run with ONE JSON line carrying "error" on rank 0's stdout and a non-zero exit -- no hang."""
     import json
     world = 2
-    port = 29000 + (os.getpid() + 13 + {"ok": 0, "shared": 1, "absent": 2}[mode]) % 2000
+    port = 31000 + (os.getpid() + {"ok": 0, "shared": 1, "absent": 2}[mode]) % 2000
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_preflight_worker, args=(r, world, port, mode, str(tmp_path))) for r in range(world)]
     for p in procs:
